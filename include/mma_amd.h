@@ -1,0 +1,130 @@
+/* mma_amd.h - C ABI of libmma_amd.so: MI355X (gfx950) kernels for the MMA message-passing hot path.
+ *
+ * The reference (asarigun/mma) is pure Python with no FFI layer; its hot path sits behind two
+ * nn.Module surfaces.  These entry points are what a binding for that path binds:
+ * each one replaces the tensor-op sequence cited next to it (file:line under /root/reference).
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; the caller owns all memory;
+ *   - no hidden allocation, no host synchronisation: work is enqueued on `stream` (a hipStream_t
+ *     passed as void*, NULL = the null stream) and the call returns immediately;
+ *   - returns 0 on success; otherwise a nonzero code, and mma_last_error() describes it
+ *     (argument checks run on the host BEFORE any launch: a bad shape never reaches the GPU);
+ *   - all floating point data is fp32, all indices int32, row-major; `ld*` are row pitches in elements;
+ *   - stateless and re-entrant (mma_last_error is thread-local).
+ */
+#ifndef MMA_AMD_H
+#define MMA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMA_ABI_VERSION 1
+#define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
+
+/* combine kinds of the node-classification aggregators (layers.py:201-728) */
+enum {
+  MMA_KIND_SUM = 0,      /* m = x_i + s            learnable_sum*   layers.py:221 */
+  MMA_KIND_MEAN = 1,     /* m = (x_i + s) / d_i    learnable_mean*  layers.py:326-329 */
+  MMA_KIND_MAX = 2,      /* m = max(x_i, s)        learnable_max*   layers.py:452 */
+  MMA_KIND_MIN = 3,      /* m = min(x_i, s)        learnable_min*   layers.py:562 */
+  MMA_KIND_SOFTMAX = 4,  /* m = (e/e)*s, e=exp(s)  learnable_softmax layers.py:676-682 */
+  MMA_KIND_SOFTMIN = 5   /* m = (e/e)*s, e=exp(-s) learnable_softmin layers.py:716-720 */
+};
+/* mask activation: sigmoid, or the raw logits the "new_sigmoid" quirk leaves (layers.py:381-385) */
+enum { MMA_ACT_SIGMOID = 0, MMA_ACT_RAW = 1 };
+
+/* dropout of the mask (F.dropout(mask0, p), training=True always: layers.py:219).
+ *   mode NONE: p == 0.  mode HASH: counter-based keep bits, DESIGN.md "dropout RNG"; p is quantised
+ *   to thr/256.  mode EXPLICIT: keep[(k*E + e)*H + h] in {0,1} supplied by the caller (parity tests). */
+enum { MMA_DROP_NONE = 0, MMA_DROP_HASH = 1, MMA_DROP_EXPLICIT = 2 };
+
+int mma_abi_version(void);
+const char* mma_last_error(void);
+
+/* ---- K1: fused masked message + K-aggregator segmented reduce, node classification form ----------
+ * Replaces, for all K selected aggregators at once, the per-node Python loop of
+ * layers.py:205-226 (gather / tile / cat / mm / sigmoid / dropout / mul / sum / combine):
+ *     z_k(i,j) = P[i, k*H:(k+1)*H] + Q[j, k*H:(k+1)*H]        ( = [x_i || x_j] @ W_k, split as
+ *                P = x @ W_k[:H], Q = x @ W_k[H:], computed once per layer by a dense GEMM )
+ *     s_k[i]   = sum_{j in N(i)} drop(act_k(z_k(i,j))) * x_j
+ *     m[k,i,:] = combine_k(x_i, s_k[i], d_i)
+ * Work is described by `items`: int32 quadruples {node, edge_begin, edge_end, slot}. slot < 0: the
+ * item covers the node's whole CSR segment and writes m directly. slot >= 0: the item is one chunk
+ * of a hub node; it writes partial sums to `partial[slot]` and `hubs` {node, slot_begin, slot_end, 0}
+ * lists the nodes whose chunks are then summed in slot order (deterministic) by a second launch.
+ * When T and sel are non-NULL (training) the kernel also saves, per node, what backward needs:
+ *     T[i, k*H+h]   = sum_j drop * act_k'(z) * x_j[h]          (so grad_P = gs * T needs no edge pass)
+ *     sel[i, k*H+h] = 0: x_i selected  1: s selected  2: tie (0.5/0.5, torch.max/min backward)  3: NaN
+ */
+int mma_nc_fused_fwd(
+    const float* x, int64_t ldx,                 /* (N,H) */
+    const float* P, const float* Q, int64_t ldpq,/* (N,K*H) each */
+    const int32_t* rowptr,                       /* (N+1) CSR by target: d_i = rowptr[i+1]-rowptr[i] */
+    const int32_t* col,                          /* (E) source node of each edge, target-major */
+    const int32_t* items, int64_t n_items,       /* (n_items,4) */
+    const int32_t* hubs, int64_t n_hubs,         /* (n_hubs,4), may be NULL when n_hubs == 0 */
+    float* partial, int64_t n_slots,             /* (n_slots, 2, K, H) scratch, NULL when n_slots == 0 */
+    float* m,                                    /* (K,N,H) out */
+    float* T, uint8_t* sel, int64_t ldt,         /* (N,K*H) out, both NULL or both non-NULL */
+    int64_t N, int64_t E, int32_t H, int32_t K,
+    const uint8_t* kind_host, const uint8_t* act_host,   /* K codes each, HOST memory */
+    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint8_t* keep, /* keep: (K,E,H) or NULL */
+    void* stream);
+
+/* ---- K2a: node-level backward of the combine (element-wise) -------------------------------------
+ * From g = dL/dm (K,N,H): gs = dL/ds (N,K*H), gP = gs * T (N,K*H) = dL/dP, gxs = sum_k dL/dx_i
+ * through the combine (N,H).  Mirrors autograd of layers.py:221,326-329,452,562 (ties split 0.5/0.5). */
+int mma_nc_bwd_node(
+    const float* g, const uint8_t* sel, const float* T, int64_t ldt, const int32_t* rowptr,
+    float* gs, int64_t ldgs, float* gP, int64_t ldgp, float* gxs, int64_t ldgx,
+    int64_t N, int32_t H, int32_t K, const uint8_t* kind_host, void* stream);
+
+/* ---- K2b: edge-level backward, source-major (no atomics, deterministic) ---------------------------
+ * Walks the TRANSPOSED CSR (edges grouped by source j): t_col[e'] = target i, t_eid[e'] = position of
+ * that edge in the forward CSR (keys the dropout bits).  Per source j:
+ *     gQ[j, k*H+h] = x_j[h] * sum_i gs[i,k,h] * drop * act_k'(z_k(i,j))
+ *     gx[j, h]     = gxs[j,h] + sum_i sum_k gs[i,k,h] * drop * act_k(z_k(i,j))
+ * items/hubs/partial as in mma_nc_fused_fwd but over the transposed segments; partial is
+ * (n_slots, K+1, H). */
+int mma_nc_fused_bwd(
+    const float* x, int64_t ldx, const float* P, const float* Q, int64_t ldpq,
+    const float* gs, int64_t ldg, const float* gxs, int64_t ldgx,
+    const int32_t* t_col, const int32_t* t_eid,
+    const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs,
+    float* partial, int64_t n_slots,
+    float* gQ, int64_t ldgq, float* gx, int64_t ldgxo,
+    int64_t N, int64_t E, int32_t H, int32_t K,
+    const uint8_t* act_host,
+    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint8_t* keep,
+    void* stream);
+
+/* ---- K5: CSR SpMM over a K-times column-stacked adjacency ----------------------------------------
+ * out[i,:] = bias + sum_{k<K} sum_{e in row i} val[e] * B[k*rows_per_block + col[e], :]
+ * = torch.spmm(cat((adj,)*K, 1), support) + bias            (layers.py:861-865; K=1: layers.py:41)
+ * val may be NULL (all ones); bias may be NULL. */
+int mma_csr_spmm(
+    const int32_t* rowptr, const int32_t* col, const float* val,
+    const float* B, int64_t ldb, int64_t rows_per_block, int32_t K,
+    const float* bias, float* out, int64_t ldo,
+    int64_t n_rows, int32_t C, void* stream);
+
+/* ---- K7: halo pack / unpack for the 1-D node-sharded multi-GPU path --------------------------------
+ * pack:   dst[r,:] = src[idx[r],:]            (send buffer for the all-to-all of halo rows)
+ * unpack: dst[idx[r],:] += src[r,:]           (reverse exchange in backward; idx rows of one call are
+ *                                              unique, so no atomics are needed) */
+int mma_pack_rows(const float* src, int64_t lds, const int32_t* idx, int64_t n_idx,
+                  float* dst, int64_t ldd, int32_t width, void* stream);
+int mma_unpack_add_rows(const float* src, int64_t lds, const int32_t* idx, int64_t n_idx,
+                        float* dst, int64_t ldd, int32_t width, void* stream);
+
+/* ---- K3/K4: graph-regression multi-aggregator scatter-reduce (declared in the GR section below) -- */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMA_AMD_H */

@@ -1,0 +1,96 @@
+// Device/host helpers shared by the libmma_amd.so kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mma_amd.h"
+
+namespace mma {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kBlock = 256;        // 4 waves per workgroup, one item stream per wave
+constexpr int kMaxGrid = 256 * 8;  // 256 CUs x 8 workgroups: grid-stride beyond this
+
+// ---- error reporting (thread-local, read back through mma_last_error) -----------------------------
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+#define MMA_REQUIRE(cond, ...) \
+  do { if (!(cond)) return ::mma::fail(1, __VA_ARGS__); } while (0)
+
+// ---- small fixed-width vectors that live in registers ----------------------------------------------
+template <int VEC> struct Vec { float v[VEC]; };
+
+template <int VEC> __device__ __forceinline__ Vec<VEC> vzero() {
+  Vec<VEC> r;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) r.v[i] = 0.f;
+  return r;
+}
+template <int VEC> __device__ __forceinline__ Vec<VEC> ldv(const float* p);
+template <> __device__ __forceinline__ Vec<4> ldv<4>(const float* p) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  Vec<4> r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
+}
+template <> __device__ __forceinline__ Vec<1> ldv<1>(const float* p) { Vec<1> r; r.v[0] = *p; return r; }
+
+template <int VEC> __device__ __forceinline__ void stv(float* p, const Vec<VEC>& a);
+template <> __device__ __forceinline__ void stv<4>(float* p, const Vec<4>& a) {
+  *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+template <> __device__ __forceinline__ void stv<1>(float* p, const Vec<1>& a) { *p = a.v[0]; }
+
+// 1 byte per element (selection codes, explicit keep masks)
+template <int VEC> __device__ __forceinline__ uint32_t ldb(const uint8_t* p);
+template <> __device__ __forceinline__ uint32_t ldb<4>(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+template <> __device__ __forceinline__ uint32_t ldb<1>(const uint8_t* p) { return *p; }
+template <int VEC> __device__ __forceinline__ void stb(uint8_t* p, uint32_t codes);
+template <> __device__ __forceinline__ void stb<4>(uint8_t* p, uint32_t c) { *reinterpret_cast<uint32_t*>(p) = c; }
+template <> __device__ __forceinline__ void stb<1>(uint8_t* p, uint32_t c) { *p = (uint8_t)c; }
+
+// ---- mask activation ---------------------------------------------------------------------------------
+// sigmoid on the hardware transcendental pipe: v_exp_f32 + v_rcp_f32 (1 ulp each)
+__device__ __forceinline__ float sigmoid_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+
+// ---- dropout keep bits: counter-based, stateless, identical in forward and backward -------------------
+// One 32-bit hash per (edge position e, mask k, feature quad q) yields 4 bytes, one per feature of the
+// quad; an element is KEPT iff its byte >= thr, so P(drop) = thr/256 and survivors scale by 256/(256-thr).
+// The numpy restatement the parity tests use is oracle/dropout_rng.py.
+__host__ __device__ __forceinline__ uint32_t drop_edge_key(uint32_t e, uint32_t seed_lo) { return e * 0x9E3779B1u + seed_lo; }
+__host__ __device__ __forceinline__ uint32_t drop_col_key(uint32_t kq, uint32_t seed_hi) { return kq * 0x85EBCA77u + seed_hi; }
+__host__ __device__ __forceinline__ uint32_t drop_mix(uint32_t a) {
+  a ^= a >> 16; a *= 0x7FEB352Du; a ^= a >> 15; a *= 0x846CA68Bu; a ^= a >> 16; return a;
+}
+
+struct DropParams {
+  int mode;             // MMA_DROP_*
+  uint32_t thr;         // 0..255
+  float scale;          // 256/(256-thr) (HASH) or 1/(1-p) = same formula (EXPLICIT)
+  uint32_t seed_lo, seed_hi;
+  const uint8_t* keep;  // EXPLICIT: (K_total, E, H)
+  int64_t E;
+};
+
+// keep multiplier (0 or scale) for the VEC features starting at column c of mask k_abs on edge e
+template <int VEC>
+__device__ __forceinline__ void drop_factors(const DropParams& d, uint32_t e, int k_abs, int c, int H, int HQ,
+                                             float (&f)[VEC]) {
+  if (d.mode == MMA_DROP_HASH) {
+    const uint32_t r = drop_mix(drop_edge_key(e, d.seed_lo) ^ drop_col_key((uint32_t)(k_abs * HQ + (c >> 2)), d.seed_hi));
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const uint32_t byte = (r >> (8 * ((c + i) & 3))) & 0xFFu;
+      f[i] = byte >= d.thr ? d.scale : 0.f;
+    }
+  } else {  // EXPLICIT
+    const uint32_t bits = ldb<VEC>(d.keep + ((size_t)k_abs * (size_t)d.E + e) * (size_t)H + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = ((bits >> (8 * i)) & 0xFFu) ? d.scale : 0.f;
+  }
+}
+
+__host__ inline int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+}  // namespace mma

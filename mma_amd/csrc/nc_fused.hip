@@ -1,0 +1,632 @@
+// K1 / K2a / K2b: fused masked-message + multi-aggregator segmented reduce for the node-classification
+// form of MMA (reference node_classification/layers.py:201-728), hand-written for gfx950.
+//
+// Mapping (wave64): one wavefront owns one work item (= one target node's CSR segment, or one chunk of
+// a hub's segment).  The 64 lanes are split into EPG = 64/LPR sub-rows of LPR lanes; a sub-row holds one
+// neighbour row at a time, each lane VEC (=4, one dwordx4) consecutive features, so one wave-instruction
+// gathers EPG whole rows with fully coalesced 16-byte accesses.  The node's own row (x_i, P_k[i]) stays in
+// registers for the whole segment; all K masks share the single gather of x_j.  Edge indices are read
+// 64 at a time (one coalesced load) and handed to the sub-rows with ds_bpermute.  Two edge steps are
+// kept in flight per lane.  Sub-row partial sums meet in a butterfly at the end of the segment; there
+// are no atomics anywhere, so results are bitwise reproducible.
+#include "common.h"
+
+namespace mma {
+
+struct NcFwdParams {
+  const float* x; int64_t ldx;
+  const float* P; const float* Q; int64_t ldpq;
+  const int32_t* rowptr; const int32_t* col;
+  const int4* items; int64_t n_items;
+  float* partial; int64_t pstride;   // floats per slot = 2*K_total*H
+  float* m; int64_t m_kstride;       // N*H
+  float* T; uint8_t* sel; int64_t ldt;
+  int H, HQ, K_total, k_base, lpr_log;
+  uint32_t kinds, acts;              // 4 bits / 1 bit per mask, indexed by absolute k
+  DropParams drop;
+};
+
+__device__ __forceinline__ int kind_of(uint32_t kinds, int k) { return (kinds >> (4 * k)) & 0xF; }
+
+// combine + selection code for one element (layers.py:221,326-329,452,562,676-682,716-720)
+__device__ __forceinline__ float nc_combine(int kind, float xi, float s, float deg, uint32_t& code) {
+  code = 1;
+  switch (kind) {
+    case MMA_KIND_SUM: return xi + s;
+    case MMA_KIND_MEAN: return (xi + s) / deg;   // deg clamped to >= 1 by the caller (SURVEY Q12 extension)
+    case MMA_KIND_MAX: code = s > xi ? 1u : (s == xi ? 2u : 0u); return s > xi ? s : xi;
+    case MMA_KIND_MIN: code = s < xi ? 1u : (s == xi ? 2u : 0u); return s < xi ? s : xi;
+    default: {  // softmax over a singleton dimension: (e / e) * s, NaN once exp over/underflows
+      const float e = expf(kind == MMA_KIND_SOFTMAX ? s : -s);
+      const float r = (e / e) * s;
+      code = (r != r) ? 3u : 1u;
+      return r;
+    }
+  }
+}
+
+template <int VEC, bool SAVE>
+__device__ __forceinline__ void nc_fwd_write(const NcFwdParams& p, int node, int k_abs, int c, const Vec<VEC>& xi,
+                                             const Vec<VEC>& s, const Vec<VEC>& t, float deg) {
+  Vec<VEC> mo;
+  uint32_t codes = 0;
+  const int kind = kind_of(p.kinds, k_abs);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    uint32_t code;
+    mo.v[i] = nc_combine(kind, xi.v[i], s.v[i], deg, code);
+    codes |= code << (8 * i);
+  }
+  stv<VEC>(p.m + (size_t)k_abs * p.m_kstride + (size_t)node * p.H + c, mo);
+  if (SAVE) {
+    const size_t o = (size_t)node * p.ldt + (size_t)k_abs * p.H + c;
+    stv<VEC>(p.T + o, t);
+    stb<VEC>(p.sel + o, codes);
+  }
+}
+
+template <int K, int VEC, bool SAVE, bool DROP>
+__global__ __launch_bounds__(kBlock) void nc_fwd_kernel(const NcFwdParams p) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << p.lpr_log;
+  const int epg = kWave >> p.lpr_log;
+  const int sub = lane >> p.lpr_log;
+  const int c = ((int)blockIdx.y * lpr + (lane & (lpr - 1))) * VEC;
+  const bool fvalid = c < p.H;
+  const int cc = fvalid ? c : 0;  // masked lanes read column 0 (valid memory), results are discarded
+  const int waves_per_block = kBlock / kWave;
+  const int64_t stride = (int64_t)gridDim.x * waves_per_block;
+
+  for (int64_t it0 = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); it0 < p.n_items; it0 += stride) {
+    const int4 item = p.items[__builtin_amdgcn_readfirstlane((int)it0)];
+    const int node = __builtin_amdgcn_readfirstlane(item.x);
+    const int ebeg = __builtin_amdgcn_readfirstlane(item.y);
+    const int eend = __builtin_amdgcn_readfirstlane(item.z);
+    const int slot = __builtin_amdgcn_readfirstlane(item.w);
+
+    const Vec<VEC> xi = ldv<VEC>(p.x + (size_t)node * p.ldx + cc);
+    Vec<VEC> pk[K], acc[K], tac[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pk[k] = ldv<VEC>(p.P + (size_t)node * p.ldpq + (size_t)(p.k_base + k) * p.H + cc);
+      acc[k] = vzero<VEC>();
+      tac[k] = vzero<VEC>();
+    }
+
+    for (int base = ebeg; base < eend; base += kWave) {
+      const int cnt = min(kWave, eend - base);
+      const int myj = (lane < cnt) ? p.col[base + lane] : 0;
+      // two edge steps (2*EPG edges) in flight per iteration
+      for (int t0 = 0; t0 < cnt; t0 += 2 * epg) {
+        int tt[2]; bool ev[2]; Vec<VEC> xj[2]; Vec<VEC> qv[2][K];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          tt[u] = t0 + u * epg + sub;
+          ev[u] = tt[u] < cnt;
+          const int j = __shfl(myj, tt[u] & (kWave - 1), kWave);
+          const int jj = ev[u] ? j : node;   // inactive sub-rows re-read the own row (cached), contribute 0
+          xj[u] = ldv<VEC>(p.x + (size_t)jj * p.ldx + cc);
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+            qv[u][k] = ldv<VEC>(p.Q + (size_t)jj * p.ldpq + (size_t)(p.k_base + k) * p.H + cc);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float on = ev[u] ? 1.f : 0.f;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const bool raw = (p.acts >> (p.k_base + k)) & 1u;
+            float f[VEC];
+            if (DROP) {
+              drop_factors<VEC>(p.drop, (uint32_t)(ev[u] ? base + tt[u] : ebeg), p.k_base + k, cc, p.H, p.HQ, f);
+            } else {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) f[i] = 1.f;
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              const float z = pk[k].v[i] + qv[u][k].v[i];
+              float a, da;
+              if (raw) { a = z; da = 1.f; }
+              else { a = sigmoid_fast(z); da = a - a * a; }
+              const float w = f[i] * on * xj[u].v[i];
+              acc[k].v[i] = fmaf(a, w, acc[k].v[i]);
+              if (SAVE) tac[k].v[i] = fmaf(da, w, tac[k].v[i]);
+            }
+          }
+        }
+      }
+    }
+
+    // butterfly over the EPG sub-rows (lanes with equal feature column)
+    for (int off = kWave / 2; off >= lpr; off >>= 1) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          acc[k].v[i] += __shfl_xor(acc[k].v[i], off, kWave);
+          if (SAVE) tac[k].v[i] += __shfl_xor(tac[k].v[i], off, kWave);
+        }
+    }
+
+    if (sub == 0 && fvalid) {
+      if (slot < 0) {
+        const float deg = (float)max(p.rowptr[node + 1] - p.rowptr[node], 1);
+#pragma unroll
+        for (int k = 0; k < K; ++k) nc_fwd_write<VEC, SAVE>(p, node, p.k_base + k, c, xi, acc[k], tac[k], deg);
+      } else {
+        float* ps = p.partial + (size_t)slot * p.pstride;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          stv<VEC>(ps + (size_t)(p.k_base + k) * p.H + c, acc[k]);
+          if (SAVE) stv<VEC>(ps + (size_t)(p.K_total + p.k_base + k) * p.H + c, tac[k]);
+        }
+      }
+    }
+  }
+}
+
+// hub nodes: sum the chunk partials in slot order, then the same epilogue
+template <int VEC, bool SAVE>
+__global__ __launch_bounds__(kBlock) void nc_fwd_finalize_kernel(const NcFwdParams p, const int4* hubs, int64_t n_hubs) {
+  const int per_row = (p.H + VEC - 1) / VEC;
+  const int64_t total = n_hubs * p.K_total * per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % per_row) * VEC;
+    const int k = (int)((idx / per_row) % p.K_total);
+    const int4 hub = hubs[idx / ((int64_t)per_row * p.K_total)];
+    Vec<VEC> s = vzero<VEC>(), t = vzero<VEC>();
+    for (int sl = hub.y; sl < hub.z; ++sl) {
+      const float* ps = p.partial + (size_t)sl * p.pstride;
+      const Vec<VEC> a = ldv<VEC>(ps + (size_t)k * p.H + c);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s.v[i] += a.v[i];
+      if (SAVE) {
+        const Vec<VEC> b = ldv<VEC>(ps + (size_t)(p.K_total + k) * p.H + c);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) t.v[i] += b.v[i];
+      }
+    }
+    const int node = hub.x;
+    const Vec<VEC> xi = ldv<VEC>(p.x + (size_t)node * p.ldx + c);
+    const float deg = (float)max(p.rowptr[node + 1] - p.rowptr[node], 1);
+    nc_fwd_write<VEC, SAVE>(p, node, k, c, xi, s, t, deg);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2a: node-level backward of the combine
+struct NcBwdNodeParams {
+  const float* g; const uint8_t* sel; const float* T; int64_t ldt; const int32_t* rowptr;
+  float* gs; int64_t ldgs; float* gP; int64_t ldgp; float* gxs; int64_t ldgx;
+  int64_t N; int H, K; uint32_t kinds;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodeParams p) {
+  const int per_row = (p.H + VEC - 1) / VEC;
+  const int64_t total = p.N * per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t node = idx / per_row;
+    const int c = (int)(idx % per_row) * VEC;
+    const float deg = (float)max(p.rowptr[node + 1] - p.rowptr[node], 1);
+    Vec<VEC> gx = vzero<VEC>();
+    for (int k = 0; k < p.K; ++k) {
+      const int kind = kind_of(p.kinds, k);
+      const Vec<VEC> g = ldv<VEC>(p.g + ((size_t)k * p.N + node) * p.H + c);
+      const size_t o = (size_t)node * p.ldt + (size_t)k * p.H + c;
+      const Vec<VEC> t = ldv<VEC>(p.T + o);
+      const uint32_t codes = ldb<VEC>(p.sel + o);
+      Vec<VEC> gsv, gpv;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const uint32_t code = (codes >> (8 * i)) & 0xFFu;
+        float fs, fx;  // d m / d s, d m / d x_i
+        switch (kind) {
+          case MMA_KIND_SUM: fs = 1.f; fx = 1.f; break;
+          case MMA_KIND_MEAN: fs = 1.f / deg; fx = fs; break;
+          case MMA_KIND_MAX:
+          case MMA_KIND_MIN: fs = code == 1u ? 1.f : (code == 2u ? 0.5f : 0.f); fx = 1.f - fs; break;
+          default: fs = code == 3u ? __builtin_nanf("") : 1.f; fx = 0.f; break;
+        }
+        gsv.v[i] = g.v[i] * fs;
+        gpv.v[i] = gsv.v[i] * t.v[i];
+        gx.v[i] = fmaf(g.v[i], fx, gx.v[i]);
+      }
+      stv<VEC>(p.gs + (size_t)node * p.ldgs + (size_t)k * p.H + c, gsv);
+      stv<VEC>(p.gP + (size_t)node * p.ldgp + (size_t)k * p.H + c, gpv);
+    }
+    stv<VEC>(p.gxs + (size_t)node * p.ldgx + c, gx);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2b: edge-level backward over the transposed CSR (grouped by source j)
+struct NcBwdParams {
+  const float* x; int64_t ldx;
+  const float* P; const float* Q; int64_t ldpq;
+  const float* gs; int64_t ldg; const float* gxs; int64_t ldgx;
+  const int32_t* t_col; const int32_t* t_eid;
+  const int4* items; int64_t n_items;
+  float* partial; int64_t pstride;   // floats per slot = (K_total+1)*H
+  float* gQ; int64_t ldgq; float* gx; int64_t ldgxo;
+  int H, HQ, K_total, k_base, lpr_log;
+  uint32_t acts;
+  DropParams drop;
+  int first_pass;  // k_base == 0: gx starts from gxs; later K-slices accumulate onto gx
+};
+
+template <int K, int VEC, bool DROP>
+__global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << p.lpr_log;
+  const int epg = kWave >> p.lpr_log;
+  const int sub = lane >> p.lpr_log;
+  const int c = ((int)blockIdx.y * lpr + (lane & (lpr - 1))) * VEC;
+  const bool fvalid = c < p.H;
+  const int cc = fvalid ? c : 0;
+  const int waves_per_block = kBlock / kWave;
+  const int64_t stride = (int64_t)gridDim.x * waves_per_block;
+
+  for (int64_t it0 = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); it0 < p.n_items; it0 += stride) {
+    const int4 item = p.items[__builtin_amdgcn_readfirstlane((int)it0)];
+    const int node = __builtin_amdgcn_readfirstlane(item.x);   // the SOURCE j
+    const int ebeg = __builtin_amdgcn_readfirstlane(item.y);
+    const int eend = __builtin_amdgcn_readfirstlane(item.z);
+    const int slot = __builtin_amdgcn_readfirstlane(item.w);
+
+    const Vec<VEC> xj = ldv<VEC>(p.x + (size_t)node * p.ldx + cc);
+    Vec<VEC> qk[K], aq[K];
+    Vec<VEC> ax = vzero<VEC>();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      qk[k] = ldv<VEC>(p.Q + (size_t)node * p.ldpq + (size_t)(p.k_base + k) * p.H + cc);
+      aq[k] = vzero<VEC>();
+    }
+
+    for (int base = ebeg; base < eend; base += kWave) {
+      const int cnt = min(kWave, eend - base);
+      const int myi = (lane < cnt) ? p.t_col[base + lane] : 0;
+      const int mye = (DROP && lane < cnt) ? p.t_eid[base + lane] : 0;
+      for (int t0 = 0; t0 < cnt; t0 += 2 * epg) {
+        int tt[2]; bool ev[2]; uint32_t eid[2]; Vec<VEC> gv[2][K]; Vec<VEC> pv[2][K];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          tt[u] = t0 + u * epg + sub;
+          ev[u] = tt[u] < cnt;
+          const int i_ = __shfl(myi, tt[u] & (kWave - 1), kWave);
+          eid[u] = DROP ? (uint32_t)__shfl(mye, tt[u] & (kWave - 1), kWave) : 0u;
+          const int ii = ev[u] ? i_ : node;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const size_t o = (size_t)(p.k_base + k) * p.H + cc;
+            gv[u][k] = ldv<VEC>(p.gs + (size_t)ii * p.ldg + o);
+            pv[u][k] = ldv<VEC>(p.P + (size_t)ii * p.ldpq + o);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float on = ev[u] ? 1.f : 0.f;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const bool raw = (p.acts >> (p.k_base + k)) & 1u;
+            float f[VEC];
+            if (DROP) {
+              drop_factors<VEC>(p.drop, eid[u], p.k_base + k, cc, p.H, p.HQ, f);
+            } else {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) f[i] = 1.f;
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              const float z = pv[u][k].v[i] + qk[k].v[i];
+              float a, da;
+              if (raw) { a = z; da = 1.f; }
+              else { a = sigmoid_fast(z); da = a - a * a; }
+              const float w = f[i] * on * gv[u][k].v[i];
+              aq[k].v[i] = fmaf(da, w, aq[k].v[i]);
+              ax.v[i] = fmaf(a, w, ax.v[i]);
+            }
+          }
+        }
+      }
+    }
+
+    for (int off = kWave / 2; off >= lpr; off >>= 1) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        ax.v[i] += __shfl_xor(ax.v[i], off, kWave);
+#pragma unroll
+        for (int k = 0; k < K; ++k) aq[k].v[i] += __shfl_xor(aq[k].v[i], off, kWave);
+      }
+    }
+
+    if (sub == 0 && fvalid) {
+      if (slot < 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          Vec<VEC> o;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o.v[i] = xj.v[i] * aq[k].v[i];
+          stv<VEC>(p.gQ + (size_t)node * p.ldgq + (size_t)(p.k_base + k) * p.H + c, o);
+        }
+        const Vec<VEC> g0 = p.first_pass ? ldv<VEC>(p.gxs + (size_t)node * p.ldgx + c)
+                                         : ldv<VEC>(p.gx + (size_t)node * p.ldgxo + c);
+        Vec<VEC> o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o.v[i] = g0.v[i] + ax.v[i];
+        stv<VEC>(p.gx + (size_t)node * p.ldgxo + c, o);
+      } else {
+        float* ps = p.partial + (size_t)slot * p.pstride;
+#pragma unroll
+        for (int k = 0; k < K; ++k) stv<VEC>(ps + (size_t)(p.k_base + k) * p.H + c, aq[k]);
+        // the x-gradient partial of this K-slice; slices are summed by the finalize kernel
+        float* px = ps + (size_t)p.K_total * p.H + c;
+        if (p.first_pass) stv<VEC>(px, ax);
+        else {
+          const Vec<VEC> prev = ldv<VEC>(px);
+          Vec<VEC> o;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o.v[i] = prev.v[i] + ax.v[i];
+          stv<VEC>(px, o);
+        }
+      }
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void nc_bwd_finalize_kernel(const NcBwdParams p, const int4* hubs, int64_t n_hubs) {
+  const int per_row = (p.H + VEC - 1) / VEC;
+  const int64_t total = n_hubs * (p.K_total + 1) * per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % per_row) * VEC;
+    const int k = (int)((idx / per_row) % (p.K_total + 1));
+    const int4 hub = hubs[idx / ((int64_t)per_row * (p.K_total + 1))];
+    Vec<VEC> s = vzero<VEC>();
+    for (int sl = hub.y; sl < hub.z; ++sl) {
+      const Vec<VEC> a = ldv<VEC>(p.partial + (size_t)sl * p.pstride + (size_t)k * p.H + c);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s.v[i] += a.v[i];
+    }
+    const int node = hub.x;
+    Vec<VEC> o;
+    if (k < p.K_total) {
+      const Vec<VEC> xj = ldv<VEC>(p.x + (size_t)node * p.ldx + c);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o.v[i] = xj.v[i] * s.v[i];
+      stv<VEC>(p.gQ + (size_t)node * p.ldgq + (size_t)k * p.H + c, o);
+    } else {
+      const Vec<VEC> g0 = ldv<VEC>(p.gxs + (size_t)node * p.ldgx + c);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o.v[i] = g0.v[i] + s.v[i];
+      stv<VEC>(p.gx + (size_t)node * p.ldgxo + c, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int pack_codes(const uint8_t* kind_host, const uint8_t* act_host, int K, uint32_t* kinds, uint32_t* acts) {
+  *kinds = 0; *acts = 0;
+  for (int k = 0; k < K; ++k) {
+    if (kind_host) {
+      if (kind_host[k] > MMA_KIND_SOFTMIN) return fail(1, "kind[%d]=%d is not an MMA_KIND_* code", k, (int)kind_host[k]);
+      *kinds |= (uint32_t)kind_host[k] << (4 * k);
+    }
+    if (act_host) {
+      if (act_host[k] > MMA_ACT_RAW) return fail(1, "act[%d]=%d is not an MMA_ACT_* code", k, (int)act_host[k]);
+      *acts |= (uint32_t)act_host[k] << k;
+    }
+  }
+  return 0;
+}
+
+static int make_drop(int32_t mode, uint32_t thr, uint64_t seed, const uint8_t* keep, int64_t E, DropParams* d) {
+  MMA_REQUIRE(mode >= MMA_DROP_NONE && mode <= MMA_DROP_EXPLICIT, "drop_mode %d unknown", mode);
+  MMA_REQUIRE(mode == MMA_DROP_NONE || thr < 256, "drop_thr %u out of range (0..255)", thr);
+  MMA_REQUIRE(mode != MMA_DROP_EXPLICIT || keep != nullptr, "drop_mode EXPLICIT needs a keep mask");
+  d->mode = mode; d->thr = thr; d->scale = 256.0f / (256.0f - (float)thr);
+  d->seed_lo = (uint32_t)seed; d->seed_hi = (uint32_t)(seed >> 32); d->keep = keep; d->E = E;
+  return 0;
+}
+
+struct Geometry { int vec, lpr_log, chunks; };
+// lanes per row: next power of two >= ceil(H/vec), at most one wave; wider rows take gridDim.y chunks
+static Geometry geometry(int H, bool vec4_ok) {
+  Geometry g;
+  g.vec = vec4_ok ? 4 : 1;
+  const int per_row = (H + g.vec - 1) / g.vec;
+  g.lpr_log = min(ilog2_ceil(per_row), 6);
+  g.chunks = (per_row + (1 << g.lpr_log) - 1) >> g.lpr_log;
+  return g;
+}
+
+static dim3 item_grid(int64_t n_items, int chunks) {
+  int64_t blocks = (n_items + (kBlock / kWave) - 1) / (kBlock / kWave);
+  if (blocks > kMaxGrid) blocks = kMaxGrid;
+  if (blocks < 1) blocks = 1;
+  return dim3((unsigned)blocks, (unsigned)chunks, 1);
+}
+
+template <int K, int VEC>
+static void launch_fwd(const NcFwdParams& p, dim3 grid, bool save, bool drop, hipStream_t st) {
+  if (save) {
+    if (drop) hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, true, true>), grid, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, true, false>), grid, dim3(kBlock), 0, st, p);
+  } else {
+    if (drop) hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, false, true>), grid, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, false, false>), grid, dim3(kBlock), 0, st, p);
+  }
+}
+template <int VEC>
+static void launch_fwd_k(int Ks, const NcFwdParams& p, dim3 grid, bool save, bool drop, hipStream_t st) {
+  switch (Ks) {
+    case 1: launch_fwd<1, VEC>(p, grid, save, drop, st); break;
+    case 2: launch_fwd<2, VEC>(p, grid, save, drop, st); break;
+    case 3: launch_fwd<3, VEC>(p, grid, save, drop, st); break;
+    case 4: launch_fwd<4, VEC>(p, grid, save, drop, st); break;
+    default: launch_fwd<8, VEC>(p, grid, save, drop, st); break;
+  }
+}
+template <int K, int VEC>
+static void launch_bwd(const NcBwdParams& p, dim3 grid, bool drop, hipStream_t st) {
+  if (drop) hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, true>), grid, dim3(kBlock), 0, st, p);
+  else hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, false>), grid, dim3(kBlock), 0, st, p);
+}
+template <int VEC>
+static void launch_bwd_k(int Ks, const NcBwdParams& p, dim3 grid, bool drop, hipStream_t st) {
+  switch (Ks) {
+    case 1: launch_bwd<1, VEC>(p, grid, drop, st); break;
+    case 2: launch_bwd<2, VEC>(p, grid, drop, st); break;
+    case 3: launch_bwd<3, VEC>(p, grid, drop, st); break;
+    case 4: launch_bwd<4, VEC>(p, grid, drop, st); break;
+    default: launch_bwd<8, VEC>(p, grid, drop, st); break;
+  }
+}
+
+// K in 1..8 is issued as slices the kernels are instantiated for: 8 | 4+{1,2,3} | {1,2,3,4}
+static int next_slice(int remaining) { return remaining >= 8 ? 8 : (remaining >= 4 ? 4 : remaining); }
+
+static int64_t elementwise_grid(int64_t total) {
+  int64_t b = (total + kBlock - 1) / kBlock;
+  return b < 1 ? 1 : (b > kMaxGrid * 4 ? kMaxGrid * 4 : b);
+}
+
+}  // namespace mma
+
+using namespace mma;
+
+extern "C" int mma_nc_fused_fwd(
+    const float* x, int64_t ldx, const float* P, const float* Q, int64_t ldpq,
+    const int32_t* rowptr, const int32_t* col,
+    const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs,
+    float* partial, int64_t n_slots, float* m, float* T, uint8_t* sel, int64_t ldt,
+    int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* kind_host, const uint8_t* act_host,
+    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint8_t* keep, void* stream) {
+  MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31), "N=%lld E=%lld out of int32 range", (long long)N, (long long)E);
+  MMA_REQUIRE(H >= 1 && K >= 1 && K <= MMA_MAX_K, "H=%d K=%d unsupported (1<=K<=%d)", H, K, MMA_MAX_K);
+  MMA_REQUIRE(ldx >= H && ldpq >= (int64_t)K * H, "row pitch too small: ldx=%lld ldpq=%lld", (long long)ldx, (long long)ldpq);
+  MMA_REQUIRE((T == nullptr) == (sel == nullptr), "T and sel must both be given or both be NULL");
+  MMA_REQUIRE(T == nullptr || ldt >= (int64_t)K * H, "ldt=%lld too small", (long long)ldt);
+  MMA_REQUIRE(n_items >= 0 && n_hubs >= 0 && n_slots >= 0 && n_items < (1LL << 31), "negative or oversize item counts");
+  MMA_REQUIRE(n_slots == 0 || (partial != nullptr && hubs != nullptr && n_hubs > 0), "hub slots without partial/hubs buffers");
+  if (N == 0 || n_items == 0) return 0;
+  MMA_REQUIRE(x && P && Q && rowptr && items && m && kind_host && act_host, "NULL argument");
+  MMA_REQUIRE(E == 0 || col != nullptr, "NULL col");
+  MMA_REQUIRE(aligned16(items) && (hubs == nullptr || aligned16(hubs)), "items/hubs must be 16-byte aligned int32 quadruples");
+  uint32_t kinds, acts;
+  if (int rc = pack_codes(kind_host, act_host, K, &kinds, &acts)) return rc;
+  NcFwdParams p{};
+  if (int rc = make_drop(drop_mode, drop_thr, seed, keep, E, &p.drop)) return rc;
+  const bool drop = drop_mode != MMA_DROP_NONE && !(drop_mode == MMA_DROP_HASH && drop_thr == 0);
+  const bool save = T != nullptr;
+  const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldpq % 4 == 0) && (!save || ldt % 4 == 0) && aligned16(x) &&
+                  aligned16(P) && aligned16(Q) && aligned16(m) && (!save || (aligned16(T) && aligned16(sel))) &&
+                  (partial == nullptr || aligned16(partial));
+  const Geometry g = geometry(H, v4);
+  p.x = x; p.ldx = ldx; p.P = P; p.Q = Q; p.ldpq = ldpq; p.rowptr = rowptr; p.col = col;
+  p.items = reinterpret_cast<const int4*>(items); p.n_items = n_items;
+  p.partial = partial; p.pstride = 2LL * K * H;
+  p.m = m; p.m_kstride = N * (int64_t)H; p.T = T; p.sel = sel; p.ldt = ldt;
+  p.H = H; p.HQ = (H + 3) / 4; p.K_total = K; p.lpr_log = g.lpr_log; p.kinds = kinds; p.acts = acts;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid = item_grid(n_items, g.chunks);
+  for (int k0 = 0; k0 < K;) {
+    const int ks = next_slice(K - k0);
+    p.k_base = k0;
+    if (g.vec == 4) launch_fwd_k<4>(ks, p, grid, save, drop, st);
+    else launch_fwd_k<1>(ks, p, grid, save, drop, st);
+    k0 += ks;
+  }
+  if (int rc = check_launch("nc_fwd_kernel")) return rc;
+  if (n_hubs > 0) {
+    const int per_row = (H + g.vec - 1) / g.vec;
+    const dim3 fg((unsigned)elementwise_grid(n_hubs * K * per_row));
+    const int4* hb = reinterpret_cast<const int4*>(hubs);
+    if (g.vec == 4) {
+      if (save) hipLaunchKernelGGL((nc_fwd_finalize_kernel<4, true>), fg, dim3(kBlock), 0, st, p, hb, n_hubs);
+      else hipLaunchKernelGGL((nc_fwd_finalize_kernel<4, false>), fg, dim3(kBlock), 0, st, p, hb, n_hubs);
+    } else {
+      if (save) hipLaunchKernelGGL((nc_fwd_finalize_kernel<1, true>), fg, dim3(kBlock), 0, st, p, hb, n_hubs);
+      else hipLaunchKernelGGL((nc_fwd_finalize_kernel<1, false>), fg, dim3(kBlock), 0, st, p, hb, n_hubs);
+    }
+    if (int rc = check_launch("nc_fwd_finalize_kernel")) return rc;
+  }
+  return 0;
+}
+
+extern "C" int mma_nc_bwd_node(
+    const float* g, const uint8_t* sel, const float* T, int64_t ldt, const int32_t* rowptr,
+    float* gs, int64_t ldgs, float* gP, int64_t ldgp, float* gxs, int64_t ldgx,
+    int64_t N, int32_t H, int32_t K, const uint8_t* kind_host, void* stream) {
+  MMA_REQUIRE(N >= 0 && N < (1LL << 31) && H >= 1 && K >= 1 && K <= MMA_MAX_K, "N=%lld H=%d K=%d unsupported", (long long)N, H, K);
+  MMA_REQUIRE(ldt >= (int64_t)K * H && ldgs >= (int64_t)K * H && ldgp >= (int64_t)K * H && ldgx >= H, "row pitch too small");
+  if (N == 0) return 0;
+  MMA_REQUIRE(g && sel && T && rowptr && gs && gP && gxs && kind_host, "NULL argument");
+  uint32_t kinds, acts;
+  if (int rc = pack_codes(kind_host, nullptr, K, &kinds, &acts)) return rc;
+  NcBwdNodeParams p{g, sel, T, ldt, rowptr, gs, ldgs, gP, ldgp, gxs, ldgx, N, H, K, kinds};
+  const bool v4 = (H % 4 == 0) && (ldt % 4 == 0) && (ldgs % 4 == 0) && (ldgp % 4 == 0) && (ldgx % 4 == 0) && aligned16(g) && aligned16(sel) &&
+                  aligned16(T) && aligned16(gs) && aligned16(gP) && aligned16(gxs);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int per_row = v4 ? H / 4 : H;
+  const dim3 grid((unsigned)elementwise_grid(N * per_row));
+  if (v4) hipLaunchKernelGGL((nc_bwd_node_kernel<4>), grid, dim3(kBlock), 0, st, p);
+  else hipLaunchKernelGGL((nc_bwd_node_kernel<1>), grid, dim3(kBlock), 0, st, p);
+  return check_launch("nc_bwd_node_kernel");
+}
+
+extern "C" int mma_nc_fused_bwd(
+    const float* x, int64_t ldx, const float* P, const float* Q, int64_t ldpq,
+    const float* gs, int64_t ldg, const float* gxs, int64_t ldgx,
+    const int32_t* t_col, const int32_t* t_eid,
+    const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs,
+    float* partial, int64_t n_slots, float* gQ, int64_t ldgq, float* gx, int64_t ldgxo,
+    int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* act_host,
+    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint8_t* keep, void* stream) {
+  MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31), "N=%lld E=%lld out of int32 range", (long long)N, (long long)E);
+  MMA_REQUIRE(H >= 1 && K >= 1 && K <= MMA_MAX_K, "H=%d K=%d unsupported (1<=K<=%d)", H, K, MMA_MAX_K);
+  MMA_REQUIRE(ldx >= H && ldpq >= (int64_t)K * H && ldg >= (int64_t)K * H && ldgq >= (int64_t)K * H && ldgx >= H && ldgxo >= H,
+              "row pitch too small");
+  MMA_REQUIRE(n_items >= 0 && n_hubs >= 0 && n_slots >= 0 && n_items < (1LL << 31), "negative or oversize item counts");
+  MMA_REQUIRE(n_slots == 0 || (partial != nullptr && hubs != nullptr && n_hubs > 0), "hub slots without partial/hubs buffers");
+  if (N == 0 || n_items == 0) return 0;
+  MMA_REQUIRE(x && P && Q && gs && gxs && items && gQ && gx && act_host, "NULL argument");
+  MMA_REQUIRE(E == 0 || (t_col != nullptr && t_eid != nullptr), "NULL transposed CSR");
+  MMA_REQUIRE(aligned16(items) && (hubs == nullptr || aligned16(hubs)), "items/hubs must be 16-byte aligned int32 quadruples");
+  uint32_t kinds, acts;
+  if (int rc = pack_codes(nullptr, act_host, K, &kinds, &acts)) return rc;
+  NcBwdParams p{};
+  if (int rc = make_drop(drop_mode, drop_thr, seed, keep, E, &p.drop)) return rc;
+  const bool drop = drop_mode != MMA_DROP_NONE && !(drop_mode == MMA_DROP_HASH && drop_thr == 0);
+  const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldpq % 4 == 0) && (ldg % 4 == 0) && (ldgx % 4 == 0) && (ldgq % 4 == 0) &&
+                  (ldgxo % 4 == 0) && aligned16(x) && aligned16(P) && aligned16(Q) && aligned16(gs) && aligned16(gxs) &&
+                  aligned16(gQ) && aligned16(gx) && (partial == nullptr || aligned16(partial));
+  const Geometry g = geometry(H, v4);
+  p.x = x; p.ldx = ldx; p.P = P; p.Q = Q; p.ldpq = ldpq; p.gs = gs; p.ldg = ldg; p.gxs = gxs; p.ldgx = ldgx;
+  p.t_col = t_col; p.t_eid = t_eid; p.items = reinterpret_cast<const int4*>(items); p.n_items = n_items;
+  p.partial = partial; p.pstride = (int64_t)(K + 1) * H; p.gQ = gQ; p.ldgq = ldgq; p.gx = gx; p.ldgxo = ldgxo;
+  p.H = H; p.HQ = (H + 3) / 4; p.K_total = K; p.lpr_log = g.lpr_log; p.acts = acts;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid = item_grid(n_items, g.chunks);
+  for (int k0 = 0; k0 < K;) {
+    const int ks = next_slice(K - k0);
+    p.k_base = k0; p.first_pass = (k0 == 0);
+    if (g.vec == 4) launch_bwd_k<4>(ks, p, grid, drop, st);
+    else launch_bwd_k<1>(ks, p, grid, drop, st);
+    k0 += ks;
+  }
+  if (int rc = check_launch("nc_bwd_kernel")) return rc;
+  if (n_hubs > 0) {
+    const int per_row = (H + g.vec - 1) / g.vec;
+    const dim3 fg((unsigned)elementwise_grid(n_hubs * (K + 1) * per_row));
+    const int4* hb = reinterpret_cast<const int4*>(hubs);
+    if (g.vec == 4) hipLaunchKernelGGL((nc_bwd_finalize_kernel<4>), fg, dim3(kBlock), 0, st, p, hb, n_hubs);
+    else hipLaunchKernelGGL((nc_bwd_finalize_kernel<1>), fg, dim3(kBlock), 0, st, p, hb, n_hubs);
+    if (int rc = check_launch("nc_bwd_finalize_kernel")) return rc;
+  }
+  return 0;
+}

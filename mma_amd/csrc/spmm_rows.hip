@@ -1,0 +1,139 @@
+// K5 (CSR SpMM over a K-times column-stacked adjacency: reference layers.py:861-865, layers.py:41) and
+// K7 (halo row pack / unpack-add for the node-sharded multi-GPU path).
+#include "common.h"
+
+namespace mma {
+
+struct SpmmParams {
+  const int32_t* rowptr; const int32_t* col; const float* val;
+  const float* B; int64_t ldb; int64_t rpb; int K;
+  const float* bias; float* out; int64_t ldo; int64_t n_rows; int C; int lpr_log;
+};
+
+// One wave per output row; LPR lanes span the C columns, 64/LPR edges are gathered per step.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void spmm_kernel(const SpmmParams p) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << p.lpr_log;
+  const int epg = kWave >> p.lpr_log;
+  const int sub = lane >> p.lpr_log;
+  const int c = ((int)blockIdx.y * lpr + (lane & (lpr - 1))) * VEC;
+  const bool fvalid = c < p.C;
+  const int cc = fvalid ? c : 0;
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave);
+  for (int64_t r0 = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); r0 < p.n_rows; r0 += stride) {
+    const int row = __builtin_amdgcn_readfirstlane((int)r0);
+    const int ebeg = p.rowptr[row], eend = p.rowptr[row + 1];
+    Vec<VEC> acc = vzero<VEC>();
+    for (int base = ebeg; base < eend; base += kWave) {
+      const int cnt = min(kWave, eend - base);
+      const int myj = (lane < cnt) ? p.col[base + lane] : 0;
+      const float myv = (lane < cnt) ? (p.val ? p.val[base + lane] : 1.f) : 0.f;
+      for (int t0 = 0; t0 < cnt; t0 += epg) {
+        const int t = t0 + sub;
+        const int j = __shfl(myj, t & (kWave - 1), kWave);
+        // cross-lane reads stay outside divergent control flow: ds_bpermute returns 0 from inactive lanes
+        const float vv = __shfl(myv, t & (kWave - 1), kWave);
+        const float v = (t < cnt) ? vv : 0.f;
+        for (int k = 0; k < p.K; ++k) {
+          const Vec<VEC> b = ldv<VEC>(p.B + ((size_t)k * p.rpb + (size_t)j) * p.ldb + cc);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(v, b.v[i], acc.v[i]);
+        }
+      }
+    }
+    for (int off = kWave / 2; off >= lpr; off >>= 1)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc.v[i] += __shfl_xor(acc.v[i], off, kWave);
+    if (sub == 0 && fvalid) {
+      if (p.bias) {
+        const Vec<VEC> b = ldv<VEC>(p.bias + c);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc.v[i] += b.v[i];
+      }
+      stv<VEC>(p.out + (size_t)row * p.ldo + c, acc);
+    }
+  }
+}
+
+struct RowsParams { const float* src; int64_t lds; const int32_t* idx; int64_t n; float* dst; int64_t ldd; int width; };
+
+template <int VEC, bool UNPACK_ADD>
+__global__ __launch_bounds__(kBlock) void rows_kernel(const RowsParams p) {
+  const int per_row = (p.width + VEC - 1) / VEC;
+  const int64_t total = p.n * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / per_row;
+    const int c = (int)(i % per_row) * VEC;
+    const int64_t node = p.idx[r];
+    if (UNPACK_ADD) {
+      const Vec<VEC> a = ldv<VEC>(p.src + r * p.lds + c);
+      Vec<VEC> d = ldv<VEC>(p.dst + node * p.ldd + c);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) d.v[q] += a.v[q];
+      stv<VEC>(p.dst + node * p.ldd + c, d);
+    } else {
+      stv<VEC>(p.dst + r * p.ldd + c, ldv<VEC>(p.src + node * p.lds + c));
+    }
+  }
+}
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace mma
+
+using namespace mma;
+
+extern "C" int mma_csr_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, int64_t ldb,
+                            int64_t rows_per_block, int32_t K, const float* bias, float* out, int64_t ldo,
+                            int64_t n_rows, int32_t C, void* stream) {
+  MMA_REQUIRE(n_rows >= 0 && n_rows < (1LL << 31) && C >= 1 && K >= 1, "n_rows=%lld C=%d K=%d unsupported", (long long)n_rows, C, K);
+  MMA_REQUIRE(ldb >= C && ldo >= C && rows_per_block >= 0, "row pitch too small");
+  if (n_rows == 0) return 0;
+  MMA_REQUIRE(rowptr && B && out, "NULL argument");
+  const bool v4 = (C % 4 == 0) && (ldb % 4 == 0) && (ldo % 4 == 0) && al16(B) && al16(out) && (!bias || al16(bias));
+  const int vec = v4 ? 4 : 1;
+  const int per_row = (C + vec - 1) / vec;
+  SpmmParams p{rowptr, col, val, B, ldb, rows_per_block, K, bias, out, ldo, n_rows, C, 0};
+  p.lpr_log = min(ilog2_ceil(per_row), 6);
+  const int chunks = (per_row + (1 << p.lpr_log) - 1) >> p.lpr_log;
+  int64_t blocks = (n_rows + 3) / 4;
+  if (blocks > kMaxGrid) blocks = kMaxGrid;
+  const dim3 grid((unsigned)blocks, (unsigned)chunks);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (v4) hipLaunchKernelGGL((spmm_kernel<4>), grid, dim3(kBlock), 0, st, p);
+  else hipLaunchKernelGGL((spmm_kernel<1>), grid, dim3(kBlock), 0, st, p);
+  return check_launch("spmm_kernel");
+}
+
+static int rows_call(bool unpack, const float* src, int64_t lds, const int32_t* idx, int64_t n_idx, float* dst, int64_t ldd,
+                     int32_t width, void* stream) {
+  MMA_REQUIRE(n_idx >= 0 && width >= 1 && lds >= width && ldd >= width, "n_idx=%lld width=%d lds=%lld ldd=%lld unsupported",
+              (long long)n_idx, width, (long long)lds, (long long)ldd);
+  if (n_idx == 0) return 0;
+  MMA_REQUIRE(src && idx && dst, "NULL argument");
+  const bool v4 = (width % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) && al16(src) && al16(dst);
+  RowsParams p{src, lds, idx, n_idx, dst, ldd, width};
+  const int per_row = v4 ? width / 4 : width;
+  int64_t blocks = (n_idx * per_row + kBlock - 1) / kBlock;
+  if (blocks > kMaxGrid * 4) blocks = kMaxGrid * 4;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)blocks);
+  if (v4) {
+    if (unpack) hipLaunchKernelGGL((rows_kernel<4, true>), grid, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((rows_kernel<4, false>), grid, dim3(kBlock), 0, st, p);
+  } else {
+    if (unpack) hipLaunchKernelGGL((rows_kernel<1, true>), grid, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((rows_kernel<1, false>), grid, dim3(kBlock), 0, st, p);
+  }
+  return check_launch("rows_kernel");
+}
+
+extern "C" int mma_pack_rows(const float* src, int64_t lds, const int32_t* idx, int64_t n_idx, float* dst, int64_t ldd,
+                             int32_t width, void* stream) {
+  return rows_call(false, src, lds, idx, n_idx, dst, ldd, width, stream);
+}
+extern "C" int mma_unpack_add_rows(const float* src, int64_t lds, const int32_t* idx, int64_t n_idx, float* dst, int64_t ldd,
+                                   int32_t width, void* stream) {
+  return rows_call(true, src, lds, idx, n_idx, dst, ldd, width, stream);
+}

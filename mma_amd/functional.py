@@ -1,0 +1,149 @@
+"""autograd wrappers over the C ABI (include/mma_amd.h).  Tensors are plumbing: every FLOP and byte of the
+hot path moves inside libmma_amd.so; torch only owns the memory, the stream and the autograd tape."""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import call, host_codes, ptr, require_gpu, stream_ptr
+
+KIND = {"sum": 0, "mean": 1, "max": 2, "min": 3, "softmax": 4, "softmin": 5}
+ACT_SIGMOID, ACT_RAW = 0, 1
+DROP_NONE, DROP_HASH, DROP_EXPLICIT = 0, 1, 2
+
+
+class DropoutSpec:
+    """Mask dropout of one layer call (reference: F.dropout(mask0, p), training=True always, layers.py:219).
+
+    HASH mode quantises p to thr/256 (exact for the reference default 0.5); `keep` (K,E,H) uint8 switches to an
+    explicit mask (parity tests)."""
+
+    def __init__(self, p=0.0, seed=None, keep=None):
+        self.p = float(p)
+        if not (0.0 <= self.p < 1.0):
+            raise ValueError("dropout probability has to be in [0, 1), but got %r" % p)
+        self.keep = keep
+        if keep is not None:
+            self.mode, self.thr = DROP_EXPLICIT, int(round(self.p * 256))
+            if self.thr / 256.0 != self.p:
+                raise ValueError("explicit keep masks need p = i/256 so that 1/(1-p) is reproduced exactly")
+        elif self.p == 0.0:
+            self.mode, self.thr = DROP_NONE, 0
+        else:
+            self.mode, self.thr = DROP_HASH, min(255, max(1, int(round(self.p * 256))))
+        if seed is None:
+            # drawn from torch's CPU generator so torch.manual_seed() controls it; no GPU sync
+            seed = int(torch.empty((), dtype=torch.int64).random_().item()) if self.mode == DROP_HASH else 0
+        self.seed = seed & 0xFFFFFFFFFFFFFFFF
+
+    def args(self):
+        return self.mode, self.thr, self.seed, ptr(self.keep)
+
+
+class _NCFused(torch.autograd.Function):
+    """m[k] = combine_k(x_i, sum_j drop(act_k(P_k[i] + Q_k[j])) * x_j)   (K1 forward, K2a + K2b backward)"""
+
+    @staticmethod
+    def forward(ctx, x_src, PQ, graph, kinds, acts, drop):
+        # x_src: (n_src,H) feature table; its first N rows are the targets (n_src > N only in the sharded path,
+        # where the tail holds halo rows).  PQ: (n_src, 2*K*H) = [P | Q] = x_src @ [W_k[:H].. | W_k[H:]..]
+        require_gpu(x_src, PQ)
+        K = len(kinds)
+        S, H = x_src.shape
+        N = graph.N
+        assert x_src.dtype == torch.float32 and PQ.dtype == torch.float32
+        assert S == graph.n_src and PQ.shape == (S, 2 * K * H) and 1 <= K <= 8
+        PQ = PQ.contiguous(); x_src = x_src.contiguous()
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        x = x_src
+        m = torch.empty((K, N, H), device=x.device, dtype=torch.float32)
+        T = torch.empty((N, K * H), device=x.device, dtype=torch.float32) if need_grad else None
+        sel = torch.empty((N, K * H), device=x.device, dtype=torch.uint8) if need_grad else None
+        partial = (torch.empty((graph.n_slots, 2 * K * H), device=x.device, dtype=torch.float32)
+                   if graph.n_slots else None)
+        P = PQ[:, :K * H]
+        Q = PQ[:, K * H:]
+        if drop.keep is not None:
+            assert drop.keep.dtype == torch.uint8 and drop.keep.is_contiguous() and drop.keep.is_cuda and \
+                tuple(drop.keep.shape) == (K, graph.E, H), "explicit keep mask must be a contiguous (K,E,H) uint8 GPU tensor"
+        mode, thr, seed, keep = drop.args()
+        # the kernel gathers x_j / Q_j from the source table and reads x_i / P_i of the target rows;
+        # targets are the first N rows of the source table
+        call("mma_nc_fused_fwd", ptr(x_src), x_src.stride(0), ptr(P), ptr(Q), PQ.stride(0),
+             ptr(graph.rowptr), ptr(graph.col), ptr(graph.items), graph.items.shape[0],
+             ptr(graph.hubs) if graph.n_slots else None, graph.hubs.shape[0], ptr(partial), graph.n_slots,
+             ptr(m), ptr(T), ptr(sel), K * H, N, graph.E, H, K, host_codes(kinds), host_codes(acts),
+             mode, thr, seed, keep, stream_ptr())
+        ctx.graph, ctx.kinds, ctx.acts, ctx.drop = graph, kinds, acts, drop
+        ctx.save_for_backward(x_src, PQ, T, sel)
+        return m
+
+    @staticmethod
+    def backward(ctx, g):
+        graph, kinds, acts, drop = ctx.graph, ctx.kinds, ctx.acts, ctx.drop
+        x_src, PQ, T, sel = ctx.saved_tensors
+        K = len(kinds)
+        N, H, S = graph.N, x_src.shape[1], graph.n_src
+        g = g.contiguous()
+        dev = g.device
+        gs = torch.empty((N, K * H), device=dev, dtype=torch.float32)
+        gPQ = torch.empty((S, 2 * K * H), device=dev, dtype=torch.float32)
+        gP = gPQ[:, :K * H]
+        gQ = gPQ[:, K * H:]
+        gxs = torch.empty((S, H), device=dev, dtype=torch.float32)
+        if S > N:  # halo rows are sources only: no target-side gradient
+            gP[N:].zero_(); gxs[N:].zero_()
+        call("mma_nc_bwd_node", ptr(g), ptr(sel), ptr(T), K * H, ptr(graph.rowptr), ptr(gs), K * H, ptr(gP),
+             gPQ.stride(0), ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
+        gx = torch.empty((S, H), device=dev, dtype=torch.float32)
+        partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32)
+                   if graph.t_n_slots else None)
+        P = PQ[:, :K * H]
+        Q = PQ[:, K * H:]
+        mode, thr, seed, keep = drop.args()
+        call("mma_nc_fused_bwd", ptr(x_src), x_src.stride(0), ptr(P), ptr(Q), PQ.stride(0),
+             ptr(gs), K * H, ptr(gxs), H, ptr(graph.t_col), ptr(graph.t_eid),
+             ptr(graph.t_items), graph.t_items.shape[0], ptr(graph.t_hubs) if graph.t_n_slots else None,
+             graph.t_hubs.shape[0], ptr(partial), graph.t_n_slots, ptr(gQ), gPQ.stride(0), ptr(gx), H,
+             S, graph.E, H, K, host_codes(acts), mode, thr, seed, keep, stream_ptr())
+        return gx, gPQ, None, None, None, None
+
+
+def nc_fused_aggregate(x, PQ, graph, kinds, acts, drop=None):
+    """Fused K-mask aggregation (K <= 8 per call) -> m (K, graph.N, H).
+
+    x: (graph.n_src, H) feature table whose first graph.N rows are the targets; PQ = x @ [Wtop | Wbot]
+    (n_src, 2*K*H); kinds/acts: MMA_KIND_* / MMA_ACT_* codes per mask."""
+    return _NCFused.apply(x, PQ, graph, tuple(kinds), tuple(acts), drop or DropoutSpec(0.0))
+
+
+class _CsrSpmm(torch.autograd.Function):
+    """out = sum_k A @ B[k] + bias  ( = torch.spmm(cat((adj,)*K, 1), B.view(K*N, C)) + bias, layers.py:861-865 )"""
+
+    @staticmethod
+    def forward(ctx, B, bias, sg, K):
+        require_gpu(B, bias)
+        B = B.contiguous()
+        rows_per_block = B.shape[0] // K
+        assert B.shape[0] == K * rows_per_block and rows_per_block == sg.n_cols
+        C = B.shape[1]
+        out = torch.empty((sg.n_rows, C), device=B.device, dtype=torch.float32)
+        call("mma_csr_spmm", ptr(sg.rowptr), ptr(sg.col), ptr(sg.val), ptr(B), B.stride(0), rows_per_block, K,
+             ptr(bias), ptr(out), C, sg.n_rows, C, stream_ptr())
+        ctx.sg, ctx.K, ctx.has_bias = sg, K, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sg, K = ctx.sg, ctx.K
+        g = g.contiguous()
+        C = g.shape[1]
+        gB1 = torch.empty((sg.n_cols, C), device=g.device, dtype=torch.float32)
+        call("mma_csr_spmm", ptr(sg.t_rowptr), ptr(sg.t_col), ptr(sg.t_val), ptr(g), g.stride(0), sg.n_rows, 1,
+             None, ptr(gB1), C, sg.n_cols, C, stream_ptr())
+        gB = gB1.unsqueeze(0).expand(K, -1, -1).reshape(K * sg.n_cols, C)  # every k-block sees the same A^T g
+        return gB, (g.sum(0) if ctx.has_bias else None), None, None
+
+
+def csr_spmm(B, bias, sg, K=1):
+    return _CsrSpmm.apply(B, bias, sg, K)

@@ -1,0 +1,109 @@
+"""Static graph plan for the NC path: CSR by target (from the reference's `add_all` neighbour lists,
+utils.py:97-100), its transpose by source, and the work-item lists the kernels walk.
+
+The reference captures `add_all` at construction time (layers.py:75), so all of this is built once per
+graph on the host with numpy and then lives in HBM as int32."""
+import numpy as np
+import torch
+
+DEFAULT_CHUNK = 512   # edges per work item; longer segments (hubs) are split and summed in a second pass
+
+
+def make_items(rowptr, chunk):
+    """Split every CSR segment into work items of at most `chunk` edges.
+
+    Returns items (n,4) int32 {node, ebeg, eend, slot}, hubs (h,4) int32 {node, slot_beg, slot_end, 0},
+    n_slots.  slot = -1: the item is the node's whole segment (also for degree 0)."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    N = len(rowptr) - 1
+    deg = np.diff(rowptr)
+    nch = np.maximum(1, -(-deg // chunk))
+    total = int(nch.sum())
+    node = np.repeat(np.arange(N, dtype=np.int64), nch)
+    first = np.cumsum(nch) - nch
+    ci = np.arange(total, dtype=np.int64) - first[node]
+    ebeg = rowptr[node] + ci * chunk
+    eend = np.minimum(ebeg + chunk, rowptr[node + 1])
+    is_hub = nch[node] > 1
+    slot = np.where(is_hub, np.cumsum(is_hub) - 1, -1)
+    items = np.stack([node, ebeg, eend, slot], 1).astype(np.int32)
+    hub_nodes = np.nonzero(nch > 1)[0]
+    n_slots = int(is_hub.sum())
+    if len(hub_nodes):
+        sb = np.cumsum(nch[hub_nodes]) - nch[hub_nodes]
+        hubs = np.stack([hub_nodes, sb, sb + nch[hub_nodes], np.zeros_like(sb)], 1).astype(np.int32)
+    else:
+        hubs = np.zeros((0, 4), dtype=np.int32)
+    return items, hubs, n_slots
+
+
+def transpose_csr(rowptr, col, n_src):
+    """Edges grouped by source: t_rowptr (n_src+1), t_col (target of each), t_eid (position in the forward CSR).
+    Stable, so within a source the targets ascend."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    N = len(rowptr) - 1
+    dst = np.repeat(np.arange(N, dtype=np.int64), np.diff(rowptr))
+    perm = np.argsort(col, kind="stable")
+    t_rowptr = np.zeros(n_src + 1, dtype=np.int64)
+    np.cumsum(np.bincount(col, minlength=n_src), out=t_rowptr[1:])
+    return t_rowptr, dst[perm], perm
+
+
+class NCGraph:
+    """Device-resident plan.  n_src >= N allows extra source rows (halo rows in the sharded path)."""
+
+    def __init__(self, rowptr, col, device, n_src=None, chunk=DEFAULT_CHUNK):
+        rowptr = np.asarray(rowptr, dtype=np.int64)
+        col = np.asarray(col, dtype=np.int64)
+        self.N = len(rowptr) - 1
+        self.E = int(rowptr[-1])
+        self.n_src = self.N if n_src is None else int(n_src)
+        assert len(col) == self.E and (self.E == 0 or (col.min() >= 0 and col.max() < self.n_src)), "bad CSR"
+        assert self.n_src < 2 ** 31 and self.E < 2 ** 31
+        self.chunk = int(chunk)
+        items, hubs, self.n_slots = make_items(rowptr, self.chunk)
+        t_rowptr, t_col, t_eid = transpose_csr(rowptr, col, self.n_src)
+        t_items, t_hubs, self.t_n_slots = make_items(t_rowptr, self.chunk)
+        dev = torch.device(device)
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        self.device = dev
+        self.rowptr, self.col = i32(rowptr), i32(col)
+        self.items, self.hubs = i32(items), i32(hubs)
+        self.t_rowptr, self.t_col, self.t_eid = i32(t_rowptr), i32(t_col), i32(t_eid)
+        self.t_items, self.t_hubs = i32(t_items), i32(t_hubs)
+        self.max_degree = int(np.diff(rowptr).max()) if self.N else 0
+
+    @classmethod
+    def from_add_all(cls, add_all, device, chunk=DEFAULT_CHUNK):
+        rowptr = np.zeros(len(add_all) + 1, dtype=np.int64)
+        rowptr[1:] = np.cumsum([len(a) for a in add_all])
+        col = (np.concatenate([np.asarray(a, dtype=np.int64) for a in add_all])
+               if len(add_all) and rowptr[-1] > 0 else np.zeros(0, np.int64))
+        return cls(rowptr, col, device, chunk=chunk)
+
+
+class SpmmGraph:
+    """CSR (and its transpose) of the adjacency the reference hands to torch.spmm (layers.py:861-862)."""
+
+    def __init__(self, row, col, val, n_rows, n_cols, device):
+        row = np.asarray(row, dtype=np.int64); col = np.asarray(col, dtype=np.int64)
+        val = None if val is None else np.asarray(val, dtype=np.float32)
+        dev = torch.device(device)
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        order = np.lexsort((col, row))
+        rp = np.zeros(n_rows + 1, dtype=np.int64); np.cumsum(np.bincount(row, minlength=n_rows), out=rp[1:])
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self.rowptr, self.col = i32(rp), i32(col[order])
+        self.val = None if val is None or np.all(val == 1.0) else f32(val[order])
+        t_order = np.lexsort((row, col))
+        trp = np.zeros(n_cols + 1, dtype=np.int64); np.cumsum(np.bincount(col, minlength=n_cols), out=trp[1:])
+        self.t_rowptr, self.t_col = i32(trp), i32(row[t_order])
+        self.t_val = None if self.val is None else f32(val[t_order])
+
+    @classmethod
+    def from_torch_sparse(cls, adj):
+        a = adj.coalesce()
+        idx = a.indices().cpu().numpy()
+        return cls(idx[0], idx[1], a.values().cpu().numpy(), a.shape[0], a.shape[1], adj.device)

@@ -84,7 +84,8 @@ def aggregate(name, x, W, rowptr, col, activation="new_sigmoid", p=0.0, keep=Non
         assert keep is not None, "explicit keep mask required for p>0 (reference RNG is not reproducible)"
         a = a * torch.as_tensor(keep, dtype=x.dtype) / (1.0 - p)   # F.dropout, training=True
     s = torch.zeros_like(x).index_add_(0, dst, a * xj_e)    # layers.py:221 sum over neighbours
-    return _combine(kind, x, s, deg.to(x.dtype).unsqueeze(1))
+    # degree-0 nodes crash the reference (Q12); the build defines s = 0 and divides by max(d,1)
+    return _combine(kind, x, s, deg.clamp(min=1).to(x.dtype).unsqueeze(1))
 
 
 def aggregate_loop(name, x, W, add_all, activation="new_sigmoid", p=0.0, keep=None):

@@ -1,0 +1,80 @@
+"""CPU-side tests (-m "not gpu"): the C-ABI library loads and exports every symbol include/mma_amd.h declares
+(no compute calls), argument checks fire on the host, and the host-side graph plan is right."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from mma_amd import _lib
+from mma_amd.graph import make_items, transpose_csr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mma_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mma_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert "mma_nc_fused_fwd" in names and "mma_nc_fused_bwd" in names and len(names) >= 8
+    for n in names:
+        assert hasattr(L, n), "libmma_amd.so does not export " + n
+    for n in _lib.PROTOTYPES:
+        assert n in names, "binding %s is not declared in the header" % n
+    assert _lib.lib().mma_abi_version() == _lib.ABI_VERSION
+
+
+def test_argument_checks_run_on_host_without_gpu():
+    # a bad shape must be refused before any launch (works with no GPU present)
+    with pytest.raises(_lib.MMALibraryError, match="K="):
+        _lib.call("mma_nc_fused_fwd", None, 4, None, None, 4, None, None, None, 0, None, 0, None, 0, None, None, None, 4,
+                  10, 10, 4, 99, None, None, 0, 0, 0, None, None)
+    with pytest.raises(_lib.MMALibraryError, match="pitch"):
+        _lib.call("mma_csr_spmm", None, None, None, None, 2, 5, 1, None, None, 2, 5, 4, None)
+
+
+def test_cpu_tensors_are_refused():
+    import mma_amd
+    from mma_amd import functional as Fn
+    x = torch.zeros(4, 4)
+    with pytest.raises(_lib.MMALibraryError, match="GPU only"):
+        Fn.nc_fused_aggregate(x, torch.zeros(4, 8), None, [0], [0])
+
+
+def test_make_items_chunks_and_hubs():
+    rowptr = np.array([0, 0, 3, 13, 14, 14, 30])     # degrees 0,3,10,1,0,16
+    items, hubs, n_slots = make_items(rowptr, chunk=4)
+    # every edge covered exactly once, in order, by its node's items
+    cover = np.zeros(30, dtype=int)
+    for node, b, e, slot in items:
+        assert rowptr[node] <= b <= e <= rowptr[node + 1] and e - b <= 4
+        cover[b:e] += 1
+    assert (cover == 1).all()
+    whole = items[items[:, 3] < 0]
+    assert sorted(whole[:, 0].tolist()) == [0, 1, 3, 4]           # degree <= chunk (incl. degree 0): one item, no slot
+    assert hubs[:, 0].tolist() == [2, 5] and n_slots == 3 + 4
+    for node, sb, se, _ in hubs:
+        sl = items[(items[:, 0] == node)][:, 3]
+        assert sl.tolist() == list(range(sb, se))                  # slots of a hub are consecutive, in edge order
+
+
+def test_transpose_csr_roundtrip():
+    rng = np.random.default_rng(0)
+    N, S = 50, 60
+    deg = rng.integers(0, 7, N)
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    col = rng.integers(0, S, rowptr[-1])
+    t_rowptr, t_col, t_eid = transpose_csr(rowptr, col, S)
+    dst = np.repeat(np.arange(N), deg)
+    assert (col[t_eid] == np.repeat(np.arange(S), np.diff(t_rowptr))).all()
+    assert (dst[t_eid] == t_col).all()
+    for s in range(S):   # stable: forward positions ascend within a source
+        seg = t_eid[t_rowptr[s]:t_rowptr[s + 1]]
+        assert (np.diff(seg) > 0).all()

@@ -1,0 +1,224 @@
+"""GPU parity tests for the node-classification hot path: the HIP kernels (through the C ABI and the drop-in
+`mma_amd.MMA` module) against (a) the golden vectors captured from the reference and (b) the CPU oracle on
+seeded random graphs with the edge cases the domain has (hubs split into chunks, degree-0/1 nodes, widths that
+are not multiples of 4 or of the wave, K = 1..8, dropout).  Bar: fp32 within 1e-5 (see golden_util.check_close);
+selection codes (max/min) and dropout keep bits bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import CASES, Golden, check_close
+from golden.inputs import ALL_MASK_NAMES
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build_module(gold, act, p, aggs, chunk=512):
+    import mma_amd
+    x, masks, weight, bias, cot = gold.torch_inputs(DEV)
+    P = lambda t: torch.nn.Parameter(t.clone())
+    mp = {n: P(masks[n]) for n in ALL_MASK_NAMES}
+    w, b = P(weight), P(bias)
+    mod = mma_amd.MMA(gold.add_all, act, 2, gold.H, gold.C, w, b, *[mp[n] for n in ALL_MASK_NAMES], p, list(aggs), DEV,
+                      chunk=chunk)
+    with torch.no_grad():   # the ctor re-initialises, like the reference: restore the fixture values
+        for n in ALL_MASK_NAMES:
+            mp[n].copy_(masks[n])
+        w.copy_(weight); b.copy_(bias)
+    return mod, mp, w, b, x, cot
+
+
+def keep_tensor(gold, aggs, p):
+    if p == 0:
+        return None
+    return torch.from_numpy(np.stack([gold.keep(a, p) for a in aggs]).astype(np.uint8)).to(DEV)
+
+
+def adj_of(gold):
+    z = gold.z
+    idx = torch.from_numpy(np.stack([z["adj_row"], z["adj_col"]]).astype(np.int64))
+    return torch.sparse_coo_tensor(idx, torch.from_numpy(z["adj_val"]), (gold.N, gold.N)).to(DEV)
+
+
+@pytest.fixture(scope="module", params=CASES)
+def gold(request):
+    return Golden(request.param)
+
+
+def test_golden_single_aggregators(gold):
+    from mma_amd import functional as Fn
+    for key in gold.single_keys():
+        _, act, p, (agg,) = gold.parse(key)
+        mod, mp, w, b, x, cot = build_module(gold, act, p, [agg])
+        if p > 0:
+            mod.drop_override = Fn.DropoutSpec(p, keep=keep_tensor(gold, [agg], p))
+        with torch.no_grad():
+            m = getattr(mod, "learnable_" + agg)(x, None)
+        check_close(m, gold.z[key], gold.rows, gold.z[key + "/stats"], what=key)
+
+
+@pytest.mark.parametrize("chunk", [512, 3])
+def test_golden_forward_and_grads(gold, chunk):
+    from mma_amd import functional as Fn
+    if chunk == 3 and gold.N > 3000:
+        pytest.skip("small-chunk (hub path) variant only on the smaller graphs")
+    adj = adj_of(gold)
+    for key in gold.set_keys():
+        _, act, p, aggs = gold.parse(key)
+        mod, mp, w, b, x, cot = build_module(gold, act, p, aggs, chunk=chunk)
+        if p > 0:
+            mod.drop_override = Fn.DropoutSpec(p, keep=keep_tensor(gold, aggs, p))
+        x.requires_grad_(True)
+        z = gold.z
+        with torch.no_grad():
+            ms = mod._aggregate_all(list(aggs), x)
+        for a, m in zip(aggs, ms):
+            check_close(m, z[key + "/m/" + a], gold.rows, z[key + "/m/" + a + "/stats"], what=key + "/m/" + a)
+        out = mod(x, adj)
+        check_close(out, z[key + "/out"], gold.rows, z[key + "/out/stats"], what=key + "/out", signed_sum=True)
+        grads = torch.autograd.grad((out * cot).sum(), [x, w, b] + [mp[a] for a in aggs])
+        check_close(grads[0], z[key + "/gx"], gold.rows, None, what=key + "/gx", signed_sum=True)
+        check_close(grads[1], z[key + "/gweight"], None, None, what=key + "/gweight", signed_sum=True)
+        check_close(grads[2], z[key + "/gbias"], None, None, what=key + "/gbias", signed_sum=True)
+        for a, g in zip(aggs, grads[3:]):
+            check_close(g, z[key + "/gmask/" + a], None, None, what=key + "/gmask/" + a, signed_sum=True)
+
+
+# ---- seeded random graphs vs the CPU oracle ------------------------------------------------------------
+def random_graph(rng, N, avg_deg, hub_deg=0, isolated=2):
+    deg = rng.poisson(avg_deg, N)
+    deg[:isolated] = 0                      # degree-0 nodes (extension Q12: s = 0, mean divides by 1)
+    deg[isolated:isolated + 2] = 1
+    if hub_deg:
+        deg[-1] = hub_deg
+        deg[-2] = hub_deg // 2 + 1
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = np.concatenate([np.sort(rng.choice(N, size=d, replace=d > N)) for d in deg]).astype(np.int64) if rowptr[-1] else np.zeros(0, np.int64)
+    return rowptr, col
+
+
+CONFIGS = [
+    # N, H, avg_deg, hub, names, activation, p, chunk
+    (300, 128, 6, 700, ["sum", "mean", "max", "min"], "new_sigmoid", 0.0, 256),
+    (300, 128, 6, 700, ["sum", "mean", "max", "min"], "new_sigmoid", 0.5, 256),
+    (257, 64, 3, 0, ["mean", "mean2"], "new_sigmoid", 0.5, 512),
+    (500, 16, 4, 200, ["min", "min2", "min3", "min4"], "new_sigmoid", 0.25, 64),
+    (120, 75, 5, 90, ["sum3", "max2", "softmax"], "sigmoid", 0.5, 32),          # H % 4 != 0 -> scalar path
+    (90, 6, 2, 0, ["mean3"], "new_sigmoid", 0.0, 512),
+    (64, 260, 3, 70, ["sum", "mean", "max", "min", "sum2", "mean2", "max2", "min2"], "new_sigmoid", 0.5, 16),  # K=8, H>256
+    (200, 32, 5, 100, ["sum", "mean", "max", "min", "sum2"], "sigmoid", 0.5, 48),   # K=5 -> slices 4+1
+    (150, 20, 4, 0, ["sum", "mean", "max", "min", "softmin", "mean4", "max4"], "new_sigmoid", 0.0, 512),  # K=7
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "N%d_H%d_K%d_p%g_c%d" % (c[0], c[1], len(c[4]), c[6], c[7]))
+def test_random_graph_vs_oracle(cfg):
+    import mma_amd
+    from mma_amd import functional as Fn
+    from oracle import nc_oracle as O
+    from oracle.dropout_rng import keep_mask
+    N, H, avg_deg, hub, names, act, p, chunk = cfg
+    rng = np.random.default_rng(1234 + N + H)
+    rowptr, col = random_graph(rng, N, avg_deg, hub)
+    E = int(rowptr[-1])
+    K = len(names)
+    x = torch.from_numpy(np.maximum(rng.standard_normal((N, H)), 0).astype(np.float32))
+    Ws = {n: torch.from_numpy(((rng.random((2 * H, H)) * 2 - 1) / np.sqrt(H)).astype(np.float32)) for n in names}
+    cot = torch.from_numpy(rng.standard_normal((K, N, H)).astype(np.float32))
+    seed, thr = 0x1234567890ABCDEF, int(round(p * 256))
+
+    # oracle (CPU), fed the keep mask the kernel's RNG produces
+    keep = keep_mask(seed, thr, K, E, H) if p > 0 else None
+    xo = x.clone().requires_grad_(True)
+    Wo = {n: Ws[n].clone().requires_grad_(True) for n in names}
+    mo = torch.stack([O.aggregate(n, xo, Wo[n], rowptr, col, act, p, None if keep is None else keep[k])
+                      for k, n in enumerate(names)])
+    go = torch.autograd.grad((mo * cot).sum(), [xo] + [Wo[n] for n in names])
+
+    # HIP
+    graph = mma_amd.NCGraph(rowptr, col, DEV, chunk=chunk)
+    if hub:
+        assert graph.n_slots > 0 and graph.t_n_slots >= 0
+    xg = x.to(DEV).requires_grad_(True)
+    Wg = {n: Ws[n].to(DEV).requires_grad_(True) for n in names}
+    kinds = [Fn.KIND[O.AGGREGATORS[n][0]] for n in names]
+    acts = [Fn.ACT_RAW if O.uses_raw_logits(n, act) else Fn.ACT_SIGMOID for n in names]
+    wcat = torch.cat([Wg[n][:H] for n in names] + [Wg[n][H:] for n in names], 1)
+    PQ = xg @ wcat
+    mg = Fn.nc_fused_aggregate(xg, PQ, graph, kinds, acts, Fn.DropoutSpec(p, seed=seed))
+    gg = torch.autograd.grad((mg * cot.to(DEV)).sum(), [xg] + [Wg[n] for n in names])
+
+    rows = np.arange(N)
+    for k, n in enumerate(names):
+        check_close(mg[k], mo[k].detach().numpy(), rows, None, what="m/" + n)
+    check_close(gg[0], go[0].numpy(), rows, None, what="gx", signed_sum=True)
+    for n, a, b in zip(names, gg[1:], go[1:]):
+        check_close(a, b.numpy(), None, None, what="gW/" + n, signed_sum=True)
+
+    # explicit-mask mode must agree bit-for-bit with hash mode given the same bits
+    if p > 0:
+        with torch.no_grad():
+            me = Fn.nc_fused_aggregate(xg.detach(), PQ.detach(), graph, kinds, acts,
+                                       Fn.DropoutSpec(thr / 256.0, keep=torch.from_numpy(keep).to(DEV)))
+        assert torch.equal(me, mg.detach()), "hash-mode and explicit-mode dropout disagree"
+    # determinism: no atomics anywhere, a second run is bitwise identical
+    with torch.no_grad():
+        m2 = Fn.nc_fused_aggregate(xg.detach(), PQ.detach(), graph, kinds, acts, Fn.DropoutSpec(p, seed=seed))
+    assert torch.equal(m2, mg.detach())
+
+
+def test_selection_codes_bit_exact_on_ties():
+    """max/min against x_i with exact ties: output and the 0.5/0.5 gradient split (torch.max backward) exact."""
+    import mma_amd
+    from mma_amd import functional as Fn
+    # 3 nodes; node 0 <- {1}; raw logits with P=Q=0.5 so mask z == 1.0 exactly => s == x_1
+    rowptr, col = np.array([0, 1, 1, 1]), np.array([1])
+    H = 4
+    x = torch.tensor([[1., 2., 3., 4.], [1., 5., 3., 0.], [0., 0., 0., 0.]], device=DEV)
+    PQ = torch.full((3, 2 * 2 * H), 0.5, device=DEV)
+    graph = mma_amd.NCGraph(rowptr, col, DEV)
+    xg = x.clone().requires_grad_(True)
+    m = Fn.nc_fused_aggregate(xg, PQ, graph, [Fn.KIND["max"], Fn.KIND["min"]], [Fn.ACT_RAW, Fn.ACT_RAW])
+    assert torch.equal(m[0, 0], torch.tensor([1., 5., 3., 4.], device=DEV))
+    assert torch.equal(m[1, 0], torch.tensor([1., 2., 3., 0.], device=DEV))
+    g = torch.zeros_like(m); g[:, 0] = 1.0
+    gx, = torch.autograd.grad((m * g).sum(), [xg])
+    # d/dx_0: max: [tie .5, 0, tie .5, 1] ; min: [tie .5, 1, tie .5, 0]
+    assert torch.equal(gx[0], torch.tensor([1.0, 1.0, 1.0, 1.0], device=DEV))
+    # d/dx_1 (through s, mask == 1): max: [.5, 1, .5, 0], min: [.5, 0, .5, 1]
+    assert torch.equal(gx[1], torch.tensor([1.0, 1.0, 1.0, 1.0], device=DEV))
+
+
+def test_spmm_matches_torch_sparse():
+    import mma_amd
+    from mma_amd import functional as Fn
+    from mma_amd.graph import SpmmGraph
+    rng = np.random.default_rng(5)
+    N, C, K = 300, 7, 3
+    nnz = 2000
+    r, c = rng.integers(0, N, nnz), rng.integers(0, N, nnz)
+    v = rng.standard_normal(nnz).astype(np.float32)
+    adj = torch.sparse_coo_tensor(torch.tensor(np.stack([r, c])), torch.tensor(v), (N, N)).coalesce()
+    B = torch.from_numpy(rng.standard_normal((K * N, C)).astype(np.float32)).requires_grad_(True)
+    bias = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).requires_grad_(True)
+    ref = torch.sparse.mm(torch.cat((adj,) * K, 1), B) + bias
+    cot = torch.from_numpy(rng.standard_normal((N, C)).astype(np.float32))
+    gref = torch.autograd.grad((ref * cot).sum(), [B, bias])
+    sg = SpmmGraph.from_torch_sparse(adj.to(DEV))
+    Bg = B.detach().to(DEV).requires_grad_(True); bg = bias.detach().to(DEV).requires_grad_(True)
+    out = Fn.csr_spmm(Bg, bg, sg, K)
+    gg = torch.autograd.grad((out * cot.to(DEV)).sum(), [Bg, bg])
+    check_close(out, ref.detach().numpy(), None, None, what="spmm", signed_sum=True)
+    check_close(gg[0], gref[0].numpy(), None, None, what="spmm/gB", signed_sum=True)
+    check_close(gg[1], gref[1].numpy(), None, None, what="spmm/gbias", signed_sum=True)
+
+
+def test_unusable_aggregators_and_errors():
+    gold = Golden("toy6_h8")
+    with pytest.raises(KeyError):
+        build_module(gold, "sigmoid", 0.0, ["mean", "bogus"])
+    mod, *_ = build_module(gold, "sigmoid", 0.0, ["std"])
+    x = gold.torch_inputs(DEV)[0]
+    with pytest.raises(NotImplementedError):
+        mod(x, adj_of(gold))
