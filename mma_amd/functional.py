@@ -7,6 +7,21 @@ import torch
 from . import _lib
 from ._lib import call, host_codes, ptr, require_gpu, stream_ptr
 
+TIMER = None   # bench.py installs an object with .span(name) -> context manager (HIP events around the calls)
+
+
+class _NoSpan:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _span(name):
+    return TIMER.span(name) if TIMER is not None else _NoSpan()
+
+
 KIND = {"sum": 0, "mean": 1, "max": 2, "min": 3, "softmax": 4, "softmin": 5}
 ACT_SIGMOID, ACT_RAW = 0, 1
 DROP_NONE, DROP_HASH, DROP_EXPLICIT = 0, 1, 2
@@ -69,7 +84,8 @@ class _NCFused(torch.autograd.Function):
         mode, thr, seed, keep = drop.args()
         # the kernel gathers x_j / Q_j from the source table and reads x_i / P_i of the target rows;
         # targets are the first N rows of the source table
-        call("mma_nc_fused_fwd", ptr(x_src), x_src.stride(0), ptr(P), ptr(Q), PQ.stride(0),
+        with _span("nc_fused_fwd"):
+          call("mma_nc_fused_fwd", ptr(x_src), x_src.stride(0), ptr(P), ptr(Q), PQ.stride(0),
              ptr(graph.rowptr), ptr(graph.col), ptr(graph.items), graph.items.shape[0],
              ptr(graph.hubs) if graph.n_slots else None, graph.hubs.shape[0], ptr(partial), graph.n_slots,
              ptr(m), ptr(T), ptr(sel), K * H, N, graph.E, H, K, host_codes(kinds), host_codes(acts),
@@ -93,7 +109,8 @@ class _NCFused(torch.autograd.Function):
         gxs = torch.empty((S, H), device=dev, dtype=torch.float32)
         if S > N:  # halo rows are sources only: no target-side gradient
             gP[N:].zero_(); gxs[N:].zero_()
-        call("mma_nc_bwd_node", ptr(g), ptr(sel), ptr(T), K * H, ptr(graph.rowptr), ptr(gs), K * H, ptr(gP),
+        with _span("nc_bwd_node"):
+          call("mma_nc_bwd_node", ptr(g), ptr(sel), ptr(T), K * H, ptr(graph.rowptr), ptr(gs), K * H, ptr(gP),
              gPQ.stride(0), ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
         gx = torch.empty((S, H), device=dev, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32)
@@ -101,7 +118,8 @@ class _NCFused(torch.autograd.Function):
         P = PQ[:, :K * H]
         Q = PQ[:, K * H:]
         mode, thr, seed, keep = drop.args()
-        call("mma_nc_fused_bwd", ptr(x_src), x_src.stride(0), ptr(P), ptr(Q), PQ.stride(0),
+        with _span("nc_fused_bwd"):
+          call("mma_nc_fused_bwd", ptr(x_src), x_src.stride(0), ptr(P), ptr(Q), PQ.stride(0),
              ptr(gs), K * H, ptr(gxs), H, ptr(graph.t_col), ptr(graph.t_eid),
              ptr(graph.t_items), graph.t_items.shape[0], ptr(graph.t_hubs) if graph.t_n_slots else None,
              graph.t_hubs.shape[0], ptr(partial), graph.t_n_slots, ptr(gQ), gPQ.stride(0), ptr(gx), H,
@@ -128,7 +146,8 @@ class _CsrSpmm(torch.autograd.Function):
         assert B.shape[0] == K * rows_per_block and rows_per_block == sg.n_cols
         C = B.shape[1]
         out = torch.empty((sg.n_rows, C), device=B.device, dtype=torch.float32)
-        call("mma_csr_spmm", ptr(sg.rowptr), ptr(sg.col), ptr(sg.val), ptr(B), B.stride(0), rows_per_block, K,
+        with _span("csr_spmm_fwd"):
+          call("mma_csr_spmm", ptr(sg.rowptr), ptr(sg.col), ptr(sg.val), ptr(B), B.stride(0), rows_per_block, K,
              ptr(bias), ptr(out), C, sg.n_rows, C, stream_ptr())
         ctx.sg, ctx.K, ctx.has_bias = sg, K, bias is not None
         return out
@@ -139,7 +158,8 @@ class _CsrSpmm(torch.autograd.Function):
         g = g.contiguous()
         C = g.shape[1]
         gB1 = torch.empty((sg.n_cols, C), device=g.device, dtype=torch.float32)
-        call("mma_csr_spmm", ptr(sg.t_rowptr), ptr(sg.t_col), ptr(sg.t_val), ptr(g), g.stride(0), sg.n_rows, 1,
+        with _span("csr_spmm_bwd"):
+          call("mma_csr_spmm", ptr(sg.t_rowptr), ptr(sg.t_col), ptr(sg.t_val), ptr(g), g.stride(0), sg.n_rows, 1,
              None, ptr(gB1), C, sg.n_cols, C, stream_ptr())
         gB = gB1.unsqueeze(0).expand(K, -1, -1).reshape(K * sg.n_cols, C)  # every k-block sees the same A^T g
         return gB, (g.sum(0) if ctx.has_bias else None), None, None

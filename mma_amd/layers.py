@@ -102,7 +102,9 @@ class MMA(Module):
         self.self_loop = None
 
         self._chunk = chunk
-        self._graph = None      # NCGraph, built once (the reference captures add_all at construction time)
+        # NCGraph, built once (the reference captures add_all at construction time).  Extension: a ready-made
+        # NCGraph may be passed as `add_all` (large graphs never materialise a Python list of arrays).
+        self._graph = add_all if isinstance(add_all, NCGraph) else None
         self._sg = None         # (adj object, SpmmGraph) cache for the tail spmm
         self.drop_override = None   # tests: a DropoutSpec (explicit keep mask / fixed seed) used instead of p
 
@@ -174,8 +176,8 @@ class MMA(Module):
         amp, att = scaler_factors(N, input.device)
         support = torch.mm(m.reshape(K * N, -1), self.weight)
         support = support * (1.0 + amp + att).repeat(K, 1)
-        if self._sg is None or self._sg[0] is not adj:
-            self._sg = (adj, SpmmGraph.from_torch_sparse(adj))
+        if self._sg is None or self._sg[0] is not adj:   # extension: a ready-made SpmmGraph is accepted as `adj`
+            self._sg = (adj, adj if isinstance(adj, SpmmGraph) else SpmmGraph.from_torch_sparse(adj))
         return Fn.csr_spmm(support, self.bias, self._sg[1], K)                  # layers.py:861-867
 
     def __repr__(self):
