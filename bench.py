@@ -100,7 +100,8 @@ def cpu_baseline(rowptr, col, H, names, activation, p, n_targets, seed):
     """The CPU oracle (oracle/nc_oracle.py, torch-CPU vectorised restatement of layers.py) on a bounded sample:
     the first n_targets target nodes with ALL their in-edges; fwd+bwd of the K aggregators + dense tail."""
     from oracle import nc_oracle as O
-    threads = os.cpu_count() or 1
+    # the box gives one GPU job a share of the host (16 cores), whatever os.cpu_count() says
+    threads = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(threads)
     e_hi = int(rowptr[n_targets])
     sub_col = col[:e_hi]
@@ -135,7 +136,8 @@ def main():
     ap.add_argument("--nclass", type=int, default=16)
     ap.add_argument("--aggregators", type=str, default="sum,mean,max,min")
     ap.add_argument("--dropout", type=float, default=0.5)
-    ap.add_argument("--cpu-sample", type=int, default=30000, help="target nodes in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--force-sharded", action="store_true", help="use the sharded (RCCL) path even at world size 1")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="target nodes in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -144,8 +146,11 @@ def main():
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
+        if "RANK" not in os.environ:      # --force-sharded without a launcher
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
         dist.init_process_group("nccl", device_id=dev)
 
     import mma_amd
@@ -163,7 +168,7 @@ def main():
     x_full = torch.relu(torch.randn(N, H, generator=gen))
     cot_full = torch.randn(N, C, generator=gen)
 
-    if world == 1:
+    if not sharded:
         graph = mma_amd.NCGraph(rowptr, col, dev)
         layer = make_layer(mma_amd, graph, H, C, names, args.dropout, dev)
         dst = np.repeat(np.arange(N, dtype=np.int64), np.diff(rowptr))
@@ -195,7 +200,7 @@ def main():
     del x_full, cot_full
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -209,7 +214,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -231,7 +236,7 @@ def main():
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None}
         cpu = None
-        if args.cpu_sample and world == 1:
+        if args.cpu_sample and not sharded:
             cpu = cpu_baseline(rowptr, col, H, names, "new_sigmoid", args.dropout, min(args.cpu_sample, N), 42)
         line = {
             "metric": "aggregated edges/sec (fwd+bwd) MultiMaskConv", "value": value, "unit": "edges/s",
@@ -246,7 +251,7 @@ def main():
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 1
+#define MMA_ABI_VERSION 2
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -62,8 +62,9 @@ const char* mma_last_error(void);
  *     sel[i, k*H+h] = 0: x_i selected  1: s selected  2: tie (0.5/0.5, torch.max/min backward)  3: NaN
  */
 int mma_nc_fused_fwd(
-    const float* x, int64_t ldx,                 /* (N,H) */
-    const float* P, const float* Q, int64_t ldpq,/* (N,K*H) each */
+    const float* x, int64_t ldx,                 /* (n_src,H): rows [0,N) are the targets, the rest source-only (halo) */
+    const float* P, int64_t ldp,                 /* (N,K*H)     P[i, k*H+h] = (x_i @ W_k[:H])[h] */
+    const float* Q, int64_t ldq,                 /* (n_src,K*H) Q[j, k*H+h] = (x_j @ W_k[H:])[h] */
     const int32_t* rowptr,                       /* (N+1) CSR by target: d_i = rowptr[i+1]-rowptr[i] */
     const int32_t* col,                          /* (E) source node of each edge, target-major */
     const int32_t* items, int64_t n_items,       /* (n_items,4) */
@@ -73,7 +74,8 @@ int mma_nc_fused_fwd(
     float* T, uint8_t* sel, int64_t ldt,         /* (N,K*H) out, both NULL or both non-NULL */
     int64_t N, int64_t E, int32_t H, int32_t K,
     const uint8_t* kind_host, const uint8_t* act_host,   /* K codes each, HOST memory */
-    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint8_t* keep, /* keep: (K,E,H) or NULL */
+    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, int64_t drop_edge_base, /* HASH key = edge position + base */
+    const uint8_t* keep,                         /* EXPLICIT: (K,E,H), else NULL */
     void* stream);
 
 /* ---- K2a: node-level backward of the combine (element-wise) -------------------------------------
@@ -90,9 +92,9 @@ int mma_nc_bwd_node(
  *     gQ[j, k*H+h] = x_j[h] * sum_i gs[i,k,h] * drop * act_k'(z_k(i,j))
  *     gx[j, h]     = gxs[j,h] + sum_i sum_k gs[i,k,h] * drop * act_k(z_k(i,j))
  * items/hubs/partial as in mma_nc_fused_fwd but over the transposed segments; partial is
- * (n_slots, K+1, H). */
+ * (n_slots, K+1, H).  N here is the number of SOURCE rows (n_src); gs and P have one row per target. */
 int mma_nc_fused_bwd(
-    const float* x, int64_t ldx, const float* P, const float* Q, int64_t ldpq,
+    const float* x, int64_t ldx, const float* P, int64_t ldp, const float* Q, int64_t ldq,
     const float* gs, int64_t ldg, const float* gxs, int64_t ldgx,
     const int32_t* t_col, const int32_t* t_eid,
     const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs,
@@ -100,7 +102,7 @@ int mma_nc_fused_bwd(
     float* gQ, int64_t ldgq, float* gx, int64_t ldgxo,
     int64_t N, int64_t E, int32_t H, int32_t K,
     const uint8_t* act_host,
-    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint8_t* keep,
+    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, int64_t drop_edge_base, const uint8_t* keep,
     void* stream);
 
 /* ---- K5: CSR SpMM over a K-times column-stacked adjacency ----------------------------------------

@@ -71,6 +71,7 @@ struct DropParams {
   uint32_t seed_lo, seed_hi;
   const uint8_t* keep;  // EXPLICIT: (K_total, E, H)
   int64_t E;
+  uint32_t edge_base;   // HASH: key = edge position + edge_base (a shard's edges keep their global ids)
 };
 
 // keep multiplier (0 or scale) for the VEC features starting at column c of mask k_abs on edge e
@@ -78,7 +79,7 @@ template <int VEC>
 __device__ __forceinline__ void drop_factors(const DropParams& d, uint32_t e, int k_abs, int c, int H, int HQ,
                                              float (&f)[VEC]) {
   if (d.mode == MMA_DROP_HASH) {
-    const uint32_t r = drop_mix(drop_edge_key(e, d.seed_lo) ^ drop_col_key((uint32_t)(k_abs * HQ + (c >> 2)), d.seed_hi));
+    const uint32_t r = drop_mix(drop_edge_key(e + d.edge_base, d.seed_lo) ^ drop_col_key((uint32_t)(k_abs * HQ + (c >> 2)), d.seed_hi));
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const uint32_t byte = (r >> (8 * ((c + i) & 3))) & 0xFFu;

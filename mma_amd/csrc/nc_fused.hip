@@ -15,7 +15,7 @@ namespace mma {
 
 struct NcFwdParams {
   const float* x; int64_t ldx;
-  const float* P; const float* Q; int64_t ldpq;
+  const float* P; int64_t ldp; const float* Q; int64_t ldq;
   const int32_t* rowptr; const int32_t* col;
   const int4* items; int64_t n_items;
   float* partial; int64_t pstride;   // floats per slot = 2*K_total*H
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void nc_fwd_kernel(const NcFwdParams p) {
     Vec<VEC> pk[K], acc[K], tac[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      pk[k] = ldv<VEC>(p.P + (size_t)node * p.ldpq + (size_t)(p.k_base + k) * p.H + cc);
+      pk[k] = ldv<VEC>(p.P + (size_t)node * p.ldp + (size_t)(p.k_base + k) * p.H + cc);
       acc[k] = vzero<VEC>();
       tac[k] = vzero<VEC>();
     }
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void nc_fwd_kernel(const NcFwdParams p) {
           xj[u] = ldv<VEC>(p.x + (size_t)jj * p.ldx + cc);
 #pragma unroll
           for (int k = 0; k < K; ++k)
-            qv[u][k] = ldv<VEC>(p.Q + (size_t)jj * p.ldpq + (size_t)(p.k_base + k) * p.H + cc);
+            qv[u][k] = ldv<VEC>(p.Q + (size_t)jj * p.ldq + (size_t)(p.k_base + k) * p.H + cc);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
 // K2b: edge-level backward over the transposed CSR (grouped by source j)
 struct NcBwdParams {
   const float* x; int64_t ldx;
-  const float* P; const float* Q; int64_t ldpq;
+  const float* P; int64_t ldp; const float* Q; int64_t ldq;
   const float* gs; int64_t ldg; const float* gxs; int64_t ldgx;
   const int32_t* t_col; const int32_t* t_eid;
   const int4* items; int64_t n_items;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
     Vec<VEC> ax = vzero<VEC>();
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      qk[k] = ldv<VEC>(p.Q + (size_t)node * p.ldpq + (size_t)(p.k_base + k) * p.H + cc);
+      qk[k] = ldv<VEC>(p.Q + (size_t)node * p.ldq + (size_t)(p.k_base + k) * p.H + cc);
       aq[k] = vzero<VEC>();
     }
 
@@ -296,12 +296,12 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
           ev[u] = tt[u] < cnt;
           const int i_ = __shfl(myi, tt[u] & (kWave - 1), kWave);
           eid[u] = DROP ? (uint32_t)__shfl(mye, tt[u] & (kWave - 1), kWave) : 0u;
-          const int ii = ev[u] ? i_ : node;
+          const int ii = ev[u] ? i_ : 0;   // inactive sub-rows read target row 0 (valid), contribute 0
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const size_t o = (size_t)(p.k_base + k) * p.H + cc;
             gv[u][k] = ldv<VEC>(p.gs + (size_t)ii * p.ldg + o);
-            pv[u][k] = ldv<VEC>(p.P + (size_t)ii * p.ldpq + o);
+            pv[u][k] = ldv<VEC>(p.P + (size_t)ii * p.ldp + o);
           }
         }
 #pragma unroll
@@ -424,7 +424,9 @@ static int pack_codes(const uint8_t* kind_host, const uint8_t* act_host, int K, 
   return 0;
 }
 
-static int make_drop(int32_t mode, uint32_t thr, uint64_t seed, const uint8_t* keep, int64_t E, DropParams* d) {
+static int make_drop(int32_t mode, uint32_t thr, uint64_t seed, int64_t edge_base, const uint8_t* keep, int64_t E, DropParams* d) {
+  MMA_REQUIRE(edge_base >= 0 && edge_base + E < (1LL << 32), "drop_edge_base %lld out of range", (long long)edge_base);
+  d->edge_base = (uint32_t)edge_base;
   MMA_REQUIRE(mode >= MMA_DROP_NONE && mode <= MMA_DROP_EXPLICIT, "drop_mode %d unknown", mode);
   MMA_REQUIRE(mode == MMA_DROP_NONE || thr < 256, "drop_thr %u out of range (0..255)", thr);
   MMA_REQUIRE(mode != MMA_DROP_EXPLICIT || keep != nullptr, "drop_mode EXPLICIT needs a keep mask");
@@ -500,15 +502,16 @@ static int64_t elementwise_grid(int64_t total) {
 using namespace mma;
 
 extern "C" int mma_nc_fused_fwd(
-    const float* x, int64_t ldx, const float* P, const float* Q, int64_t ldpq,
+    const float* x, int64_t ldx, const float* P, int64_t ldp, const float* Q, int64_t ldq,
     const int32_t* rowptr, const int32_t* col,
     const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots, float* m, float* T, uint8_t* sel, int64_t ldt,
     int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* kind_host, const uint8_t* act_host,
-    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint8_t* keep, void* stream) {
+    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, int64_t drop_edge_base, const uint8_t* keep, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31), "N=%lld E=%lld out of int32 range", (long long)N, (long long)E);
   MMA_REQUIRE(H >= 1 && K >= 1 && K <= MMA_MAX_K, "H=%d K=%d unsupported (1<=K<=%d)", H, K, MMA_MAX_K);
-  MMA_REQUIRE(ldx >= H && ldpq >= (int64_t)K * H, "row pitch too small: ldx=%lld ldpq=%lld", (long long)ldx, (long long)ldpq);
+  MMA_REQUIRE(ldx >= H && ldp >= (int64_t)K * H && ldq >= (int64_t)K * H, "row pitch too small: ldx=%lld ldp=%lld ldq=%lld",
+              (long long)ldx, (long long)ldp, (long long)ldq);
   MMA_REQUIRE((T == nullptr) == (sel == nullptr), "T and sel must both be given or both be NULL");
   MMA_REQUIRE(T == nullptr || ldt >= (int64_t)K * H, "ldt=%lld too small", (long long)ldt);
   MMA_REQUIRE(n_items >= 0 && n_hubs >= 0 && n_slots >= 0 && n_items < (1LL << 31), "negative or oversize item counts");
@@ -520,14 +523,14 @@ extern "C" int mma_nc_fused_fwd(
   uint32_t kinds, acts;
   if (int rc = pack_codes(kind_host, act_host, K, &kinds, &acts)) return rc;
   NcFwdParams p{};
-  if (int rc = make_drop(drop_mode, drop_thr, seed, keep, E, &p.drop)) return rc;
+  if (int rc = make_drop(drop_mode, drop_thr, seed, drop_edge_base, keep, E, &p.drop)) return rc;
   const bool drop = drop_mode != MMA_DROP_NONE && !(drop_mode == MMA_DROP_HASH && drop_thr == 0);
   const bool save = T != nullptr;
-  const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldpq % 4 == 0) && (!save || ldt % 4 == 0) && aligned16(x) &&
+  const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldp % 4 == 0) && (ldq % 4 == 0) && (!save || ldt % 4 == 0) && aligned16(x) &&
                   aligned16(P) && aligned16(Q) && aligned16(m) && (!save || (aligned16(T) && aligned16(sel))) &&
                   (partial == nullptr || aligned16(partial));
   const Geometry g = geometry(H, v4);
-  p.x = x; p.ldx = ldx; p.P = P; p.Q = Q; p.ldpq = ldpq; p.rowptr = rowptr; p.col = col;
+  p.x = x; p.ldx = ldx; p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.rowptr = rowptr; p.col = col;
   p.items = reinterpret_cast<const int4*>(items); p.n_items = n_items;
   p.partial = partial; p.pstride = 2LL * K * H;
   p.m = m; p.m_kstride = N * (int64_t)H; p.T = T; p.sel = sel; p.ldt = ldt;
@@ -580,16 +583,16 @@ extern "C" int mma_nc_bwd_node(
 }
 
 extern "C" int mma_nc_fused_bwd(
-    const float* x, int64_t ldx, const float* P, const float* Q, int64_t ldpq,
+    const float* x, int64_t ldx, const float* P, int64_t ldp, const float* Q, int64_t ldq,
     const float* gs, int64_t ldg, const float* gxs, int64_t ldgx,
     const int32_t* t_col, const int32_t* t_eid,
     const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots, float* gQ, int64_t ldgq, float* gx, int64_t ldgxo,
     int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* act_host,
-    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint8_t* keep, void* stream) {
+    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, int64_t drop_edge_base, const uint8_t* keep, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31), "N=%lld E=%lld out of int32 range", (long long)N, (long long)E);
   MMA_REQUIRE(H >= 1 && K >= 1 && K <= MMA_MAX_K, "H=%d K=%d unsupported (1<=K<=%d)", H, K, MMA_MAX_K);
-  MMA_REQUIRE(ldx >= H && ldpq >= (int64_t)K * H && ldg >= (int64_t)K * H && ldgq >= (int64_t)K * H && ldgx >= H && ldgxo >= H,
+  MMA_REQUIRE(ldx >= H && ldp >= (int64_t)K * H && ldq >= (int64_t)K * H && ldg >= (int64_t)K * H && ldgq >= (int64_t)K * H && ldgx >= H && ldgxo >= H,
               "row pitch too small");
   MMA_REQUIRE(n_items >= 0 && n_hubs >= 0 && n_slots >= 0 && n_items < (1LL << 31), "negative or oversize item counts");
   MMA_REQUIRE(n_slots == 0 || (partial != nullptr && hubs != nullptr && n_hubs > 0), "hub slots without partial/hubs buffers");
@@ -600,13 +603,13 @@ extern "C" int mma_nc_fused_bwd(
   uint32_t kinds, acts;
   if (int rc = pack_codes(nullptr, act_host, K, &kinds, &acts)) return rc;
   NcBwdParams p{};
-  if (int rc = make_drop(drop_mode, drop_thr, seed, keep, E, &p.drop)) return rc;
+  if (int rc = make_drop(drop_mode, drop_thr, seed, drop_edge_base, keep, E, &p.drop)) return rc;
   const bool drop = drop_mode != MMA_DROP_NONE && !(drop_mode == MMA_DROP_HASH && drop_thr == 0);
-  const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldpq % 4 == 0) && (ldg % 4 == 0) && (ldgx % 4 == 0) && (ldgq % 4 == 0) &&
+  const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldp % 4 == 0) && (ldq % 4 == 0) && (ldg % 4 == 0) && (ldgx % 4 == 0) && (ldgq % 4 == 0) &&
                   (ldgxo % 4 == 0) && aligned16(x) && aligned16(P) && aligned16(Q) && aligned16(gs) && aligned16(gxs) &&
                   aligned16(gQ) && aligned16(gx) && (partial == nullptr || aligned16(partial));
   const Geometry g = geometry(H, v4);
-  p.x = x; p.ldx = ldx; p.P = P; p.Q = Q; p.ldpq = ldpq; p.gs = gs; p.ldg = ldg; p.gxs = gxs; p.ldgx = ldgx;
+  p.x = x; p.ldx = ldx; p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.gs = gs; p.ldg = ldg; p.gxs = gxs; p.ldgx = ldgx;
   p.t_col = t_col; p.t_eid = t_eid; p.items = reinterpret_cast<const int4*>(items); p.n_items = n_items;
   p.partial = partial; p.pstride = (int64_t)(K + 1) * H; p.gQ = gQ; p.ldgq = ldgq; p.gx = gx; p.ldgxo = ldgxo;
   p.H = H; p.HQ = (H + 3) / 4; p.K_total = K; p.lpr_log = g.lpr_log; p.acts = acts;

@@ -59,80 +59,77 @@ class _NCFused(torch.autograd.Function):
     """m[k] = combine_k(x_i, sum_j drop(act_k(P_k[i] + Q_k[j])) * x_j)   (K1 forward, K2a + K2b backward)"""
 
     @staticmethod
-    def forward(ctx, x_src, PQ, graph, kinds, acts, drop):
+    def forward(ctx, x_src, P, Q, graph, kinds, acts, drop):
         # x_src: (n_src,H) feature table; its first N rows are the targets (n_src > N only in the sharded path,
-        # where the tail holds halo rows).  PQ: (n_src, 2*K*H) = [P | Q] = x_src @ [W_k[:H].. | W_k[H:]..]
-        require_gpu(x_src, PQ)
+        # where the tail holds halo rows).  P: (N,K*H) = x_src[:N] @ [W_k[:H]..], Q: (n_src,K*H) = x_src @ [W_k[H:]..]
+        require_gpu(x_src, P, Q)
         K = len(kinds)
         S, H = x_src.shape
         N = graph.N
-        assert x_src.dtype == torch.float32 and PQ.dtype == torch.float32
-        assert S == graph.n_src and PQ.shape == (S, 2 * K * H) and 1 <= K <= 8
-        PQ = PQ.contiguous(); x_src = x_src.contiguous()
-        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        x = x_src
-        m = torch.empty((K, N, H), device=x.device, dtype=torch.float32)
-        T = torch.empty((N, K * H), device=x.device, dtype=torch.float32) if need_grad else None
-        sel = torch.empty((N, K * H), device=x.device, dtype=torch.uint8) if need_grad else None
-        partial = (torch.empty((graph.n_slots, 2 * K * H), device=x.device, dtype=torch.float32)
-                   if graph.n_slots else None)
-        P = PQ[:, :K * H]
-        Q = PQ[:, K * H:]
+        assert x_src.dtype == torch.float32 and P.dtype == torch.float32 and Q.dtype == torch.float32
+        assert S == graph.n_src and P.shape == (N, K * H) and Q.shape == (S, K * H) and 1 <= K <= 8
+        x_src = x_src.contiguous()
+        if P.stride(1) != 1:
+            P = P.contiguous()
+        if Q.stride(1) != 1:
+            Q = Q.contiguous()
+        need_grad = any(ctx.needs_input_grad[:3])
+        dev = x_src.device
+        m = torch.empty((K, N, H), device=dev, dtype=torch.float32)
+        T = torch.empty((N, K * H), device=dev, dtype=torch.float32) if need_grad else None
+        sel = torch.empty((N, K * H), device=dev, dtype=torch.uint8) if need_grad else None
+        partial = torch.empty((graph.n_slots, 2 * K * H), device=dev, dtype=torch.float32) if graph.n_slots else None
         if drop.keep is not None:
             assert drop.keep.dtype == torch.uint8 and drop.keep.is_contiguous() and drop.keep.is_cuda and \
                 tuple(drop.keep.shape) == (K, graph.E, H), "explicit keep mask must be a contiguous (K,E,H) uint8 GPU tensor"
         mode, thr, seed, keep = drop.args()
-        # the kernel gathers x_j / Q_j from the source table and reads x_i / P_i of the target rows;
-        # targets are the first N rows of the source table
         with _span("nc_fused_fwd"):
-          call("mma_nc_fused_fwd", ptr(x_src), x_src.stride(0), ptr(P), ptr(Q), PQ.stride(0),
-             ptr(graph.rowptr), ptr(graph.col), ptr(graph.items), graph.items.shape[0],
-             ptr(graph.hubs) if graph.n_slots else None, graph.hubs.shape[0], ptr(partial), graph.n_slots,
-             ptr(m), ptr(T), ptr(sel), K * H, N, graph.E, H, K, host_codes(kinds), host_codes(acts),
-             mode, thr, seed, keep, stream_ptr())
+            call("mma_nc_fused_fwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
+                 ptr(graph.rowptr), ptr(graph.col), ptr(graph.items), graph.items.shape[0],
+                 ptr(graph.hubs) if graph.n_slots else None, graph.hubs.shape[0], ptr(partial), graph.n_slots,
+                 ptr(m), ptr(T), ptr(sel), K * H, N, graph.E, H, K, host_codes(kinds), host_codes(acts),
+                 mode, thr, seed, graph.edge_base, keep, stream_ptr())
         ctx.graph, ctx.kinds, ctx.acts, ctx.drop = graph, kinds, acts, drop
-        ctx.save_for_backward(x_src, PQ, T, sel)
+        ctx.save_for_backward(x_src, P, Q, T, sel)
         return m
 
     @staticmethod
     def backward(ctx, g):
         graph, kinds, acts, drop = ctx.graph, ctx.kinds, ctx.acts, ctx.drop
-        x_src, PQ, T, sel = ctx.saved_tensors
+        x_src, P, Q, T, sel = ctx.saved_tensors
         K = len(kinds)
         N, H, S = graph.N, x_src.shape[1], graph.n_src
         g = g.contiguous()
         dev = g.device
         gs = torch.empty((N, K * H), device=dev, dtype=torch.float32)
-        gPQ = torch.empty((S, 2 * K * H), device=dev, dtype=torch.float32)
-        gP = gPQ[:, :K * H]
-        gQ = gPQ[:, K * H:]
+        gP = torch.empty((N, K * H), device=dev, dtype=torch.float32)
+        gQ = torch.empty((S, K * H), device=dev, dtype=torch.float32)
         gxs = torch.empty((S, H), device=dev, dtype=torch.float32)
         if S > N:  # halo rows are sources only: no target-side gradient
-            gP[N:].zero_(); gxs[N:].zero_()
+            gxs[N:].zero_()
         with _span("nc_bwd_node"):
-          call("mma_nc_bwd_node", ptr(g), ptr(sel), ptr(T), K * H, ptr(graph.rowptr), ptr(gs), K * H, ptr(gP),
-             gPQ.stride(0), ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
+            call("mma_nc_bwd_node", ptr(g), ptr(sel), ptr(T), K * H, ptr(graph.rowptr), ptr(gs), K * H, ptr(gP), K * H,
+                 ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
         gx = torch.empty((S, H), device=dev, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32)
                    if graph.t_n_slots else None)
-        P = PQ[:, :K * H]
-        Q = PQ[:, K * H:]
         mode, thr, seed, keep = drop.args()
         with _span("nc_fused_bwd"):
-          call("mma_nc_fused_bwd", ptr(x_src), x_src.stride(0), ptr(P), ptr(Q), PQ.stride(0),
-             ptr(gs), K * H, ptr(gxs), H, ptr(graph.t_col), ptr(graph.t_eid),
-             ptr(graph.t_items), graph.t_items.shape[0], ptr(graph.t_hubs) if graph.t_n_slots else None,
-             graph.t_hubs.shape[0], ptr(partial), graph.t_n_slots, ptr(gQ), gPQ.stride(0), ptr(gx), H,
-             S, graph.E, H, K, host_codes(acts), mode, thr, seed, keep, stream_ptr())
-        return gx, gPQ, None, None, None, None
+            call("mma_nc_fused_bwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
+                 ptr(gs), K * H, ptr(gxs), H, ptr(graph.t_col), ptr(graph.t_eid),
+                 ptr(graph.t_items), graph.t_items.shape[0], ptr(graph.t_hubs) if graph.t_n_slots else None,
+                 graph.t_hubs.shape[0], ptr(partial), graph.t_n_slots, ptr(gQ), K * H, ptr(gx), H,
+                 S, graph.E, H, K, host_codes(acts), mode, thr, seed, graph.edge_base, keep, stream_ptr())
+        return gx, gP, gQ, None, None, None, None
 
 
-def nc_fused_aggregate(x, PQ, graph, kinds, acts, drop=None):
+def nc_fused_aggregate(x, P, Q, graph, kinds, acts, drop=None):
     """Fused K-mask aggregation (K <= 8 per call) -> m (K, graph.N, H).
 
-    x: (graph.n_src, H) feature table whose first graph.N rows are the targets; PQ = x @ [Wtop | Wbot]
-    (n_src, 2*K*H); kinds/acts: MMA_KIND_* / MMA_ACT_* codes per mask."""
-    return _NCFused.apply(x, PQ, graph, tuple(kinds), tuple(acts), drop or DropoutSpec(0.0))
+    x: (graph.n_src, H) feature table whose first graph.N rows are the targets; P = x[:N] @ Wtop (N, K*H),
+    Q = x @ Wbot (n_src, K*H) with Wtop/Wbot the column-concatenated top/bottom halves of the K mask weights;
+    kinds/acts: MMA_KIND_* / MMA_ACT_* codes per mask."""
+    return _NCFused.apply(x, P, Q, graph, tuple(kinds), tuple(acts), drop or DropoutSpec(0.0))
 
 
 class _CsrSpmm(torch.autograd.Function):

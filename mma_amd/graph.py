@@ -53,7 +53,7 @@ def transpose_csr(rowptr, col, n_src):
 class NCGraph:
     """Device-resident plan.  n_src >= N allows extra source rows (halo rows in the sharded path)."""
 
-    def __init__(self, rowptr, col, device, n_src=None, chunk=DEFAULT_CHUNK):
+    def __init__(self, rowptr, col, device, n_src=None, chunk=DEFAULT_CHUNK, edge_base=0):
         rowptr = np.asarray(rowptr, dtype=np.int64)
         col = np.asarray(col, dtype=np.int64)
         self.N = len(rowptr) - 1
@@ -62,6 +62,7 @@ class NCGraph:
         assert len(col) == self.E and (self.E == 0 or (col.min() >= 0 and col.max() < self.n_src)), "bad CSR"
         assert self.n_src < 2 ** 31 and self.E < 2 ** 31
         self.chunk = int(chunk)
+        self.edge_base = int(edge_base)   # global position of this shard's first edge (keys the dropout hash)
         items, hubs, self.n_slots = make_items(rowptr, self.chunk)
         t_rowptr, t_col, t_eid = transpose_csr(rowptr, col, self.n_src)
         t_items, t_hubs, self.t_n_slots = make_items(t_rowptr, self.chunk)

@@ -148,10 +148,10 @@ class MMA(Module):
         H = input.shape[1]
         kinds, acts = self._codes(names)
         masks = [getattr(self, "mask_" + n) for n in names]
-        # [x_i || x_j] @ W_k  ==  x_i @ W_k[:H] + x_j @ W_k[H:]: one dense GEMM (MFMA fp32) for all K masks
-        wcat = torch.cat([w[:H] for w in masks] + [w[H:] for w in masks], 1)     # (H, 2*K*H)
-        PQ = torch.mm(input, wcat)
-        return Fn.nc_fused_aggregate(input, PQ, self.graph(input.device), kinds, acts, drop or self._drop(names))
+        # [x_i || x_j] @ W_k  ==  x_i @ W_k[:H] + x_j @ W_k[H:]: dense GEMMs (MFMA fp32) shared by all K masks
+        P = torch.mm(input, torch.cat([w[:H] for w in masks], 1))               # (N, K*H)
+        Q = torch.mm(input, torch.cat([w[H:] for w in masks], 1))               # (N, K*H)
+        return Fn.nc_fused_aggregate(input, P, Q, self.graph(input.device), kinds, acts, drop or self._drop(names))
 
     def _aggregate_all(self, names, input):
         outs = []

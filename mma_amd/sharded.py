@@ -1,0 +1,201 @@
+"""1-D node-sharded MMA layer: one process per GPU, RCCL all-to-all halo exchange over xGMI.
+
+The reference has no distributed code; this is the MI355X-first scale-out of its hot path.
+Targets are independent units, so rank r owns a contiguous, EDGE-balanced range of target nodes, their CSR
+rows, their feature rows and their outputs.  Sources outside the range are halo rows.  Per layer call:
+
+  forward   all-to-all #1: x rows of the halo (H floats each) - Q of the halo rows is recomputed locally by the
+            GEMM, so only x travels ((K+1)x fewer bytes than sending [x|Q]);   fused aggregate on [own | halo];
+            all-to-all #2: the (N,C) tail rows the K-stacked SpMM needs from the halo (C floats each);
+  backward  the two reverse all-to-alls, summed at the owner (per-peer unpack-add, unique rows => no atomics);
+            grad of the (tiny) parameters is all-reduced by `allreduce_grads()`.
+
+xGMI is point-to-point (7 links per GPU): an all-to-all drives all links at once, which is why the exchange is
+an all-to-all-v (torch.distributed.all_to_all_single on the "nccl" = RCCL backend) and not a ring collective.
+A contiguous target range is also a contiguous range of the global CSR, so the dropout hash keeps the global
+edge ids (NCGraph.edge_base) and the sharded result equals the single-GPU one for the same seed.
+
+With the "gloo" backend (tests; CPU-only rendezvous) GPU buffers are staged through the host."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import functional as Fn
+from ._lib import call, ptr, require_gpu, stream_ptr
+from .graph import DEFAULT_CHUNK, NCGraph, SpmmGraph
+from .layers import _AGG
+from .scalers import scaler_factors
+
+
+def partition_bounds(rowptr, world):
+    """Contiguous target ranges with (nearly) equal edge counts: bounds[r] .. bounds[r+1]."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    N, E = len(rowptr) - 1, int(rowptr[-1])
+    cuts = np.searchsorted(rowptr, (E * np.arange(1, world, dtype=np.float64) / world).astype(np.int64), side="left")
+    bounds = np.concatenate([[0], np.clip(cuts, 0, N), [N]]).astype(np.int64)
+    return np.maximum.accumulate(bounds)
+
+
+def _backend(group=None):
+    return dist.get_backend(group) if dist.is_initialized() else None
+
+
+def all_to_all_rows(send, send_counts, recv_counts, group=None):
+    """All-to-all-v of row blocks: rows [sum(send_counts[:q]) ..) of `send` go to rank q."""
+    width = send.shape[1:]
+    n_recv = int(sum(recv_counts))
+    if _backend(group) == "gloo" and send.is_cuda:      # test path: stage through the host
+        r = torch.empty((n_recv,) + tuple(width), dtype=send.dtype)
+        dist.all_to_all_single(r, send.cpu(), [int(c) for c in recv_counts], [int(c) for c in send_counts], group=group)
+        return r.to(send.device)
+    recv = torch.empty((n_recv,) + tuple(width), dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(recv, send.contiguous(), [int(c) for c in recv_counts], [int(c) for c in send_counts], group=group)
+    return recv
+
+
+def all_reduce_sum(t, group=None):
+    if _backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+class HaloPlan:
+    """Who sends which rows to whom, for one rank.  Built once per (graph, partition) with one index exchange."""
+
+    def __init__(self, rowptr_own, col_global, bounds, rank, world, comm_device="cpu", group=None):
+        bounds = np.asarray(bounds, dtype=np.int64)
+        self.rank, self.world, self.group = rank, world, group
+        self.lo, self.hi = int(bounds[rank]), int(bounds[rank + 1])
+        self.n_own = self.hi - self.lo
+        rowptr_own = np.asarray(rowptr_own, dtype=np.int64)
+        col_global = np.asarray(col_global, dtype=np.int64)
+        assert len(rowptr_own) == self.n_own + 1 and rowptr_own[0] == 0 and rowptr_own[-1] == len(col_global)
+        own = (col_global >= self.lo) & (col_global < self.hi)
+        self.halo_ids = np.unique(col_global[~own])                       # ascending => grouped by owner
+        self.n_halo = len(self.halo_ids)
+        self.n_src = self.n_own + self.n_halo
+        owner = np.searchsorted(bounds, self.halo_ids, side="right") - 1
+        self.recv_counts = np.bincount(owner, minlength=world).astype(np.int64)
+        assert self.recv_counts[rank] == 0
+        # local column ids: own rows first, then halo rows in halo_ids order
+        col_local = np.where(own, col_global - self.lo, 0)
+        col_local[~own] = self.n_own + np.searchsorted(self.halo_ids, col_global[~own])
+        self.rowptr, self.col = rowptr_own, col_local
+        # index exchange: tell every owner which of its rows this rank needs
+        dev = torch.device(comm_device)
+        rc = torch.from_numpy(self.recv_counts).to(dev)
+        sc = torch.empty_like(rc)
+        dist.all_to_all_single(sc, rc, group=group)
+        self.send_counts = sc.cpu().numpy().astype(np.int64)
+        want = torch.from_numpy(self.halo_ids).to(dev)
+        give = torch.empty(int(self.send_counts.sum()), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(give, want, [int(c) for c in self.send_counts], [int(c) for c in self.recv_counts], group=group)
+        give = give.cpu().numpy()
+        assert len(give) == 0 or (give.min() >= self.lo and give.max() < self.hi), "peer asked for rows this rank does not own"
+        self.send_idx = (give - self.lo).astype(np.int64)               # local row ids, concatenated per peer
+        self.send_offsets = np.concatenate([[0], np.cumsum(self.send_counts)]).astype(np.int64)
+
+
+class _HaloExchange(torch.autograd.Function):
+    """forward: rows of `x_own` other ranks need -> their halo; returns this rank's halo rows (n_halo, W).
+    backward: reverse exchange, contributions summed into the owner's rows."""
+
+    @staticmethod
+    def forward(ctx, x_own, plan, send_idx_dev):
+        require_gpu(x_own)
+        x_own = x_own.contiguous()
+        W = x_own.shape[1]
+        n_send = int(plan.send_counts.sum())
+        send = torch.empty((n_send, W), device=x_own.device, dtype=torch.float32)
+        with Fn._span("halo_pack"):
+            call("mma_pack_rows", ptr(x_own), x_own.stride(0), ptr(send_idx_dev), n_send, ptr(send), W, W, stream_ptr())
+        with Fn._span("halo_all_to_all"):
+            recv = all_to_all_rows(send, plan.send_counts, plan.recv_counts, plan.group)
+        ctx.plan, ctx.idx, ctx.shape = plan, send_idx_dev, x_own.shape
+        return recv
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, idx = ctx.plan, ctx.idx
+        g = g.contiguous()
+        W = g.shape[1]
+        with Fn._span("halo_all_to_all"):
+            back = all_to_all_rows(g, plan.recv_counts, plan.send_counts, plan.group)      # (n_send, W)
+        gx = torch.zeros(ctx.shape, device=g.device, dtype=torch.float32)
+        with Fn._span("halo_unpack"):
+            for q in range(plan.world):      # one call per peer: rows are unique within a peer's list
+                o0, o1 = int(plan.send_offsets[q]), int(plan.send_offsets[q + 1])
+                if o1 > o0:
+                    call("mma_unpack_add_rows", ptr(back[o0:o1]), W, ptr(idx[o0:o1]), o1 - o0, ptr(gx), W, W, stream_ptr())
+        return gx, None, None
+
+
+class ShardedMMA(torch.nn.Module):
+    """The MMA layer (layers.py:54-872 semantics, as mma_amd.MMA) on this rank's shard of the graph."""
+
+    def __init__(self, plan, device, H, C, names, masks, weight, bias, dropout, activation="new_sigmoid", edge_base=0,
+                 chunk=DEFAULT_CHUNK, adj_val=None):
+        super().__init__()
+        self.plan, self.names, self.activation, self.dropout = plan, list(names), activation, dropout
+        self.H, self.C = H, C
+        self.lo, self.hi = plan.lo, plan.hi
+        dev = torch.device(device)
+        self.graph = NCGraph(plan.rowptr, plan.col, dev, n_src=plan.n_src, chunk=chunk, edge_base=edge_base)
+        dst = np.repeat(np.arange(plan.n_own, dtype=np.int64), np.diff(plan.rowptr))
+        self.sg = SpmmGraph(dst, plan.col, adj_val, plan.n_own, plan.n_src, dev)
+        self.send_idx = torch.from_numpy(plan.send_idx.astype(np.int32)).to(dev)
+        self.masks = masks          # dict name -> Parameter (2H,H), owned by the caller, identical on every rank
+        self.weight, self.bias = weight, bias
+        self.owned = [weight, bias] + [masks[n] for n in self.names]
+        self.local_edges = int(plan.rowptr[-1])
+        self.n_total = None         # global node count (scalers quirk Q1 uses N); set by build()
+        self.drop_override = None
+
+    @classmethod
+    def build(cls, rowptr, col, rank, world, device, H, C, names, dropout, seed=42, chunk=DEFAULT_CHUNK, group=None):
+        """Convenience for bench/tests: every rank holds the full CSR and slices its shard; parameters are
+        initialised identically on all ranks (layers.py:143-198 distributions)."""
+        rowptr = np.asarray(rowptr, dtype=np.int64)
+        bounds = partition_bounds(rowptr, world)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        e0, e1 = int(rowptr[lo]), int(rowptr[hi])
+        comm_dev = "cpu" if _backend(group) == "gloo" else device
+        plan = HaloPlan(rowptr[lo:hi + 1] - e0, np.asarray(col[e0:e1]), bounds, rank, world, comm_dev, group)
+        g = torch.Generator().manual_seed(seed)
+        b = 1.0 / np.sqrt(H)
+        P = lambda *s: torch.nn.Parameter(((torch.rand(*s, generator=g) * 2 - 1) * b).to(device))
+        masks = {n: P(2 * H, H) for n in names}
+        weight, bias = P(H, C), P(C)
+        mod = cls(plan, device, H, C, names, masks, weight, bias, dropout, edge_base=e0, chunk=chunk)
+        mod.n_total = len(rowptr) - 1
+        return mod
+
+    def _drop(self):
+        return self.drop_override if self.drop_override is not None else Fn.DropoutSpec(self.dropout)
+
+    def forward(self, x_own):
+        require_gpu(x_own)
+        H, K, n = self.H, len(self.names), self.plan.n_own
+        kinds = [Fn.KIND[_AGG[a][0]] for a in self.names]
+        acts = [Fn.ACT_RAW if (_AGG[a][1] and self.activation == "new_sigmoid") else Fn.ACT_SIGMOID for a in self.names]
+        ws = [self.masks[a] for a in self.names]
+        x_halo = _HaloExchange.apply(x_own, self.plan, self.send_idx)
+        x_src = torch.cat([x_own, x_halo], 0)
+        P = torch.mm(x_own, torch.cat([w[:H] for w in ws], 1))
+        Q = torch.mm(x_src, torch.cat([w[H:] for w in ws], 1))
+        m = Fn.nc_fused_aggregate(x_src, P, Q, self.graph, kinds, acts, self._drop())      # (K, n_own, H)
+        amp, att = scaler_factors(self.n_total or n, x_own.device)                          # Q1: identical rows
+        c3 = (1.0 + amp[:1] + att[:1])
+        # sum_k A (m_k W) == A ((sum_k m_k W)): only the (n,C) row sums travel and enter the SpMM
+        S = (torch.mm(m.reshape(K * n, H), self.weight).view(K, n, self.C) * c3).sum(0)
+        S_halo = _HaloExchange.apply(S, self.plan, self.send_idx)
+        return Fn.csr_spmm(torch.cat([S, S_halo], 0), self.bias, self.sg, 1)
+
+    def allreduce_grads(self):
+        for p in self.owned:
+            if p.grad is not None:
+                all_reduce_sum(p.grad, self.plan.group)

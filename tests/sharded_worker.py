@@ -1,0 +1,141 @@
+"""Worker for the multi-process tests (launched by torch.distributed.run with WORLD_SIZE ranks).
+
+  mode cpu : gloo, CPU only.  Checks the HaloPlan (index exchange), the all-to-all plumbing and the sharding algebra
+             by emulating the sharded layer with the CPU oracle as the compute (test infrastructure) and comparing
+             with the unsharded oracle, forward and backward.
+  mode gpu : gloo rendezvous, every rank computes on cuda:0 with the HIP kernels (halo buffers staged through the
+             host).  Checks mma_amd.sharded.ShardedMMA against the single-GPU mma_amd.MMA, forward and backward.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def graph(seed, N, avg):
+    rng = np.random.default_rng(seed)
+    deg = rng.poisson(avg, N) + 1
+    deg[N // 3] = 5 * N // 4            # a hub that needs rows from every rank
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = np.concatenate([np.sort(rng.choice(N, size=d, replace=d > N)) for d in deg]).astype(np.int64)
+    return rowptr, col
+
+
+def close(a, b, what, tol=1e-5):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    scale = max(b.abs().max().item(), 1e-30)
+    assert err <= tol * scale + 1e-6, "%s: err %.3g vs scale %.3g" % (what, err, scale)
+
+
+def run_cpu(rank, world):
+    from mma_amd.sharded import HaloPlan, all_to_all_rows, partition_bounds
+    from oracle import nc_oracle as O
+    N, H, C, names, act = 157, 12, 5, ["sum", "mean", "max", "min"], "new_sigmoid"
+    rowptr, col = graph(3, N, 4)
+    g = torch.Generator().manual_seed(0)
+    x = torch.relu(torch.randn(N, H, generator=g))
+    Ws, weight, bias = O.init_like_reference(H, C, names, 1)
+    cot = torch.randn(N, C, generator=g)
+    dst = np.repeat(np.arange(N), np.diff(rowptr))
+    # unsharded oracle
+    xf = x.clone().requires_grad_(True)
+    out_f = O.mma_forward(names, xf, Ws, weight, bias, rowptr, col, dst, col, np.ones(len(col), np.float32), act)
+    gx_f, = torch.autograd.grad((out_f * cot).sum(), [xf])
+
+    bounds = partition_bounds(rowptr, world)
+    assert bounds[0] == 0 and bounds[-1] == N and (np.diff(bounds) >= 0).all()
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    e0, e1 = int(rowptr[lo]), int(rowptr[hi])
+    plan = HaloPlan(rowptr[lo:hi + 1] - e0, col[e0:e1], bounds, rank, world, "cpu")
+    # (a) the plan delivers exactly the halo rows
+    x_own = x[lo:hi].clone().requires_grad_(True)
+    sidx = torch.from_numpy(plan.send_idx)
+
+    class Exchange(torch.autograd.Function):       # CPU stand-in for mma_amd.sharded._HaloExchange (pack = index_select)
+        @staticmethod
+        def forward(ctx, t):
+            ctx.n = t.shape[0]
+            return all_to_all_rows(t.index_select(0, sidx), plan.send_counts, plan.recv_counts)
+
+        @staticmethod
+        def backward(ctx, gr):
+            back = all_to_all_rows(gr.contiguous(), plan.recv_counts, plan.send_counts)
+            return torch.zeros(ctx.n, gr.shape[1]).index_add_(0, sidx, back)
+
+    x_halo = Exchange.apply(x_own)
+    assert torch.equal(x_halo, x[torch.from_numpy(plan.halo_ids)]), "halo rows differ"
+    # (b) the sharded layer algebra with the oracle as compute
+    x_src = torch.cat([x_own, x_halo], 0)
+    n = plan.n_own
+    rp_pad = np.concatenate([plan.rowptr, np.full(plan.n_halo, plan.rowptr[-1])])      # halo rows: degree 0
+    ms = [O.aggregate(a, x_src, Ws[a], rp_pad, plan.col, act)[:n] for a in names]
+    amp, att = O.scaler_factors(N)
+    S = sum((m @ weight) * (1.0 + amp[:1] + att[:1]) for m in ms)
+    S_src = torch.cat([S, Exchange.apply(S)], 0)
+    dl = np.repeat(np.arange(n), np.diff(plan.rowptr))
+    out = torch.zeros(n, C).index_add(0, torch.from_numpy(dl), S_src.index_select(0, torch.from_numpy(plan.col))) + bias
+    close(out, out_f[lo:hi], "sharded out (rank %d)" % rank)
+    gx, = torch.autograd.grad((out * cot[lo:hi]).sum(), [x_own])
+    close(gx, gx_f[lo:hi], "sharded gx (rank %d)" % rank)
+
+
+def run_gpu(rank, world):
+    import mma_amd
+    from mma_amd import functional as Fn
+    from mma_amd.layers import _MASK_NAMES
+    from mma_amd.sharded import ShardedMMA
+    dev = "cuda:0"
+    N, H, C, names, p = 400, 32, 6, ["sum", "mean", "max", "min"], 0.5
+    rowptr, col = graph(5, N, 5)
+    g = torch.Generator().manual_seed(0)
+    x = torch.relu(torch.randn(N, H, generator=g))
+    cot = torch.randn(N, C, generator=g)
+    sh = ShardedMMA.build(rowptr, col, rank, world, dev, H, C, names, p, seed=7, chunk=64)
+    seed = 0xABCDEF1234
+    sh.drop_override = Fn.DropoutSpec(p, seed=seed)
+    xo = x[sh.lo:sh.hi].to(dev).requires_grad_(True)
+    out = sh(xo)
+    out.backward(cot[sh.lo:sh.hi].to(dev))
+    sh.allreduce_grads()
+    # single-GPU layer with the same parameters
+    PP = lambda t: torch.nn.Parameter(t.detach().clone())
+    masks = {n_: PP(sh.masks[n_]) if n_ in names else torch.nn.Parameter(torch.zeros(2, 1, device=dev)) for n_ in _MASK_NAMES}
+    w, b = PP(sh.weight), PP(sh.bias)
+    add_all = [col[rowptr[i]:rowptr[i + 1]] for i in range(N)]
+    ref = mma_amd.MMA(add_all, "new_sigmoid", 2, H, C, w, b, *[masks[n_] for n_ in _MASK_NAMES], p, names, dev, chunk=64)
+    with torch.no_grad():
+        for n_ in names:
+            masks[n_].copy_(sh.masks[n_])
+        w.copy_(sh.weight); b.copy_(sh.bias)
+    ref.drop_override = Fn.DropoutSpec(p, seed=seed)
+    dst = np.repeat(np.arange(N), np.diff(rowptr))
+    adj = mma_amd.graph.SpmmGraph(dst, col, None, N, N, dev)
+    xf = x.to(dev).requires_grad_(True)
+    of = ref(xf, adj)
+    of.backward(cot.to(dev))
+    close(out, of[sh.lo:sh.hi], "out rank %d" % rank)
+    close(xo.grad, xf.grad[sh.lo:sh.hi], "gx rank %d" % rank)
+    close(sh.weight.grad, w.grad, "gweight")
+    close(sh.bias.grad, b.grad, "gbias")
+    for n_ in names:
+        close(sh.masks[n_].grad, masks[n_].grad, "gmask " + n_)
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    try:
+        (run_cpu if mode == "cpu" else run_gpu)(rank, world)
+        dist.barrier()
+        if rank == 0:
+            print("SHARDED_%s_OK world=%d" % (mode.upper(), world), flush=True)
+    finally:
+        dist.destroy_process_group()

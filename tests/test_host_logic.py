@@ -34,8 +34,8 @@ def test_library_exports_every_declared_symbol():
 def test_argument_checks_run_on_host_without_gpu():
     # a bad shape must be refused before any launch (works with no GPU present)
     with pytest.raises(_lib.MMALibraryError, match="K="):
-        _lib.call("mma_nc_fused_fwd", None, 4, None, None, 4, None, None, None, 0, None, 0, None, 0, None, None, None, 4,
-                  10, 10, 4, 99, None, None, 0, 0, 0, None, None)
+        _lib.call("mma_nc_fused_fwd", None, 4, None, 4, None, 4, None, None, None, 0, None, 0, None, 0, None, None, None, 4,
+                  10, 10, 4, 99, None, None, 0, 0, 0, 0, None, None)
     with pytest.raises(_lib.MMALibraryError, match="pitch"):
         _lib.call("mma_csr_spmm", None, None, None, None, 2, 5, 1, None, None, 2, 5, 4, None)
 
@@ -45,7 +45,7 @@ def test_cpu_tensors_are_refused():
     from mma_amd import functional as Fn
     x = torch.zeros(4, 4)
     with pytest.raises(_lib.MMALibraryError, match="GPU only"):
-        Fn.nc_fused_aggregate(x, torch.zeros(4, 8), None, [0], [0])
+        Fn.nc_fused_aggregate(x, torch.zeros(4, 4), torch.zeros(4, 4), None, [0], [0])
 
 
 def test_make_items_chunks_and_hubs():

@@ -144,9 +144,9 @@ def test_random_graph_vs_oracle(cfg):
     Wg = {n: Ws[n].to(DEV).requires_grad_(True) for n in names}
     kinds = [Fn.KIND[O.AGGREGATORS[n][0]] for n in names]
     acts = [Fn.ACT_RAW if O.uses_raw_logits(n, act) else Fn.ACT_SIGMOID for n in names]
-    wcat = torch.cat([Wg[n][:H] for n in names] + [Wg[n][H:] for n in names], 1)
-    PQ = xg @ wcat
-    mg = Fn.nc_fused_aggregate(xg, PQ, graph, kinds, acts, Fn.DropoutSpec(p, seed=seed))
+    P = xg @ torch.cat([Wg[n][:H] for n in names], 1)
+    Q = xg @ torch.cat([Wg[n][H:] for n in names], 1)
+    mg = Fn.nc_fused_aggregate(xg, P, Q, graph, kinds, acts, Fn.DropoutSpec(p, seed=seed))
     gg = torch.autograd.grad((mg * cot.to(DEV)).sum(), [xg] + [Wg[n] for n in names])
 
     rows = np.arange(N)
@@ -159,12 +159,12 @@ def test_random_graph_vs_oracle(cfg):
     # explicit-mask mode must agree bit-for-bit with hash mode given the same bits
     if p > 0:
         with torch.no_grad():
-            me = Fn.nc_fused_aggregate(xg.detach(), PQ.detach(), graph, kinds, acts,
+            me = Fn.nc_fused_aggregate(xg.detach(), P.detach(), Q.detach(), graph, kinds, acts,
                                        Fn.DropoutSpec(thr / 256.0, keep=torch.from_numpy(keep).to(DEV)))
         assert torch.equal(me, mg.detach()), "hash-mode and explicit-mode dropout disagree"
     # determinism: no atomics anywhere, a second run is bitwise identical
     with torch.no_grad():
-        m2 = Fn.nc_fused_aggregate(xg.detach(), PQ.detach(), graph, kinds, acts, Fn.DropoutSpec(p, seed=seed))
+        m2 = Fn.nc_fused_aggregate(xg.detach(), P.detach(), Q.detach(), graph, kinds, acts, Fn.DropoutSpec(p, seed=seed))
     assert torch.equal(m2, mg.detach())
 
 
@@ -176,10 +176,11 @@ def test_selection_codes_bit_exact_on_ties():
     rowptr, col = np.array([0, 1, 1, 1]), np.array([1])
     H = 4
     x = torch.tensor([[1., 2., 3., 4.], [1., 5., 3., 0.], [0., 0., 0., 0.]], device=DEV)
-    PQ = torch.full((3, 2 * 2 * H), 0.5, device=DEV)
+    P = torch.full((3, 2 * H), 0.5, device=DEV)
+    Q = torch.full((3, 2 * H), 0.5, device=DEV)
     graph = mma_amd.NCGraph(rowptr, col, DEV)
     xg = x.clone().requires_grad_(True)
-    m = Fn.nc_fused_aggregate(xg, PQ, graph, [Fn.KIND["max"], Fn.KIND["min"]], [Fn.ACT_RAW, Fn.ACT_RAW])
+    m = Fn.nc_fused_aggregate(xg, P, Q, graph, [Fn.KIND["max"], Fn.KIND["min"]], [Fn.ACT_RAW, Fn.ACT_RAW])
     assert torch.equal(m[0, 0], torch.tensor([1., 5., 3., 4.], device=DEV))
     assert torch.equal(m[1, 0], torch.tensor([1., 2., 3., 0.], device=DEV))
     g = torch.zeros_like(m); g[:, 0] = 1.0
