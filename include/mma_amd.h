@@ -124,7 +124,46 @@ int mma_pack_rows(const float* src, int64_t lds, const int32_t* idx, int64_t n_i
 int mma_unpack_add_rows(const float* src, int64_t lds, const int32_t* idx, int64_t n_idx,
                         float* dst, int64_t ldd, int32_t width, void* stream);
 
-/* ---- K3/K4: graph-regression multi-aggregator scatter-reduce (declared in the GR section below) -- */
+/* ---- K6: CSR by key, built on the device (graph-regression batches change every call) ----------------
+ * Stable radix sort (rocPRIM) of edge positions by key[e] (int64 node ids as PyG's edge_index holds them):
+ *   rowptr (N+1), perm (E) = original edge positions grouped by key, ascending inside a group (so min/max ties
+ *   resolve to the lowest edge position, like torch_scatter), other_sorted[p] = other[perm[p]] (may be NULL).
+ * Replaces the implicit grouping inside torch_scatter.scatter / PyG propagate (mma_conv.py:130,166). */
+int64_t mma_csr_workspace_bytes(int64_t E, int64_t N);
+int mma_build_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N,
+                  int32_t* rowptr, int32_t* perm, int32_t* other_sorted,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/* aggregator / scaler codes of the graph-regression path (mma_conv.py:164-172, 181-194) */
+enum { MMA_GR_SUM = 0, MMA_GR_MEAN = 1, MMA_GR_MIN = 2, MMA_GR_MAX = 3, MMA_GR_VAR = 4, MMA_GR_STD = 5 };
+enum { MMA_SC_IDENTITY = 0, MMA_SC_AMPLIFICATION = 1, MMA_SC_ATTENUATION = 2, MMA_SC_LINEAR = 3, MMA_SC_INVERSE_LINEAR = 4 };
+
+/* ---- K3: fused message + K-aggregator scatter-reduce + degree scalers, graph-regression form --------
+ * One pass over each target's edge segment replaces MMAConv.message + MMAConv.aggregate
+ * (mma_conv.py:138-196: cat, per-tower Linear, dropout, K x torch_scatter.scatter, degree, compounding scalers, cat):
+ *   h_e = drop(U[i] + V[j] + Z[e])      with i = target, j = src[p], e = perm[p]   (fused-message mode), or
+ *   h_e = inputs[e]                                                                (given-messages mode = aggregate())
+ *   out[n, t, s*K*F + k*F + f] = aggr_k over {h_e[t*F+f] : target(e) = n}, times the running product of scalers 0..s.
+ * U,V: (N,T*F) with U = x @ W_i^T + b, V = x @ W_j^T; Z: (E,T*F) = enc(edge_attr) @ W_e^T or NULL.
+ * Saved for backward when non-NULL: amin/amax (N,T*F) original edge position of the extremum (-1: empty target,
+ * ties -> lowest position), mean/var (N,T*F). */
+int mma_gr_fused_fwd(
+    const int32_t* rowptr, const int32_t* src, const int32_t* perm,
+    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
+    float* out, int32_t* amin, int32_t* amax, float* mean, float* var,
+    int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
+    float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, void* stream);
+
+/* ---- K4: backward of K3 w.r.t. every edge message: gmsg[e, :] (E,T*F) by original edge position ------
+ * min/max route the gradient to the saved arg edge only (torch_scatter), mean divides by the count, var/std use the
+ * saved mean/var; in fused-message mode the dropout factor of the edge is applied, so gmsg = dL/d(U[i]+V[j]+Z[e]). */
+int mma_gr_fused_bwd(
+    const int32_t* rowptr, const int32_t* src, const int32_t* perm,
+    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
+    const float* gout, const int32_t* amin, const int32_t* amax, const float* mean, const float* var,
+    float* gmsg, int64_t ldg,
+    int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
+    float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, void* stream);
 
 #ifdef __cplusplus
 }

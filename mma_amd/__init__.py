@@ -8,5 +8,7 @@ from . import _lib  # noqa: F401
 from .graph import NCGraph  # noqa: F401
 from .functional import nc_fused_aggregate, csr_spmm  # noqa: F401
 from .layers import MMA, GraphConvolution  # noqa: F401
+from .mask_aggr import MaskAggregateLinear  # noqa: F401
+from .mma_conv import MMAConv  # noqa: F401
 
-__all__ = ["MMA", "GraphConvolution", "NCGraph", "nc_fused_aggregate", "csr_spmm"]
+__all__ = ["MMA", "GraphConvolution", "MMAConv", "MaskAggregateLinear", "NCGraph", "nc_fused_aggregate", "csr_spmm"]

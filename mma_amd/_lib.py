@@ -19,6 +19,11 @@ PROTOTYPES = {
     "mma_nc_fused_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _I64,
                          _P, _I64, _P, _I64, _I64, _I64, _I32, _I32, _P, _I32, _U32, _U64, _I64, _P, _P],
     "mma_csr_spmm": [_P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _I64, _I64, _I32, _P],
+    "mma_build_csr": [_P, _P, _I64, _I64, _P, _P, _P, _P, _I64, _P],
+    "mma_gr_fused_fwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P,
+                         _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P],
+    "mma_gr_fused_bwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64,
+                         _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P],
     "mma_pack_rows": [_P, _I64, _P, _I64, _P, _I64, _I32, _P],
     "mma_unpack_add_rows": [_P, _I64, _P, _I64, _P, _I64, _I32, _P],
 }
@@ -43,6 +48,7 @@ def lib():
         L.mma_last_error.restype = _c.c_char_p
         if L.mma_abi_version() != ABI_VERSION:
             raise MMALibraryError("mma_amd: %s has ABI %d, expected %d: rebuild" % (LIB_PATH, L.mma_abi_version(), ABI_VERSION))
+        L.mma_csr_workspace_bytes.argtypes, L.mma_csr_workspace_bytes.restype = [_I64, _I64], _I64
         for name, args in PROTOTYPES.items():
             fn = getattr(L, name)  # AttributeError if a declared symbol is missing
             fn.argtypes, fn.restype = args, _I32

@@ -164,3 +164,127 @@ class _CsrSpmm(torch.autograd.Function):
 
 def csr_spmm(B, bias, sg, K=1):
     return _CsrSpmm.apply(B, bias, sg, K)
+
+
+# ---- graph-regression path (K3/K4/K6) ----------------------------------------------------------------------
+GR_AGGR = {"sum": 0, "mean": 1, "min": 2, "max": 3, "var": 4, "std": 5}
+GR_SCALER = {"identity": 0, "amplification": 1, "attenuation": 2, "linear": 3, "inverse_linear": 4}
+_csr_ws = {}
+
+
+class DeviceCSR:
+    """Edges grouped by `key` (stable): rowptr (N+1), perm (E) original positions, other (E) = other[perm]."""
+
+    def __init__(self, key, other, N):
+        require_gpu(key)
+        E = key.numel()
+        dev = key.device
+        key = key.contiguous()
+        assert key.dtype == torch.int64 and (other is None or (other.dtype == torch.int64 and other.numel() == E))
+        self.N, self.E = int(N), int(E)
+        self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        self.perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        self.other = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if other is not None else self.perm
+        nbytes = _lib.lib().mma_csr_workspace_bytes(E, N)
+        if nbytes < 0:
+            raise _lib.MMALibraryError("graph too large for int32 CSR: E=%d N=%d" % (E, N))
+        ws = _csr_ws.get(dev)
+        if ws is None or ws.numel() < nbytes:
+            ws = _csr_ws[dev] = torch.empty(int(nbytes * 1.5) + 1024, dtype=torch.uint8, device=dev)
+        with _span("csr_build"):
+            call("mma_build_csr", ptr(key), ptr(other.contiguous()) if other is not None else None, E, N, ptr(self.rowptr),
+                 ptr(self.perm), ptr(self.other) if other is not None else None, ptr(ws), ws.numel(), stream_ptr())
+
+
+class GRGraph:
+    """Both groupings of one edge_index (by target for the forward, by source for dV), built lazily, cached per
+    edge_index tensor by the caller."""
+
+    def __init__(self, edge_index, N):
+        self.edge_index, self.N, self.E = edge_index, int(N), int(edge_index.shape[1])
+        self.by_target = DeviceCSR(edge_index[1], edge_index[0], N)
+        self._by_source = None
+
+    @property
+    def by_source(self):
+        if self._by_source is None:
+            self._by_source = DeviceCSR(self.edge_index[0], None, self.N)
+        return self._by_source
+
+
+def _gr_call(fn, csr, U, V, Z, inputs, extra, N, E, T, F, aggr, scalers, avg_log, avg_lin, drop):
+    D = T * F
+    lduv = U.stride(0) if U is not None else 0
+    call(fn, ptr(csr.rowptr), ptr(csr.other), ptr(csr.perm), ptr(U), ptr(V), lduv, ptr(Z), Z.stride(0) if Z is not None else 0,
+         ptr(inputs), D if inputs is not None else 0, *extra, N, E, T, F, host_codes(aggr), len(aggr), host_codes(scalers),
+         len(scalers), float(avg_log), float(avg_lin), drop.mode, drop.thr, drop.seed, stream_ptr())
+
+
+class _GRAggregate(torch.autograd.Function):
+    """K aggregators + compounding degree scalers over target segments (mma_conv.py:159-196), messages either given
+    (`inputs`, the public aggregate() API) or formed in-kernel as drop(U[i] + V[j] + Z[e]) (fused forward)."""
+
+    @staticmethod
+    def forward(ctx, inputs, U, V, Z, graph, T, F, aggr, scalers, avg_log, avg_lin, drop):
+        fused = inputs is None
+        csr = graph.by_target
+        N, E, D = graph.N, graph.E, T * F
+        K, S = len(aggr), len(scalers)
+        ref = U if fused else inputs
+        require_gpu(ref)
+        dev = ref.device
+        if fused:
+            U, V = U.contiguous(), V.contiguous()
+            Z = Z.contiguous() if Z is not None else None
+            assert U.shape == (N, D) and V.shape == (N, D) and (Z is None or Z.shape == (E, D))
+        else:
+            inputs = inputs.contiguous()
+            assert inputs.shape == (E, T, F)
+        out = torch.empty((N, T, S * K * F), device=dev, dtype=torch.float32)
+        need = any(ctx.needs_input_grad[:4])
+        amin = torch.empty((N, D), dtype=torch.int32, device=dev) if need and 2 in aggr else None
+        amax = torch.empty((N, D), dtype=torch.int32, device=dev) if need and 3 in aggr else None
+        stats = need and (4 in aggr or 5 in aggr)
+        mean = torch.empty((N, D), device=dev) if stats else None
+        var = torch.empty((N, D), device=dev) if stats else None
+        with _span("gr_fused_fwd"):
+            _gr_call("mma_gr_fused_fwd", csr, U, V, Z, inputs, (ptr(out), ptr(amin), ptr(amax), ptr(mean), ptr(var)),
+                     N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
+        ctx.cfg = (graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, Z is not None)
+        ctx.save_for_backward(inputs, U, V, Z, amin, amax, mean, var)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, has_z = ctx.cfg
+        inputs, U, V, Z, amin, amax, mean, var = ctx.saved_tensors
+        csr = graph.by_target
+        N, E, D = graph.N, graph.E, T * F
+        gout = gout.contiguous()
+        gmsg = torch.empty((E, D), device=gout.device, dtype=torch.float32)
+        with _span("gr_fused_bwd"):
+            _gr_call("mma_gr_fused_bwd", csr, U, V, Z, inputs, (ptr(gout), ptr(amin), ptr(amax), ptr(mean), ptr(var), ptr(gmsg), D),
+                     N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
+        if not fused:
+            return (gmsg.view(E, T, F),) + (None,) * 11
+        # dU[i] = sum of its target segment, dV[j] = sum over the edges leaving j: two segment sums (K5 kernel)
+        gU = torch.empty((N, D), device=gout.device, dtype=torch.float32)
+        gV = torch.empty((N, D), device=gout.device, dtype=torch.float32)
+        cs = graph.by_source
+        with _span("gr_segsum"):
+            call("mma_csr_spmm", ptr(csr.rowptr), ptr(csr.perm), None, ptr(gmsg), D, E, 1, None, ptr(gU), D, N, D, stream_ptr())
+            call("mma_csr_spmm", ptr(cs.rowptr), ptr(cs.perm), None, ptr(gmsg), D, E, 1, None, ptr(gV), D, N, D, stream_ptr())
+        return (None, gU, gV, gmsg if has_z else None) + (None,) * 8
+
+
+def gr_aggregate(inputs, graph, aggregators, scalers, avg_log, avg_lin):
+    """aggregate() on given messages (E,T,F) -> (N,T,S*K*F)."""
+    E, T, F = inputs.shape
+    return _GRAggregate.apply(inputs, None, None, None, graph, T, F, tuple(GR_AGGR[a] for a in aggregators),
+                              tuple(GR_SCALER[s] for s in scalers), avg_log, avg_lin, DropoutSpec(0.0))
+
+
+def gr_fused_conv(U, V, Z, graph, T, F, aggregators, scalers, avg_log, avg_lin, drop):
+    """message + aggregate fused: messages drop(U[i] + V[j] + Z[e]) never materialise."""
+    return _GRAggregate.apply(None, U, V, Z, graph, T, F, tuple(GR_AGGR[a] for a in aggregators),
+                              tuple(GR_SCALER[s] for s in scalers), avg_log, avg_lin, drop)

@@ -1,0 +1,198 @@
+"""Drop-in `MMAConv` (reference graph_regression/mma_conv.py:20-201, a PNAConv fork on PyG MessagePassing).
+
+Same constructor, `forward(x, edge_index, edge_attr=None)`, `message`, `aggregate(inputs, index, dim_size=None)`,
+public `dropout` attribute and error behaviour, without torch_geometric / torch_scatter.  forward() runs the fused
+HIP path: three dense GEMMs (U = x W_i^T + b, V = x W_j^T, Z = enc(e) W_e^T) and ONE kernel that forms the per-edge
+message, applies the always-on dropout and reduces all K aggregators with their degree scalers (K3); `aggregate()`
+on given messages uses the same kernel.  Reference quirks kept:
+  G1  only the LAST aggregator's pre_nns is applied; all K aggregators reduce the same message;
+  G2  pre_nns is a plain dict of ModuleLists => mask Linears are unregistered (not in parameters()/state_dict);
+  G3  reset_parameters() iterates dict keys => no-op for pre_nns;   G4  dropout p=0.5 hard-coded, always on;
+  G5  the whole aggregator string goes to scatter => only sum|mean|min|max are valid through forward();
+  G6  var/std reachable only through aggregate();   G7  scalers compound;   G8  avg_deg from the histogram values;
+  G11 x replicated across towers (shared GEMM);   G13 deg.clamp_(1), empty targets give 0.
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+from torch.nn import ModuleList, ReLU, Sequential
+
+from . import functional as Fn
+from ._lib import require_gpu
+from .mask_aggr import MaskAggregateLinear
+from .pyg_compat import Linear, reset
+
+_SCATTER_REDUCE = ("sum", "mean", "min", "max")
+
+
+class MMAConv(torch.nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, aggregators: List[str], scalers: List[str], deg: Tensor,
+                 edge_dim: Optional[int] = None, towers: int = 1, pre_layers: int = 1, post_layers: int = 1,
+                 mask: bool = True, divide_input: bool = False, **kwargs):
+        kwargs.setdefault('aggr', None)      # accepted for signature compatibility with MessagePassing(node_dim=0, **kwargs)
+        super().__init__()
+        if divide_input:
+            assert in_channels % towers == 0
+        assert out_channels % towers == 0
+
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.aggregators = aggregators
+        self.scalers = scalers
+        self.edge_dim = edge_dim
+        self.towers = towers
+        self.divide_input = divide_input
+        self.dropout = 0.5
+        self.mask = mask
+        self.pre_layers, self.post_layers = pre_layers, post_layers
+
+        self.F_in = in_channels // towers if divide_input else in_channels
+        self.F_out = self.out_channels // towers
+
+        deg = deg.to(torch.float)
+        self.avg_deg: Dict[str, float] = {
+            'lin': deg.mean().item(),
+            'log': (deg + 1).log().mean().item(),
+            'exp': deg.exp().mean().item(),
+        }
+
+        if self.edge_dim is not None:
+            self.edge_encoder = Linear(edge_dim, self.F_in)
+
+        self.pre_nns = {}
+        for i, aggr in enumerate(aggregators):
+            self.pre_nns[aggr] = ModuleList()
+
+        self.post_nns = ModuleList()
+        for _ in range(towers):
+            for aggr in aggregators:
+                modules = [MaskAggregateLinear((3 if edge_dim else 2) * self.F_in, self.F_in, aggregators, aggr, mask=self.mask)]
+                for _ in range(pre_layers - 1):
+                    modules += [ReLU()]
+                    modules += [MaskAggregateLinear(self.F_in, self.F_in, aggregators, aggr, mask=self.mask)]
+                self.pre_nns[aggr].append(Sequential(*modules))
+            in_channels = (len(aggregators) * len(scalers) + 1) * self.F_in
+            modules = [Linear(in_channels, self.F_out)]
+            for _ in range(post_layers - 1):
+                modules += [ReLU()]
+                modules += [Linear(self.F_out, self.F_out)]
+            self.post_nns.append(Sequential(*modules))
+
+        self.lin = Linear(out_channels, out_channels)
+        self.reset_parameters()
+
+        self._graph_cache = None      # (edge_index tensor, version, N) -> GRGraph
+        self.drop_override = None     # tests: a functional.DropoutSpec with a fixed seed
+
+    def reset_parameters(self):
+        if self.edge_dim is not None:
+            self.edge_encoder.reset_parameters()
+        for aggr in self.pre_nns:       # iterates the KEYS (strings): a no-op, as in the reference (G3)
+            for nn in aggr:
+                reset(nn)
+        for nn in self.post_nns:
+            reset(nn)
+        self.lin.reset_parameters()
+
+    # ---- graph plan ---------------------------------------------------------------------------------------
+    def _graph(self, edge_index, N):
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), N)
+        if self._graph_cache is None or self._graph_cache[0] != key:
+            self._graph_cache = (key, Fn.GRGraph(edge_index, N))
+        return self._graph_cache[1]
+
+    def _check_aggregators(self):
+        for aggregator in self.aggregators:
+            if not aggregator.startswith(('sum', 'mean', 'min', 'max')):
+                raise ValueError(f'Unknown aggregator "{aggregator}".')        # mma_conv.py:153-154
+            if aggregator not in _SCATTER_REDUCE:                               # torch_scatter rejects e.g. "sum2" (G5)
+                raise ValueError(f'Unknown aggregator "{aggregator}".')
+
+    def _fusable(self):
+        return self.pre_layers == 1 and self.mask != "no_linear"
+
+    def _drop(self):
+        return self.drop_override if self.drop_override is not None else Fn.DropoutSpec(self.dropout)
+
+    # ---- forward ------------------------------------------------------------------------------------------
+    def forward(self, x: Tensor, edge_index, edge_attr: Optional[Tensor] = None) -> Tensor:
+        require_gpu(x)
+        T, Fi = self.towers, self.F_in
+        if self.divide_input:
+            x = x.view(-1, T, Fi)
+        else:
+            x = x.view(-1, 1, Fi).repeat(1, T, 1)
+        N = x.shape[0]
+        graph = self._graph(edge_index, N)
+        if self._fusable():
+            self._check_aggregators()
+            last = self.aggregators[-1]                                         # G1
+            lins = [seq[0].active_linear() for seq in self.pre_nns[last]]       # T Linears (F_in, 3F|2F)
+            Wi = torch.stack([l.weight[:, :Fi] for l in lins])                  # (T, F, F_in)
+            Wj = torch.stack([l.weight[:, Fi:2 * Fi] for l in lins])
+            b = torch.stack([l.bias for l in lins]).reshape(1, T * Fi) if lins[0].bias is not None else None
+            if self.divide_input:
+                U = torch.einsum('ntf,tgf->ntg', x, Wi).reshape(N, T * Fi)
+                V = torch.einsum('ntf,tgf->ntg', x, Wj).reshape(N, T * Fi)
+            else:                                                               # G11: towers share x -> one GEMM each
+                x0 = x[:, 0]
+                U = x0 @ Wi.reshape(T * Fi, Fi).t()
+                V = x0 @ Wj.reshape(T * Fi, Fi).t()
+            if b is not None:
+                U = U + b
+            Z = None
+            if edge_attr is not None:
+                We = torch.stack([l.weight[:, 2 * Fi:] for l in lins])
+                Z = self.edge_encoder(edge_attr) @ We.reshape(T * Fi, Fi).t()   # (E, T*F)
+            out = Fn.gr_fused_conv(U, V, Z, graph, T, Fi, self.aggregators, self.scalers,
+                                   self.avg_deg['log'], self.avg_deg['lin'], self._drop())
+        else:
+            src, dst = edge_index[0], edge_index[1]
+            hs = self.message(x.index_select(0, dst), x.index_select(0, src), edge_attr)
+            out = self.aggregate(hs, dst, N, _graph=graph)
+
+        out = torch.cat([x, out], dim=-1)
+        outs = [nn(out[:, i]) for i, nn in enumerate(self.post_nns)]
+        out = torch.cat(outs, dim=1)
+        return self.lin(out)
+
+    def message(self, x_i: Tensor, x_j: Tensor, edge_attr: Optional[Tensor]) -> Tensor:
+        """mma_conv.py:138-157 with dense torch ops (only used when the fused path does not apply)."""
+        h: Tensor = x_i
+        if edge_attr is not None:
+            edge_attr = self.edge_encoder(edge_attr)
+            edge_attr = edge_attr.view(-1, 1, self.F_in)
+            edge_attr = edge_attr.repeat(1, self.towers, 1)
+            h = torch.cat([x_i, x_j, edge_attr], dim=-1)
+        else:
+            h = torch.cat([x_i, x_j], dim=-1)
+        for aggregator in self.aggregators:
+            if aggregator.startswith(('sum', 'mean', 'min', 'max')):
+                hs = [nn(h[:, i]) for i, nn in enumerate(self.pre_nns[aggregator])]
+            else:
+                raise ValueError(f'Unknown aggregator "{aggregator}".')
+        hs = torch.stack(hs, dim=1)
+        return F.dropout(hs, self.dropout)
+
+    def aggregate(self, inputs: Tensor, index: Tensor, dim_size: Optional[int] = None, _graph=None) -> Tensor:
+        """mma_conv.py:159-196 on given messages (E,T,F): the HIP kernel in given-messages mode."""
+        require_gpu(inputs)
+        for aggregator in self.aggregators:
+            if not (aggregator in _SCATTER_REDUCE or aggregator in ('var', 'std')):
+                raise ValueError(f'Unknown aggregator "{aggregator}".')
+        for scaler in self.scalers:
+            if scaler not in Fn.GR_SCALER:
+                raise ValueError(f'Unknown scaler "{scaler}".')
+        if dim_size is None:
+            dim_size = int(index.max()) + 1 if index.numel() else 0
+        graph = _graph
+        if graph is None:
+            ei = torch.stack([index, index])        # sources are not needed for given messages
+            graph = Fn.GRGraph(ei, dim_size)
+        return Fn.gr_aggregate(inputs, graph, self.aggregators, self.scalers, self.avg_deg['log'], self.avg_deg['lin'])
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}({self.in_channels}, {self.out_channels}, towers={self.towers}, '
+                f'edge_dim={self.edge_dim})')

@@ -1,0 +1,122 @@
+"""CPU oracle for the graph-regression (GR) MMA hot path.  TEST INFRASTRUCTURE ONLY (see oracle/nc_oracle.py).
+
+PARITY UNPINNED: the GR reference (graph_regression/mma_conv.py, mask_aggr.py) cannot be imported here -
+`torch_geometric` and `torch_scatter` are not installed, there is no network, and the reference pins no versions
+(README.md:36-38: "PyTorch 1.9, CUDA 11.1" => torch-scatter 2.0.7-2.0.9, torch-geometric 2.0.x) and ships no tests
+or golden vectors for this path.  This file therefore restates mma_conv.py:121-196 and mask_aggr.py:53-68 line by
+line on top of the PUBLISHED semantics of the third-party calls at the reference's own call sites:
+
+  torch_scatter.scatter(src, index, 0, None, dim_size, reduce)   mma_conv.py:166,168,169
+      output zero-initialised; sum; mean = sum / clamp(count, 1); min/max of an EMPTY target = 0;
+      arg of min/max = the FIRST (lowest edge position) extremal edge (CPU kernel: strict </> sequential update);
+      backward of min/max routes the gradient to the arg edge only (gather), never split among ties.
+  MessagePassing.propagate (flow source_to_target)                 mma_conv.py:130
+      x_j = x[edge_index[0]], x_i = x[edge_index[1]], index = edge_index[1], dim_size = N.
+  torch_geometric.nn.dense.linear.Linear                           mma_conv.py:82,99-105, mask_aggr.py:50
+      y = x @ W.T + b with W (out,in).
+  torch_geometric.utils.degree(index, N)                           mma_conv.py:178   = scatter_add of ones.
+
+It is anchored by hand-computed known-answer tests (tests/test_gr_oracle.py): ties -> lowest edge id, empty target -> 0,
+compounding scalers, avg_deg from the histogram tensor itself, only the LAST aggregator's pre-Linear applied.
+"""
+import math
+
+import torch
+
+
+def scatter(src, index, dim_size, reduce):
+    """torch_scatter.scatter(src, index, dim=0, dim_size=dim_size, reduce=reduce) for src (E, ...)."""
+    E = src.shape[0]
+    feat = src.shape[1:]
+    idx = index.view(-1, *([1] * len(feat))).expand_as(src)
+    out = torch.zeros((dim_size,) + tuple(feat), dtype=src.dtype)
+    if reduce in ("sum", "add"):
+        return out.index_add(0, index, src)
+    cnt = torch.zeros(dim_size, dtype=src.dtype).index_add(0, index, torch.ones(E, dtype=src.dtype))
+    if reduce == "mean":
+        s = out.index_add(0, index, src)
+        return s / cnt.clamp(min=1).view(-1, *([1] * len(feat)))
+    if reduce in ("min", "max"):
+        red = "amin" if reduce == "min" else "amax"
+        ext = torch.zeros_like(out).scatter_reduce(0, idx, src.detach(), red, include_self=False)
+        pos = torch.arange(E).view(-1, *([1] * len(feat))).expand_as(src)
+        is_ext = src.detach() == ext.gather(0, idx)
+        big = torch.full_like(pos, E)
+        arg = torch.full(out.shape, E, dtype=torch.int64).scatter_reduce(0, idx, torch.where(is_ext, pos, big), "amin",
+                                                                       include_self=True)
+        has = arg < E
+        val = src.gather(0, arg.clamp(max=max(E - 1, 0))) if E > 0 else out      # gradient flows to the arg edge only
+        return torch.where(has, val, torch.zeros_like(out))
+    raise ValueError(reduce)
+
+
+def aggregate(inputs, index, dim_size, aggregators, scalers, avg_deg):
+    """MMAConv.aggregate (mma_conv.py:159-196): inputs (E,T,F) -> (N,T,S*K*F)."""
+    outs = []
+    for aggregator in aggregators:
+        if aggregator.startswith(("sum", "mean", "min", "max")):
+            out = scatter(inputs, index, dim_size, aggregator)      # the WHOLE name is passed (G5): sum|mean|min|max only
+        elif aggregator in ("var", "std"):
+            mean = scatter(inputs, index, dim_size, "mean")
+            mean_squares = scatter(inputs * inputs, index, dim_size, "mean")
+            out = mean_squares - mean * mean
+            if aggregator == "std":
+                out = torch.sqrt(torch.relu(out) + 1e-5)
+        else:
+            raise ValueError('Unknown aggregator "%s".' % aggregator)
+        outs.append(out)
+    out = torch.cat(outs, dim=-1)
+    deg = torch.zeros(dim_size, dtype=inputs.dtype).index_add(0, index, torch.ones(len(index), dtype=inputs.dtype))
+    deg = deg.clamp_(1).view(-1, 1, 1)
+    outs = []
+    for scaler in scalers:                                             # compounding (G7): out = out * ...
+        if scaler == "identity":
+            pass
+        elif scaler == "amplification":
+            out = out * (torch.log(deg + 1) / avg_deg["log"])
+        elif scaler == "attenuation":
+            out = out * (avg_deg["log"] / torch.log(deg + 1))
+        elif scaler == "linear":
+            out = out * (deg / avg_deg["lin"])
+        elif scaler == "inverse_linear":
+            out = out * (avg_deg["lin"] / deg)
+        else:
+            raise ValueError('Unknown scaler "%s".' % scaler)
+        outs.append(out)
+    return torch.cat(outs, dim=-1)
+
+
+def avg_deg_from_histogram(deg_hist):
+    """mma_conv.py:73-78 (G8): statistics of the histogram tensor's own values."""
+    d = deg_hist.to(torch.float)
+    return {"lin": d.mean().item(), "log": (d + 1).log().mean().item(), "exp": d.exp().mean().item()}
+
+
+def message(x_i, x_j, edge_attr, enc_w, enc_b, pre_w, pre_b, towers, keep=None, p=0.5):
+    """MMAConv.message (mma_conv.py:138-157) for pre_layers == 1.
+    pre_w/pre_b: per tower (F, 3F|2F)/(F,) of the LAST aggregator (G1).  keep: (E,T,F) {0,1} or None (p treated as 0)."""
+    if edge_attr is not None:
+        e = edge_attr @ enc_w.t() + enc_b
+        e = e.view(-1, 1, e.shape[-1]).repeat(1, towers, 1)
+        h = torch.cat([x_i, x_j, e], dim=-1)
+    else:
+        h = torch.cat([x_i, x_j], dim=-1)
+    hs = torch.stack([h[:, t] @ pre_w[t].t() + pre_b[t] for t in range(towers)], dim=1)
+    if keep is not None:
+        hs = hs * keep / (1.0 - p)                                     # F.dropout(hs, 0.5), training=True always (G4)
+    return hs
+
+
+def conv_forward(x, edge_index, edge_attr, prm, aggregators, scalers, avg_deg, towers, divide_input=False, keep=None, p=0.5):
+    """MMAConv.forward (mma_conv.py:121-136) for pre_layers == post_layers == 1.
+    prm: dict with enc_w, enc_b, pre_w[t], pre_b[t], post_w[t], post_b[t], lin_w, lin_b."""
+    N = x.shape[0]
+    F_in = x.shape[1] // towers if divide_input else x.shape[1]
+    xt = x.view(-1, towers, F_in) if divide_input else x.view(-1, 1, F_in).repeat(1, towers, 1)
+    src, dst = edge_index[0], edge_index[1]
+    hs = message(xt[dst], xt[src], edge_attr, prm.get("enc_w"), prm.get("enc_b"), prm["pre_w"], prm["pre_b"], towers, keep, p)
+    out = aggregate(hs, dst, N, aggregators, scalers, avg_deg)
+    out = torch.cat([xt, out], dim=-1)
+    outs = [out[:, t] @ prm["post_w"][t].t() + prm["post_b"][t] for t in range(towers)]
+    out = torch.cat(outs, dim=1)
+    return out @ prm["lin_w"].t() + prm["lin_b"]

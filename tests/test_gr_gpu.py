@@ -1,0 +1,206 @@
+"""GPU parity tests for the graph-regression hot path (K3/K4/K6 through the C ABI and the drop-in MMAConv /
+MaskAggregateLinear modules) against the CPU oracle (oracle/gr_oracle.py; parity unpinned - see its header) and the
+hand-computed known answers: ties -> lowest edge position (bit-exact arg), empty target -> 0, compounding scalers."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import check_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_csr_build_is_stable_sort():
+    from mma_amd import functional as Fn
+    rng = np.random.default_rng(0)
+    for E, N in ((0, 5), (1, 1), (1000, 37), (50000, 20000)):
+        key = rng.integers(0, N, E)
+        other = rng.integers(0, N, E)
+        csr = Fn.DeviceCSR(torch.from_numpy(key).to(DEV), torch.from_numpy(other).to(DEV), N)
+        perm = np.argsort(key, kind="stable")
+        rowptr = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=N))])
+        assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
+        if E:
+            assert np.array_equal(csr.perm.cpu().numpy()[:E], perm)
+            assert np.array_equal(csr.other.cpu().numpy()[:E], other[perm])
+
+
+def make_conv(aggregators, scalers, towers=1, F=8, edge_dim=None, divide_input=False, hist=(0, 10, 30, 50, 10), **kw):
+    import mma_amd
+    torch.manual_seed(0)
+    cin = F * towers if divide_input else F
+    conv = mma_amd.MMAConv(cin, F * towers if not divide_input else cin, aggregators, scalers, torch.tensor(hist),
+                           edge_dim=edge_dim, towers=towers, divide_input=divide_input, **kw)
+    return conv.to(DEV)
+
+
+def test_aggregate_known_answers_and_tie_gradient():
+    conv = make_conv(["sum", "mean", "max", "min"], ["identity"], towers=1, F=2)
+    src = torch.tensor([[1., 5.], [3., 5.], [3., 2.], [7., 7.], [-1., 4.]], device=DEV).view(5, 1, 2).requires_grad_(True)
+    index = torch.tensor([0, 0, 0, 2, 2], device=DEV)
+    out = conv.aggregate(src, index, 4)
+    want = torch.tensor([[7., 12., 7 / 3, 4., 3., 5., 1., 2.], [0.] * 8, [6., 11., 3., 5.5, 7., 7., -1., 4.], [0.] * 8], device=DEV)
+    assert torch.allclose(out.view(4, 8), want, atol=1e-6)
+    assert torch.equal(out.view(4, 8)[:, 4:], want[:, 4:])           # max/min values exact, empty targets exactly 0
+    g, = torch.autograd.grad(out[:, :, 4:6].sum(), [src])            # gradient of the max block only
+    assert torch.equal(g.view(5, 2), torch.tensor([[0., 1.], [1., 0.], [0., 0.], [1., 1.], [0., 0.]], device=DEV))
+
+
+AGG_CASES = [
+    (["min", "max"], ["identity", "amplification", "linear"], 5, 75),          # ZINC config (BASELINE configs[1])
+    (["sum", "mean", "min", "max", "var", "std"], ["identity", "amplification", "attenuation", "linear", "inverse_linear"], 2, 6),
+    (["std"], ["attenuation"], 1, 130),
+    (["mean", "max"], ["inverse_linear", "identity"], 3, 20),
+]
+
+
+@pytest.mark.parametrize("aggs,scalers,T,F", AGG_CASES, ids=lambda v: "-".join(v) if isinstance(v, list) else str(v))
+def test_aggregate_random_vs_oracle(aggs, scalers, T, F):
+    from oracle import gr_oracle as G
+    rng = np.random.default_rng(T * 100 + F)
+    N, E = 150, 900
+    index = rng.integers(0, N - 10, E)                 # last 10 targets empty
+    index[:70] = 3                                     # one segment longer than a wave
+    vals = rng.integers(-4, 5, (E, T, F)).astype(np.float32) * 0.25      # many exact ties
+    conv = make_conv(aggs, scalers, towers=T, F=F)
+    xi = torch.from_numpy(vals).requires_grad_(True)
+    cot = torch.from_numpy(rng.standard_normal((N, T, len(aggs) * len(scalers) * F)).astype(np.float32))
+    want = G.aggregate(xi, torch.from_numpy(index), N, aggs, scalers, conv.avg_deg)
+    gw, = torch.autograd.grad((want * cot).sum(), [xi], retain_graph=True)
+    xg = torch.from_numpy(vals).to(DEV).requires_grad_(True)
+    got = conv.aggregate(xg, torch.from_numpy(index).to(DEV), N)
+    gg, = torch.autograd.grad((got * cot.to(DEV)).sum(), [xg], retain_graph=True)
+    check_close(got, want.detach().numpy(), None, None, what="aggregate")
+    check_close(gg, gw.numpy(), None, None, what="aggregate grad", signed_sum=True)
+    # arg selection is bit-exact: the gradient of a pure min/max block is a 0/1 pattern identical to the oracle's
+    if "max" in aggs and scalers[0] == "identity":
+        k = aggs.index("max")
+        g1, = torch.autograd.grad(got[:, :, k * F:(k + 1) * F].sum(), [xg])
+        w1, = torch.autograd.grad(want[:, :, k * F:(k + 1) * F].sum(), [xi])
+        assert torch.equal(g1.cpu(), w1)
+
+
+def conv_params(conv):
+    last = conv.aggregators[-1]
+    lins = [seq[0].active_linear() for seq in conv.pre_nns[last]]
+    prm = {"pre_w": [l.weight.detach().cpu() for l in lins], "pre_b": [l.bias.detach().cpu() for l in lins],
+           "post_w": [s[0].weight.detach().cpu() for s in conv.post_nns], "post_b": [s[0].bias.detach().cpu() for s in conv.post_nns],
+           "lin_w": conv.lin.weight.detach().cpu(), "lin_b": conv.lin.bias.detach().cpu()}
+    if conv.edge_dim is not None:
+        prm["enc_w"], prm["enc_b"] = conv.edge_encoder.weight.detach().cpu(), conv.edge_encoder.bias.detach().cpu()
+    return prm
+
+
+def molecule_batch(rng, n_graphs=12):
+    """ZINC-like: trees of ~23 nodes + ring closures, max degree 4, symmetrised."""
+    src, dst, off = [], [], 0
+    for _ in range(n_graphs):
+        n = int(rng.integers(12, 30))
+        deg = np.zeros(n, int)
+        for v in range(1, n):
+            cand = [u for u in range(v) if deg[u] < 3]
+            u = int(rng.choice(cand))
+            src += [off + u, off + v]; dst += [off + v, off + u]; deg[u] += 1; deg[v] += 1
+        for _ in range(int(rng.integers(1, 4))):
+            u, v = rng.choice(n, 2, replace=False)
+            if deg[u] < 4 and deg[v] < 4:
+                src += [off + u, off + v]; dst += [off + v, off + u]; deg[u] += 1; deg[v] += 1
+        off += n
+    return np.array([src, dst]), off
+
+
+CONV_CASES = [
+    dict(aggregators=["min", "max"], scalers=["identity", "amplification", "linear"], towers=5, F=75, edge_dim=50),   # mma.py:92-95
+    dict(aggregators=["sum", "mean"], scalers=["identity", "attenuation"], towers=2, F=6, edge_dim=None),
+    dict(aggregators=["max", "sum", "min"], scalers=["inverse_linear"], towers=3, F=4, edge_dim=5, divide_input=True),
+    dict(aggregators=["mean"], scalers=["identity"], towers=1, F=16, edge_dim=3),
+]
+
+
+@pytest.mark.parametrize("cfg", CONV_CASES, ids=lambda c: "T%d_F%d_%s" % (c["towers"], c["F"], "".join(a[:2] for a in c["aggregators"])))
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_mmaconv_forward_backward_vs_oracle(cfg, p):
+    from mma_amd import functional as Fn
+    from oracle import gr_oracle as G
+    from oracle.dropout_rng import keep_mask
+    rng = np.random.default_rng(7)
+    conv = make_conv(**cfg)
+    T, F = cfg["towers"], cfg["F"]
+    ei, N = molecule_batch(rng)
+    E = ei.shape[1]
+    cin = conv.in_channels
+    x = rng.standard_normal((N, cin)).astype(np.float32)
+    ea = rng.standard_normal((E, cfg["edge_dim"])).astype(np.float32) if cfg.get("edge_dim") else None
+    cot = rng.standard_normal((N, conv.out_channels)).astype(np.float32)
+    seed = 0x5EED5EED12345
+    conv.drop_override = Fn.DropoutSpec(p, seed=seed)
+    keep = None
+    if p > 0:
+        keep = torch.from_numpy(keep_mask(seed, int(p * 256), 1, E, T * F)[0].reshape(E, T, F).astype(np.float32))
+    # oracle
+    xo = torch.from_numpy(x).requires_grad_(True)
+    eo = torch.from_numpy(ea).requires_grad_(True) if ea is not None else None
+    want = G.conv_forward(xo, torch.from_numpy(ei), eo, conv_params(conv), cfg["aggregators"], cfg["scalers"], conv.avg_deg, T,
+                          cfg.get("divide_input", False), keep, p)
+    gw = torch.autograd.grad((want * torch.from_numpy(cot)).sum(), [xo] + ([eo] if eo is not None else []))
+    # HIP
+    xg = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    eg = torch.from_numpy(ea).to(DEV).requires_grad_(True) if ea is not None else None
+    eig = torch.from_numpy(ei).to(DEV)
+    got = conv(xg, eig, eg)
+    params = [p_ for p_ in conv.parameters()]
+    gg = torch.autograd.grad((got * torch.from_numpy(cot).to(DEV)).sum(), [xg] + ([eg] if eg is not None else []) + params,
+                             allow_unused=True)
+    check_close(got, want.detach().numpy(), None, None, what="conv out", signed_sum=True)
+    check_close(gg[0], gw[0].numpy(), None, None, what="conv gx", signed_sum=True)
+    if eg is not None:
+        check_close(gg[1], gw[1].numpy(), None, None, what="conv g(edge_attr)", signed_sum=True)
+    # G2: the mask Linears are unregistered => not among parameters(), every registered parameter got a gradient
+    names = [n for n, _ in conv.named_parameters()]
+    assert not any("pre_nns" in n or "aggregation_layers" in n for n in names)
+    assert all(g is not None for g in gg)
+
+
+def test_only_last_aggregators_mask_is_used():     # G1
+    conv = make_conv(["min", "max"], ["identity"], towers=2, F=4, edge_dim=3)
+    from mma_amd import functional as Fn
+    rng = np.random.default_rng(1)
+    ei, N = molecule_batch(rng, 3)
+    x = torch.from_numpy(rng.standard_normal((N, 4)).astype(np.float32)).to(DEV)
+    ea = torch.from_numpy(rng.standard_normal((ei.shape[1], 3)).astype(np.float32)).to(DEV)
+    eig = torch.from_numpy(ei).to(DEV)
+    conv.drop_override = Fn.DropoutSpec(0.5, seed=11)
+    a = conv(x, eig, ea)
+    with torch.no_grad():
+        for seq in conv.pre_nns["min"]:
+            seq[0].aggregation_layers["min"].weight.add_(10.0)      # the first aggregator's own mask: unused
+            seq[0].aggregation_layers["max"].weight.add_(10.0)      # its copy of the LAST aggregator's name: unused too
+    assert torch.equal(a, conv(x, eig, ea))
+    with torch.no_grad():
+        conv.pre_nns["max"][0][0].aggregation_layers["max"].weight.add_(1.0)
+    assert not torch.equal(a, conv(x, eig, ea))
+
+
+def test_error_behaviour():
+    import mma_amd
+    with pytest.raises(AssertionError):
+        mma_amd.MMAConv(8, 9, ["sum"], ["identity"], torch.tensor([1, 2]), towers=2)            # mma_conv.py:56-58
+    conv = make_conv(["sum", "bogus"], ["identity"], F=4)
+    x = torch.zeros(3, 4, device=DEV); ei = torch.tensor([[0, 1], [1, 2]], device=DEV)
+    with pytest.raises(ValueError, match="Unknown aggregator"):
+        conv(x, ei)
+    conv = make_conv(["var"], ["identity"], F=4)             # var/std: unreachable through forward (G6) ...
+    with pytest.raises(ValueError, match="Unknown aggregator"):
+        conv(x, ei)
+    out = conv.aggregate(torch.ones(2, 1, 4, device=DEV), torch.tensor([1, 2], device=DEV), 3)   # ... but aggregate() works
+    assert out.shape == (3, 1, 4)
+    conv = make_conv(["sum"], ["bogus"], F=4)
+    with pytest.raises(ValueError, match="Unknown scaler"):
+        conv.aggregate(torch.ones(2, 1, 4, device=DEV), torch.tensor([1, 2], device=DEV), 3)
+    m = mma_amd.MaskAggregateLinear(4, 4, ["sum", "max"], "min")
+    with pytest.raises(ValueError, match="Invalid aggregation type"):
+        m(torch.zeros(2, 4, device=DEV))
+    m2 = mma_amd.MaskAggregateLinear(4, 4, ["sum"], "sum", mask="no_linear")
+    t = torch.ones(2, 4, device=DEV)
+    assert m2(t) is t

@@ -1,0 +1,68 @@
+"""Known-answer tests that anchor the GR oracle (oracle/gr_oracle.py) - the GR reference is not importable here
+(no torch_geometric / torch_scatter), so its third-party semantics are pinned by hand-computed cases
+(ties -> lowest edge id, empty target -> 0, mean clamp, compounding scalers, avg_deg from the histogram)."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import gr_oracle as G
+
+
+def test_scatter_known_answers():
+    #           e0   e1   e2   e3   e4
+    src = torch.tensor([[1., 5.], [3., 5.], [3., 2.], [7., 7.], [-1., 4.]], requires_grad=True)
+    index = torch.tensor([0, 0, 0, 2, 2])          # target 1 and 3 are empty
+    assert torch.equal(G.scatter(src, index, 4, "sum"), torch.tensor([[7., 12.], [0., 0.], [6., 11.], [0., 0.]]))
+    assert torch.equal(G.scatter(src, index, 4, "mean"), torch.tensor([[7 / 3, 4.], [0., 0.], [3., 5.5], [0., 0.]]))
+    mx = G.scatter(src, index, 4, "max")
+    mn = G.scatter(src, index, 4, "min")
+    assert torch.equal(mx, torch.tensor([[3., 5.], [0., 0.], [7., 7.], [0., 0.]]))   # empty target -> 0
+    assert torch.equal(mn, torch.tensor([[1., 2.], [0., 0.], [-1., 4.], [0., 0.]]))
+    # ties: max of column 0 in target 0 is 3 (e1 and e2) -> gradient to e1 only; column 1: 5 (e0, e1) -> e0 only
+    g, = torch.autograd.grad(mx.sum(), [src])
+    assert torch.equal(g, torch.tensor([[0., 1.], [1., 0.], [0., 0.], [1., 1.], [0., 0.]]))
+
+
+def test_scatter_matches_torch_scatter_reduce_values():
+    rng = np.random.default_rng(0)
+    E, N = 500, 60
+    src = torch.from_numpy(rng.integers(-3, 4, (E, 2, 5)).astype(np.float32))     # many ties
+    index = torch.from_numpy(rng.integers(0, N - 5, E))                           # last 5 targets empty
+    idx = index.view(-1, 1, 1).expand_as(src)
+    for red, name in (("amin", "min"), ("amax", "max"), ("sum", "sum"), ("mean", "mean")):
+        want = torch.zeros(N, 2, 5).scatter_reduce(0, idx, src, red, include_self=False)
+        assert torch.allclose(G.scatter(src, index, N, name), want, atol=1e-6), name
+
+
+def test_compounding_scalers_and_layout():
+    inputs = torch.tensor([[[1., 2.]], [[3., 6.]], [[5., 0.]]])      # (E=3, T=1, F=2)
+    index = torch.tensor([0, 0, 1])
+    avg = {"lin": 2.0, "log": 0.5}
+    out = G.aggregate(inputs, index, 2, ["min", "max"], ["identity", "amplification", "linear"], avg)
+    base = torch.tensor([[[1., 2., 3., 6.]], [[5., 0., 5., 0.]]])   # [min F | max F]
+    deg = torch.tensor([2., 1.]).view(2, 1, 1)
+    a = torch.log(deg + 1) / 0.5
+    l = deg / 2.0
+    want = torch.cat([base, base * a, base * a * l], -1)             # G7: each stage appends the RUNNING product
+    assert out.shape == (2, 1, 12) and torch.allclose(out, want)
+    # attenuation / inverse_linear, degree clamp(1) on an empty target
+    out2 = G.aggregate(inputs, index, 3, ["sum"], ["attenuation", "inverse_linear"], avg)
+    deg3 = torch.tensor([2., 1., 1.]).view(3, 1, 1)
+    b = torch.tensor([[[4., 8.]], [[5., 0.]], [[0., 0.]]])
+    t = 0.5 / torch.log(deg3 + 1)
+    assert torch.allclose(out2, torch.cat([b * t, b * t * (2.0 / deg3)], -1))
+
+
+def test_var_std_branch():
+    inputs = torch.tensor([[[1.]], [[3.]], [[4.]]])
+    index = torch.tensor([0, 0, 1])
+    out = G.aggregate(inputs, index, 3, ["var", "std"], ["identity"], {"lin": 1., "log": 1.})
+    assert torch.allclose(out[:, 0, 0], torch.tensor([1., 0., 0.]))                       # E[x^2]-E[x]^2
+    assert torch.allclose(out[:, 0, 1], torch.sqrt(torch.tensor([1., 0., 0.]) + 1e-5))
+
+
+def test_avg_deg_uses_histogram_values():
+    hist = torch.tensor([0, 10, 30, 50, 10])
+    a = G.avg_deg_from_histogram(hist)
+    assert math.isclose(a["lin"], 20.0) and math.isclose(a["log"], float(torch.log(hist.float() + 1).mean()), rel_tol=1e-6)
