@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 2
+#define MMA_ABI_VERSION 3
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -70,7 +70,9 @@ int mma_nc_fused_fwd(
     const int32_t* items, int64_t n_items,       /* (n_items,4) */
     const int32_t* hubs, int64_t n_hubs,         /* (n_hubs,4), may be NULL when n_hubs == 0 */
     float* partial, int64_t n_slots,             /* (n_slots, 2, K, H) scratch, NULL when n_slots == 0 */
-    float* m,                                    /* (K,N,H) out */
+    float* m,                                    /* (K,N,H) out: m[k] = learnable_<k>(x); may be NULL if m_sum is given */
+    float* m_sum, int64_t ldms,                  /* (N,H) out: sum_k m[k] (all MMA.forward needs, since
+                                                    sum_k A (m_k W) = A ((sum_k m_k) W)); may be NULL */
     float* T, uint8_t* sel, int64_t ldt,         /* (N,K*H) out, both NULL or both non-NULL */
     int64_t N, int64_t E, int32_t H, int32_t K,
     const uint8_t* kind_host, const uint8_t* act_host,   /* K codes each, HOST memory */
@@ -80,9 +82,11 @@ int mma_nc_fused_fwd(
 
 /* ---- K2a: node-level backward of the combine (element-wise) -------------------------------------
  * From g = dL/dm (K,N,H): gs = dL/ds (N,K*H), gP = gs * T (N,K*H) = dL/dP, gxs = sum_k dL/dx_i
- * through the combine (N,H).  Mirrors autograd of layers.py:221,326-329,452,562 (ties split 0.5/0.5). */
+ * through the combine (N,H).  Mirrors autograd of layers.py:221,326-329,452,562 (ties split 0.5/0.5).
+ * gs may be NULL (shared-gradient form: K2b rebuilds it on the fly). */
 int mma_nc_bwd_node(
-    const float* g, const uint8_t* sel, const float* T, int64_t ldt, const int32_t* rowptr,
+    const float* g, int64_t g_kstride, int64_t ldgr, /* g[k*g_kstride + i*ldgr + h]; g_kstride = 0: one (N,H) gradient for all k */
+    const uint8_t* sel, const float* T, int64_t ldt, const int32_t* rowptr,
     float* gs, int64_t ldgs, float* gP, int64_t ldgp, float* gxs, int64_t ldgx,
     int64_t N, int32_t H, int32_t K, const uint8_t* kind_host, void* stream);
 
@@ -95,7 +99,11 @@ int mma_nc_bwd_node(
  * (n_slots, K+1, H).  N here is the number of SOURCE rows (n_src); gs and P have one row per target. */
 int mma_nc_fused_bwd(
     const float* x, int64_t ldx, const float* P, int64_t ldp, const float* Q, int64_t ldq,
-    const float* gs, int64_t ldg, const float* gxs, int64_t ldgx,
+    const float* gs, int64_t ldg,                /* (n_tgt,K*H) from K2a, or NULL for the shared-gradient form: */
+    const float* gM, int64_t ldgm,               /*   gM (n_tgt,H) = dL/d(sum_k m_k); gs_k[i] is rebuilt per edge from gM[i], */
+    const uint8_t* sel, int64_t ldsel,           /*   the saved selection codes, 1/d_i and the kinds: K*H+... -> H floats + */
+    const float* inv_deg, const uint8_t* kind_host, /* K*H bytes gathered per edge instead of K*H floats */
+    const float* gxs, int64_t ldgx,
     const int32_t* t_col, const int32_t* t_eid,
     const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots,

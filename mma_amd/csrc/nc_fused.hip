@@ -19,7 +19,8 @@ struct NcFwdParams {
   const int32_t* rowptr; const int32_t* col;
   const int4* items; int64_t n_items;
   float* partial; int64_t pstride;   // floats per slot = 2*K_total*H
-  float* m; int64_t m_kstride;       // N*H
+  float* m; int64_t m_kstride;       // (K,N,H) per-mask outputs, may be NULL
+  float* msum; int64_t ldms;         // (N,H) sum over the K masks, may be NULL
   float* T; uint8_t* sel; int64_t ldt;
   int H, HQ, K_total, k_base, lpr_log;
   uint32_t kinds, acts;              // 4 bits / 1 bit per mask, indexed by absolute k
@@ -46,8 +47,8 @@ __device__ __forceinline__ float nc_combine(int kind, float xi, float s, float d
 }
 
 template <int VEC, bool SAVE>
-__device__ __forceinline__ void nc_fwd_write(const NcFwdParams& p, int node, int k_abs, int c, const Vec<VEC>& xi,
-                                             const Vec<VEC>& s, const Vec<VEC>& t, float deg) {
+__device__ __forceinline__ Vec<VEC> nc_fwd_write(const NcFwdParams& p, int node, int k_abs, int c, const Vec<VEC>& xi,
+                                                 const Vec<VEC>& s, const Vec<VEC>& t, float deg) {
   Vec<VEC> mo;
   uint32_t codes = 0;
   const int kind = kind_of(p.kinds, k_abs);
@@ -57,12 +58,25 @@ __device__ __forceinline__ void nc_fwd_write(const NcFwdParams& p, int node, int
     mo.v[i] = nc_combine(kind, xi.v[i], s.v[i], deg, code);
     codes |= code << (8 * i);
   }
-  stv<VEC>(p.m + (size_t)k_abs * p.m_kstride + (size_t)node * p.H + c, mo);
+  if (p.m) stv<VEC>(p.m + (size_t)k_abs * p.m_kstride + (size_t)node * p.H + c, mo);
   if (SAVE) {
     const size_t o = (size_t)node * p.ldt + (size_t)k_abs * p.H + c;
     stv<VEC>(p.T + o, t);
     stb<VEC>(p.sel + o, codes);
   }
+  return mo;
+}
+
+// sum over the masks of one launch (K-slices after the first accumulate onto the stored row)
+template <int VEC>
+__device__ __forceinline__ void nc_msum_store(const NcFwdParams& p, int node, int c, Vec<VEC> ms, bool accumulate) {
+  float* o = p.msum + (size_t)node * p.ldms + c;
+  if (accumulate) {
+    const Vec<VEC> prev = ldv<VEC>(o);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) ms.v[i] += prev.v[i];
+  }
+  stv<VEC>(o, ms);
 }
 
 template <int K, int VEC, bool SAVE, bool DROP>
@@ -152,8 +166,14 @@ __global__ __launch_bounds__(kBlock) void nc_fwd_kernel(const NcFwdParams p) {
     if (sub == 0 && fvalid) {
       if (slot < 0) {
         const float deg = (float)max(p.rowptr[node + 1] - p.rowptr[node], 1);
+        Vec<VEC> ms = vzero<VEC>();
 #pragma unroll
-        for (int k = 0; k < K; ++k) nc_fwd_write<VEC, SAVE>(p, node, p.k_base + k, c, xi, acc[k], tac[k], deg);
+        for (int k = 0; k < K; ++k) {
+          const Vec<VEC> mo = nc_fwd_write<VEC, SAVE>(p, node, p.k_base + k, c, xi, acc[k], tac[k], deg);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) ms.v[i] += mo.v[i];
+        }
+        if (p.msum) nc_msum_store<VEC>(p, node, c, ms, p.k_base > 0);
       } else {
         float* ps = p.partial + (size_t)slot * p.pstride;
 #pragma unroll
@@ -170,34 +190,40 @@ __global__ __launch_bounds__(kBlock) void nc_fwd_kernel(const NcFwdParams p) {
 template <int VEC, bool SAVE>
 __global__ __launch_bounds__(kBlock) void nc_fwd_finalize_kernel(const NcFwdParams p, const int4* hubs, int64_t n_hubs) {
   const int per_row = (p.H + VEC - 1) / VEC;
-  const int64_t total = n_hubs * p.K_total * per_row;
+  const int64_t total = n_hubs * per_row;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(idx % per_row) * VEC;
-    const int k = (int)((idx / per_row) % p.K_total);
-    const int4 hub = hubs[idx / ((int64_t)per_row * p.K_total)];
-    Vec<VEC> s = vzero<VEC>(), t = vzero<VEC>();
-    for (int sl = hub.y; sl < hub.z; ++sl) {
-      const float* ps = p.partial + (size_t)sl * p.pstride;
-      const Vec<VEC> a = ldv<VEC>(ps + (size_t)k * p.H + c);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) s.v[i] += a.v[i];
-      if (SAVE) {
-        const Vec<VEC> b = ldv<VEC>(ps + (size_t)(p.K_total + k) * p.H + c);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) t.v[i] += b.v[i];
-      }
-    }
+    const int4 hub = hubs[idx / per_row];
     const int node = hub.x;
     const Vec<VEC> xi = ldv<VEC>(p.x + (size_t)node * p.ldx + c);
     const float deg = (float)max(p.rowptr[node + 1] - p.rowptr[node], 1);
-    nc_fwd_write<VEC, SAVE>(p, node, k, c, xi, s, t, deg);
+    Vec<VEC> ms = vzero<VEC>();
+    for (int k = 0; k < p.K_total; ++k) {
+      Vec<VEC> s = vzero<VEC>(), t = vzero<VEC>();
+      for (int sl = hub.y; sl < hub.z; ++sl) {
+        const float* ps = p.partial + (size_t)sl * p.pstride;
+        const Vec<VEC> a = ldv<VEC>(ps + (size_t)k * p.H + c);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.v[i] += a.v[i];
+        if (SAVE) {
+          const Vec<VEC> b = ldv<VEC>(ps + (size_t)(p.K_total + k) * p.H + c);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) t.v[i] += b.v[i];
+        }
+      }
+      const Vec<VEC> mo = nc_fwd_write<VEC, SAVE>(p, node, k, c, xi, s, t, deg);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) ms.v[i] += mo.v[i];
+    }
+    if (p.msum) nc_msum_store<VEC>(p, node, c, ms, false);
   }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // K2a: node-level backward of the combine
 struct NcBwdNodeParams {
-  const float* g; const uint8_t* sel; const float* T; int64_t ldt; const int32_t* rowptr;
+  const float* g; int64_t g_kstride, ldgr;   // g[k*g_kstride + node*ldgr + c]; g_kstride == 0: one (N,H) gradient shared by all masks
+  const uint8_t* sel; const float* T; int64_t ldt; const int32_t* rowptr;
   float* gs; int64_t ldgs; float* gP; int64_t ldgp; float* gxs; int64_t ldgx;
   int64_t N; int H, K; uint32_t kinds;
 };
@@ -213,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
     Vec<VEC> gx = vzero<VEC>();
     for (int k = 0; k < p.K; ++k) {
       const int kind = kind_of(p.kinds, k);
-      const Vec<VEC> g = ldv<VEC>(p.g + ((size_t)k * p.N + node) * p.H + c);
+      const Vec<VEC> g = ldv<VEC>(p.g + (size_t)k * p.g_kstride + (size_t)node * p.ldgr + c);
       const size_t o = (size_t)node * p.ldt + (size_t)k * p.H + c;
       const Vec<VEC> t = ldv<VEC>(p.T + o);
       const uint32_t codes = ldb<VEC>(p.sel + o);
@@ -233,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
         gpv.v[i] = gsv.v[i] * t.v[i];
         gx.v[i] = fmaf(g.v[i], fx, gx.v[i]);
       }
-      stv<VEC>(p.gs + (size_t)node * p.ldgs + (size_t)k * p.H + c, gsv);
+      if (p.gs) stv<VEC>(p.gs + (size_t)node * p.ldgs + (size_t)k * p.H + c, gsv);
       stv<VEC>(p.gP + (size_t)node * p.ldgp + (size_t)k * p.H + c, gpv);
     }
     stv<VEC>(p.gxs + (size_t)node * p.ldgx + c, gx);
@@ -246,6 +272,8 @@ struct NcBwdParams {
   const float* x; int64_t ldx;
   const float* P; int64_t ldp; const float* Q; int64_t ldq;
   const float* gs; int64_t ldg; const float* gxs; int64_t ldgx;
+  // SHARED mode (gs == NULL): all masks share one upstream gradient gM (N,H); gs_k[i] = gM[i] * f(kind_k, sel_k[i], 1/d_i)
+  const float* gM; int64_t ldgm; const uint8_t* sel; int64_t ldsel; const float* inv_deg; uint32_t kinds;
   const int32_t* t_col; const int32_t* t_eid;
   const int4* items; int64_t n_items;
   float* partial; int64_t pstride;   // floats per slot = (K_total+1)*H
@@ -256,7 +284,18 @@ struct NcBwdParams {
   int first_pass;  // k_base == 0: gx starts from gxs; later K-slices accumulate onto gx
 };
 
-template <int K, int VEC, bool DROP>
+// dm/ds of the combine from the saved selection code (same table as nc_bwd_node_kernel)
+__device__ __forceinline__ float combine_ds(int kind, uint32_t code, float inv_deg) {
+  switch (kind) {
+    case MMA_KIND_SUM: return 1.f;
+    case MMA_KIND_MEAN: return inv_deg;
+    case MMA_KIND_MAX:
+    case MMA_KIND_MIN: return code == 1u ? 1.f : (code == 2u ? 0.5f : 0.f);
+    default: return code == 3u ? __builtin_nanf("") : 1.f;
+  }
+}
+
+template <int K, int VEC, bool DROP, bool SHARED>
 __global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log;
@@ -289,7 +328,9 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
       const int myi = (lane < cnt) ? p.t_col[base + lane] : 0;
       const int mye = (DROP && lane < cnt) ? p.t_eid[base + lane] : 0;
       for (int t0 = 0; t0 < cnt; t0 += 2 * epg) {
-        int tt[2]; bool ev[2]; uint32_t eid[2]; Vec<VEC> gv[2][K]; Vec<VEC> pv[2][K];
+        // load phase: raw operands only (no arithmetic on loaded values, so both edge steps stay in flight)
+        int tt[2]; bool ev[2]; uint32_t eid[2]; Vec<VEC> gv[2][SHARED ? 1 : K]; Vec<VEC> pv[2][K];
+        uint32_t codes[2][K]; float idg[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           tt[u] = t0 + u * epg + sub;
@@ -297,10 +338,19 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
           const int i_ = __shfl(myi, tt[u] & (kWave - 1), kWave);
           eid[u] = DROP ? (uint32_t)__shfl(mye, tt[u] & (kWave - 1), kWave) : 0u;
           const int ii = ev[u] ? i_ : 0;   // inactive sub-rows read target row 0 (valid), contribute 0
+          if (SHARED) {
+            gv[u][0] = ldv<VEC>(p.gM + (size_t)ii * p.ldgm + cc);
+            idg[u] = p.inv_deg[ii];
+          }
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const size_t o = (size_t)(p.k_base + k) * p.H + cc;
-            gv[u][k] = ldv<VEC>(p.gs + (size_t)ii * p.ldg + o);
+            if (SHARED) {
+              // sum/mean never look at the code: a constant "s selected" keeps the arithmetic below branch-free
+              codes[u][k] = (kind_of(p.kinds, p.k_base + k) >= MMA_KIND_MAX) ? ldb<VEC>(p.sel + (size_t)ii * p.ldsel + o) : 0x01010101u;
+            } else {
+              gv[u][k] = ldv<VEC>(p.gs + (size_t)ii * p.ldg + o);
+            }
             pv[u][k] = ldv<VEC>(p.P + (size_t)ii * p.ldp + o);
           }
         }
@@ -310,6 +360,7 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const bool raw = (p.acts >> (p.k_base + k)) & 1u;
+            const float kscale = (SHARED && kind_of(p.kinds, p.k_base + k) == MMA_KIND_MEAN) ? idg[u] : 1.f;
             float f[VEC];
             if (DROP) {
               drop_factors<VEC>(p.drop, eid[u], p.k_base + k, cc, p.H, p.HQ, f);
@@ -323,7 +374,15 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
               float a, da;
               if (raw) { a = z; da = 1.f; }
               else { a = sigmoid_fast(z); da = a - a * a; }
-              const float w = f[i] * on * gv[u][k].v[i];
+              float gsv;
+              if (SHARED) {
+                const uint32_t code = (codes[u][k] >> (8 * i)) & 0xFFu;   // 1: s selected  2: tie  3: NaN  0: x_i selected
+                const float cf = code == 1u ? 1.f : (code == 2u ? 0.5f : (code == 3u ? __builtin_nanf("") : 0.f));
+                gsv = gv[u][0].v[i] * cf * kscale;
+              } else {
+                gsv = gv[u][k].v[i];
+              }
+              const float w = f[i] * on * gsv;
               aq[k].v[i] = fmaf(da, w, aq[k].v[i]);
               ax.v[i] = fmaf(a, w, ax.v[i]);
             }
@@ -475,8 +534,14 @@ static void launch_fwd_k(int Ks, const NcFwdParams& p, dim3 grid, bool save, boo
 }
 template <int K, int VEC>
 static void launch_bwd(const NcBwdParams& p, dim3 grid, bool drop, hipStream_t st) {
-  if (drop) hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, true>), grid, dim3(kBlock), 0, st, p);
-  else hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, false>), grid, dim3(kBlock), 0, st, p);
+  const bool shared = p.gs == nullptr;
+  if (shared) {
+    if (drop) hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, true, true>), grid, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, false, true>), grid, dim3(kBlock), 0, st, p);
+  } else {
+    if (drop) hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, true, false>), grid, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, false, false>), grid, dim3(kBlock), 0, st, p);
+  }
 }
 template <int VEC>
 static void launch_bwd_k(int Ks, const NcBwdParams& p, dim3 grid, bool drop, hipStream_t st) {
@@ -505,7 +570,7 @@ extern "C" int mma_nc_fused_fwd(
     const float* x, int64_t ldx, const float* P, int64_t ldp, const float* Q, int64_t ldq,
     const int32_t* rowptr, const int32_t* col,
     const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs,
-    float* partial, int64_t n_slots, float* m, float* T, uint8_t* sel, int64_t ldt,
+    float* partial, int64_t n_slots, float* m, float* m_sum, int64_t ldms, float* T, uint8_t* sel, int64_t ldt,
     int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* kind_host, const uint8_t* act_host,
     int32_t drop_mode, uint32_t drop_thr, uint64_t seed, int64_t drop_edge_base, const uint8_t* keep, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31), "N=%lld E=%lld out of int32 range", (long long)N, (long long)E);
@@ -517,7 +582,9 @@ extern "C" int mma_nc_fused_fwd(
   MMA_REQUIRE(n_items >= 0 && n_hubs >= 0 && n_slots >= 0 && n_items < (1LL << 31), "negative or oversize item counts");
   MMA_REQUIRE(n_slots == 0 || (partial != nullptr && hubs != nullptr && n_hubs > 0), "hub slots without partial/hubs buffers");
   if (N == 0 || n_items == 0) return 0;
-  MMA_REQUIRE(x && P && Q && rowptr && items && m && kind_host && act_host, "NULL argument");
+  MMA_REQUIRE(x && P && Q && rowptr && items && kind_host && act_host, "NULL argument");
+  MMA_REQUIRE(m != nullptr || m_sum != nullptr, "give m (K,N,H), m_sum (N,H), or both");
+  MMA_REQUIRE(m_sum == nullptr || ldms >= H, "ldms=%lld too small", (long long)ldms);
   MMA_REQUIRE(E == 0 || col != nullptr, "NULL col");
   MMA_REQUIRE(aligned16(items) && (hubs == nullptr || aligned16(hubs)), "items/hubs must be 16-byte aligned int32 quadruples");
   uint32_t kinds, acts;
@@ -527,13 +594,13 @@ extern "C" int mma_nc_fused_fwd(
   const bool drop = drop_mode != MMA_DROP_NONE && !(drop_mode == MMA_DROP_HASH && drop_thr == 0);
   const bool save = T != nullptr;
   const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldp % 4 == 0) && (ldq % 4 == 0) && (!save || ldt % 4 == 0) && aligned16(x) &&
-                  aligned16(P) && aligned16(Q) && aligned16(m) && (!save || (aligned16(T) && aligned16(sel))) &&
+                  aligned16(P) && aligned16(Q) && (!m || aligned16(m)) && (!m_sum || (aligned16(m_sum) && ldms % 4 == 0)) && (!save || (aligned16(T) && aligned16(sel))) &&
                   (partial == nullptr || aligned16(partial));
   const Geometry g = geometry(H, v4);
   p.x = x; p.ldx = ldx; p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.rowptr = rowptr; p.col = col;
   p.items = reinterpret_cast<const int4*>(items); p.n_items = n_items;
   p.partial = partial; p.pstride = 2LL * K * H;
-  p.m = m; p.m_kstride = N * (int64_t)H; p.T = T; p.sel = sel; p.ldt = ldt;
+  p.m = m; p.m_kstride = N * (int64_t)H; p.msum = m_sum; p.ldms = ldms; p.T = T; p.sel = sel; p.ldt = ldt;
   p.H = H; p.HQ = (H + 3) / 4; p.K_total = K; p.lpr_log = g.lpr_log; p.kinds = kinds; p.acts = acts;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid = item_grid(n_items, g.chunks);
@@ -547,7 +614,7 @@ extern "C" int mma_nc_fused_fwd(
   if (int rc = check_launch("nc_fwd_kernel")) return rc;
   if (n_hubs > 0) {
     const int per_row = (H + g.vec - 1) / g.vec;
-    const dim3 fg((unsigned)elementwise_grid(n_hubs * K * per_row));
+    const dim3 fg((unsigned)elementwise_grid(n_hubs * per_row));
     const int4* hb = reinterpret_cast<const int4*>(hubs);
     if (g.vec == 4) {
       if (save) hipLaunchKernelGGL((nc_fwd_finalize_kernel<4, true>), fg, dim3(kBlock), 0, st, p, hb, n_hubs);
@@ -562,18 +629,20 @@ extern "C" int mma_nc_fused_fwd(
 }
 
 extern "C" int mma_nc_bwd_node(
-    const float* g, const uint8_t* sel, const float* T, int64_t ldt, const int32_t* rowptr,
+    const float* g, int64_t g_kstride, int64_t ldgr, const uint8_t* sel, const float* T, int64_t ldt, const int32_t* rowptr,
     float* gs, int64_t ldgs, float* gP, int64_t ldgp, float* gxs, int64_t ldgx,
     int64_t N, int32_t H, int32_t K, const uint8_t* kind_host, void* stream) {
   MMA_REQUIRE(N >= 0 && N < (1LL << 31) && H >= 1 && K >= 1 && K <= MMA_MAX_K, "N=%lld H=%d K=%d unsupported", (long long)N, H, K);
-  MMA_REQUIRE(ldt >= (int64_t)K * H && ldgs >= (int64_t)K * H && ldgp >= (int64_t)K * H && ldgx >= H, "row pitch too small");
+  MMA_REQUIRE(ldt >= (int64_t)K * H && (!gs || ldgs >= (int64_t)K * H) && ldgp >= (int64_t)K * H && ldgx >= H && ldgr >= H &&
+              g_kstride >= 0, "row pitch too small");
   if (N == 0) return 0;
-  MMA_REQUIRE(g && sel && T && rowptr && gs && gP && gxs && kind_host, "NULL argument");
+  MMA_REQUIRE(g && sel && T && rowptr && gP && gxs && kind_host, "NULL argument");
   uint32_t kinds, acts;
   if (int rc = pack_codes(kind_host, nullptr, K, &kinds, &acts)) return rc;
-  NcBwdNodeParams p{g, sel, T, ldt, rowptr, gs, ldgs, gP, ldgp, gxs, ldgx, N, H, K, kinds};
-  const bool v4 = (H % 4 == 0) && (ldt % 4 == 0) && (ldgs % 4 == 0) && (ldgp % 4 == 0) && (ldgx % 4 == 0) && aligned16(g) && aligned16(sel) &&
-                  aligned16(T) && aligned16(gs) && aligned16(gP) && aligned16(gxs);
+  NcBwdNodeParams p{g, g_kstride, ldgr, sel, T, ldt, rowptr, gs, ldgs, gP, ldgp, gxs, ldgx, N, H, K, kinds};
+  const bool v4 = (H % 4 == 0) && (ldt % 4 == 0) && (!gs || ldgs % 4 == 0) && (ldgp % 4 == 0) && (ldgx % 4 == 0) &&
+                  (ldgr % 4 == 0) && (g_kstride % 4 == 0) && aligned16(g) && aligned16(sel) &&
+                  aligned16(T) && (!gs || aligned16(gs)) && aligned16(gP) && aligned16(gxs);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int per_row = v4 ? H / 4 : H;
   const dim3 grid((unsigned)elementwise_grid(N * per_row));
@@ -584,7 +653,8 @@ extern "C" int mma_nc_bwd_node(
 
 extern "C" int mma_nc_fused_bwd(
     const float* x, int64_t ldx, const float* P, int64_t ldp, const float* Q, int64_t ldq,
-    const float* gs, int64_t ldg, const float* gxs, int64_t ldgx,
+    const float* gs, int64_t ldg, const float* gM, int64_t ldgm, const uint8_t* sel, int64_t ldsel, const float* inv_deg,
+    const uint8_t* kind_host, const float* gxs, int64_t ldgx,
     const int32_t* t_col, const int32_t* t_eid,
     const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots, float* gQ, int64_t ldgq, float* gx, int64_t ldgxo,
@@ -592,24 +662,28 @@ extern "C" int mma_nc_fused_bwd(
     int32_t drop_mode, uint32_t drop_thr, uint64_t seed, int64_t drop_edge_base, const uint8_t* keep, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31), "N=%lld E=%lld out of int32 range", (long long)N, (long long)E);
   MMA_REQUIRE(H >= 1 && K >= 1 && K <= MMA_MAX_K, "H=%d K=%d unsupported (1<=K<=%d)", H, K, MMA_MAX_K);
-  MMA_REQUIRE(ldx >= H && ldp >= (int64_t)K * H && ldq >= (int64_t)K * H && ldg >= (int64_t)K * H && ldgq >= (int64_t)K * H && ldgx >= H && ldgxo >= H,
-              "row pitch too small");
+  MMA_REQUIRE(ldx >= H && ldp >= (int64_t)K * H && ldq >= (int64_t)K * H && (!gs || ldg >= (int64_t)K * H) && ldgq >= (int64_t)K * H &&
+              ldgx >= H && ldgxo >= H, "row pitch too small");
+  MMA_REQUIRE(gs != nullptr || (gM && sel && inv_deg && kind_host && ldgm >= H && ldsel >= (int64_t)K * H),
+              "give gs (N,K*H), or the shared-gradient form gM (N,H) + sel + inv_deg + kinds");
   MMA_REQUIRE(n_items >= 0 && n_hubs >= 0 && n_slots >= 0 && n_items < (1LL << 31), "negative or oversize item counts");
   MMA_REQUIRE(n_slots == 0 || (partial != nullptr && hubs != nullptr && n_hubs > 0), "hub slots without partial/hubs buffers");
   if (N == 0 || n_items == 0) return 0;
-  MMA_REQUIRE(x && P && Q && gs && gxs && items && gQ && gx && act_host, "NULL argument");
+  MMA_REQUIRE(x && P && Q && gxs && items && gQ && gx && act_host, "NULL argument");
   MMA_REQUIRE(E == 0 || (t_col != nullptr && t_eid != nullptr), "NULL transposed CSR");
   MMA_REQUIRE(aligned16(items) && (hubs == nullptr || aligned16(hubs)), "items/hubs must be 16-byte aligned int32 quadruples");
   uint32_t kinds, acts;
-  if (int rc = pack_codes(nullptr, act_host, K, &kinds, &acts)) return rc;
+  if (int rc = pack_codes(gs ? nullptr : kind_host, act_host, K, &kinds, &acts)) return rc;
   NcBwdParams p{};
   if (int rc = make_drop(drop_mode, drop_thr, seed, drop_edge_base, keep, E, &p.drop)) return rc;
   const bool drop = drop_mode != MMA_DROP_NONE && !(drop_mode == MMA_DROP_HASH && drop_thr == 0);
-  const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldp % 4 == 0) && (ldq % 4 == 0) && (ldg % 4 == 0) && (ldgx % 4 == 0) && (ldgq % 4 == 0) &&
-                  (ldgxo % 4 == 0) && aligned16(x) && aligned16(P) && aligned16(Q) && aligned16(gs) && aligned16(gxs) &&
+  const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldp % 4 == 0) && (ldq % 4 == 0) && (ldgx % 4 == 0) && (ldgq % 4 == 0) &&
+                  (gs ? (ldg % 4 == 0 && aligned16(gs)) : (ldgm % 4 == 0 && ldsel % 4 == 0 && aligned16(gM) && aligned16(sel))) &&
+                  (ldgxo % 4 == 0) && aligned16(x) && aligned16(P) && aligned16(Q) && aligned16(gxs) &&
                   aligned16(gQ) && aligned16(gx) && (partial == nullptr || aligned16(partial));
   const Geometry g = geometry(H, v4);
   p.x = x; p.ldx = ldx; p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.gs = gs; p.ldg = ldg; p.gxs = gxs; p.ldgx = ldgx;
+  p.gM = gM; p.ldgm = ldgm; p.sel = sel; p.ldsel = ldsel; p.inv_deg = inv_deg; p.kinds = kinds;
   p.t_col = t_col; p.t_eid = t_eid; p.items = reinterpret_cast<const int4*>(items); p.n_items = n_items;
   p.partial = partial; p.pstride = (int64_t)(K + 1) * H; p.gQ = gQ; p.ldgq = ldgq; p.gx = gx; p.ldgxo = ldgxo;
   p.H = H; p.HQ = (H + 3) / 4; p.K_total = K; p.lpr_log = g.lpr_log; p.acts = acts;

@@ -7,6 +7,10 @@ import torch
 from . import _lib
 from ._lib import call, host_codes, ptr, require_gpu, stream_ptr
 
+# K2b variant for the reduce_k (shared upstream gradient) backward: rebuild dL/ds_k per edge from the (N,H) gradient and
+# the selection codes instead of gathering a materialised (N,K*H) gs.  Fewer bytes per edge (2.8 vs 4 KB at K=4,H=128)
+# but more separate row accesses; measured slower on MI355X (C4, p=0.5: 10.2 vs 6.9 ms), so it is off by default.
+SHARED_GRAD_BWD = False
 TIMER = None   # bench.py installs an object with .span(name) -> context manager (HIP events around the calls)
 
 
@@ -56,10 +60,12 @@ class DropoutSpec:
 
 
 class _NCFused(torch.autograd.Function):
-    """m[k] = combine_k(x_i, sum_j drop(act_k(P_k[i] + Q_k[j])) * x_j)   (K1 forward, K2a + K2b backward)"""
+    """m[k] = combine_k(x_i, sum_j drop(act_k(P_k[i] + Q_k[j])) * x_j)   (K1 forward, K2a + K2b backward).
+    reduce_k: return sum_k m[k] (N,H) instead of (K,N,H) - all MMA.forward needs; backward then takes the
+    shared-gradient form (K2b rebuilds dL/ds_k per edge from the (N,H) gradient and the saved selection codes)."""
 
     @staticmethod
-    def forward(ctx, x_src, P, Q, graph, kinds, acts, drop):
+    def forward(ctx, x_src, P, Q, graph, kinds, acts, drop, reduce_k):
         # x_src: (n_src,H) feature table; its first N rows are the targets (n_src > N only in the sharded path,
         # where the tail holds halo rows).  P: (N,K*H) = x_src[:N] @ [W_k[:H]..], Q: (n_src,K*H) = x_src @ [W_k[H:]..]
         require_gpu(x_src, P, Q)
@@ -75,7 +81,8 @@ class _NCFused(torch.autograd.Function):
             Q = Q.contiguous()
         need_grad = any(ctx.needs_input_grad[:3])
         dev = x_src.device
-        m = torch.empty((K, N, H), device=dev, dtype=torch.float32)
+        m = None if reduce_k else torch.empty((K, N, H), device=dev, dtype=torch.float32)
+        msum = torch.empty((N, H), device=dev, dtype=torch.float32) if reduce_k else None
         T = torch.empty((N, K * H), device=dev, dtype=torch.float32) if need_grad else None
         sel = torch.empty((N, K * H), device=dev, dtype=torch.uint8) if need_grad else None
         partial = torch.empty((graph.n_slots, 2 * K * H), device=dev, dtype=torch.float32) if graph.n_slots else None
@@ -87,49 +94,52 @@ class _NCFused(torch.autograd.Function):
             call("mma_nc_fused_fwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
                  ptr(graph.rowptr), ptr(graph.col), ptr(graph.items), graph.items.shape[0],
                  ptr(graph.hubs) if graph.n_slots else None, graph.hubs.shape[0], ptr(partial), graph.n_slots,
-                 ptr(m), ptr(T), ptr(sel), K * H, N, graph.E, H, K, host_codes(kinds), host_codes(acts),
+                 ptr(m), ptr(msum), H, ptr(T), ptr(sel), K * H, N, graph.E, H, K, host_codes(kinds), host_codes(acts),
                  mode, thr, seed, graph.edge_base, keep, stream_ptr())
-        ctx.graph, ctx.kinds, ctx.acts, ctx.drop = graph, kinds, acts, drop
+        ctx.graph, ctx.kinds, ctx.acts, ctx.drop, ctx.reduce_k = graph, kinds, acts, drop, reduce_k
         ctx.save_for_backward(x_src, P, Q, T, sel)
-        return m
+        return msum if reduce_k else m
 
     @staticmethod
     def backward(ctx, g):
-        graph, kinds, acts, drop = ctx.graph, ctx.kinds, ctx.acts, ctx.drop
+        graph, kinds, acts, drop, reduce_k = ctx.graph, ctx.kinds, ctx.acts, ctx.drop, ctx.reduce_k
+        shared = reduce_k and SHARED_GRAD_BWD
         x_src, P, Q, T, sel = ctx.saved_tensors
         K = len(kinds)
         N, H, S = graph.N, x_src.shape[1], graph.n_src
         g = g.contiguous()
         dev = g.device
-        gs = torch.empty((N, K * H), device=dev, dtype=torch.float32)
+        gs = None if shared else torch.empty((N, K * H), device=dev, dtype=torch.float32)
         gP = torch.empty((N, K * H), device=dev, dtype=torch.float32)
         gQ = torch.empty((S, K * H), device=dev, dtype=torch.float32)
         gxs = torch.empty((S, H), device=dev, dtype=torch.float32)
         if S > N:  # halo rows are sources only: no target-side gradient
             gxs[N:].zero_()
         with _span("nc_bwd_node"):
-            call("mma_nc_bwd_node", ptr(g), ptr(sel), ptr(T), K * H, ptr(graph.rowptr), ptr(gs), K * H, ptr(gP), K * H,
-                 ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
+            call("mma_nc_bwd_node", ptr(g), 0 if reduce_k else N * H, H, ptr(sel), ptr(T), K * H, ptr(graph.rowptr),
+                 ptr(gs), K * H, ptr(gP), K * H, ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
         gx = torch.empty((S, H), device=dev, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32)
                    if graph.t_n_slots else None)
         mode, thr, seed, keep = drop.args()
         with _span("nc_fused_bwd"):
             call("mma_nc_fused_bwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
-                 ptr(gs), K * H, ptr(gxs), H, ptr(graph.t_col), ptr(graph.t_eid),
+                 ptr(gs), K * H, ptr(g) if shared else None, H, ptr(sel) if shared else None, K * H,
+                 ptr(graph.inv_deg) if shared else None, host_codes(kinds) if shared else None, ptr(gxs), H,
+                 ptr(graph.t_col), ptr(graph.t_eid),
                  ptr(graph.t_items), graph.t_items.shape[0], ptr(graph.t_hubs) if graph.t_n_slots else None,
                  graph.t_hubs.shape[0], ptr(partial), graph.t_n_slots, ptr(gQ), K * H, ptr(gx), H,
                  S, graph.E, H, K, host_codes(acts), mode, thr, seed, graph.edge_base, keep, stream_ptr())
-        return gx, gP, gQ, None, None, None, None
+        return gx, gP, gQ, None, None, None, None, None
 
 
-def nc_fused_aggregate(x, P, Q, graph, kinds, acts, drop=None):
-    """Fused K-mask aggregation (K <= 8 per call) -> m (K, graph.N, H).
+def nc_fused_aggregate(x, P, Q, graph, kinds, acts, drop=None, reduce_k=False):
+    """Fused K-mask aggregation (K <= 8 per call) -> m (K, graph.N, H), or sum_k m[k] (graph.N, H) with reduce_k.
 
     x: (graph.n_src, H) feature table whose first graph.N rows are the targets; P = x[:N] @ Wtop (N, K*H),
     Q = x @ Wbot (n_src, K*H) with Wtop/Wbot the column-concatenated top/bottom halves of the K mask weights;
     kinds/acts: MMA_KIND_* / MMA_ACT_* codes per mask."""
-    return _NCFused.apply(x, P, Q, graph, tuple(kinds), tuple(acts), drop or DropoutSpec(0.0))
+    return _NCFused.apply(x, P, Q, graph, tuple(kinds), tuple(acts), drop or DropoutSpec(0.0), bool(reduce_k))
 
 
 class _CsrSpmm(torch.autograd.Function):

@@ -142,8 +142,8 @@ class MMA(Module):
             return self.drop_override
         return Fn.DropoutSpec(self.dropout)
 
-    def _aggregate(self, names, input, drop=None):
-        """All aggregators in `names` (<= 8) in one fused launch -> (K, N, H)."""
+    def _aggregate(self, names, input, drop=None, reduce_k=False):
+        """All aggregators in `names` (<= 8) in one fused launch -> (K, N, H), or their sum (N, H) with reduce_k."""
         require_gpu(input)
         H = input.shape[1]
         kinds, acts = self._codes(names)
@@ -151,9 +151,9 @@ class MMA(Module):
         # [x_i || x_j] @ W_k  ==  x_i @ W_k[:H] + x_j @ W_k[H:]: dense GEMMs (MFMA fp32) shared by all K masks
         P = torch.mm(input, torch.cat([w[:H] for w in masks], 1))               # (N, K*H)
         Q = torch.mm(input, torch.cat([w[H:] for w in masks], 1))               # (N, K*H)
-        return Fn.nc_fused_aggregate(input, P, Q, self.graph(input.device), kinds, acts, drop or self._drop(names))
+        return Fn.nc_fused_aggregate(input, P, Q, self.graph(input.device), kinds, acts, drop or self._drop(names), reduce_k)
 
-    def _aggregate_all(self, names, input):
+    def _aggregate_all(self, names, input, reduce_k=False):
         outs = []
         base = self._drop(names)
         for g0 in range(0, len(names), 8):
@@ -163,22 +163,24 @@ class MMA(Module):
                 drop = Fn.DropoutSpec(base.p, keep=base.keep[g0:g0 + 8].contiguous())
             elif g0:
                 drop = Fn.DropoutSpec(base.p, seed=base.seed + g0)
-            outs.append(self._aggregate(grp, input, drop))
+            outs.append(self._aggregate(grp, input, drop, reduce_k))
+        if reduce_k:
+            return outs[0] if len(outs) == 1 else torch.stack(outs).sum(0)
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
     # ---- forward ------------------------------------------------------------------------------------------
     def forward(self, input, adj):
-        K = self.num_aggregators
         N = input.shape[0]
-        m = self._aggregate_all(self.aggregator_names, input)                  # (K,N,H) == cat(dim 0), layers.py:855
-        # layers.py:856-860: cat of the 3 scalers on dim 1, times [W;W;W].  The scalers are row factors that the
-        # reference evaluates to 1.0 (Q1), so [m, a*m, t*m] @ [W;W;W] = (1 + a + t) * (m @ W) row-wise.
+        # layers.py:855-862 computes  spmm(cat((adj,)*K,1), cat_k(m_k) scaled @ [W;W;W]).  The scalers are row factors
+        # the reference evaluates to 1.0 (Q1) and everything after the aggregators is linear, so
+        #     sum_k A (c * m_k W)  ==  A (c * (sum_k m_k) W):
+        # the fused kernel emits sum_k m_k (N,H) directly - K x fewer bytes through the GEMM and the SpMM.
+        msum = self._aggregate_all(self.aggregator_names, input, reduce_k=True)
         amp, att = scaler_factors(N, input.device)
-        support = torch.mm(m.reshape(K * N, -1), self.weight)
-        support = support * (1.0 + amp + att).repeat(K, 1)
+        support = torch.mm(msum, self.weight) * (1.0 + amp + att)
         if self._sg is None or self._sg[0] is not adj:   # extension: a ready-made SpmmGraph is accepted as `adj`
             self._sg = (adj, adj if isinstance(adj, SpmmGraph) else SpmmGraph.from_torch_sparse(adj))
-        return Fn.csr_spmm(support, self.bias, self._sg[1], K)                  # layers.py:861-867
+        return Fn.csr_spmm(support, self.bias, self._sg[1], 1)                  # layers.py:861-867
 
     def __repr__(self):
         return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'

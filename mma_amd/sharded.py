@@ -187,11 +187,11 @@ class ShardedMMA(torch.nn.Module):
         x_src = torch.cat([x_own, x_halo], 0)
         P = torch.mm(x_own, torch.cat([w[:H] for w in ws], 1))
         Q = torch.mm(x_src, torch.cat([w[H:] for w in ws], 1))
-        m = Fn.nc_fused_aggregate(x_src, P, Q, self.graph, kinds, acts, self._drop())      # (K, n_own, H)
+        msum = Fn.nc_fused_aggregate(x_src, P, Q, self.graph, kinds, acts, self._drop(), reduce_k=True)   # (n_own, H)
         amp, att = scaler_factors(self.n_total or n, x_own.device)                          # Q1: identical rows
         c3 = (1.0 + amp[:1] + att[:1])
-        # sum_k A (m_k W) == A ((sum_k m_k W)): only the (n,C) row sums travel and enter the SpMM
-        S = (torch.mm(m.reshape(K * n, H), self.weight).view(K, n, self.C) * c3).sum(0)
+        # sum_k A (m_k W) == A ((sum_k m_k) W): only the (n,C) rows travel and enter the SpMM
+        S = torch.mm(msum, self.weight) * c3
         S_halo = _HaloExchange.apply(S, self.plan, self.send_idx)
         return Fn.csr_spmm(torch.cat([S, S_halo], 0), self.bias, self.sg, 1)
 

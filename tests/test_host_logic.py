@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_argument_checks_run_on_host_without_gpu():
     # a bad shape must be refused before any launch (works with no GPU present)
     with pytest.raises(_lib.MMALibraryError, match="K="):
-        _lib.call("mma_nc_fused_fwd", None, 4, None, 4, None, 4, None, None, None, 0, None, 0, None, 0, None, None, None, 4,
+        _lib.call("mma_nc_fused_fwd", None, 4, None, 4, None, 4, None, None, None, 0, None, 0, None, 0, None, None, 4, None, None, 4,
                   10, 10, 4, 99, None, None, 0, 0, 0, 0, None, None)
     with pytest.raises(_lib.MMALibraryError, match="pitch"):
         _lib.call("mma_csr_spmm", None, None, None, None, 2, 5, 1, None, None, 2, 5, 4, None)
@@ -61,8 +61,10 @@ def test_make_items_chunks_and_hubs():
     assert sorted(whole[:, 0].tolist()) == [0, 1, 3, 4]           # degree <= chunk (incl. degree 0): one item, no slot
     assert hubs[:, 0].tolist() == [2, 5] and n_slots == 3 + 4
     for node, sb, se, _ in hubs:
-        sl = items[(items[:, 0] == node)][:, 3]
-        assert sl.tolist() == list(range(sb, se))                  # slots of a hub are consecutive, in edge order
+        mine = items[(items[:, 0] == node)]
+        mine = mine[np.argsort(mine[:, 1])]
+        assert mine[:, 3].tolist() == list(range(sb, se))          # slots of a hub are consecutive, in edge order
+    assert (np.diff(items[:, 2] - items[:, 1]) <= 0).all()        # longest items first
 
 
 def test_transpose_csr_roundtrip():

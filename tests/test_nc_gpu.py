@@ -58,11 +58,12 @@ def test_golden_single_aggregators(gold):
         check_close(m, gold.z[key], gold.rows, gold.z[key + "/stats"], what=key)
 
 
-@pytest.mark.parametrize("chunk", [512, 3])
-def test_golden_forward_and_grads(gold, chunk):
+@pytest.mark.parametrize("chunk,shared_bwd", [(512, False), (3, False), (512, True), (3, True)])
+def test_golden_forward_and_grads(gold, chunk, shared_bwd, monkeypatch):
     from mma_amd import functional as Fn
     if chunk == 3 and gold.N > 3000:
         pytest.skip("small-chunk (hub path) variant only on the smaller graphs")
+    monkeypatch.setattr(Fn, "SHARED_GRAD_BWD", shared_bwd)      # both K2b forms of the shared-gradient backward
     adj = adj_of(gold)
     for key in gold.set_keys():
         _, act, p, aggs = gold.parse(key)
