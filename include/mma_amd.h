@@ -123,6 +123,13 @@ int mma_csr_spmm(
     const float* bias, float* out, int64_t ldo,
     int64_t n_rows, int32_t C, void* stream);
 
+/* K5, item-driven form for K = 1 (the form MMA.forward and GraphConvolution use): rows cut into work items
+ * {row, ebeg, eend, slot} (longest first) with hub partials, exactly as in mma_nc_fused_fwd; partial is (n_slots, C). */
+int mma_csr_spmm_items(
+    const int32_t* col, const float* val, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldo,
+    const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs, float* partial, int64_t n_slots,
+    int32_t C, void* stream);
+
 /* ---- K7: halo pack / unpack for the 1-D node-sharded multi-GPU path --------------------------------
  * pack:   dst[r,:] = src[idx[r],:]            (send buffer for the all-to-all of halo rows)
  * unpack: dst[idx[r],:] += src[r,:]           (reverse exchange in backward; idx rows of one call are

@@ -24,6 +24,7 @@ PROTOTYPES = {
                          _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P],
     "mma_gr_fused_bwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64,
                          _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P],
+    "mma_csr_spmm_items": [_P, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _P],
     "mma_pack_rows": [_P, _I64, _P, _I64, _P, _I64, _I32, _P],
     "mma_unpack_add_rows": [_P, _I64, _P, _I64, _P, _I64, _I32, _P],
 }

@@ -56,6 +56,81 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const SpmmParams p) {
   }
 }
 
+// Item-driven variant (K = 1): rows are cut into work items of bounded length, longest first (mma_amd/graph.py),
+// so one 26 k-edge hub row no longer serialises the launch on a single wave.  Hub chunks write partials that the
+// finalize kernel sums in slot order (deterministic, no atomics).
+struct SpmmItemParams {
+  const int32_t* col; const float* val; const float* B; int64_t ldb; const float* bias; float* out; int64_t ldo;
+  const int4* items; int64_t n_items; float* partial; int C, lpr_log;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void spmm_items_kernel(const SpmmItemParams p) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << p.lpr_log;
+  const int epg = kWave >> p.lpr_log;
+  const int sub = lane >> p.lpr_log;
+  const int c = ((int)blockIdx.y * lpr + (lane & (lpr - 1))) * VEC;
+  const bool fvalid = c < p.C;
+  const int cc = fvalid ? c : 0;
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave);
+  for (int64_t it0 = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); it0 < p.n_items; it0 += stride) {
+    const int4 item = p.items[__builtin_amdgcn_readfirstlane((int)it0)];
+    const int row = __builtin_amdgcn_readfirstlane(item.x);
+    const int ebeg = __builtin_amdgcn_readfirstlane(item.y);
+    const int eend = __builtin_amdgcn_readfirstlane(item.z);
+    const int slot = __builtin_amdgcn_readfirstlane(item.w);
+    Vec<VEC> acc = vzero<VEC>();
+    for (int base = ebeg; base < eend; base += kWave) {
+      const int cnt = min(kWave, eend - base);
+      const int myj = (lane < cnt) ? p.col[base + lane] : 0;
+      const float myv = (lane < cnt) ? (p.val ? p.val[base + lane] : 1.f) : 0.f;
+      for (int t0 = 0; t0 < cnt; t0 += 2 * epg) {
+        Vec<VEC> b[2]; float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = t0 + u * epg + sub;
+          const int j = __shfl(myj, t & (kWave - 1), kWave);
+          const float vv = __shfl(myv, t & (kWave - 1), kWave);
+          v[u] = (t < cnt) ? vv : 0.f;
+          b[u] = ldv<VEC>(p.B + (size_t)((t < cnt) ? j : 0) * p.ldb + cc);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(v[u], b[u].v[i], acc.v[i]);
+      }
+    }
+    for (int off = kWave / 2; off >= lpr; off >>= 1)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc.v[i] += __shfl_xor(acc.v[i], off, kWave);
+    if (sub == 0 && fvalid) {
+      if (slot < 0) {
+        if (p.bias) {
+          const Vec<VEC> bb = ldv<VEC>(p.bias + c);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc.v[i] += bb.v[i];
+        }
+        stv<VEC>(p.out + (size_t)row * p.ldo + c, acc);
+      } else {
+        stv<VEC>(p.partial + (size_t)slot * p.C + c, acc);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void spmm_items_finalize_kernel(const SpmmItemParams p, const int4* hubs, int64_t n_hubs) {
+  const int64_t total = n_hubs * p.C;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % p.C);
+    const int4 hub = hubs[idx / p.C];
+    float s = 0.f;
+    for (int sl = hub.y; sl < hub.z; ++sl) s += p.partial[(size_t)sl * p.C + c];
+    if (p.bias) s += p.bias[c];
+    p.out[(size_t)hub.x * p.ldo + c] = s;
+  }
+}
+
 struct RowsParams { const float* src; int64_t lds; const int32_t* idx; int64_t n; float* dst; int64_t ldd; int width; };
 
 template <int VEC, bool UNPACK_ADD>
@@ -104,6 +179,37 @@ extern "C" int mma_csr_spmm(const int32_t* rowptr, const int32_t* col, const flo
   if (v4) hipLaunchKernelGGL((spmm_kernel<4>), grid, dim3(kBlock), 0, st, p);
   else hipLaunchKernelGGL((spmm_kernel<1>), grid, dim3(kBlock), 0, st, p);
   return check_launch("spmm_kernel");
+}
+
+extern "C" int mma_csr_spmm_items(const int32_t* col, const float* val, const float* B, int64_t ldb, const float* bias,
+                                  float* out, int64_t ldo, const int32_t* items, int64_t n_items, const int32_t* hubs,
+                                  int64_t n_hubs, float* partial, int64_t n_slots, int32_t C, void* stream) {
+  MMA_REQUIRE(C >= 1 && ldb >= C && ldo >= C && n_items >= 0 && n_items < (1LL << 31) && n_hubs >= 0 && n_slots >= 0,
+              "C=%d ldb=%lld ldo=%lld n_items=%lld unsupported", C, (long long)ldb, (long long)ldo, (long long)n_items);
+  MMA_REQUIRE(n_slots == 0 || (partial && hubs && n_hubs > 0), "hub slots without partial/hubs buffers");
+  if (n_items == 0) return 0;
+  MMA_REQUIRE(B && out && items && al16(items) && (!hubs || al16(hubs)), "NULL or misaligned argument");
+  const bool v4 = (C % 4 == 0) && (ldb % 4 == 0) && (ldo % 4 == 0) && al16(B) && al16(out) && (!bias || al16(bias)) &&
+                  (!partial || al16(partial));
+  const int vec = v4 ? 4 : 1;
+  const int per_row = (C + vec - 1) / vec;
+  SpmmItemParams p{col, val, B, ldb, bias, out, ldo, reinterpret_cast<const int4*>(items), n_items, partial, C, 0};
+  p.lpr_log = min(ilog2_ceil(per_row), 6);
+  const int chunks = (per_row + (1 << p.lpr_log) - 1) >> p.lpr_log;
+  int64_t blocks = (n_items + 3) / 4;
+  if (blocks > kMaxGrid) blocks = kMaxGrid;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)blocks, (unsigned)chunks);
+  if (v4) hipLaunchKernelGGL((spmm_items_kernel<4>), grid, dim3(kBlock), 0, st, p);
+  else hipLaunchKernelGGL((spmm_items_kernel<1>), grid, dim3(kBlock), 0, st, p);
+  if (int rc = check_launch("spmm_items_kernel")) return rc;
+  if (n_hubs > 0) {
+    int64_t fb = (n_hubs * C + kBlock - 1) / kBlock;
+    if (fb > kMaxGrid) fb = kMaxGrid;
+    hipLaunchKernelGGL(spmm_items_finalize_kernel, dim3((unsigned)fb), dim3(kBlock), 0, st, p, reinterpret_cast<const int4*>(hubs), n_hubs);
+    return check_launch("spmm_items_finalize_kernel");
+  }
+  return 0;
 }
 
 static int rows_call(bool unpack, const float* src, int64_t lds, const int32_t* idx, int64_t n_idx, float* dst, int64_t ldd,

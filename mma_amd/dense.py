@@ -1,0 +1,47 @@
+"""Dense pre/post transforms of the hot path: plain library GEMMs (rocBLAS / hipBLASLt fp32 MFMA through torch.mm),
+with one MI355X-specific twist in backward.
+
+The weight gradients are (in, N) @ (N, out) products whose reduction dimension is the node count (1 M at C4) and whose
+output is tiny (128 x 512): a single GEMM call leaves most of the 256 CUs idle (measured 49-75 TFLOP/s, and 3.4 TFLOP/s
+for the (128,N)@(N,16) tail).  Splitting the reduction into ~N/8192 batches (strided-batched GEMM + a sum over the
+batch) fills the chip: 140 TFLOP/s, 89 % of the fp32 MFMA peak (0.97 ms instead of 2.7 ms per mask-weight half)."""
+import torch
+
+_ROWS_PER_BATCH = 8192
+
+
+class _MM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.mm(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.mm(g, w.t())
+        if ctx.needs_input_grad[1]:
+            gw = xt_g(x, g)
+        return gx, gw
+
+
+def xt_g(x, g):
+    """x^T @ g for tall x (N,in), g (N,out): split-N batched GEMM + sum."""
+    N = x.shape[0]
+    B = N // _ROWS_PER_BATCH
+    if B < 4:
+        return torch.mm(x.t(), g)
+    n = B * _ROWS_PER_BATCH
+    x = x.contiguous()
+    g = g.contiguous()
+    out = torch.bmm(x[:n].view(B, _ROWS_PER_BATCH, -1).transpose(1, 2), g[:n].view(B, _ROWS_PER_BATCH, -1)).sum(0)
+    if n < N:
+        out = out + torch.mm(x[n:].t(), g[n:])
+    return out
+
+
+def mm(x, w):
+    """x @ w with the split-reduction weight gradient."""
+    return _MM.apply(x, w)

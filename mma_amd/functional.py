@@ -142,6 +142,16 @@ def nc_fused_aggregate(x, P, Q, graph, kinds, acts, drop=None, reduce_k=False):
     return _NCFused.apply(x, P, Q, graph, tuple(kinds), tuple(acts), drop or DropoutSpec(0.0), bool(reduce_k))
 
 
+def _spmm_call(rowptr, col, val, items, hubs, n_slots, B, rows_per_block, K, bias, out, n_rows, C):
+    if K == 1 and items is not None:
+        partial = torch.empty((n_slots, C), device=B.device, dtype=torch.float32) if n_slots else None
+        call("mma_csr_spmm_items", ptr(col), ptr(val), ptr(B), B.stride(0), ptr(bias), ptr(out), C, ptr(items), items.shape[0],
+             ptr(hubs) if n_slots else None, hubs.shape[0], ptr(partial), n_slots, C, stream_ptr())
+    else:
+        call("mma_csr_spmm", ptr(rowptr), ptr(col), ptr(val), ptr(B), B.stride(0), rows_per_block, K,
+             ptr(bias), ptr(out), C, n_rows, C, stream_ptr())
+
+
 class _CsrSpmm(torch.autograd.Function):
     """out = sum_k A @ B[k] + bias  ( = torch.spmm(cat((adj,)*K, 1), B.view(K*N, C)) + bias, layers.py:861-865 )"""
 
@@ -154,8 +164,7 @@ class _CsrSpmm(torch.autograd.Function):
         C = B.shape[1]
         out = torch.empty((sg.n_rows, C), device=B.device, dtype=torch.float32)
         with _span("csr_spmm_fwd"):
-          call("mma_csr_spmm", ptr(sg.rowptr), ptr(sg.col), ptr(sg.val), ptr(B), B.stride(0), rows_per_block, K,
-             ptr(bias), ptr(out), C, sg.n_rows, C, stream_ptr())
+            _spmm_call(sg.rowptr, sg.col, sg.val, sg.items, sg.hubs, sg.n_slots, B, rows_per_block, K, bias, out, sg.n_rows, C)
         ctx.sg, ctx.K, ctx.has_bias = sg, K, bias is not None
         return out
 
@@ -166,9 +175,8 @@ class _CsrSpmm(torch.autograd.Function):
         C = g.shape[1]
         gB1 = torch.empty((sg.n_cols, C), device=g.device, dtype=torch.float32)
         with _span("csr_spmm_bwd"):
-          call("mma_csr_spmm", ptr(sg.t_rowptr), ptr(sg.t_col), ptr(sg.t_val), ptr(g), g.stride(0), sg.n_rows, 1,
-             None, ptr(gB1), C, sg.n_cols, C, stream_ptr())
-        gB = gB1.unsqueeze(0).expand(K, -1, -1).reshape(K * sg.n_cols, C)  # every k-block sees the same A^T g
+            _spmm_call(sg.t_rowptr, sg.t_col, sg.t_val, sg.t_items, sg.t_hubs, sg.t_n_slots, g, sg.n_rows, 1, None, gB1, sg.n_cols, C)
+        gB = gB1 if K == 1 else gB1.unsqueeze(0).expand(K, -1, -1).reshape(K * sg.n_cols, C)  # every k-block sees the same A^T g
         return gB, (g.sum(0) if ctx.has_bias else None), None, None
 
 

@@ -109,6 +109,10 @@ class SpmmGraph:
         trp = np.zeros(n_cols + 1, dtype=np.int64); np.cumsum(np.bincount(col, minlength=n_cols), out=trp[1:])
         self.t_rowptr, self.t_col = i32(trp), i32(row[t_order])
         self.t_val = None if self.val is None else f32(val[t_order])
+        it, hb, self.n_slots = make_items(rp, DEFAULT_CHUNK)
+        self.items, self.hubs = i32(it), i32(hb)
+        it, hb, self.t_n_slots = make_items(trp, DEFAULT_CHUNK)
+        self.t_items, self.t_hubs = i32(it), i32(hb)
 
     @classmethod
     def from_torch_sparse(cls, adj):

@@ -18,6 +18,7 @@ import torch
 from torch.nn.modules.module import Module
 
 from . import functional as Fn
+from .dense import mm
 from ._lib import require_gpu
 from .graph import DEFAULT_CHUNK, NCGraph, SpmmGraph
 from .scalers import SCALERS, scaler_factors
@@ -55,7 +56,7 @@ class GraphConvolution(Module):
         require_gpu(input)
         if self._sg is None or self._sg[0] is not adj:
             self._sg = (adj, SpmmGraph.from_torch_sparse(adj))
-        support = torch.mm(input, self.weight)
+        support = mm(input, self.weight)
         return Fn.csr_spmm(support, self.bias, self._sg[1], 1)
 
     def __repr__(self):
@@ -149,8 +150,8 @@ class MMA(Module):
         kinds, acts = self._codes(names)
         masks = [getattr(self, "mask_" + n) for n in names]
         # [x_i || x_j] @ W_k  ==  x_i @ W_k[:H] + x_j @ W_k[H:]: dense GEMMs (MFMA fp32) shared by all K masks
-        P = torch.mm(input, torch.cat([w[:H] for w in masks], 1))               # (N, K*H)
-        Q = torch.mm(input, torch.cat([w[H:] for w in masks], 1))               # (N, K*H)
+        P = mm(input, torch.cat([w[:H] for w in masks], 1))                     # (N, K*H)
+        Q = mm(input, torch.cat([w[H:] for w in masks], 1))                     # (N, K*H)
         return Fn.nc_fused_aggregate(input, P, Q, self.graph(input.device), kinds, acts, drop or self._drop(names), reduce_k)
 
     def _aggregate_all(self, names, input, reduce_k=False):
@@ -177,7 +178,7 @@ class MMA(Module):
         # the fused kernel emits sum_k m_k (N,H) directly - K x fewer bytes through the GEMM and the SpMM.
         msum = self._aggregate_all(self.aggregator_names, input, reduce_k=True)
         amp, att = scaler_factors(N, input.device)
-        support = torch.mm(msum, self.weight) * (1.0 + amp + att)
+        support = mm(msum, self.weight) * (1.0 + amp + att)
         if self._sg is None or self._sg[0] is not adj:   # extension: a ready-made SpmmGraph is accepted as `adj`
             self._sg = (adj, adj if isinstance(adj, SpmmGraph) else SpmmGraph.from_torch_sparse(adj))
         return Fn.csr_spmm(support, self.bias, self._sg[1], 1)                  # layers.py:861-867

@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import functional as Fn
+from .dense import mm
 from ._lib import call, ptr, require_gpu, stream_ptr
 from .graph import DEFAULT_CHUNK, NCGraph, SpmmGraph
 from .layers import _AGG
@@ -185,13 +186,13 @@ class ShardedMMA(torch.nn.Module):
         ws = [self.masks[a] for a in self.names]
         x_halo = _HaloExchange.apply(x_own, self.plan, self.send_idx)
         x_src = torch.cat([x_own, x_halo], 0)
-        P = torch.mm(x_own, torch.cat([w[:H] for w in ws], 1))
-        Q = torch.mm(x_src, torch.cat([w[H:] for w in ws], 1))
+        P = mm(x_own, torch.cat([w[:H] for w in ws], 1))
+        Q = mm(x_src, torch.cat([w[H:] for w in ws], 1))
         msum = Fn.nc_fused_aggregate(x_src, P, Q, self.graph, kinds, acts, self._drop(), reduce_k=True)   # (n_own, H)
         amp, att = scaler_factors(self.n_total or n, x_own.device)                          # Q1: identical rows
         c3 = (1.0 + amp[:1] + att[:1])
         # sum_k A (m_k W) == A ((sum_k m_k) W): only the (n,C) rows travel and enter the SpMM
-        S = torch.mm(msum, self.weight) * c3
+        S = mm(msum, self.weight) * c3
         S_halo = _HaloExchange.apply(S, self.plan, self.send_idx)
         return Fn.csr_spmm(torch.cat([S, S_halo], 0), self.bias, self.sg, 1)
 
