@@ -96,6 +96,26 @@ def algorithmic_bytes(N, E, H, K):
     return {"nc_fused_fwd": fwd, "nc_fused_bwd": bwd}
 
 
+PMC_KERNEL = {"nc_fused_fwd": "mma::nc_fwd_kernel", "nc_fused_bwd": "mma::nc_bwd_kernel"}
+
+
+def pmc_traffic(name, N, E, H, K):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes of THIS command
+    (profiles/r*_pmc_traffic.json, made by tools/pmc_summary.py); None when no profile matches the workload."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") != {"nodes": N, "edges": E, "hidden": H, "K": K}:
+            continue
+        for k, v in d["kernels"].items():
+            if PMC_KERNEL.get(name, "?") in k and "finalize" not in k:
+                return v["traffic_bytes"]
+    return None
+
+
 def cpu_baseline(rowptr, col, H, names, activation, p, n_targets, seed):
     """The CPU oracle (oracle/nc_oracle.py, torch-CPU vectorised restatement of layers.py) on a bounded sample:
     the first n_targets target nodes with ALL their in-edges; fwd+bwd of the K aggregators + dense tail."""
@@ -137,7 +157,7 @@ def main():
     ap.add_argument("--aggregators", type=str, default="sum,mean,max,min")
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded (RCCL) path even at world size 1")
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="target nodes in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=150000, help="target nodes in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -234,7 +254,8 @@ def main():
             kernels[name] = k
         dom = max((n for n in kernels if n in ab), key=lambda n: kernels[n]["avg_ms"])
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None}
+                "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(dom, N, E, H, K) if not sharded else None}
         cpu = None
         if args.cpu_sample and not sharded:
             cpu = cpu_baseline(rowptr, col, H, names, "new_sigmoid", args.dropout, min(args.cpu_sample, N), 42)
