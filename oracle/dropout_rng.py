@@ -16,12 +16,13 @@ def _mix(a):
     return a
 
 
-def keep_mask(seed, thr, K, E, H):
-    """(K,E,H) uint8 in {0,1}: element kept iff its hash byte >= thr.  scale for survivors: 256/(256-thr)."""
+def keep_mask(seed, thr, K, E, H, edge_ids=None):
+    """(K,E,H) uint8 in {0,1}: element kept iff its hash byte >= thr.  scale for survivors: 256/(256-thr).
+    edge_ids: the (global) edge positions to generate for (default arange(E))."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     seed_lo, seed_hi = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
     HQ = (H + 3) // 4
-    e = np.arange(E, dtype=np.uint64)
+    e = np.arange(E, dtype=np.uint64) if edge_ids is None else np.asarray(edge_ids).astype(np.uint64)
     ek = ((e * np.uint64(0x9E3779B1)) + seed_lo) & _M32                                   # (E,)
     kq = np.arange(K * HQ, dtype=np.uint64)
     ck = ((kq * np.uint64(0x85EBCA77)) + seed_hi) & _M32                                  # (K*HQ,)
