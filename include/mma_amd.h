@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 3
+#define MMA_ABI_VERSION 5
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -68,6 +68,9 @@ int mma_nc_fused_fwd(
     const int32_t* rowptr,                       /* (N+1) CSR by target: d_i = rowptr[i+1]-rowptr[i] */
     const int32_t* col,                          /* (E) source node of each edge, target-major */
     const int32_t* items, int64_t n_items,       /* (n_items,4) */
+    int64_t n_wave_items,                        /* items [0,n_wave_items) run one per wavefront (long segments), the rest one per
+                                                    H/4-lane group, 64/(H/4) per wavefront (short segments: more items in flight);
+                                                    pass n_items to run all per wavefront.  Speed only, results are identical. */
     const int32_t* hubs, int64_t n_hubs,         /* (n_hubs,4), may be NULL when n_hubs == 0 */
     float* partial, int64_t n_slots,             /* (n_slots, 2, K, H) scratch, NULL when n_slots == 0 */
     float* m,                                    /* (K,N,H) out: m[k] = learnable_<k>(x); may be NULL if m_sum is given */
@@ -87,8 +90,13 @@ int mma_nc_fused_fwd(
 int mma_nc_bwd_node(
     const float* g, int64_t g_kstride, int64_t ldgr, /* g[k*g_kstride + i*ldgr + h]; g_kstride = 0: one (N,H) gradient for all k */
     const uint8_t* sel, const float* T, int64_t ldt, const int32_t* rowptr,
-    float* gs, int64_t ldgs, float* gP, int64_t ldgp, float* gxs, int64_t ldgx,
+    float* gs, int64_t ldgs,                     /* (N,K*H) out, or NULL */
+    float* aux, int64_t ldaux,                   /* shared-gradient form only (g_kstride 0), or NULL: one packed row per target
+                                                    [ g (H floats) | 1/d_i,0,0,0 | 1-byte codes of each max/min/softmax/softmin mask,
+                                                    ceil(H/4) words each ]; pitch >= mma_nc_aux_row_floats() */
+    float* gP, int64_t ldgp, float* gxs, int64_t ldgx,
     int64_t N, int32_t H, int32_t K, const uint8_t* kind_host, void* stream);
+int64_t mma_nc_aux_row_floats(int32_t H, int32_t K, const uint8_t* kind_host);
 
 /* ---- K2b: edge-level backward, source-major (no atomics, deterministic) ---------------------------
  * Walks the TRANSPOSED CSR (edges grouped by source j): t_col[e'] = target i, t_eid[e'] = position of
@@ -100,12 +108,11 @@ int mma_nc_bwd_node(
 int mma_nc_fused_bwd(
     const float* x, int64_t ldx, const float* P, int64_t ldp, const float* Q, int64_t ldq,
     const float* gs, int64_t ldg,                /* (n_tgt,K*H) from K2a, or NULL for the shared-gradient form: */
-    const float* gM, int64_t ldgm,               /*   gM (n_tgt,H) = dL/d(sum_k m_k); gs_k[i] is rebuilt per edge from gM[i], */
-    const uint8_t* sel, int64_t ldsel,           /*   the saved selection codes, 1/d_i and the kinds: K*H+... -> H floats + */
-    const float* inv_deg, const uint8_t* kind_host, /* K*H bytes gathered per edge instead of K*H floats */
+    const float* aux, int64_t ldaux,             /*   the packed rows K2a wrote; gs_k[i] is rebuilt per edge from g[i], the codes */
+    const uint8_t* kind_host,                    /*   and 1/d_i: ~(1+K_sel/4)*H floats gathered per edge instead of K*H */
     const float* gxs, int64_t ldgx,
     const int32_t* t_col, const int32_t* t_eid,
-    const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs,
+    const int32_t* items, int64_t n_items, int64_t n_wave_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots,
     float* gQ, int64_t ldgq, float* gx, int64_t ldgxo,
     int64_t N, int64_t E, int32_t H, int32_t K,

@@ -6,17 +6,17 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmma_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 5
 
 _c = ctypes
 _P, _I64, _I32, _U32, _U64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_uint64
 
 # name -> argtypes, exactly the prototypes of include/mma_amd.h
 PROTOTYPES = {
-    "mma_nc_fused_fwd": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64,
+    "mma_nc_fused_fwd": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64,
                          _I64, _I64, _I32, _I32, _P, _P, _I32, _U32, _U64, _I64, _P, _P],
-    "mma_nc_bwd_node": [_P, _I64, _I64, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P],
-    "mma_nc_fused_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _I64,
+    "mma_nc_bwd_node": [_P, _I64, _I64, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P],
+    "mma_nc_fused_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64,
                          _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I32, _I32, _P, _I32, _U32, _U64, _I64, _P, _P],
     "mma_csr_spmm": [_P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _I64, _I64, _I32, _P],
     "mma_build_csr": [_P, _P, _I64, _I64, _P, _P, _P, _P, _I64, _P],
@@ -49,6 +49,7 @@ def lib():
         L.mma_last_error.restype = _c.c_char_p
         if L.mma_abi_version() != ABI_VERSION:
             raise MMALibraryError("mma_amd: %s has ABI %d, expected %d: rebuild" % (LIB_PATH, L.mma_abi_version(), ABI_VERSION))
+        L.mma_nc_aux_row_floats.argtypes, L.mma_nc_aux_row_floats.restype = [_I32, _I32, _P], _I64
         L.mma_csr_workspace_bytes.argtypes, L.mma_csr_workspace_bytes.restype = [_I64, _I64], _I64
         for name, args in PROTOTYPES.items():
             fn = getattr(L, name)  # AttributeError if a declared symbol is missing

@@ -11,6 +11,9 @@
 // are no atomics anywhere, so results are bitwise reproducible.
 #include "common.h"
 
+#ifndef MMA_MIN_WAVES
+#define MMA_MIN_WAVES 2   // register cap of the fused kernels in waves per SIMD (3 = 168 VGPRs spills and measured 5-25 % slower)
+#endif
 namespace mma {
 
 struct NcFwdParams {
@@ -79,24 +82,48 @@ __device__ __forceinline__ void nc_msum_store(const NcFwdParams& p, int node, in
   stv<VEC>(o, ms);
 }
 
-template <int K, int VEC, bool SAVE, bool DROP>
-__global__ __launch_bounds__(kBlock) void nc_fwd_kernel(const NcFwdParams p) {
+// MULTI = false: one item per wavefront (EPG = 64/LPR neighbour rows per step) - long segments.
+// MULTI = true : one item per group of G = LPR lanes, 64/G items per wavefront - short segments, where the per-item
+//                latency chain (item -> indices -> rows -> store) dominates and more items in flight is what pays.
+template <int K, int VEC, bool SAVE, bool DROP, bool MULTI>
+__global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_kernel(const NcFwdParams p) {
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log;
-  const int epg = kWave >> p.lpr_log;
-  const int sub = lane >> p.lpr_log;
+  const int G = MULTI ? lpr : kWave;            // lanes per item
+  const int epg = G >> p.lpr_log;               // neighbour rows a group gathers per step
+  const int gpw = kWave / G;                    // items per wavefront
+  const int grp = MULTI ? lane / G : 0;
+  const int gl = lane & (G - 1);
+  const int gbase = grp * G;
+  const int sub = gl >> p.lpr_log;
   const int c = ((int)blockIdx.y * lpr + (lane & (lpr - 1))) * VEC;
   const bool fvalid = c < p.H;
   const int cc = fvalid ? c : 0;  // masked lanes read column 0 (valid memory), results are discarded
   const int waves_per_block = kBlock / kWave;
   const int64_t stride = (int64_t)gridDim.x * waves_per_block;
+  const int64_t n_witems = (p.n_items + gpw - 1) / gpw;
 
-  for (int64_t it0 = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); it0 < p.n_items; it0 += stride) {
-    const int4 item = p.items[__builtin_amdgcn_readfirstlane((int)it0)];
-    const int node = __builtin_amdgcn_readfirstlane(item.x);
-    const int ebeg = __builtin_amdgcn_readfirstlane(item.y);
-    const int eend = __builtin_amdgcn_readfirstlane(item.z);
-    const int slot = __builtin_amdgcn_readfirstlane(item.w);
+  for (int64_t it0 = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); it0 < n_witems; it0 += stride) {
+    int node, ebeg, eend, slot;
+    bool ivalid = true;
+    if (MULTI) {
+      const int64_t idx = it0 * gpw + grp;
+      ivalid = idx < p.n_items;
+      const int4 item = p.items[ivalid ? idx : 0];
+      node = item.x; ebeg = item.y; eend = ivalid ? item.z : item.y; slot = item.w;
+    } else {
+      const int4 item = p.items[__builtin_amdgcn_readfirstlane((int)it0)];
+      node = __builtin_amdgcn_readfirstlane(item.x);
+      ebeg = __builtin_amdgcn_readfirstlane(item.y);
+      eend = __builtin_amdgcn_readfirstlane(item.z);
+      slot = __builtin_amdgcn_readfirstlane(item.w);
+    }
+    const int len = eend - ebeg;
+    int maxlen = len;
+    if (MULTI) {
+      for (int off = G; off < kWave; off <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, kWave));
+      maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    }
 
     const Vec<VEC> xi = ldv<VEC>(p.x + (size_t)node * p.ldx + cc);
     Vec<VEC> pk[K], acc[K], tac[K];
@@ -107,17 +134,18 @@ __global__ __launch_bounds__(kBlock) void nc_fwd_kernel(const NcFwdParams p) {
       tac[k] = vzero<VEC>();
     }
 
-    for (int base = ebeg; base < eend; base += kWave) {
-      const int cnt = min(kWave, eend - base);
-      const int myj = (lane < cnt) ? p.col[base + lane] : 0;
-      // two edge steps (2*EPG edges) in flight per iteration
-      for (int t0 = 0; t0 < cnt; t0 += 2 * epg) {
+    for (int base = 0; base < maxlen; base += G) {
+      const int cnt = min(G, max(len - base, 0));      // edges of MY item in this index chunk
+      const int ucnt = min(G, maxlen - base);          // wave-uniform trip bound
+      const int myj = (gl < cnt) ? p.col[ebeg + base + gl] : 0;
+      // two edge steps (2*EPG rows per group) in flight per iteration
+      for (int t0 = 0; t0 < ucnt; t0 += 2 * epg) {
         int tt[2]; bool ev[2]; Vec<VEC> xj[2]; Vec<VEC> qv[2][K];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           tt[u] = t0 + u * epg + sub;
           ev[u] = tt[u] < cnt;
-          const int j = __shfl(myj, tt[u] & (kWave - 1), kWave);
+          const int j = __shfl(myj, gbase + (tt[u] & (G - 1)), kWave);
           const int jj = ev[u] ? j : node;   // inactive sub-rows re-read the own row (cached), contribute 0
           xj[u] = ldv<VEC>(p.x + (size_t)jj * p.ldx + cc);
 #pragma unroll
@@ -132,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void nc_fwd_kernel(const NcFwdParams p) {
             const bool raw = (p.acts >> (p.k_base + k)) & 1u;
             float f[VEC];
             if (DROP) {
-              drop_factors<VEC>(p.drop, (uint32_t)(ev[u] ? base + tt[u] : ebeg), p.k_base + k, cc, p.H, p.HQ, f);
+              drop_factors<VEC>(p.drop, (uint32_t)(ev[u] ? ebeg + base + tt[u] : ebeg), p.k_base + k, cc, p.H, p.HQ, f);
             } else {
 #pragma unroll
               for (int i = 0; i < VEC; ++i) f[i] = 1.f;
@@ -152,8 +180,8 @@ __global__ __launch_bounds__(kBlock) void nc_fwd_kernel(const NcFwdParams p) {
       }
     }
 
-    // butterfly over the EPG sub-rows (lanes with equal feature column)
-    for (int off = kWave / 2; off >= lpr; off >>= 1) {
+    // butterfly over the sub-rows of a group (lanes with equal feature column)
+    for (int off = G / 2; off >= lpr; off >>= 1) {
 #pragma unroll
       for (int k = 0; k < K; ++k)
 #pragma unroll
@@ -163,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void nc_fwd_kernel(const NcFwdParams p) {
         }
     }
 
-    if (sub == 0 && fvalid) {
+    if (sub == 0 && fvalid && ivalid) {
       if (slot < 0) {
         const float deg = (float)max(p.rowptr[node + 1] - p.rowptr[node], 1);
         Vec<VEC> ms = vzero<VEC>();
@@ -226,6 +254,8 @@ struct NcBwdNodeParams {
   const uint8_t* sel; const float* T; int64_t ldt; const int32_t* rowptr;
   float* gs; int64_t ldgs; float* gP; int64_t ldgp; float* gxs; int64_t ldgx;
   int64_t N; int H, K; uint32_t kinds;
+  // shared-gradient form: one packed row per target for K2b, [ g (H floats) | 1/d_i, 0, 0, 0 | codes of sel-kind 0 (HQ words) | ... ]
+  float* aux; int64_t ldaux; int HQ; uint8_t sel_slot[MMA_MAX_K];
 };
 
 template <int VEC>
@@ -260,6 +290,15 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
         gx.v[i] = fmaf(g.v[i], fx, gx.v[i]);
       }
       if (p.gs) stv<VEC>(p.gs + (size_t)node * p.ldgs + (size_t)k * p.H + c, gsv);
+      if (p.aux) {
+        float* row = p.aux + (size_t)node * p.ldaux;
+        if (k == 0) {
+          stv<VEC>(row + c, g);                                   // the shared gradient itself
+          if (c == 0) row[p.H] = 1.f / deg;
+        }
+        if (p.sel_slot[k] != 0xFF)
+          stb<VEC>(reinterpret_cast<uint8_t*>(row + p.H + 4 + (size_t)p.sel_slot[k] * p.HQ) + c, codes);
+      }
       stv<VEC>(p.gP + (size_t)node * p.ldgp + (size_t)k * p.H + c, gpv);
     }
     stv<VEC>(p.gxs + (size_t)node * p.ldgx + c, gx);
@@ -272,8 +311,9 @@ struct NcBwdParams {
   const float* x; int64_t ldx;
   const float* P; int64_t ldp; const float* Q; int64_t ldq;
   const float* gs; int64_t ldg; const float* gxs; int64_t ldgx;
-  // SHARED mode (gs == NULL): all masks share one upstream gradient gM (N,H); gs_k[i] = gM[i] * f(kind_k, sel_k[i], 1/d_i)
-  const float* gM; int64_t ldgm; const uint8_t* sel; int64_t ldsel; const float* inv_deg; uint32_t kinds;
+  // SHARED mode (gs == NULL): all masks share one upstream gradient; gs_k[i] = g[i] * f(kind_k, code_k[i], 1/d_i) is
+  // rebuilt per edge from ONE packed row per target written by K2a: [ g (H) | 1/d_i,0,0,0 | codes per sel-kind (HQ words) ]
+  const float* aux; int64_t ldaux; uint8_t sel_slot[MMA_MAX_K]; uint32_t kinds;
   const int32_t* t_col; const int32_t* t_eid;
   const int4* items; int64_t n_items;
   float* partial; int64_t pstride;   // floats per slot = (K_total+1)*H
@@ -295,24 +335,45 @@ __device__ __forceinline__ float combine_ds(int kind, uint32_t code, float inv_d
   }
 }
 
-template <int K, int VEC, bool DROP, bool SHARED>
-__global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
+template <int K, int VEC, bool DROP, bool SHARED, bool MULTI>
+__global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_kernel(const NcBwdParams p) {
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log;
-  const int epg = kWave >> p.lpr_log;
-  const int sub = lane >> p.lpr_log;
+  const int G = MULTI ? lpr : kWave;
+  const int epg = G >> p.lpr_log;
+  const int gpw = kWave / G;
+  const int grp = MULTI ? lane / G : 0;
+  const int gl = lane & (G - 1);
+  const int gbase = grp * G;
+  const int sub = gl >> p.lpr_log;
   const int c = ((int)blockIdx.y * lpr + (lane & (lpr - 1))) * VEC;
   const bool fvalid = c < p.H;
   const int cc = fvalid ? c : 0;
   const int waves_per_block = kBlock / kWave;
   const int64_t stride = (int64_t)gridDim.x * waves_per_block;
+  const int64_t n_witems = (p.n_items + gpw - 1) / gpw;
 
-  for (int64_t it0 = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); it0 < p.n_items; it0 += stride) {
-    const int4 item = p.items[__builtin_amdgcn_readfirstlane((int)it0)];
-    const int node = __builtin_amdgcn_readfirstlane(item.x);   // the SOURCE j
-    const int ebeg = __builtin_amdgcn_readfirstlane(item.y);
-    const int eend = __builtin_amdgcn_readfirstlane(item.z);
-    const int slot = __builtin_amdgcn_readfirstlane(item.w);
+  for (int64_t it0 = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); it0 < n_witems; it0 += stride) {
+    int node, ebeg, eend, slot;     // node = the SOURCE j
+    bool ivalid = true;
+    if (MULTI) {
+      const int64_t idx = it0 * gpw + grp;
+      ivalid = idx < p.n_items;
+      const int4 item = p.items[ivalid ? idx : 0];
+      node = item.x; ebeg = item.y; eend = ivalid ? item.z : item.y; slot = item.w;
+    } else {
+      const int4 item = p.items[__builtin_amdgcn_readfirstlane((int)it0)];
+      node = __builtin_amdgcn_readfirstlane(item.x);
+      ebeg = __builtin_amdgcn_readfirstlane(item.y);
+      eend = __builtin_amdgcn_readfirstlane(item.z);
+      slot = __builtin_amdgcn_readfirstlane(item.w);
+    }
+    const int len = eend - ebeg;
+    int maxlen = len;
+    if (MULTI) {
+      for (int off = G; off < kWave; off <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, kWave));
+      maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    }
 
     const Vec<VEC> xj = ldv<VEC>(p.x + (size_t)node * p.ldx + cc);
     Vec<VEC> qk[K], aq[K];
@@ -323,11 +384,12 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
       aq[k] = vzero<VEC>();
     }
 
-    for (int base = ebeg; base < eend; base += kWave) {
-      const int cnt = min(kWave, eend - base);
-      const int myi = (lane < cnt) ? p.t_col[base + lane] : 0;
-      const int mye = (DROP && lane < cnt) ? p.t_eid[base + lane] : 0;
-      for (int t0 = 0; t0 < cnt; t0 += 2 * epg) {
+    for (int base = 0; base < maxlen; base += G) {
+      const int cnt = min(G, max(len - base, 0));
+      const int ucnt = min(G, maxlen - base);
+      const int myi = (gl < cnt) ? p.t_col[ebeg + base + gl] : 0;
+      const int mye = (DROP && gl < cnt) ? p.t_eid[ebeg + base + gl] : 0;
+      for (int t0 = 0; t0 < ucnt; t0 += 2 * epg) {
         // load phase: raw operands only (no arithmetic on loaded values, so both edge steps stay in flight)
         int tt[2]; bool ev[2]; uint32_t eid[2]; Vec<VEC> gv[2][SHARED ? 1 : K]; Vec<VEC> pv[2][K];
         uint32_t codes[2][K]; float idg[2];
@@ -335,19 +397,22 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
         for (int u = 0; u < 2; ++u) {
           tt[u] = t0 + u * epg + sub;
           ev[u] = tt[u] < cnt;
-          const int i_ = __shfl(myi, tt[u] & (kWave - 1), kWave);
-          eid[u] = DROP ? (uint32_t)__shfl(mye, tt[u] & (kWave - 1), kWave) : 0u;
+          const int i_ = __shfl(myi, gbase + (tt[u] & (G - 1)), kWave);
+          eid[u] = DROP ? (uint32_t)__shfl(mye, gbase + (tt[u] & (G - 1)), kWave) : 0u;
           const int ii = ev[u] ? i_ : 0;   // inactive sub-rows read target row 0 (valid), contribute 0
+          const float* arow = SHARED ? p.aux + (size_t)ii * p.ldaux : nullptr;
           if (SHARED) {
-            gv[u][0] = ldv<VEC>(p.gM + (size_t)ii * p.ldgm + cc);
-            idg[u] = p.inv_deg[ii];
+            gv[u][0] = ldv<VEC>(arow + cc);
+            idg[u] = arow[p.H];
           }
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const size_t o = (size_t)(p.k_base + k) * p.H + cc;
             if (SHARED) {
               // sum/mean never look at the code: a constant "s selected" keeps the arithmetic below branch-free
-              codes[u][k] = (kind_of(p.kinds, p.k_base + k) >= MMA_KIND_MAX) ? ldb<VEC>(p.sel + (size_t)ii * p.ldsel + o) : 0x01010101u;
+              const uint32_t sslot = p.sel_slot[p.k_base + k];
+              codes[u][k] = (sslot != 0xFFu) ? ldb<VEC>(reinterpret_cast<const uint8_t*>(arow + p.H + 4 + (size_t)sslot * p.HQ) + cc)
+                                             : 0x01010101u;
             } else {
               gv[u][k] = ldv<VEC>(p.gs + (size_t)ii * p.ldg + o);
             }
@@ -391,7 +456,7 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
       }
     }
 
-    for (int off = kWave / 2; off >= lpr; off >>= 1) {
+    for (int off = G / 2; off >= lpr; off >>= 1) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         ax.v[i] += __shfl_xor(ax.v[i], off, kWave);
@@ -400,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_kernel(const NcBwdParams p) {
       }
     }
 
-    if (sub == 0 && fvalid) {
+    if (sub == 0 && fvalid && ivalid) {
       if (slot < 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -483,6 +548,15 @@ static int pack_codes(const uint8_t* kind_host, const uint8_t* act_host, int K, 
   return 0;
 }
 
+// sel-kinds (max/min/softmax/softmin) get consecutive code slots in the packed aux row; returns the row length in floats
+static int fill_sel_slots(const uint8_t* kind_host, int K, int H, uint8_t* slots) {
+  int n = 0;
+  for (int k = 0; k < MMA_MAX_K; ++k) slots[k] = 0xFF;
+  for (int k = 0; k < K; ++k)
+    if (kind_host[k] >= MMA_KIND_MAX) slots[k] = (uint8_t)n++;
+  return ((H + 4 + n * ((H + 3) / 4)) + 3) & ~3;
+}
+
 static int make_drop(int32_t mode, uint32_t thr, uint64_t seed, int64_t edge_base, const uint8_t* keep, int64_t E, DropParams* d) {
   MMA_REQUIRE(edge_base >= 0 && edge_base + E < (1LL << 32), "drop_edge_base %lld out of range", (long long)edge_base);
   d->edge_base = (uint32_t)edge_base;
@@ -505,52 +579,53 @@ static Geometry geometry(int H, bool vec4_ok) {
   return g;
 }
 
-static dim3 item_grid(int64_t n_items, int chunks) {
-  int64_t blocks = (n_items + (kBlock / kWave) - 1) / (kBlock / kWave);
+static dim3 item_grid(int64_t n_items, int chunks, int items_per_wave = 1) {
+  const int64_t per_block = (int64_t)(kBlock / kWave) * items_per_wave;
+  int64_t blocks = (n_items + per_block - 1) / per_block;
   if (blocks > kMaxGrid) blocks = kMaxGrid;
   if (blocks < 1) blocks = 1;
   return dim3((unsigned)blocks, (unsigned)chunks, 1);
 }
 
-template <int K, int VEC>
+template <int K, int VEC, bool MULTI>
 static void launch_fwd(const NcFwdParams& p, dim3 grid, bool save, bool drop, hipStream_t st) {
   if (save) {
-    if (drop) hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, true, true>), grid, dim3(kBlock), 0, st, p);
-    else hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, true, false>), grid, dim3(kBlock), 0, st, p);
+    if (drop) hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, true, true, MULTI>), grid, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, true, false, MULTI>), grid, dim3(kBlock), 0, st, p);
   } else {
-    if (drop) hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, false, true>), grid, dim3(kBlock), 0, st, p);
-    else hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, false, false>), grid, dim3(kBlock), 0, st, p);
+    if (drop) hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, false, true, MULTI>), grid, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, false, false, MULTI>), grid, dim3(kBlock), 0, st, p);
   }
 }
-template <int VEC>
+template <int VEC, bool MULTI>
 static void launch_fwd_k(int Ks, const NcFwdParams& p, dim3 grid, bool save, bool drop, hipStream_t st) {
   switch (Ks) {
-    case 1: launch_fwd<1, VEC>(p, grid, save, drop, st); break;
-    case 2: launch_fwd<2, VEC>(p, grid, save, drop, st); break;
-    case 3: launch_fwd<3, VEC>(p, grid, save, drop, st); break;
-    case 4: launch_fwd<4, VEC>(p, grid, save, drop, st); break;
-    default: launch_fwd<8, VEC>(p, grid, save, drop, st); break;
+    case 1: launch_fwd<1, VEC, MULTI>(p, grid, save, drop, st); break;
+    case 2: launch_fwd<2, VEC, MULTI>(p, grid, save, drop, st); break;
+    case 3: launch_fwd<3, VEC, MULTI>(p, grid, save, drop, st); break;
+    case 4: launch_fwd<4, VEC, MULTI>(p, grid, save, drop, st); break;
+    default: launch_fwd<8, VEC, MULTI>(p, grid, save, drop, st); break;
   }
 }
-template <int K, int VEC>
+template <int K, int VEC, bool MULTI>
 static void launch_bwd(const NcBwdParams& p, dim3 grid, bool drop, hipStream_t st) {
   const bool shared = p.gs == nullptr;
   if (shared) {
-    if (drop) hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, true, true>), grid, dim3(kBlock), 0, st, p);
-    else hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, false, true>), grid, dim3(kBlock), 0, st, p);
+    if (drop) hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, true, true, MULTI>), grid, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, false, true, MULTI>), grid, dim3(kBlock), 0, st, p);
   } else {
-    if (drop) hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, true, false>), grid, dim3(kBlock), 0, st, p);
-    else hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, false, false>), grid, dim3(kBlock), 0, st, p);
+    if (drop) hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, true, false, MULTI>), grid, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, false, false, MULTI>), grid, dim3(kBlock), 0, st, p);
   }
 }
-template <int VEC>
+template <int VEC, bool MULTI>
 static void launch_bwd_k(int Ks, const NcBwdParams& p, dim3 grid, bool drop, hipStream_t st) {
   switch (Ks) {
-    case 1: launch_bwd<1, VEC>(p, grid, drop, st); break;
-    case 2: launch_bwd<2, VEC>(p, grid, drop, st); break;
-    case 3: launch_bwd<3, VEC>(p, grid, drop, st); break;
-    case 4: launch_bwd<4, VEC>(p, grid, drop, st); break;
-    default: launch_bwd<8, VEC>(p, grid, drop, st); break;
+    case 1: launch_bwd<1, VEC, MULTI>(p, grid, drop, st); break;
+    case 2: launch_bwd<2, VEC, MULTI>(p, grid, drop, st); break;
+    case 3: launch_bwd<3, VEC, MULTI>(p, grid, drop, st); break;
+    case 4: launch_bwd<4, VEC, MULTI>(p, grid, drop, st); break;
+    default: launch_bwd<8, VEC, MULTI>(p, grid, drop, st); break;
   }
 }
 
@@ -569,7 +644,7 @@ using namespace mma;
 extern "C" int mma_nc_fused_fwd(
     const float* x, int64_t ldx, const float* P, int64_t ldp, const float* Q, int64_t ldq,
     const int32_t* rowptr, const int32_t* col,
-    const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs,
+    const int32_t* items, int64_t n_items, int64_t n_wave_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots, float* m, float* m_sum, int64_t ldms, float* T, uint8_t* sel, int64_t ldt,
     int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* kind_host, const uint8_t* act_host,
     int32_t drop_mode, uint32_t drop_thr, uint64_t seed, int64_t drop_edge_base, const uint8_t* keep, void* stream) {
@@ -579,7 +654,7 @@ extern "C" int mma_nc_fused_fwd(
               (long long)ldx, (long long)ldp, (long long)ldq);
   MMA_REQUIRE((T == nullptr) == (sel == nullptr), "T and sel must both be given or both be NULL");
   MMA_REQUIRE(T == nullptr || ldt >= (int64_t)K * H, "ldt=%lld too small", (long long)ldt);
-  MMA_REQUIRE(n_items >= 0 && n_hubs >= 0 && n_slots >= 0 && n_items < (1LL << 31), "negative or oversize item counts");
+  MMA_REQUIRE(n_items >= 0 && n_hubs >= 0 && n_slots >= 0 && n_items < (1LL << 31) && n_wave_items >= 0, "negative or oversize item counts");
   MMA_REQUIRE(n_slots == 0 || (partial != nullptr && hubs != nullptr && n_hubs > 0), "hub slots without partial/hubs buffers");
   if (N == 0 || n_items == 0) return 0;
   MMA_REQUIRE(x && P && Q && rowptr && items && kind_host && act_host, "NULL argument");
@@ -603,13 +678,23 @@ extern "C" int mma_nc_fused_fwd(
   p.m = m; p.m_kstride = N * (int64_t)H; p.msum = m_sum; p.ldms = ldms; p.T = T; p.sel = sel; p.ldt = ldt;
   p.H = H; p.HQ = (H + 3) / 4; p.K_total = K; p.lpr_log = g.lpr_log; p.kinds = kinds; p.acts = acts;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid = item_grid(n_items, g.chunks);
-  for (int k0 = 0; k0 < K;) {
-    const int ks = next_slice(K - k0);
-    p.k_base = k0;
-    if (g.vec == 4) launch_fwd_k<4>(ks, p, grid, save, drop, st);
-    else launch_fwd_k<1>(ks, p, grid, save, drop, st);
-    k0 += ks;
+  // items [0, n_wave_items): one per wavefront; items [n_wave_items, n_items): one per LPR-lane group (short segments)
+  const int ipw = kWave >> g.lpr_log;
+  if (ipw == 1 || n_wave_items > n_items) n_wave_items = n_items;
+  const int4* all_items = p.items;
+  for (int part = 0; part < 2; ++part) {
+    const int64_t cnt = part == 0 ? n_wave_items : n_items - n_wave_items;
+    if (cnt <= 0) continue;
+    p.items = all_items + (part == 0 ? 0 : n_wave_items);
+    p.n_items = cnt;
+    const dim3 grid = item_grid(cnt, g.chunks, part == 0 ? 1 : ipw);
+    for (int k0 = 0; k0 < K;) {
+      const int ks = next_slice(K - k0);
+      p.k_base = k0;
+      if (g.vec == 4) { if (part == 0) launch_fwd_k<4, false>(ks, p, grid, save, drop, st); else launch_fwd_k<4, true>(ks, p, grid, save, drop, st); }
+      else { if (part == 0) launch_fwd_k<1, false>(ks, p, grid, save, drop, st); else launch_fwd_k<1, true>(ks, p, grid, save, drop, st); }
+      k0 += ks;
+    }
   }
   if (int rc = check_launch("nc_fwd_kernel")) return rc;
   if (n_hubs > 0) {
@@ -628,9 +713,15 @@ extern "C" int mma_nc_fused_fwd(
   return 0;
 }
 
+extern "C" int64_t mma_nc_aux_row_floats(int32_t H, int32_t K, const uint8_t* kind_host) {
+  if (H < 1 || K < 1 || K > MMA_MAX_K || !kind_host) return -1;
+  uint8_t slots[MMA_MAX_K];
+  return fill_sel_slots(kind_host, K, H, slots);
+}
+
 extern "C" int mma_nc_bwd_node(
     const float* g, int64_t g_kstride, int64_t ldgr, const uint8_t* sel, const float* T, int64_t ldt, const int32_t* rowptr,
-    float* gs, int64_t ldgs, float* gP, int64_t ldgp, float* gxs, int64_t ldgx,
+    float* gs, int64_t ldgs, float* aux, int64_t ldaux, float* gP, int64_t ldgp, float* gxs, int64_t ldgx,
     int64_t N, int32_t H, int32_t K, const uint8_t* kind_host, void* stream) {
   MMA_REQUIRE(N >= 0 && N < (1LL << 31) && H >= 1 && K >= 1 && K <= MMA_MAX_K, "N=%lld H=%d K=%d unsupported", (long long)N, H, K);
   MMA_REQUIRE(ldt >= (int64_t)K * H && (!gs || ldgs >= (int64_t)K * H) && ldgp >= (int64_t)K * H && ldgx >= H && ldgr >= H &&
@@ -640,6 +731,10 @@ extern "C" int mma_nc_bwd_node(
   uint32_t kinds, acts;
   if (int rc = pack_codes(kind_host, nullptr, K, &kinds, &acts)) return rc;
   NcBwdNodeParams p{g, g_kstride, ldgr, sel, T, ldt, rowptr, gs, ldgs, gP, ldgp, gxs, ldgx, N, H, K, kinds};
+  p.aux = aux; p.ldaux = ldaux; p.HQ = (H + 3) / 4;
+  const int aux_len = fill_sel_slots(kind_host, K, H, p.sel_slot);
+  MMA_REQUIRE(!aux || (g_kstride == 0 && ldaux >= aux_len && ldaux % 4 == 0 && aligned16(aux)),
+              "aux needs the shared-gradient form (g_kstride 0) and a 16-byte aligned pitch >= %d floats", aux_len);
   const bool v4 = (H % 4 == 0) && (ldt % 4 == 0) && (!gs || ldgs % 4 == 0) && (ldgp % 4 == 0) && (ldgx % 4 == 0) &&
                   (ldgr % 4 == 0) && (g_kstride % 4 == 0) && aligned16(g) && aligned16(sel) &&
                   aligned16(T) && (!gs || aligned16(gs)) && aligned16(gP) && aligned16(gxs);
@@ -653,10 +748,9 @@ extern "C" int mma_nc_bwd_node(
 
 extern "C" int mma_nc_fused_bwd(
     const float* x, int64_t ldx, const float* P, int64_t ldp, const float* Q, int64_t ldq,
-    const float* gs, int64_t ldg, const float* gM, int64_t ldgm, const uint8_t* sel, int64_t ldsel, const float* inv_deg,
-    const uint8_t* kind_host, const float* gxs, int64_t ldgx,
+    const float* gs, int64_t ldg, const float* aux, int64_t ldaux, const uint8_t* kind_host, const float* gxs, int64_t ldgx,
     const int32_t* t_col, const int32_t* t_eid,
-    const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs,
+    const int32_t* items, int64_t n_items, int64_t n_wave_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots, float* gQ, int64_t ldgq, float* gx, int64_t ldgxo,
     int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* act_host,
     int32_t drop_mode, uint32_t drop_thr, uint64_t seed, int64_t drop_edge_base, const uint8_t* keep, void* stream) {
@@ -664,9 +758,8 @@ extern "C" int mma_nc_fused_bwd(
   MMA_REQUIRE(H >= 1 && K >= 1 && K <= MMA_MAX_K, "H=%d K=%d unsupported (1<=K<=%d)", H, K, MMA_MAX_K);
   MMA_REQUIRE(ldx >= H && ldp >= (int64_t)K * H && ldq >= (int64_t)K * H && (!gs || ldg >= (int64_t)K * H) && ldgq >= (int64_t)K * H &&
               ldgx >= H && ldgxo >= H, "row pitch too small");
-  MMA_REQUIRE(gs != nullptr || (gM && sel && inv_deg && kind_host && ldgm >= H && ldsel >= (int64_t)K * H),
-              "give gs (N,K*H), or the shared-gradient form gM (N,H) + sel + inv_deg + kinds");
-  MMA_REQUIRE(n_items >= 0 && n_hubs >= 0 && n_slots >= 0 && n_items < (1LL << 31), "negative or oversize item counts");
+  MMA_REQUIRE(gs != nullptr || (aux && kind_host), "give gs (N,K*H), or the shared-gradient form: aux rows from mma_nc_bwd_node + kinds");
+  MMA_REQUIRE(n_items >= 0 && n_hubs >= 0 && n_slots >= 0 && n_items < (1LL << 31) && n_wave_items >= 0, "negative or oversize item counts");
   MMA_REQUIRE(n_slots == 0 || (partial != nullptr && hubs != nullptr && n_hubs > 0), "hub slots without partial/hubs buffers");
   if (N == 0 || n_items == 0) return 0;
   MMA_REQUIRE(x && P && Q && gxs && items && gQ && gx && act_host, "NULL argument");
@@ -678,23 +771,36 @@ extern "C" int mma_nc_fused_bwd(
   if (int rc = make_drop(drop_mode, drop_thr, seed, drop_edge_base, keep, E, &p.drop)) return rc;
   const bool drop = drop_mode != MMA_DROP_NONE && !(drop_mode == MMA_DROP_HASH && drop_thr == 0);
   const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldp % 4 == 0) && (ldq % 4 == 0) && (ldgx % 4 == 0) && (ldgq % 4 == 0) &&
-                  (gs ? (ldg % 4 == 0 && aligned16(gs)) : (ldgm % 4 == 0 && ldsel % 4 == 0 && aligned16(gM) && aligned16(sel))) &&
+                  (gs ? (ldg % 4 == 0 && aligned16(gs)) : (ldaux % 4 == 0 && aligned16(aux))) &&
                   (ldgxo % 4 == 0) && aligned16(x) && aligned16(P) && aligned16(Q) && aligned16(gxs) &&
                   aligned16(gQ) && aligned16(gx) && (partial == nullptr || aligned16(partial));
   const Geometry g = geometry(H, v4);
   p.x = x; p.ldx = ldx; p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.gs = gs; p.ldg = ldg; p.gxs = gxs; p.ldgx = ldgx;
-  p.gM = gM; p.ldgm = ldgm; p.sel = sel; p.ldsel = ldsel; p.inv_deg = inv_deg; p.kinds = kinds;
+  p.aux = aux; p.ldaux = ldaux; p.kinds = kinds;
+  if (!gs) {
+    const int aux_len = fill_sel_slots(kind_host, K, H, p.sel_slot);
+    MMA_REQUIRE(ldaux >= aux_len, "ldaux=%lld < %d", (long long)ldaux, aux_len);
+  }
   p.t_col = t_col; p.t_eid = t_eid; p.items = reinterpret_cast<const int4*>(items); p.n_items = n_items;
   p.partial = partial; p.pstride = (int64_t)(K + 1) * H; p.gQ = gQ; p.ldgq = ldgq; p.gx = gx; p.ldgxo = ldgxo;
   p.H = H; p.HQ = (H + 3) / 4; p.K_total = K; p.lpr_log = g.lpr_log; p.acts = acts;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid = item_grid(n_items, g.chunks);
-  for (int k0 = 0; k0 < K;) {
-    const int ks = next_slice(K - k0);
-    p.k_base = k0; p.first_pass = (k0 == 0);
-    if (g.vec == 4) launch_bwd_k<4>(ks, p, grid, drop, st);
-    else launch_bwd_k<1>(ks, p, grid, drop, st);
-    k0 += ks;
+  const int ipw = kWave >> g.lpr_log;
+  if (ipw == 1 || n_wave_items > n_items) n_wave_items = n_items;
+  const int4* all_items = p.items;
+  for (int part = 0; part < 2; ++part) {
+    const int64_t cnt = part == 0 ? n_wave_items : n_items - n_wave_items;
+    if (cnt <= 0) continue;
+    p.items = all_items + (part == 0 ? 0 : n_wave_items);
+    p.n_items = cnt;
+    const dim3 grid = item_grid(cnt, g.chunks, part == 0 ? 1 : ipw);
+    for (int k0 = 0; k0 < K;) {
+      const int ks = next_slice(K - k0);
+      p.k_base = k0; p.first_pass = (k0 == 0);
+      if (g.vec == 4) { if (part == 0) launch_bwd_k<4, false>(ks, p, grid, drop, st); else launch_bwd_k<4, true>(ks, p, grid, drop, st); }
+      else { if (part == 0) launch_bwd_k<1, false>(ks, p, grid, drop, st); else launch_bwd_k<1, true>(ks, p, grid, drop, st); }
+      k0 += ks;
+    }
   }
   if (int rc = check_launch("nc_bwd_kernel")) return rc;
   if (n_hubs > 0) {

@@ -7,9 +7,10 @@ import torch
 from . import _lib
 from ._lib import call, host_codes, ptr, require_gpu, stream_ptr
 
-# K2b variant for the reduce_k (shared upstream gradient) backward: rebuild dL/ds_k per edge from the (N,H) gradient and
-# the selection codes instead of gathering a materialised (N,K*H) gs.  Fewer bytes per edge (2.8 vs 4 KB at K=4,H=128)
-# but more separate row accesses; measured slower on MI355X (C4, p=0.5: 10.2 vs 6.9 ms), so it is off by default.
+# K2b variant for the reduce_k (shared upstream gradient) backward: rebuild dL/ds_k per edge from one packed row per target
+# [g | 1/d | selection codes] written by K2a instead of gathering a materialised (N,K*H) gs.  30 % fewer bytes per edge
+# (2.8 vs 4 KB at K=4, H=128) and faster WITHOUT dropout (C4: 6.6 vs 6.8 ms), but the per-element code decode on top of the
+# dropout hash makes it VALU-limited at the 2 waves/SIMD the kernel runs at (p=0.5: 8.9 vs 7.1 ms), so it is off by default.
 SHARED_GRAD_BWD = False
 TIMER = None   # bench.py installs an object with .span(name) -> context manager (HIP events around the calls)
 
@@ -92,7 +93,7 @@ class _NCFused(torch.autograd.Function):
         mode, thr, seed, keep = drop.args()
         with _span("nc_fused_fwd"):
             call("mma_nc_fused_fwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
-                 ptr(graph.rowptr), ptr(graph.col), ptr(graph.items), graph.items.shape[0],
+                 ptr(graph.rowptr), ptr(graph.col), ptr(graph.items), graph.items.shape[0], graph.n_wave_items,
                  ptr(graph.hubs) if graph.n_slots else None, graph.hubs.shape[0], ptr(partial), graph.n_slots,
                  ptr(m), ptr(msum), H, ptr(T), ptr(sel), K * H, N, graph.E, H, K, host_codes(kinds), host_codes(acts),
                  mode, thr, seed, graph.edge_base, keep, stream_ptr())
@@ -110,6 +111,10 @@ class _NCFused(torch.autograd.Function):
         g = g.contiguous()
         dev = g.device
         gs = None if shared else torch.empty((N, K * H), device=dev, dtype=torch.float32)
+        aux, ldaux = None, 0
+        if shared:
+            ldaux = int(_lib.lib().mma_nc_aux_row_floats(H, K, host_codes(kinds)))
+            aux = torch.empty((N, ldaux), device=dev, dtype=torch.float32)
         gP = torch.empty((N, K * H), device=dev, dtype=torch.float32)
         gQ = torch.empty((S, K * H), device=dev, dtype=torch.float32)
         gxs = torch.empty((S, H), device=dev, dtype=torch.float32)
@@ -117,17 +122,17 @@ class _NCFused(torch.autograd.Function):
             gxs[N:].zero_()
         with _span("nc_bwd_node"):
             call("mma_nc_bwd_node", ptr(g), 0 if reduce_k else N * H, H, ptr(sel), ptr(T), K * H, ptr(graph.rowptr),
-                 ptr(gs), K * H, ptr(gP), K * H, ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
+                 ptr(gs), K * H, ptr(aux), ldaux, ptr(gP), K * H, ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
         gx = torch.empty((S, H), device=dev, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32)
                    if graph.t_n_slots else None)
         mode, thr, seed, keep = drop.args()
         with _span("nc_fused_bwd"):
             call("mma_nc_fused_bwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
-                 ptr(gs), K * H, ptr(g) if shared else None, H, ptr(sel) if shared else None, K * H,
-                 ptr(graph.inv_deg) if shared else None, host_codes(kinds) if shared else None, ptr(gxs), H,
+                 ptr(gs), K * H, ptr(aux), ldaux, host_codes(kinds) if shared else None, ptr(gxs), H,
                  ptr(graph.t_col), ptr(graph.t_eid),
-                 ptr(graph.t_items), graph.t_items.shape[0], ptr(graph.t_hubs) if graph.t_n_slots else None,
+                 ptr(graph.t_items), graph.t_items.shape[0], graph.t_n_wave_items,
+                 ptr(graph.t_hubs) if graph.t_n_slots else None,
                  graph.t_hubs.shape[0], ptr(partial), graph.t_n_slots, ptr(gQ), K * H, ptr(gx), H,
                  S, graph.E, H, K, host_codes(acts), mode, thr, seed, graph.edge_base, keep, stream_ptr())
         return gx, gP, gQ, None, None, None, None, None

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 DEFAULT_CHUNK = 512   # edges per work item; longer segments (hubs) are split and summed in a second pass
+GROUP_BELOW = 16      # items shorter than this run one per H/4-lane group (several per wavefront) instead of one per wavefront
 
 
 def make_items(rowptr, chunk):
@@ -58,7 +59,7 @@ def transpose_csr(rowptr, col, n_src):
 class NCGraph:
     """Device-resident plan.  n_src >= N allows extra source rows (halo rows in the sharded path)."""
 
-    def __init__(self, rowptr, col, device, n_src=None, chunk=DEFAULT_CHUNK, edge_base=0):
+    def __init__(self, rowptr, col, device, n_src=None, chunk=DEFAULT_CHUNK, edge_base=0, group_below=GROUP_BELOW):
         rowptr = np.asarray(rowptr, dtype=np.int64)
         col = np.asarray(col, dtype=np.int64)
         self.N = len(rowptr) - 1
@@ -71,6 +72,9 @@ class NCGraph:
         items, hubs, self.n_slots = make_items(rowptr, self.chunk)
         t_rowptr, t_col, t_eid = transpose_csr(rowptr, col, self.n_src)
         t_items, t_hubs, self.t_n_slots = make_items(t_rowptr, self.chunk)
+        # the lists are sorted longest first: the head runs one item per wavefront, the short tail grouped
+        self.n_wave_items = int(((items[:, 2] - items[:, 1]) >= group_below).sum())
+        self.t_n_wave_items = int(((t_items[:, 2] - t_items[:, 1]) >= group_below).sum())
         dev = torch.device(device)
         i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
         self.device = dev
