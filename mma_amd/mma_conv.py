@@ -153,9 +153,23 @@ class MMAConv(torch.nn.Module):
             hs = self.message(x.index_select(0, dst), x.index_select(0, src), edge_attr)
             out = self.aggregate(hs, dst, N, _graph=graph)
 
-        out = torch.cat([x, out], dim=-1)
-        outs = [nn(out[:, i]) for i, nn in enumerate(self.post_nns)]
-        out = torch.cat(outs, dim=1)
+        if self.post_layers == 1:
+            # post_nns[t](cat[x_t, out_t]) = x_t Wx_t^T + out_t Wo_t^T + b_t  (mma_conv.py:132-134) as ONE strided-batched
+            # GEMM over the towers: neither the (N,T,(K*S+1)*F) concatenation nor the per-tower slices are materialised.
+            Wp = torch.stack([seq[0].weight for seq in self.post_nns])                   # (T, F_out, (K*S+1)*F_in)
+            bp = torch.stack([seq[0].bias for seq in self.post_nns])                     # (T, F_out)
+            Wx, Wo = Wp[:, :, :Fi], Wp[:, :, Fi:]
+            y = torch.bmm(out.transpose(0, 1), Wo.transpose(1, 2))                       # (T, N, F_out), no copy of `out`
+            if self.divide_input:
+                y = y + torch.bmm(x.transpose(0, 1), Wx.transpose(1, 2))
+                y = y.transpose(0, 1)
+            else:
+                y = y.transpose(0, 1) + (x[:, 0] @ Wx.reshape(T * self.F_out, Fi).t()).view(N, T, self.F_out)
+            out = (y + bp).reshape(N, T * self.F_out)
+        else:
+            out = torch.cat([x, out], dim=-1)
+            outs = [nn(out[:, i]) for i, nn in enumerate(self.post_nns)]
+            out = torch.cat(outs, dim=1)
         return self.lin(out)
 
     def message(self, x_i: Tensor, x_j: Tensor, edge_attr: Optional[Tensor]) -> Tensor:
