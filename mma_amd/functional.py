@@ -291,6 +291,9 @@ class _GRAggregate(torch.autograd.Function):
         if not fused:
             return (gmsg.view(E, T, F),) + (None,) * 11
         # dU[i] = sum of its target segment, dV[j] = sum over the edges leaving j: two segment sums (K5 kernel)
+        if E == 0:
+            z = torch.zeros((N, D), device=gout.device, dtype=torch.float32)
+            return (None, z, z.clone(), gmsg if has_z else None) + (None,) * 8
         gU = torch.empty((N, D), device=gout.device, dtype=torch.float32)
         gV = torch.empty((N, D), device=gout.device, dtype=torch.float32)
         cs = graph.by_source

@@ -204,3 +204,17 @@ def test_error_behaviour():
     m2 = mma_amd.MaskAggregateLinear(4, 4, ["sum"], "sum", mask="no_linear")
     t = torch.ones(2, 4, device=DEV)
     assert m2(t) is t
+
+
+def test_gr_degenerate_inputs():
+    """No edges at all, and a batch whose last nodes receive nothing: zeros out, zero gradients, no crash."""
+    conv = make_conv(["sum", "mean", "min", "max"], ["identity", "amplification"], towers=2, F=4, edge_dim=3)
+    x = torch.randn(6, 4, device=DEV, requires_grad=True)
+    ei = torch.zeros((2, 0), dtype=torch.int64, device=DEV)
+    ea = torch.zeros((0, 3), device=DEV)
+    out = conv(x, ei, ea)
+    assert out.shape == (6, 8) and torch.isfinite(out).all()
+    out.sum().backward()
+    assert torch.isfinite(x.grad).all()
+    agg = conv.aggregate(torch.zeros(0, 2, 4, device=DEV), torch.zeros(0, dtype=torch.int64, device=DEV), 5)
+    assert agg.shape == (5, 2, 32) and (agg == 0).all()

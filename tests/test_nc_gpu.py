@@ -224,3 +224,38 @@ def test_unusable_aggregators_and_errors():
     x = gold.torch_inputs(DEV)[0]
     with pytest.raises(NotImplementedError):
         mod(x, adj_of(gold))
+
+
+@pytest.mark.parametrize("N,H,names,edges", [
+    (1, 4, ["sum"], []),                                   # single isolated node
+    (5, 1, ["mean", "max"], [(0, 1), (1, 0), (4, 4)]),     # H = 1, a self loop, isolated nodes
+    (7, 12, ["sum", "mean", "max", "min", "softmax", "softmin"], []),          # no edges at all, K = 6
+    (3, 8, ["min"], [(0, 1), (0, 1), (0, 2), (1, 0)]),     # duplicate (multi-)edges
+])
+def test_degenerate_graphs(N, H, names, edges):
+    import mma_amd
+    from mma_amd import functional as Fn
+    from oracle import nc_oracle as O
+    rng = np.random.default_rng(N * 10 + H)
+    deg = np.zeros(N, dtype=np.int64)
+    for i, _ in edges:
+        deg[i] += 1
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    col = np.array([j for i in range(N) for (t, j) in edges if t == i], dtype=np.int64)
+    x = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32))
+    Ws = {n: torch.from_numpy((rng.standard_normal((2 * H, H)) * 0.3).astype(np.float32)) for n in names}
+    xo = x.clone().requires_grad_(True)
+    mo = torch.stack([O.aggregate(n, xo, Ws[n], rowptr, col, "new_sigmoid") for n in names])
+    go, = torch.autograd.grad(mo.sum(), [xo])
+    graph = mma_amd.NCGraph(rowptr, col, DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    kinds = [Fn.KIND[O.AGGREGATORS[n][0]] for n in names]
+    acts = [Fn.ACT_RAW if O.uses_raw_logits(n, "new_sigmoid") else Fn.ACT_SIGMOID for n in names]
+    P = xg @ torch.cat([Ws[n][:H] for n in names], 1).to(DEV)
+    Q = xg @ torch.cat([Ws[n][H:] for n in names], 1).to(DEV)
+    mg = Fn.nc_fused_aggregate(xg, P, Q, graph, kinds, acts)
+    gg, = torch.autograd.grad(mg.sum(), [xg])
+    check_close(mg.reshape(-1, H), mo.detach().reshape(-1, H).numpy(), None, None, what="degenerate m")
+    check_close(gg, go.numpy(), None, None, what="degenerate gx", signed_sum=True)
+    ms = Fn.nc_fused_aggregate(xg.detach(), P.detach(), Q.detach(), graph, kinds, acts, reduce_k=True)
+    check_close(ms, mo.detach().sum(0).numpy(), None, None, what="degenerate msum", signed_sum=True)
