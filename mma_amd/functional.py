@@ -270,6 +270,11 @@ class _GRAggregate(torch.autograd.Function):
         stats = need and (4 in aggr or 5 in aggr)
         mean = torch.empty((N, D), device=dev) if stats else None
         var = torch.empty((N, D), device=dev) if stats else None
+        if E == 0:          # nothing to aggregate: every target is empty -> 0 (and a zero gradient)
+            out.zero_()
+            ctx.cfg = (graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, Z is not None)
+            ctx.save_for_backward(inputs, U, V, Z, None, None, None, None)
+            return out
         with _span("gr_fused_fwd"):
             _gr_call("mma_gr_fused_fwd", csr, U, V, Z, inputs, (ptr(out), ptr(amin), ptr(amax), ptr(mean), ptr(var)),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
@@ -285,15 +290,17 @@ class _GRAggregate(torch.autograd.Function):
         N, E, D = graph.N, graph.E, T * F
         gout = gout.contiguous()
         gmsg = torch.empty((E, D), device=gout.device, dtype=torch.float32)
+        if E == 0:
+            if not fused:
+                return (gmsg.view(E, T, F),) + (None,) * 11
+            z = torch.zeros((N, D), device=gout.device, dtype=torch.float32)
+            return (None, z, z.clone(), gmsg if has_z else None) + (None,) * 8
         with _span("gr_fused_bwd"):
             _gr_call("mma_gr_fused_bwd", csr, U, V, Z, inputs, (ptr(gout), ptr(amin), ptr(amax), ptr(mean), ptr(var), ptr(gmsg), D),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
         if not fused:
             return (gmsg.view(E, T, F),) + (None,) * 11
         # dU[i] = sum of its target segment, dV[j] = sum over the edges leaving j: two segment sums (K5 kernel)
-        if E == 0:
-            z = torch.zeros((N, D), device=gout.device, dtype=torch.float32)
-            return (None, z, z.clone(), gmsg if has_z else None) + (None,) * 8
         gU = torch.empty((N, D), device=gout.device, dtype=torch.float32)
         gV = torch.empty((N, D), device=gout.device, dtype=torch.float32)
         cs = graph.by_source
