@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 5
+#define MMA_ABI_VERSION 6
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -136,6 +136,17 @@ int mma_csr_spmm_items(
     const int32_t* col, const float* val, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldo,
     const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs, float* partial, int64_t n_slots,
     int32_t C, void* stream);
+
+/* ---- GEMM-pre/post: fp32-accurate tall-skinny GEMM on the bf16 matrix cores ("bf16x3") -------------------
+ * C (M,N) = A (M,K) @ B (K,N) for M >> N,K: the x @ W_k products of layers.py:215-216 hoisted out of the node loop
+ * (P = x Wtop, Q = x Wbot) and their dL/dx.  gfx950 has no TF32/xf32 and its fp32-input MFMA runs at the vector
+ * rate, so A and B are split exactly into three bf16 pieces each and the six significant piece products are
+ * accumulated in fp32 by v_mfma_f32_32x32x16_bf16: accuracy of an fp32 GEMM, HBM-bound instead of MFMA-bound.
+ * Bt3: (3,N,K) bf16 = the three pieces of B^T (k contiguous), made by mma_split_bf16x3 from a row-major (N,K) fp32
+ * matrix.  Requires N % 32 == 0, K % 128 == 0 and (K == 128 or N <= 128). */
+int mma_split_bf16x3(const float* in, int64_t n, void* out_3n_bf16, void* stream);
+int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, float* C, int64_t ldc,
+                    int64_t M, int32_t N, int32_t K, void* stream);
 
 /* ---- K7: halo pack / unpack for the 1-D node-sharded multi-GPU path --------------------------------
  * pack:   dst[r,:] = src[idx[r],:]            (send buffer for the all-to-all of halo rows)

@@ -7,13 +7,38 @@ for the (128,N)@(N,16) tail).  Splitting the reduction into ~N/8192 batches (str
 batch) fills the chip: 140 TFLOP/s, 89 % of the fp32 MFMA peak (0.97 ms instead of 2.7 ms per mask-weight half)."""
 import torch
 
+from ._lib import call, ptr, stream_ptr
+
 _ROWS_PER_BATCH = 8192
+USE_BF16X3 = True     # fp32-accurate GEMM on the bf16 matrix cores (csrc/gemm_x3.hip) where the shape allows
+_MIN_ROWS_X3 = 4096
+
+
+def _x3_ok(a, w):
+    K, N = w.shape
+    return (USE_BF16X3 and a.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32 and a.shape[0] >= _MIN_ROWS_X3
+            and N % 32 == 0 and K % 128 == 0 and (K == 128 or N <= 128))
+
+
+def gemm_bf16x3(a, w):
+    """a (M,K) @ w (K,N) with fp32 accuracy on the bf16 MFMA path (three-piece split of both operands)."""
+    a = a.contiguous()
+    M, K = a.shape
+    N = w.shape[1]
+    wt = w.t().contiguous()                                  # (N,K): B^T, k contiguous
+    bt3 = torch.empty((3, N, K), device=a.device, dtype=torch.bfloat16)
+    call("mma_split_bf16x3", ptr(wt), N * K, ptr(bt3), stream_ptr())
+    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(bt3), ptr(out), N, M, N, K, stream_ptr())
+    return out
 
 
 def _rows_mm(a, w):
     """a (N,in) @ w (in,out) for tall a, issued as a strided-batched GEMM over row blocks (w broadcast): rocBLAS then
     picks a kernel that runs 15-25 % faster than the single tall-skinny GEMM (C4: 94 -> 114 TFLOP/s forward,
     105 -> 135 TFLOP/s for g @ W^T)."""
+    if _x3_ok(a, w):
+        return gemm_bf16x3(a, w)
     N = a.shape[0]
     B = N // _ROWS_PER_BATCH
     if B < 4:

@@ -1,0 +1,45 @@
+"""The bf16x3 GEMM (fp32 accuracy on the bf16 matrix cores) against an fp64 product: its error must be at the level of a
+plain fp32 GEMM's (which is what the reference computes with), far inside the 1e-5 parity bar."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("M,K,N", [(5000, 128, 512), (4099, 512, 128), (9001, 256, 64), (4096, 128, 32), (70000, 384, 96)])
+def test_gemm_bf16x3_accuracy(M, K, N):
+    from mma_amd import dense
+    rng = np.random.default_rng(M + K + N)
+    a = torch.from_numpy((rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, 1)))).astype(np.float32)).to(DEV)
+    w = torch.from_numpy(((rng.random((K, N)) * 2 - 1) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    ref = a.double() @ w.double()
+    got = dense.gemm_bf16x3(a, w)
+    f32 = a @ w
+    scale = (a.double().abs() @ w.double().abs())            # per-element sum of |terms|
+    e_got = ((got.double() - ref).abs() / scale).max().item()
+    e_f32 = ((f32.double() - ref).abs() / scale).max().item()
+    assert e_got < 5e-7 and e_got < 1.5 * e_f32 + 1e-7, (e_got, e_f32)   # fp32 eps 6e-8; the fp32 library GEMM sits at 1-3e-7
+    # exactness of the split on values that fit one piece, and determinism
+    assert torch.equal(dense.gemm_bf16x3(a, w), got)
+    ones = torch.ones(M, K, device=DEV)
+    wi = torch.zeros(K, N, device=DEV); wi[:N, :] = torch.eye(N, device=DEV) if K >= N else 0
+    if K >= N:
+        assert torch.equal(dense.gemm_bf16x3(ones, wi), torch.ones(M, N, device=DEV))
+
+
+def test_mm_autograd_uses_x3_and_matches():
+    from mma_amd import dense
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.standard_normal((20000, 128)).astype(np.float32)).to(DEV).requires_grad_(True)
+    w = torch.from_numpy((rng.standard_normal((128, 512)) * 0.1).astype(np.float32)).to(DEV).requires_grad_(True)
+    cot = torch.from_numpy(rng.standard_normal((20000, 512)).astype(np.float32)).to(DEV)
+    y = dense.mm(x, w)
+    gx, gw = torch.autograd.grad((y * cot).sum(), [x, w])
+    yr = x.double() @ w.double()
+    gxr = cot.double() @ w.double().t()
+    gwr = x.double().t() @ cot.double()
+    for a, b, name in ((y, yr, "y"), (gx, gxr, "gx"), (gw, gwr, "gw")):
+        err = (a.double() - b).abs().max().item() / b.abs().max().item()
+        assert err < 1e-5, (name, err)
