@@ -6,8 +6,11 @@
 // exactly into three bf16 pieces, a = a1 + a2 + a3 (8+8+8 mantissa bits), and the product is summed from the six
 // piece products that matter,   a b ~= a1b3 + a2b2 + a3b1 + a1b2 + a2b1 + a1b1   (dropped terms < 2^-24 |ab|),
 // every piece product being exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  The result is as accurate as
-// an fp32 GEMM (measured max error 3.6e-7 vs 7.1e-7 for the fp32 library GEMM, both against fp64) at 6/16 of its
-// matrix-core time, which turns these GEMMs from MFMA-bound into HBM-bound (they stream A in and C out once).
+// an fp32 GEMM (measured max error 2.4e-7 vs 3.0e-7 for the fp32 library GEMM, both relative to sum|a||b| against
+// fp64) at 6/16 of its matrix-core time.  Measured (C4, M = 2^20): 1.06 ms per (M,128)x(128,512) or (M,512)x(512,128)
+// product vs 1.3-1.45 ms for rocBLAS fp32; PMC: MFMA pipe 51 % busy at a 1.6 GHz effective clock - the A load/split,
+// MFMA and C-store phases of a workgroup still run back to back (ablation: 0.2 + 0.5 + 0.35 ms), which is the next
+// thing to fix (LDS-DMA slabs to free 24 VGPRs for a second accumulator so stores drain under the next tile's MFMAs).
 //
 // Layout: one workgroup = 4 waves = 128 rows of A; a wave keeps its 32 rows x 128 k of A in registers, already split
 // (3 x 8 k-steps x 8 bf16 = 96 VGPRs) and walks the 32-column tiles of B; the three bf16 pieces of the B tile
@@ -69,8 +72,10 @@ __device__ __forceinline__ void slab_store(unsigned char* dst, int tid, const Sl
 
 // NCT > 0: K > 128, the NCT (= N/32 <= 4) accumulator tiles persist across the K chunks (compile-time indices only).
 // NCT == 0: K == 128, any number of column tiles, one accumulator tile at a time.
-template <int NCT>
-__global__ __launch_bounds__(kBlock, (NCT >= 3 ? 1 : 2)) void gemm_x3_kernel(const GemmParams p) {
+// FULL: every row of the block exists (no guards: the C stores are unconditional, so the compiler can count them in
+// vmcnt and never waits for a store); the last partial block is a separate guarded launch.
+template <int NCT, bool FULL>
+__global__ __launch_bounds__(kBlock, (NCT >= 3 ? 1 : 2)) void gemm_x3_kernel(const GemmParams p, int64_t blk0, int64_t n_blocks) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kSlab];
   constexpr bool PERSIST = NCT > 0;
   const int tid = threadIdx.x;
@@ -78,11 +83,10 @@ __global__ __launch_bounds__(kBlock, (NCT >= 3 ? 1 : 2)) void gemm_x3_kernel(con
   const int r31 = lane & 31, h = lane >> 5;
   const int n_kc = p.K / kKC, n_ct = PERSIST ? NCT : p.N / 32;
   const int n_it = n_kc * n_ct;
-  const int64_t n_blocks = (p.M + 127) / 128;
 
-  for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+  for (int64_t blk = blk0 + blockIdx.x; blk < blk0 + n_blocks; blk += gridDim.x) {
     const int64_t row0 = blk * 128 + wave * 32;
-    const int64_t arow = min(row0 + r31, p.M - 1);           // rows past M re-read the last row, never stored
+    const int64_t arow = FULL ? row0 + r31 : min(row0 + r31, p.M - 1);   // rows past M re-read the last row, never stored
     const float* ap = p.A + arow * p.lda + 8 * h;
 
     f32x16 acc[PERSIST ? NCT : 1];
@@ -93,30 +97,20 @@ __global__ __launch_bounds__(kBlock, (NCT >= 3 ? 1 : 2)) void gemm_x3_kernel(con
 
     SlabRegs nxt = slab_load(p, tid, 0, 0);                  // slab prefetch registers: 6 x 16 B per thread
     slab_store(lds, tid, nxt);
+    if (n_it > 1) nxt = slab_load(p, tid, 1 / n_ct, 1 % n_ct);
     __syncthreads();
 
     bf16x8 af[8][3];
     int it = 0;
 // one 32-column tile of one K chunk: prefetch the next slab, 8 k-steps x 6 piece products, (last chunk) the C store,
 // publish the prefetched slab.  A macro, not a lambda: register arrays captured by a closure end up in scratch.
-#ifdef X3_NO_STORE
-#define X3_STORE_COND(L) ((L) && p.M < 0)
-#else
-#define X3_STORE_COND(L) (L)
-#endif
-#ifdef X3_NO_MFMA
-#define X3_KSTEPS 1
-#else
-#define X3_KSTEPS 8
-#endif
+// Order inside a tile: MFMAs on slab `it` | publish slab it+1 (loaded one tile ago) | issue the loads of slab it+2 |
+// C stores | barrier.  vmcnt is in-order and counts stores: a load issued AFTER a tile's stores could only be waited
+// for together with them, so the prefetch is issued BEFORE the stores and its wait (a tile later) leaves them in flight.
 #define MMA_X3_TILE(C_, CT_, LAST_)                                                                          \
     {                                                                                                        \
-      if (it + 1 < n_it) {                                                                                   \
-        const int nk = (it + 1) / n_ct;                                                                      \
-        nxt = slab_load(p, tid, nk, it + 1 - nk * n_ct);                                                     \
-      }                                                                                                      \
       const unsigned char* sb = lds + (it & 1) * kSlab + r31 * kRowPitch + h * 16;                           \
-      _Pragma("unroll") for (int ks = 0; ks < X3_KSTEPS; ++ks) {                                             \
+      _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                             \
         const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 0 * kPiece + ks * 32);                       \
         const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(sb + 1 * kPiece + ks * 32);                       \
         const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(sb + 2 * kPiece + ks * 32);                       \
@@ -127,14 +121,16 @@ __global__ __launch_bounds__(kBlock, (NCT >= 3 ? 1 : 2)) void gemm_x3_kernel(con
         C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1], b1, C_, 0, 0, 0);                            \
         C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], b1, C_, 0, 0, 0);                            \
       }                                                                                                      \
-      /* publish the prefetched slab BEFORE the C stores: vmcnt is in-order and counts stores too, so a wait placed  \
-         after the stores would hold the LDS write (and the barrier) until the stores have reached memory */          \
       if (it + 1 < n_it) slab_store(lds + ((it + 1) & 1) * kSlab, tid, nxt);                                 \
-      if (X3_STORE_COND(LAST_)) { /* acc reg r holds row (r&3) + 8*(r>>2) + 4*h, column r31 of the 32x32 tile */            \
+      if (it + 2 < n_it) {                                                                                   \
+        const int nk = (it + 2) / n_ct;                                                                      \
+        nxt = slab_load(p, tid, nk, it + 2 - nk * n_ct);                                                     \
+      }                                                                                                      \
+      if (LAST_) { /* acc reg r holds row (r&3) + 8*(r>>2) + 4*h, column r31 of the tile */   \
         float* cp = p.C + (size_t)((CT_) * 32 + r31);                                                        \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                     \
           const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;                                         \
-          if (row < p.M) cp[row * p.ldc] = C_[r];                                                            \
+          if (FULL || row < p.M) cp[row * p.ldc] = C_[r];                                                    \
         }                                                                                                    \
       }                                                                                                      \
       /* raw barrier: __syncthreads() would also drain vmcnt, i.e. wait for the C stores to reach memory */         \
@@ -208,13 +204,25 @@ extern "C" int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, flo
   MMA_REQUIRE(A && Bt3 && C && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt3) & 15) == 0,
               "NULL or misaligned argument");
   GemmParams p{A, lda, static_cast<const __bf16*>(Bt3), C, ldc, M, N, K};
-  int64_t blocks = (M + 127) / 128;
-  if (blocks > 512) blocks = 512;                 // 2 workgroups per CU (52 KB LDS, ~200 VGPRs each)
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (K == kKC) hipLaunchKernelGGL((gemm_x3_kernel<0>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);
-  else if (N == 32) hipLaunchKernelGGL((gemm_x3_kernel<1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);
-  else if (N == 64) hipLaunchKernelGGL((gemm_x3_kernel<2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);
-  else if (N == 96) hipLaunchKernelGGL((gemm_x3_kernel<3>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);
-  else hipLaunchKernelGGL((gemm_x3_kernel<4>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);
+  const int nct = K == kKC ? 0 : N / 32;
+  const int64_t n_full = M / 128;
+  for (int part = 0; part < 2; ++part) {
+    const bool full = part == 0;
+    const int64_t blk0 = full ? 0 : n_full, nb = full ? n_full : ((M % 128) ? 1 : 0);
+    if (nb == 0) continue;
+    const dim3 grid((unsigned)(nb < 512 ? nb : 512));      // 2 workgroups per CU (52 KB LDS, ~250 VGPRs each)
+#define MMA_X3_LAUNCH(NCT_)                                                                                       \
+    if (full) hipLaunchKernelGGL((gemm_x3_kernel<NCT_, true>), grid, dim3(kBlock), 0, st, p, blk0, nb);           \
+    else hipLaunchKernelGGL((gemm_x3_kernel<NCT_, false>), grid, dim3(kBlock), 0, st, p, blk0, nb);
+    switch (nct) {
+      case 0: MMA_X3_LAUNCH(0) break;
+      case 1: MMA_X3_LAUNCH(1) break;
+      case 2: MMA_X3_LAUNCH(2) break;
+      case 3: MMA_X3_LAUNCH(3) break;
+      default: MMA_X3_LAUNCH(4) break;
+    }
+#undef MMA_X3_LAUNCH
+  }
   return check_launch("gemm_x3_kernel");
 }
