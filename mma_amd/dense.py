@@ -20,7 +20,7 @@ def _x3_ok(a, w):
             and N % 32 == 0 and K % 128 == 0 and (K == 128 or N <= 128))
 
 
-def gemm_bf16x3(a, w):
+def gemm_bf16x3(a, w, out=None):
     """a (M,K) @ w (K,N) with fp32 accuracy on the bf16 MFMA path (three-piece split of both operands)."""
     a = a.contiguous()
     M, K = a.shape
@@ -28,9 +28,25 @@ def gemm_bf16x3(a, w):
     wt = w.t().contiguous()                                  # (N,K): B^T, k contiguous
     bt3 = torch.empty((3, N, K), device=a.device, dtype=torch.bfloat16)
     call("mma_split_bf16x3", ptr(wt), N * K, ptr(bt3), stream_ptr())
-    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
-    call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(bt3), ptr(out), N, M, N, K, stream_ptr())
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(bt3), ptr(out), out.stride(0), M, N, K, stream_ptr())
     return out
+
+
+def mm_into(a, w, out):
+    """out[...] = a @ w (no autograd): the forward GEMMs of the sharded layer write row blocks of one buffer."""
+    if a.shape[0] == 0:
+        return out
+    if _x3_ok(a, w):
+        return gemm_bf16x3(a, w, out)
+    return torch.mm(a, w, out=out)
+
+
+def rows_mm(a, w):
+    """a @ w for tall a, no autograd (bf16x3 kernel or row-batched library GEMM)."""
+    return _rows_mm(a, w)
 
 
 def _rows_mm(a, w):

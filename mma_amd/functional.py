@@ -60,46 +60,87 @@ class DropoutSpec:
         return self.mode, self.thr, self.seed, ptr(self.keep)
 
 
+def nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, save):
+    """K1 on prepared operands -> (m or msum, T, sel).  No autograd; shared by _NCFused and the sharded layer."""
+    K = len(kinds)
+    S, H = x_src.shape
+    N = graph.N
+    assert x_src.dtype == torch.float32 and P.dtype == torch.float32 and Q.dtype == torch.float32
+    assert S == graph.n_src and P.shape == (N, K * H) and Q.shape == (S, K * H) and 1 <= K <= 8
+    assert x_src.is_contiguous() and P.stride(1) == 1 and Q.stride(1) == 1
+    dev = x_src.device
+    m = None if reduce_k else torch.empty((K, N, H), device=dev, dtype=torch.float32)
+    msum = torch.empty((N, H), device=dev, dtype=torch.float32) if reduce_k else None
+    T = torch.empty((N, K * H), device=dev, dtype=torch.float32) if save else None
+    sel = torch.empty((N, K * H), device=dev, dtype=torch.uint8) if save else None
+    partial = torch.empty((graph.n_slots, 2 * K * H), device=dev, dtype=torch.float32) if graph.n_slots else None
+    if drop.keep is not None:
+        assert drop.keep.dtype == torch.uint8 and drop.keep.is_contiguous() and drop.keep.is_cuda and \
+            tuple(drop.keep.shape) == (K, graph.E, H), "explicit keep mask must be a contiguous (K,E,H) uint8 GPU tensor"
+    mode, thr, seed, keep = drop.args()
+    with _span("nc_fused_fwd"):
+        call("mma_nc_fused_fwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
+             ptr(graph.rowptr), ptr(graph.col), ptr(graph.items), graph.items.shape[0], graph.n_wave_items,
+             ptr(graph.hubs) if graph.n_slots else None, graph.hubs.shape[0], ptr(partial), graph.n_slots,
+             ptr(m), ptr(msum), H, ptr(T), ptr(sel), K * H, N, graph.E, H, K, host_codes(kinds), host_codes(acts),
+             mode, thr, seed, graph.edge_base, keep, stream_ptr())
+    return (msum if reduce_k else m), T, sel
+
+
+def nc_bwd_node_launch(g, reduce_k, sel, T, graph, kinds, H, shared):
+    """K2a -> (gs or None, aux or None, ldaux, gP (N,K*H), gxs (n_src,H) with zero halo rows)."""
+    K, N, S = len(kinds), graph.N, graph.n_src
+    dev = g.device
+    gs = None if shared else torch.empty((N, K * H), device=dev, dtype=torch.float32)
+    aux, ldaux = None, 0
+    if shared:
+        ldaux = int(_lib.lib().mma_nc_aux_row_floats(H, K, host_codes(kinds)))
+        aux = torch.empty((N, ldaux), device=dev, dtype=torch.float32)
+    gP = torch.empty((N, K * H), device=dev, dtype=torch.float32)
+    gxs = torch.empty((S, H), device=dev, dtype=torch.float32)
+    if S > N:  # halo rows are sources only: no target-side gradient
+        gxs[N:].zero_()
+    with _span("nc_bwd_node"):
+        call("mma_nc_bwd_node", ptr(g), 0 if reduce_k else N * H, H, ptr(sel), ptr(T), K * H, ptr(graph.rowptr),
+             ptr(gs), K * H, ptr(aux), ldaux, ptr(gP), K * H, ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
+    return gs, aux, ldaux, gP, gxs
+
+
+def nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, part=None):
+    """K2b over the transposed CSR; `part` = (items, n_wave_items, hubs) restricts it to a subset of the sources."""
+    K = len(acts)
+    S, H = x_src.shape
+    items, n_wave, hubs = part if part is not None else (graph.t_items, graph.t_n_wave_items, graph.t_hubs)
+    shared = gs is None
+    mode, thr, seed, keep = drop.args()
+    with _span("nc_fused_bwd"):
+        call("mma_nc_fused_bwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
+             ptr(gs), K * H, ptr(aux), ldaux, host_codes(kinds) if shared else None, ptr(gxs), H,
+             ptr(graph.t_col), ptr(graph.t_eid), ptr(items), items.shape[0], n_wave,
+             ptr(hubs) if hubs.shape[0] else None, hubs.shape[0], ptr(partial), graph.t_n_slots if hubs.shape[0] else 0,
+             ptr(gQ), gQ.stride(0), ptr(gx), H, S, graph.E, H, K, host_codes(acts), mode, thr, seed, graph.edge_base, keep,
+             stream_ptr())
+
+
 class _NCFused(torch.autograd.Function):
     """m[k] = combine_k(x_i, sum_j drop(act_k(P_k[i] + Q_k[j])) * x_j)   (K1 forward, K2a + K2b backward).
     reduce_k: return sum_k m[k] (N,H) instead of (K,N,H) - all MMA.forward needs; backward then takes the
-    shared-gradient form (K2b rebuilds dL/ds_k per edge from the (N,H) gradient and the saved selection codes)."""
+    shared-gradient form (one (N,H) upstream gradient for all masks)."""
 
     @staticmethod
     def forward(ctx, x_src, P, Q, graph, kinds, acts, drop, reduce_k):
         # x_src: (n_src,H) feature table; its first N rows are the targets (n_src > N only in the sharded path,
         # where the tail holds halo rows).  P: (N,K*H) = x_src[:N] @ [W_k[:H]..], Q: (n_src,K*H) = x_src @ [W_k[H:]..]
         require_gpu(x_src, P, Q)
-        K = len(kinds)
-        S, H = x_src.shape
-        N = graph.N
-        assert x_src.dtype == torch.float32 and P.dtype == torch.float32 and Q.dtype == torch.float32
-        assert S == graph.n_src and P.shape == (N, K * H) and Q.shape == (S, K * H) and 1 <= K <= 8
         x_src = x_src.contiguous()
         if P.stride(1) != 1:
             P = P.contiguous()
         if Q.stride(1) != 1:
             Q = Q.contiguous()
-        need_grad = any(ctx.needs_input_grad[:3])
-        dev = x_src.device
-        m = None if reduce_k else torch.empty((K, N, H), device=dev, dtype=torch.float32)
-        msum = torch.empty((N, H), device=dev, dtype=torch.float32) if reduce_k else None
-        T = torch.empty((N, K * H), device=dev, dtype=torch.float32) if need_grad else None
-        sel = torch.empty((N, K * H), device=dev, dtype=torch.uint8) if need_grad else None
-        partial = torch.empty((graph.n_slots, 2 * K * H), device=dev, dtype=torch.float32) if graph.n_slots else None
-        if drop.keep is not None:
-            assert drop.keep.dtype == torch.uint8 and drop.keep.is_contiguous() and drop.keep.is_cuda and \
-                tuple(drop.keep.shape) == (K, graph.E, H), "explicit keep mask must be a contiguous (K,E,H) uint8 GPU tensor"
-        mode, thr, seed, keep = drop.args()
-        with _span("nc_fused_fwd"):
-            call("mma_nc_fused_fwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
-                 ptr(graph.rowptr), ptr(graph.col), ptr(graph.items), graph.items.shape[0], graph.n_wave_items,
-                 ptr(graph.hubs) if graph.n_slots else None, graph.hubs.shape[0], ptr(partial), graph.n_slots,
-                 ptr(m), ptr(msum), H, ptr(T), ptr(sel), K * H, N, graph.E, H, K, host_codes(kinds), host_codes(acts),
-                 mode, thr, seed, graph.edge_base, keep, stream_ptr())
+        out, T, sel = nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, any(ctx.needs_input_grad[:3]))
         ctx.graph, ctx.kinds, ctx.acts, ctx.drop, ctx.reduce_k = graph, kinds, acts, drop, reduce_k
         ctx.save_for_backward(x_src, P, Q, T, sel)
-        return msum if reduce_k else m
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -107,34 +148,15 @@ class _NCFused(torch.autograd.Function):
         shared = reduce_k and SHARED_GRAD_BWD
         x_src, P, Q, T, sel = ctx.saved_tensors
         K = len(kinds)
-        N, H, S = graph.N, x_src.shape[1], graph.n_src
+        H, S = x_src.shape[1], graph.n_src
         g = g.contiguous()
         dev = g.device
-        gs = None if shared else torch.empty((N, K * H), device=dev, dtype=torch.float32)
-        aux, ldaux = None, 0
-        if shared:
-            ldaux = int(_lib.lib().mma_nc_aux_row_floats(H, K, host_codes(kinds)))
-            aux = torch.empty((N, ldaux), device=dev, dtype=torch.float32)
-        gP = torch.empty((N, K * H), device=dev, dtype=torch.float32)
+        gs, aux, ldaux, gP, gxs = nc_bwd_node_launch(g, reduce_k, sel, T, graph, kinds, H, shared)
         gQ = torch.empty((S, K * H), device=dev, dtype=torch.float32)
-        gxs = torch.empty((S, H), device=dev, dtype=torch.float32)
-        if S > N:  # halo rows are sources only: no target-side gradient
-            gxs[N:].zero_()
-        with _span("nc_bwd_node"):
-            call("mma_nc_bwd_node", ptr(g), 0 if reduce_k else N * H, H, ptr(sel), ptr(T), K * H, ptr(graph.rowptr),
-                 ptr(gs), K * H, ptr(aux), ldaux, ptr(gP), K * H, ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
         gx = torch.empty((S, H), device=dev, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32)
                    if graph.t_n_slots else None)
-        mode, thr, seed, keep = drop.args()
-        with _span("nc_fused_bwd"):
-            call("mma_nc_fused_bwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
-                 ptr(gs), K * H, ptr(aux), ldaux, host_codes(kinds) if shared else None, ptr(gxs), H,
-                 ptr(graph.t_col), ptr(graph.t_eid),
-                 ptr(graph.t_items), graph.t_items.shape[0], graph.t_n_wave_items,
-                 ptr(graph.t_hubs) if graph.t_n_slots else None,
-                 graph.t_hubs.shape[0], ptr(partial), graph.t_n_slots, ptr(gQ), K * H, ptr(gx), H,
-                 S, graph.E, H, K, host_codes(acts), mode, thr, seed, graph.edge_base, keep, stream_ptr())
+        nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial)
         return gx, gP, gQ, None, None, None, None, None
 
 

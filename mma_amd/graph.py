@@ -82,6 +82,17 @@ class NCGraph:
         self.items, self.hubs = i32(items), i32(hubs)
         self.t_rowptr, self.t_col, self.t_eid = i32(t_rowptr), i32(t_col), i32(t_eid)
         self.t_items, self.t_hubs = i32(t_items), i32(t_hubs)
+        # sharded path: sources >= N are halo rows.  Their backward items go first (their gradient has to travel), the
+        # own sources' items run while it is on the wire.  Each part keeps the longest-first order.
+        self.t_parts = None
+        if self.n_src > self.N:
+            parts = []
+            for sel_halo in (True, False):
+                mi = (t_items[:, 0] >= self.N) == sel_halo
+                mh = (t_hubs[:, 0] >= self.N) == sel_halo
+                it = t_items[mi]
+                parts.append((i32(it), int(((it[:, 2] - it[:, 1]) >= group_below).sum()), i32(t_hubs[mh])))
+            self.t_parts = parts
         deg = np.diff(rowptr)
         self.max_degree = int(deg.max()) if self.N else 0
         self.inv_deg = torch.from_numpy((1.0 / np.maximum(deg, 1)).astype(np.float32)).to(dev)   # mean-kind backward

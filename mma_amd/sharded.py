@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import functional as Fn
-from .dense import mm
+from .dense import mm, mm_into, rows_mm, xt_g
 from ._lib import call, ptr, require_gpu, stream_ptr
 from .graph import DEFAULT_CHUNK, NCGraph, SpmmGraph
 from .layers import _AGG
@@ -52,6 +52,37 @@ def all_to_all_rows(send, send_counts, recv_counts, group=None):
     recv = torch.empty((n_recv,) + tuple(width), dtype=send.dtype, device=send.device)
     dist.all_to_all_single(recv, send.contiguous(), [int(c) for c in recv_counts], [int(c) for c in send_counts], group=group)
     return recv
+
+
+class _A2AHandle:
+    """An all-to-all-v in flight.  NCCL/RCCL: runs on the communicator's own stream beside the compute stream;
+    wait() makes the compute stream wait for it (no host sync).  gloo (tests): already done when returned."""
+
+    def __init__(self, work, recv, keep):
+        self.work, self.recv, self.keep = work, recv, keep
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        self.keep = None
+        return self.recv
+
+
+def all_to_all_rows_start(send, send_counts, recv_counts, group=None, out=None):
+    """Start an all-to-all-v of row blocks; `out` (n_recv, W) may be a row slice of a larger buffer."""
+    n_recv = int(sum(recv_counts))
+    if _backend(group) == "gloo" and send.is_cuda:      # test path: synchronous, staged through the host
+        r = all_to_all_rows(send, send_counts, recv_counts, group)
+        if out is not None:
+            out.copy_(r)
+            r = out
+        return _A2AHandle(None, r, None)
+    recv = out if out is not None else torch.empty((n_recv,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    send = send.contiguous()
+    work = dist.all_to_all_single(recv, send, [int(c) for c in recv_counts], [int(c) for c in send_counts], group=group,
+                                  async_op=True)
+    return _A2AHandle(work, recv, send)
 
 
 def all_reduce_sum(t, group=None):
@@ -135,6 +166,79 @@ class _HaloExchange(torch.autograd.Function):
         return gx, None, None
 
 
+class _ShardedAggregate(torch.autograd.Function):
+    """Fused K-mask aggregate on a shard, with the halo traffic hidden behind independent work.
+
+    forward : pack -> all-to-all of x halo rows (async) || P = x_own Wtop, Q_own = x_own Wbot ;  wait ;  Q_halo = x_halo Wbot ;  K1
+    backward: K2a ; K2b on the HALO sources ; their dL/dx (direct + through Q) -> reverse all-to-all (async) ||
+              K2b on the own sources, dL/dx_own, dL/dWtop, dL/dWbot ;  wait ;  unpack-add at the owner."""
+
+    @staticmethod
+    def forward(ctx, x_own, wtop, wbot, mod, kinds, acts, drop):
+        require_gpu(x_own)
+        plan, graph = mod.plan, mod.graph
+        n, S, H = plan.n_own, plan.n_src, x_own.shape[1]
+        K = len(kinds)
+        dev = x_own.device
+        x_own = x_own.contiguous()
+        x_src = torch.empty((S, H), device=dev, dtype=torch.float32)
+        n_send = int(plan.send_counts.sum())
+        send = torch.empty((n_send, H), device=dev, dtype=torch.float32)
+        with Fn._span("halo_pack"):
+            call("mma_pack_rows", ptr(x_own), H, ptr(mod.send_idx), n_send, ptr(send), H, H, stream_ptr())
+        h = all_to_all_rows_start(send, plan.send_counts, plan.recv_counts, plan.group, out=x_src[n:])
+        x_src[:n].copy_(x_own)
+        P = torch.empty((n, K * H), device=dev, dtype=torch.float32)
+        Q = torch.empty((S, K * H), device=dev, dtype=torch.float32)
+        mm_into(x_own, wtop, P)
+        mm_into(x_own, wbot, Q[:n])
+        with Fn._span("halo_wait"):
+            h.wait()
+        mm_into(x_src[n:], wbot, Q[n:])
+        need = any(ctx.needs_input_grad[:3])
+        msum, T, sel = Fn.nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, True, need)
+        ctx.mod, ctx.kinds, ctx.acts, ctx.drop = mod, kinds, acts, drop
+        ctx.save_for_backward(x_src, P, Q, T, sel, wtop, wbot)
+        return msum
+
+    @staticmethod
+    def backward(ctx, g):
+        mod, kinds, acts, drop = ctx.mod, ctx.kinds, ctx.acts, ctx.drop
+        plan, graph = mod.plan, mod.graph
+        x_src, P, Q, T, sel, wtop, wbot = ctx.saved_tensors
+        n, S, H = plan.n_own, plan.n_src, x_src.shape[1]
+        K = len(kinds)
+        dev = g.device
+        g = g.contiguous()
+        shared = Fn.SHARED_GRAD_BWD
+        gs, aux, ldaux, gP, gxs = Fn.nc_bwd_node_launch(g, True, sel, T, graph, kinds, H, shared)
+        gQ = torch.empty((S, K * H), device=dev, dtype=torch.float32)
+        gx = torch.empty((S, H), device=dev, dtype=torch.float32)
+        partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32) if graph.t_n_slots else None)
+        back = None
+        if S > n:
+            halo_part, own_part = graph.t_parts
+            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, halo_part)
+            gxh = gx[n:] + rows_mm(gQ[n:], wbot.t())          # dL/dx of the halo rows: direct + through Q = x Wbot
+            back = all_to_all_rows_start(gxh, plan.recv_counts, plan.send_counts, plan.group)
+            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, own_part)
+        else:
+            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial)
+        gx_own = gx[:n] + rows_mm(gP, wtop.t()) + rows_mm(gQ[:n], wbot.t())
+        gwtop = xt_g(x_src[:n], gP) if ctx.needs_input_grad[1] else None
+        gwbot = xt_g(x_src, gQ) if ctx.needs_input_grad[2] else None
+        if back is not None:
+            with Fn._span("halo_wait"):
+                rows = back.wait()                                                       # (n_send, H)
+            with Fn._span("halo_unpack"):
+                for q in range(plan.world):      # one call per peer: rows are unique within a peer's list
+                    o0, o1 = int(plan.send_offsets[q]), int(plan.send_offsets[q + 1])
+                    if o1 > o0:
+                        call("mma_unpack_add_rows", ptr(rows[o0:o1]), H, ptr(mod.send_idx[o0:o1]), o1 - o0, ptr(gx_own), H, H,
+                             stream_ptr())
+        return gx_own, gwtop, gwbot, None, None, None, None
+
+
 class ShardedMMA(torch.nn.Module):
     """The MMA layer (layers.py:54-872 semantics, as mma_amd.MMA) on this rank's shard of the graph."""
 
@@ -184,11 +288,8 @@ class ShardedMMA(torch.nn.Module):
         kinds = [Fn.KIND[_AGG[a][0]] for a in self.names]
         acts = [Fn.ACT_RAW if (_AGG[a][1] and self.activation == "new_sigmoid") else Fn.ACT_SIGMOID for a in self.names]
         ws = [self.masks[a] for a in self.names]
-        x_halo = _HaloExchange.apply(x_own, self.plan, self.send_idx)
-        x_src = torch.cat([x_own, x_halo], 0)
-        P = mm(x_own, torch.cat([w[:H] for w in ws], 1))
-        Q = mm(x_src, torch.cat([w[H:] for w in ws], 1))
-        msum = Fn.nc_fused_aggregate(x_src, P, Q, self.graph, kinds, acts, self._drop(), reduce_k=True)   # (n_own, H)
+        msum = _ShardedAggregate.apply(x_own, torch.cat([w[:H] for w in ws], 1), torch.cat([w[H:] for w in ws], 1), self,
+                                       tuple(kinds), tuple(acts), self._drop())                 # (n_own, H)
         amp, att = scaler_factors(self.n_total or n, x_own.device)                          # Q1: identical rows
         c3 = (1.0 + amp[:1] + att[:1])
         # sum_k A (m_k W) == A ((sum_k m_k) W): only the (n,C) rows travel and enter the SpMM
