@@ -1,0 +1,31 @@
+"""Model glue for the node-classification path (reference node_classification/models.py:10-68): GCN layer -> ReLU ->
+dropout -> MMA layer -> log_softmax, with all 25 Parameters owned by the model exactly like the reference - minus its
+hard-coded `torch.cuda.FloatTensor` / 'cuda:2' device pins.  (a caller of the hot path, provided so that
+train.py-style scripts run end to end on the HIP kernels.)"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .layers import _MASK_NAMES, GraphConvolution, MMA
+
+
+class MMAConv(nn.Module):
+    def __init__(self, add_all, activation, k, nfeat, nhid, nclass, dropout, aggregator_list, device):
+        super().__init__()
+        self.device = device
+        new = lambda *shape: nn.Parameter(torch.empty(*shape, device=device))
+        self.weight0, self.bias0 = new(nfeat, nhid), new(nhid)
+        self.weight1, self.bias1 = new(nhid, nclass), new(nclass)
+        for name in _MASK_NAMES:                      # weight_moment_3, weight_sum, ... (models.py:23-43)
+            setattr(self, "weight_" + name, new(2 * nhid, nhid))
+        self.add_all = add_all
+        self.gc1 = GraphConvolution(nfeat, nhid, self.weight0, self.bias0, device)
+        self.gc2 = MMA(self.add_all, activation, k, nhid, nclass, self.weight1, self.bias1,
+                       *[getattr(self, "weight_" + name) for name in _MASK_NAMES], dropout, aggregator_list, device)
+        self.dropout = dropout
+
+    def forward(self, x, adj):
+        x = F.relu(self.gc1(x, adj))
+        x = F.dropout(x, self.dropout, training=self.training)
+        x = self.gc2(x, adj)
+        return F.log_softmax(x, dim=1)

@@ -1,0 +1,79 @@
+"""End-to-end smoke of the model glue on the HIP path: the reference's two training loops
+(node_classification/train.py:72-96, graph_regression/mma.py:139-161) on small synthetic data - the loss must go down.
+Not a parity test (the reference's always-on dropout makes training stochastic); it proves the drop-in modules train."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_node_classification_training_loop():
+    from mma_amd.models import MMAConv
+    from mma_amd.utils import accuracy, sparse_mx_to_torch_sparse_tensor
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    N, C, nfeat = 600, 3, 32
+    labels = rng.integers(0, C, N)
+    same = labels[:, None] == labels[None, :]
+    a = (rng.random((N, N)) < np.where(same, 0.03, 0.002))
+    a = np.triu(a, 1); a = a | a.T
+    for i in np.nonzero(a.sum(1) == 0)[0]:                 # the reference needs degree >= 1 (Q12)
+        j = (i + 1) % N; a[i, j] = a[j, i] = True
+    adj_sp = sp.csr_matrix(a.astype(np.float32))
+    add_all = [adj_sp.indices[adj_sp.indptr[i]:adj_sp.indptr[i + 1]] for i in range(N)]
+    feats = (np.eye(C)[labels] @ rng.standard_normal((C, nfeat)) + rng.standard_normal((N, nfeat))).astype(np.float32)
+    torch.manual_seed(42)
+    model = MMAConv(add_all, "new_sigmoid", 2, nfeat, 16, C, 0.5, ["mean", "max", "min"], DEV).to(DEV)
+    adj = sparse_mx_to_torch_sparse_tensor(adj_sp).to(DEV)
+    x, y = torch.from_numpy(feats).to(DEV), torch.from_numpy(labels).to(DEV)
+    idx_train = torch.arange(0, 400, device=DEV); idx_val = torch.arange(400, 600, device=DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+    losses = []
+    for epoch in range(60):
+        model.train(); opt.zero_grad()
+        out = model(x, adj)
+        loss = F.nll_loss(out[idx_train], y[idx_train])
+        loss.backward(); opt.step()
+        losses.append(loss.item())
+    model.eval()
+    with torch.no_grad():
+        acc = accuracy(model(x, adj)[idx_val], y[idx_val]).item()
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.6 * np.mean(losses[:5]), losses[::10]
+    assert acc > 0.55, acc          # chance is 0.33
+    assert len(list(model.parameters())) == 25      # weight0,bias0,weight1,bias1 + 21 masks, as models.py:45-50
+
+
+def test_graph_regression_training_loop():
+    from mma_amd.net import Net
+    from test_gr_gpu import molecule_batch
+    rng = np.random.default_rng(1)
+    batches = []
+    for _ in range(4):
+        ei, N, sizes = molecule_batch(rng, 16, return_sizes=True)
+        comp = np.repeat(np.arange(16), sizes)                  # the `batch` vector of a PyG mini-batch
+        xt = rng.integers(0, 21, (N, 1))
+        et = rng.integers(1, 4, ei.shape[1])
+        yv = np.bincount(comp, weights=(xt[:, 0] % 5).astype(np.float64), minlength=16) / 10.0
+        batches.append((torch.from_numpy(xt).to(DEV), torch.from_numpy(ei).to(DEV), torch.from_numpy(et).to(DEV),
+                        torch.from_numpy(comp).to(DEV), torch.from_numpy(yv.astype(np.float32)).to(DEV)))
+    deg = torch.zeros(5, dtype=torch.long)
+    for _, ei, _, comp, _ in batches:
+        d = torch.bincount(ei[1].cpu(), minlength=comp.numel())
+        deg += torch.bincount(d, minlength=5)[:5]
+    torch.manual_seed(0)
+    model = Net(["min", "max"], ["identity", "amplification", "linear"], deg).to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=0.003)
+    hist = []
+    for epoch in range(25):
+        tot = 0.0
+        for xt, ei, et, comp, yv in batches:
+            opt.zero_grad()
+            out = model(xt, ei, et, comp)
+            loss = (out.squeeze() - yv).abs().mean()
+            loss.backward(); opt.step()
+            tot += loss.item()
+        hist.append(tot / len(batches))
+    assert np.isfinite(hist).all() and np.mean(hist[-3:]) < 0.7 * np.mean(hist[:3]), hist[::5]

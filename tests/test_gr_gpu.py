@@ -92,9 +92,9 @@ def conv_params(conv):
     return prm
 
 
-def molecule_batch(rng, n_graphs=12):
+def molecule_batch(rng, n_graphs=12, return_sizes=False):
     """ZINC-like: trees of ~23 nodes + ring closures, max degree 4, symmetrised."""
-    src, dst, off = [], [], 0
+    src, dst, off, sizes = [], [], 0, []
     for _ in range(n_graphs):
         n = int(rng.integers(12, 30))
         deg = np.zeros(n, int)
@@ -107,6 +107,9 @@ def molecule_batch(rng, n_graphs=12):
             if deg[u] < 4 and deg[v] < 4:
                 src += [off + u, off + v]; dst += [off + v, off + u]; deg[u] += 1; deg[v] += 1
         off += n
+        sizes.append(n)
+    if return_sizes:
+        return np.array([src, dst]), off, np.array(sizes)
     return np.array([src, dst]), off
 
 
