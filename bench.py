@@ -96,7 +96,7 @@ def algorithmic_bytes(N, E, H, K):
     return {"nc_fused_fwd": fwd, "nc_fused_bwd": bwd}
 
 
-PMC_KERNEL = {"nc_fused_fwd": "mma::nc_fwd_kernel", "nc_fused_bwd": "mma::nc_bwd_kernel"}
+PMC_KERNEL = {"nc_fused_fwd": "mma::nc_fwd_", "nc_fused_bwd": "mma::nc_bwd_k"}   # fwd: kernel + finalize; bwd: kernel only (nc_bwd_node is K2a)
 
 
 def pmc_traffic(name, N, E, H, K):
@@ -110,9 +110,10 @@ def pmc_traffic(name, N, E, H, K):
             continue
         if d.get("workload") != {"nodes": N, "edges": E, "hidden": H, "K": K}:
             continue
-        for k, v in d["kernels"].items():
-            if PMC_KERNEL.get(name, "?") in k and "finalize" not in k:
-                return v["traffic_bytes"]
+        # one C-ABI call = up to two launches of the kernel (items run one per wavefront / grouped) + the hub finalize
+        parts = [v["traffic_bytes"] for k, v in d["kernels"].items() if PMC_KERNEL.get(name, "?") in k]
+        if parts:
+            return sum(parts)
     return None
 
 
