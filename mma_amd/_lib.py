@@ -5,7 +5,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmma_amd.so")
+LIB_PATH = os.environ.get("MMA_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "libmma_amd.so")   # override: A/B builds in development
 ABI_VERSION = 6
 
 _c = ctypes

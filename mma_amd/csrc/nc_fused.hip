@@ -11,6 +11,12 @@
 // are no atomics anywhere, so results are bitwise reproducible.
 #include "common.h"
 
+#ifndef NC_FWD_UNROLL
+#define NC_FWD_UNROLL(K) ((K) >= 3 ? 1 : 2)   // measured (C4, K=4): 2 -> 1 takes 183 -> ~160 VGPRs, 2 -> 3 waves/SIMD, 5.4 -> 4.8 ms
+#endif
+#ifndef NC_BWD_UNROLL
+#define NC_BWD_UNROLL(K) ((K) >= 3 ? 1 : 2)
+#endif
 #ifndef MMA_MIN_WAVES
 #define MMA_MIN_WAVES 2   // register cap of the fused kernels in waves per SIMD (3 = 168 VGPRs spills and measured 5-25 % slower)
 #endif
@@ -87,6 +93,9 @@ __device__ __forceinline__ void nc_msum_store(const NcFwdParams& p, int node, in
 //                latency chain (item -> indices -> rows -> store) dominates and more items in flight is what pays.
 template <int K, int VEC, bool SAVE, bool DROP, bool MULTI>
 __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_kernel(const NcFwdParams p) {
+  // edge steps in flight per lane: 2 (2*(K+1) row loads before the first use); 1 for K = 8, where two would need all
+  // 256 VGPRs and leave a single wave per SIMD
+  constexpr int U = NC_FWD_UNROLL(K);
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log;
   const int G = MULTI ? lpr : kWave;            // lanes per item
@@ -138,11 +147,11 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_k
       const int cnt = min(G, max(len - base, 0));      // edges of MY item in this index chunk
       const int ucnt = min(G, maxlen - base);          // wave-uniform trip bound
       const int myj = (gl < cnt) ? p.col[ebeg + base + gl] : 0;
-      // two edge steps (2*EPG rows per group) in flight per iteration
-      for (int t0 = 0; t0 < ucnt; t0 += 2 * epg) {
-        int tt[2]; bool ev[2]; Vec<VEC> xj[2]; Vec<VEC> qv[2][K];
+      // U edge steps (U*EPG rows per group) in flight per iteration
+      for (int t0 = 0; t0 < ucnt; t0 += U * epg) {
+        int tt[U]; bool ev[U]; Vec<VEC> xj[U]; Vec<VEC> qv[U][K];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
           tt[u] = t0 + u * epg + sub;
           ev[u] = tt[u] < cnt;
           const int j = __shfl(myj, gbase + (tt[u] & (G - 1)), kWave);
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_k
             qv[u][k] = ldv<VEC>(p.Q + (size_t)jj * p.ldq + (size_t)(p.k_base + k) * p.H + cc);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
           const float on = ev[u] ? 1.f : 0.f;
 #pragma unroll
           for (int k = 0; k < K; ++k) {
@@ -337,6 +346,7 @@ __device__ __forceinline__ float combine_ds(int kind, uint32_t code, float inv_d
 
 template <int K, int VEC, bool DROP, bool SHARED, bool MULTI>
 __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_kernel(const NcBwdParams p) {
+  constexpr int U = NC_BWD_UNROLL(K);           // edge steps in flight per lane (see nc_fwd_kernel)
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log;
   const int G = MULTI ? lpr : kWave;
@@ -389,12 +399,12 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
       const int ucnt = min(G, maxlen - base);
       const int myi = (gl < cnt) ? p.t_col[ebeg + base + gl] : 0;
       const int mye = (DROP && gl < cnt) ? p.t_eid[ebeg + base + gl] : 0;
-      for (int t0 = 0; t0 < ucnt; t0 += 2 * epg) {
-        // load phase: raw operands only (no arithmetic on loaded values, so both edge steps stay in flight)
-        int tt[2]; bool ev[2]; uint32_t eid[2]; Vec<VEC> gv[2][SHARED ? 1 : K]; Vec<VEC> pv[2][K];
-        uint32_t codes[2][K]; float idg[2];
+      for (int t0 = 0; t0 < ucnt; t0 += U * epg) {
+        // load phase: raw operands only (no arithmetic on loaded values, so all edge steps stay in flight)
+        int tt[U]; bool ev[U]; uint32_t eid[U]; Vec<VEC> gv[U][SHARED ? 1 : K]; Vec<VEC> pv[U][K];
+        uint32_t codes[U][K]; float idg[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
           tt[u] = t0 + u * epg + sub;
           ev[u] = tt[u] < cnt;
           const int i_ = __shfl(myi, gbase + (tt[u] & (G - 1)), kWave);
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
           }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
           const float on = ev[u] ? 1.f : 0.f;
 #pragma unroll
           for (int k = 0; k < K; ++k) {
