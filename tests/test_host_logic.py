@@ -80,3 +80,13 @@ def test_transpose_csr_roundtrip():
     for s in range(S):   # stable: forward positions ascend within a source
         seg = t_eid[t_rowptr[s]:t_rowptr[s + 1]]
         assert (np.diff(seg) > 0).all()
+
+
+def test_integration_md_stub_matches_binding():
+    """The ctypes stub shown to the reference's maintainers must have the ABI's current prototype."""
+    src = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"L\.mma_nc_fused_fwd\.argtypes = \[(.*?)\]", src, re.S)
+    toks = [t.strip() for t in m.group(1).replace("\n", " ").split(",") if t.strip()]
+    names = {"P": _lib._P, "I64": _lib._I64, "I32": _lib._I32, "U32": _lib._U32, "U64": _lib._U64}
+    assert [names[t] for t in toks] == _lib.PROTOTYPES["mma_nc_fused_fwd"]
+    assert "ABI version %d" % _lib.ABI_VERSION in src
