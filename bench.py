@@ -88,11 +88,15 @@ class KernelTimer:
         return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.spans.items()}
 
 
-def algorithmic_bytes(N, E, H, K):
-    """Zero-reuse byte counts per launch (DESIGN.md 'algorithmic bytes'; fwd = SURVEY 8d B_fwd)."""
+def algorithmic_bytes(N, E, H, K, n_sel=None):
+    """Zero-reuse byte counts per call (DESIGN.md 'algorithmic bytes'; fwd = SURVEY 8d B_fwd).
+    n_sel: number of max/min/softmax-type masks when K2b runs in the shared-gradient form, None for the gs form."""
     fwd = 4 * (E * (1 + (K + 1) * H) + N * (1 + (2 * K + 1) * H))
-    # K2b: per edge t_col,t_eid + gs,P rows; per node x,Q,gxs in, gQ,gx out
-    bwd = 4 * (E * (2 + 2 * K * H) + N * (1 + (2 * K + 3) * H))
+    per_node = 4 * N * (1 + (2 * K + 3) * H)                      # x, Q, gxs in; gQ, gx out
+    if n_sel is None:                                             # per edge: t_col, t_eid + gs and P rows
+        bwd = 4 * E * (2 + 2 * K * H) + per_node
+    else:                                                         # per edge: t_col, t_eid + P row + packed [g | 1/d | codes] row
+        bwd = E * (8 + 4 * K * H + 4 * H + 16 + n_sel * H) + per_node
     return {"nc_fused_fwd": fwd, "nc_fused_bwd": bwd}
 
 
@@ -244,7 +248,8 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = E * args.steps / dt
-        ab = algorithmic_bytes(n_local, local_edges, H, K)
+        n_sel = sum(1 for a in names if a.rstrip("234") in ("max", "min", "softmax", "softmin")) if Fn.SHARED_GRAD_BWD else None
+        ab = algorithmic_bytes(n_local, local_edges, H, K, n_sel)
         kernels = {}
         for name, (cnt, tot_ms) in spans.items():
             avg = tot_ms / max(cnt, 1)

@@ -305,8 +305,17 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
           stv<VEC>(row + c, g);                                   // the shared gradient itself
           if (c == 0) row[p.H] = 1.f / deg;
         }
-        if (p.sel_slot[k] != 0xFF)
-          stb<VEC>(reinterpret_cast<uint8_t*>(row + p.H + 4 + (size_t)p.sel_slot[k] * p.HQ) + c, codes);
+        if (p.sel_slot[k] != 0xFF) {
+          // one byte per element = 2 * (dm/ds): 0 x_i selected, 1 tie, 2 s selected, 255 NaN.  K2b turns it back into
+          // the factor with a single v_cvt_f32_ubyte + multiply.
+          uint32_t tf = 0;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const uint32_t code = (codes >> (8 * i)) & 0xFFu;
+            tf |= (code == 1u ? 2u : (code == 2u ? 1u : (code == 3u ? 255u : 0u))) << (8 * i);
+          }
+          stb<VEC>(reinterpret_cast<uint8_t*>(row + p.H + 4 + (size_t)p.sel_slot[k] * p.HQ) + c, tf);
+        }
       }
       stv<VEC>(p.gP + (size_t)node * p.ldgp + (size_t)k * p.H + c, gpv);
     }
@@ -419,10 +428,11 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
           for (int k = 0; k < K; ++k) {
             const size_t o = (size_t)(p.k_base + k) * p.H + cc;
             if (SHARED) {
-              // sum/mean never look at the code: a constant "s selected" keeps the arithmetic below branch-free
+              // sum/mean never look at the code: a constant "s selected" (2 = twice the factor 1.0) keeps the arithmetic
+              // below branch-free
               const uint32_t sslot = p.sel_slot[p.k_base + k];
               codes[u][k] = (sslot != 0xFFu) ? ldb<VEC>(reinterpret_cast<const uint8_t*>(arow + p.H + 4 + (size_t)sslot * p.HQ) + cc)
-                                             : 0x01010101u;
+                                             : 0x02020202u;
             } else {
               gv[u][k] = ldv<VEC>(p.gs + (size_t)ii * p.ldg + o);
             }
@@ -435,7 +445,8 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const bool raw = (p.acts >> (p.k_base + k)) & 1u;
-            const float kscale = (SHARED && kind_of(p.kinds, p.k_base + k) == MMA_KIND_MEAN) ? idg[u] : 1.f;
+            const int kind = SHARED ? kind_of(p.kinds, p.k_base + k) : 0;
+            const float kscale = 0.5f * (kind == MMA_KIND_MEAN ? idg[u] : 1.f);   // the code byte holds TWICE dm/ds
             float f[VEC];
             if (DROP) {
               drop_factors<VEC>(p.drop, eid[u], p.k_base + k, cc, p.H, p.HQ, f);
@@ -451,9 +462,10 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
               else { a = sigmoid_fast(z); da = a - a * a; }
               float gsv;
               if (SHARED) {
-                const uint32_t code = (codes[u][k] >> (8 * i)) & 0xFFu;   // 1: s selected  2: tie  3: NaN  0: x_i selected
-                const float cf = code == 1u ? 1.f : (code == 2u ? 0.5f : (code == 3u ? __builtin_nanf("") : 0.f));
-                gsv = gv[u][0].v[i] * cf * kscale;
+                const uint32_t tf = (codes[u][k] >> (8 * i)) & 0xFFu;      // v_cvt_f32_ubyte<i>
+                float cf = (float)tf;
+                if (kind >= MMA_KIND_SOFTMAX && tf == 255u) cf = __builtin_nanf("");   // exp overflow in the forward combine
+                gsv = gv[u][0].v[i] * (cf * kscale);
               } else {
                 gsv = gv[u][k].v[i];
               }

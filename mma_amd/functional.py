@@ -7,11 +7,11 @@ import torch
 from . import _lib
 from ._lib import call, host_codes, ptr, require_gpu, stream_ptr
 
-# K2b variant for the reduce_k (shared upstream gradient) backward: rebuild dL/ds_k per edge from one packed row per target
-# [g | 1/d | selection codes] written by K2a instead of gathering a materialised (N,K*H) gs.  30 % fewer bytes per edge
-# (2.8 vs 4 KB at K=4, H=128) and faster WITHOUT dropout (C4: 6.6 vs 6.8 ms), but the per-element code decode on top of the
-# dropout hash makes it VALU-limited at the 2 waves/SIMD the kernel runs at (p=0.5: 8.9 vs 7.1 ms), so it is off by default.
-SHARED_GRAD_BWD = False
+# K2b form for the reduce_k (shared upstream gradient) backward.  True: dL/ds_k is rebuilt per edge from ONE packed row per
+# target, [g (H floats) | 1/d | one byte per element and max/min-type mask = 2*dm/ds], written by K2a - 2.8 KB instead of
+# 4 KB gathered per edge at K=4, H=128 (C4: 5.5 vs 6.7 ms with dropout, 5.2 vs 6.8 ms without; K2a 1.3 vs 1.8 ms).
+# False: gather a materialised (N,K*H) gs.  Both forms are covered by the parity tests.
+SHARED_GRAD_BWD = True
 TIMER = None   # bench.py installs an object with .span(name) -> context manager (HIP events around the calls)
 
 
