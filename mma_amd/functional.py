@@ -87,8 +87,9 @@ def nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, save):
     return (msum if reduce_k else m), T, sel
 
 
-def nc_bwd_node_launch(g, reduce_k, sel, T, graph, kinds, H, shared):
-    """K2a -> (gs or None, aux or None, ldaux, gP (N,K*H), gxs (n_src,H) with zero halo rows)."""
+def nc_bwd_node_launch(g, reduce_k, sel, T, graph, kinds, H, shared, gP=None):
+    """K2a -> (gs or None, aux or None, ldaux, gP (N,K*H), gxs (n_src,H) with zero halo rows).
+    gP may be a (N,K*H) column block of a wider buffer (row pitch = its stride(0))."""
     K, N, S = len(kinds), graph.N, graph.n_src
     dev = g.device
     gs = None if shared else torch.empty((N, K * H), device=dev, dtype=torch.float32)
@@ -96,13 +97,14 @@ def nc_bwd_node_launch(g, reduce_k, sel, T, graph, kinds, H, shared):
     if shared:
         ldaux = int(_lib.lib().mma_nc_aux_row_floats(H, K, host_codes(kinds)))
         aux = torch.empty((N, ldaux), device=dev, dtype=torch.float32)
-    gP = torch.empty((N, K * H), device=dev, dtype=torch.float32)
+    if gP is None:
+        gP = torch.empty((N, K * H), device=dev, dtype=torch.float32)
     gxs = torch.empty((S, H), device=dev, dtype=torch.float32)
     if S > N:  # halo rows are sources only: no target-side gradient
         gxs[N:].zero_()
     with _span("nc_bwd_node"):
         call("mma_nc_bwd_node", ptr(g), 0 if reduce_k else N * H, H, ptr(sel), ptr(T), K * H, ptr(graph.rowptr),
-             ptr(gs), K * H, ptr(aux), ldaux, ptr(gP), K * H, ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
+             ptr(gs), K * H, ptr(aux), ldaux, ptr(gP), gP.stride(0), ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
     return gs, aux, ldaux, gP, gxs
 
 
@@ -158,6 +160,53 @@ class _NCFused(torch.autograd.Function):
                    if graph.t_n_slots else None)
         nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial)
         return gx, gP, gQ, None, None, None, None, None
+
+
+class _NCLocalLayer(torch.autograd.Function):
+    """sum_k m_k from (x, Wtop, Wbot) in one autograd node: owns its GEMMs, so P and Q (and their gradients) are column
+    blocks of ONE (N,2*K*H) buffer - one forward GEMM, one dL/dx GEMM over the concatenated reduction, one dW GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, wtop, wbot, graph, kinds, acts, drop):
+        from .dense import mm_into
+        require_gpu(x)
+        x = x.contiguous()
+        N, H = x.shape
+        K = len(kinds)
+        KH = K * H
+        PQ = torch.empty((N, 2 * KH), device=x.device, dtype=torch.float32)
+        wcat = torch.cat([wtop, wbot], 1)                                   # (H, 2*K*H)
+        mm_into(x, wcat, PQ)
+        need = any(ctx.needs_input_grad[:3])
+        msum, T, sel = nc_fwd_launch(x, PQ[:, :KH], PQ[:, KH:], graph, kinds, acts, drop, True, need)
+        ctx.graph, ctx.kinds, ctx.acts, ctx.drop = graph, kinds, acts, drop
+        ctx.save_for_backward(x, PQ, T, sel, wcat)
+        return msum
+
+    @staticmethod
+    def backward(ctx, g):
+        from .dense import rows_mm, xt_g
+        graph, kinds, acts, drop = ctx.graph, ctx.kinds, ctx.acts, ctx.drop
+        x, PQ, T, sel, wcat = ctx.saved_tensors
+        N, H = x.shape
+        K = len(kinds)
+        KH = K * H
+        g = g.contiguous()
+        gPQ = torch.empty((N, 2 * KH), device=g.device, dtype=torch.float32)
+        gs, aux, ldaux, gP, gxs = nc_bwd_node_launch(g, True, sel, T, graph, kinds, H, SHARED_GRAD_BWD, gP=gPQ[:, :KH])
+        gx = torch.empty((N, H), device=g.device, dtype=torch.float32)
+        partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=g.device, dtype=torch.float32)
+                   if graph.t_n_slots else None)
+        nc_bwd_edges_launch(x, PQ[:, :KH], PQ[:, KH:], gs, aux, ldaux, gxs, graph, kinds, acts, drop, gPQ[:, KH:], gx, partial)
+        gx = gx + rows_mm(gPQ, wcat.t())                                     # direct + through P and Q in one GEMM
+        gw = xt_g(x, gPQ) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
+        return gx, (gw[:, :KH] if gw is not None else None), (gw[:, KH:] if gw is not None else None), None, None, None, None
+
+
+def nc_local_layer(x, wtop, wbot, graph, kinds, acts, drop=None):
+    """sum_k m_k (graph.N, H) straight from the features and the concatenated mask weights (unsharded graphs)."""
+    assert graph.n_src == graph.N
+    return _NCLocalLayer.apply(x, wtop, wbot, graph, tuple(kinds), tuple(acts), drop or DropoutSpec(0.0))
 
 
 def nc_fused_aggregate(x, P, Q, graph, kinds, acts, drop=None, reduce_k=False):

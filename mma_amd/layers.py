@@ -149,10 +149,12 @@ class MMA(Module):
         H = input.shape[1]
         kinds, acts = self._codes(names)
         masks = [getattr(self, "mask_" + n) for n in names]
-        # [x_i || x_j] @ W_k  ==  x_i @ W_k[:H] + x_j @ W_k[H:]: dense GEMMs (MFMA fp32) shared by all K masks
-        P = mm(input, torch.cat([w[:H] for w in masks], 1))                     # (N, K*H)
-        Q = mm(input, torch.cat([w[H:] for w in masks], 1))                     # (N, K*H)
-        return Fn.nc_fused_aggregate(input, P, Q, self.graph(input.device), kinds, acts, drop or self._drop(names), reduce_k)
+        # [x_i || x_j] @ W_k  ==  x_i @ W_k[:H] + x_j @ W_k[H:]: dense GEMMs (matrix cores) shared by all K masks
+        wtop, wbot = torch.cat([w[:H] for w in masks], 1), torch.cat([w[H:] for w in masks], 1)      # (H, K*H) each
+        graph = self.graph(input.device)
+        if reduce_k:
+            return Fn.nc_local_layer(input, wtop, wbot, graph, kinds, acts, drop or self._drop(names))
+        return Fn.nc_fused_aggregate(input, mm(input, wtop), mm(input, wbot), graph, kinds, acts, drop or self._drop(names))
 
     def _aggregate_all(self, names, input, reduce_k=False):
         outs = []
