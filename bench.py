@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--aggregators", type=str, default="sum,mean,max,min")
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded (RCCL) path even at world size 1")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' (halo staged through the host) lets "
+                    "several ranks share one GPU to rehearse the N>1 path on a 1-GPU box")
     ap.add_argument("--cpu-sample", type=int, default=150000, help="target nodes in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -169,6 +171,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+    if args.backend == "gloo":
+        local_rank = 0                      # rehearsal: all ranks on cuda:0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
@@ -176,7 +180,10 @@ def main():
         import torch.distributed as dist
         if "RANK" not in os.environ:      # --force-sharded without a launcher
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import mma_amd
     from mma_amd import functional as Fn
@@ -252,7 +259,7 @@ def main():
         ab = algorithmic_bytes(n_local, local_edges, H, K, n_sel)
         kernels = {}
         for name, (cnt, tot_ms) in spans.items():
-            avg = tot_ms / max(cnt, 1)
+            avg = tot_ms / args.steps           # per step (a sharded backward issues the call twice: halo / own sources)
             k = {"launches": cnt, "avg_ms": avg}
             if name in ab:
                 k["algorithmic_bytes"] = ab[name]
