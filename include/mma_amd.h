@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 6
+#define MMA_ABI_VERSION 7
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -79,7 +79,10 @@ int mma_nc_fused_fwd(
     float* T, uint8_t* sel, int64_t ldt,         /* (N,K*H) out, both NULL or both non-NULL */
     int64_t N, int64_t E, int32_t H, int32_t K,
     const uint8_t* kind_host, const uint8_t* act_host,   /* K codes each, HOST memory */
-    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, int64_t drop_edge_base, /* HASH key = edge position + base */
+    int32_t drop_mode, uint32_t drop_thr, uint64_t seed,
+    const uint64_t* seed_dev,                    /* optional DEVICE seed (overrides `seed`): a hipGraph replay then draws fresh
+                                                    dropout bits without re-capture, the host only rewrites 8 bytes */
+    int64_t drop_edge_base,                      /* HASH key = edge position + base */
     const uint8_t* keep,                         /* EXPLICIT: (K,E,H), else NULL */
     void* stream);
 
@@ -117,7 +120,7 @@ int mma_nc_fused_bwd(
     float* gQ, int64_t ldgq, float* gx, int64_t ldgxo,
     int64_t N, int64_t E, int32_t H, int32_t K,
     const uint8_t* act_host,
-    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, int64_t drop_edge_base, const uint8_t* keep,
+    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, int64_t drop_edge_base, const uint8_t* keep,
     void* stream);
 
 /* ---- K5: CSR SpMM over a K-times column-stacked adjacency ----------------------------------------
@@ -185,7 +188,7 @@ int mma_gr_fused_fwd(
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
     float* out, int32_t* amin, int32_t* amax, float* mean, float* var,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
-    float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, void* stream);
+    float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* ---- K4: backward of K3 w.r.t. every edge message: gmsg[e, :] (E,T*F) by original edge position ------
  * min/max route the gradient to the saved arg edge only (torch_scatter), mean divides by the count, var/std use the
@@ -196,7 +199,7 @@ int mma_gr_fused_bwd(
     const float* gout, const int32_t* amin, const int32_t* amax, const float* mean, const float* var,
     float* gmsg, int64_t ldg,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
-    float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, void* stream);
+    float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMA_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "libmma_amd.so")   # override: A/B builds in development
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c = ctypes
 _P, _I64, _I32, _U32, _U64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_uint64
@@ -14,16 +14,16 @@ _P, _I64, _I32, _U32, _U64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _
 # name -> argtypes, exactly the prototypes of include/mma_amd.h
 PROTOTYPES = {
     "mma_nc_fused_fwd": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64,
-                         _I64, _I64, _I32, _I32, _P, _P, _I32, _U32, _U64, _I64, _P, _P],
+                         _I64, _I64, _I32, _I32, _P, _P, _I32, _U32, _U64, _P, _I64, _P, _P],
     "mma_nc_bwd_node": [_P, _I64, _I64, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P],
     "mma_nc_fused_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64,
-                         _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I32, _I32, _P, _I32, _U32, _U64, _I64, _P, _P],
+                         _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I32, _I32, _P, _I32, _U32, _U64, _P, _I64, _P, _P],
     "mma_csr_spmm": [_P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _I64, _I64, _I32, _P],
     "mma_build_csr": [_P, _P, _I64, _I64, _P, _P, _P, _P, _I64, _P],
     "mma_gr_fused_fwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P,
-                         _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P],
+                         _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P, _P],
     "mma_gr_fused_bwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64,
-                         _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P],
+                         _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P, _P],
     "mma_csr_spmm_items": [_P, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _P],
     "mma_split_bf16x3": [_P, _I64, _P, _P],
     "mma_gemm_bf16x3": [_P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P],

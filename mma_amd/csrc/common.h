@@ -69,10 +69,20 @@ struct DropParams {
   uint32_t thr;         // 0..255
   float scale;          // 256/(256-thr) (HASH) or 1/(1-p) = same formula (EXPLICIT)
   uint32_t seed_lo, seed_hi;
+  const uint64_t* seed_dev;   // optional: the seed lives in device memory (graph replays draw a fresh one without re-capture)
   const uint8_t* keep;  // EXPLICIT: (K_total, E, H)
   int64_t E;
   uint32_t edge_base;   // HASH: key = edge position + edge_base (a shard's edges keep their global ids)
 };
+
+// kernel entry: a seed in device memory overrides the one passed by value (one uniform 8-byte load per wave)
+__device__ __forceinline__ DropParams drop_resolve(DropParams d) {
+  if (d.mode == MMA_DROP_HASH && d.seed_dev != nullptr) {
+    const uint64_t s = *d.seed_dev;
+    d.seed_lo = (uint32_t)s; d.seed_hi = (uint32_t)(s >> 32);
+  }
+  return d;
+}
 
 // keep multiplier (0 or scale) for the VEC features starting at column c of mask k_abs on edge e
 template <int VEC>

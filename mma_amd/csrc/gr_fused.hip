@@ -41,19 +41,20 @@ __device__ __forceinline__ float scaler_factor(int code, float deg, float avg_lo
   }
 }
 
-__device__ __forceinline__ float gr_message(const GrParams& p, bool fused, float u, int j, uint32_t e, int cc) {
+__device__ __forceinline__ float gr_message(const GrParams& p, const DropParams& dp, bool fused, float u, int j, uint32_t e, int cc) {
   if (!fused) return p.inputs[(size_t)e * p.ldi + cc];
   float h = u + p.V[(size_t)j * p.lduv + cc];
   if (p.Z) h += p.Z[(size_t)e * p.ldz + cc];
-  if (p.drop.mode != MMA_DROP_NONE) {
+  if (dp.mode != MMA_DROP_NONE) {
     float f[1];
-    drop_factors<1>(p.drop, e, 0, cc, p.D, 0, f);
+    drop_factors<1>(dp, e, 0, cc, p.D, 0, f);
     h *= f[0];
   }
   return h;
 }
 
 __global__ __launch_bounds__(kBlock) void gr_fwd_kernel(const GrParams p) {
+  const DropParams dp = drop_resolve(p.drop);
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log, epg = kWave >> p.lpr_log;
   const int sub = lane >> p.lpr_log;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(kBlock) void gr_fwd_kernel(const GrParams p) {
         const bool ev = t < cnt;
         const int j = ev ? j_ : node;
         const int e = ev ? e_ : mye;       // any valid edge id of this segment
-        const float h = gr_message(p, fused, u, j, (uint32_t)e, cc);
+        const float h = gr_message(p, dp, fused, u, j, (uint32_t)e, cc);
         if (ev) {
           sum += h; sq += h * h;
           if (h < mn) { mn = h; an = e; }   // strict: the first (lowest position) extremal edge wins
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(kBlock) void gr_fwd_kernel(const GrParams p) {
 
 // K4: gradient w.r.t. every edge message, written by original edge id (each edge has exactly one target: no conflicts)
 __global__ __launch_bounds__(kBlock) void gr_bwd_kernel(const GrParams p) {
+  const DropParams dp = drop_resolve(p.drop);
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log, epg = kWave >> p.lpr_log;
   const int sub = lane >> p.lpr_log;
@@ -179,10 +181,10 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_kernel(const GrParams p) {
         const int e_ = __shfl(mye, tt & (kWave - 1), kWave);
         if (tt < cnt && valid) {
           float g = c_all + (e_ == an ? c_min : 0.f) + (e_ == ax ? c_max : 0.f);
-          if (need_h) g += c_var * (gr_message(p, fused, u, j_, (uint32_t)e_, cc) - mean);
-          if (fused && p.drop.mode != MMA_DROP_NONE) {
+          if (need_h) g += c_var * (gr_message(p, dp, fused, u, j_, (uint32_t)e_, cc) - mean);
+          if (fused && dp.mode != MMA_DROP_NONE) {
             float fd[1];
-            drop_factors<1>(p.drop, (uint32_t)e_, 0, cc, p.D, 0, fd);
+            drop_factors<1>(dp, (uint32_t)e_, 0, cc, p.D, 0, fd);
             g *= fd[0];
           }
           p.gmsg[(size_t)e_ * p.ldg + cc] = g;
@@ -285,7 +287,7 @@ extern "C" int mma_gr_fused_fwd(
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
     float* out, int32_t* amin, int32_t* amax, float* mean, float* var,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
-    float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, void* stream) {
+    float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31) && T >= 1 && F >= 1, "N=%lld E=%lld T=%d F=%d unsupported",
               (long long)N, (long long)E, T, F);
   GrParams p{};
@@ -303,7 +305,7 @@ extern "C" int mma_gr_fused_fwd(
   p.N = (int)N; p.D = D; p.T = T; p.F = F; p.avg_log = avg_log; p.avg_lin = avg_lin;
   p.drop.mode = (drop_mode == MMA_DROP_HASH && drop_thr > 0 && !inputs) ? MMA_DROP_HASH : MMA_DROP_NONE;
   p.drop.thr = drop_thr; p.drop.scale = 256.f / (256.f - (float)drop_thr);
-  p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.keep = nullptr; p.drop.E = E; p.drop.edge_base = 0;
+  p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.seed_dev = seed_dev; p.drop.keep = nullptr; p.drop.E = E; p.drop.edge_base = 0;
   const dim3 grid = gr_grid(N, D, &p.lpr_log);
   hipLaunchKernelGGL(gr_fwd_kernel, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
   return check_launch("gr_fwd_kernel");
@@ -315,7 +317,7 @@ extern "C" int mma_gr_fused_bwd(
     const float* gout, const int32_t* amin, const int32_t* amax, const float* mean, const float* var,
     float* gmsg, int64_t ldg,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
-    float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, void* stream) {
+    float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31) && T >= 1 && F >= 1, "N=%lld E=%lld T=%d F=%d unsupported",
               (long long)N, (long long)E, T, F);
   GrParams p{};
@@ -337,7 +339,7 @@ extern "C" int mma_gr_fused_bwd(
   p.N = (int)N; p.D = D; p.T = T; p.F = F; p.avg_log = avg_log; p.avg_lin = avg_lin;
   p.drop.mode = (drop_mode == MMA_DROP_HASH && drop_thr > 0 && !inputs) ? MMA_DROP_HASH : MMA_DROP_NONE;
   p.drop.thr = drop_thr; p.drop.scale = 256.f / (256.f - (float)drop_thr);
-  p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.keep = nullptr; p.drop.E = E; p.drop.edge_base = 0;
+  p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.seed_dev = seed_dev; p.drop.keep = nullptr; p.drop.E = E; p.drop.edge_base = 0;
   const dim3 grid = gr_grid(N, D, &p.lpr_log);
   hipLaunchKernelGGL(gr_bwd_kernel, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
   return check_launch("gr_bwd_kernel");

@@ -93,6 +93,7 @@ __device__ __forceinline__ void nc_msum_store(const NcFwdParams& p, int node, in
 //                latency chain (item -> indices -> rows -> store) dominates and more items in flight is what pays.
 template <int K, int VEC, bool SAVE, bool DROP, bool MULTI>
 __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_kernel(const NcFwdParams p) {
+  const DropParams dp = DROP ? drop_resolve(p.drop) : p.drop;
   // edge steps in flight per lane: 2 (2*(K+1) row loads before the first use); 1 for K = 8, where two would need all
   // 256 VGPRs and leave a single wave per SIMD
   constexpr int U = NC_FWD_UNROLL(K);
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_k
             const bool raw = (p.acts >> (p.k_base + k)) & 1u;
             float f[VEC];
             if (DROP) {
-              drop_factors<VEC>(p.drop, (uint32_t)(ev[u] ? ebeg + base + tt[u] : ebeg), p.k_base + k, cc, p.H, p.HQ, f);
+              drop_factors<VEC>(dp, (uint32_t)(ev[u] ? ebeg + base + tt[u] : ebeg), p.k_base + k, cc, p.H, p.HQ, f);
             } else {
 #pragma unroll
               for (int i = 0; i < VEC; ++i) f[i] = 1.f;
@@ -355,6 +356,7 @@ __device__ __forceinline__ float combine_ds(int kind, uint32_t code, float inv_d
 
 template <int K, int VEC, bool DROP, bool SHARED, bool MULTI>
 __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_kernel(const NcBwdParams p) {
+  const DropParams dp = DROP ? drop_resolve(p.drop) : p.drop;
   constexpr int U = NC_BWD_UNROLL(K);           // edge steps in flight per lane (see nc_fwd_kernel)
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log;
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
             const float kscale = 0.5f * (kind == MMA_KIND_MEAN ? idg[u] : 1.f);   // the code byte holds TWICE dm/ds
             float f[VEC];
             if (DROP) {
-              drop_factors<VEC>(p.drop, eid[u], p.k_base + k, cc, p.H, p.HQ, f);
+              drop_factors<VEC>(dp, eid[u], p.k_base + k, cc, p.H, p.HQ, f);
             } else {
 #pragma unroll
               for (int i = 0; i < VEC; ++i) f[i] = 1.f;
@@ -579,7 +581,9 @@ static int fill_sel_slots(const uint8_t* kind_host, int K, int H, uint8_t* slots
   return ((H + 4 + n * ((H + 3) / 4)) + 3) & ~3;
 }
 
-static int make_drop(int32_t mode, uint32_t thr, uint64_t seed, int64_t edge_base, const uint8_t* keep, int64_t E, DropParams* d) {
+static int make_drop(int32_t mode, uint32_t thr, uint64_t seed, const uint64_t* seed_dev, int64_t edge_base, const uint8_t* keep,
+                     int64_t E, DropParams* d) {
+  d->seed_dev = seed_dev;
   MMA_REQUIRE(edge_base >= 0 && edge_base + E < (1LL << 32), "drop_edge_base %lld out of range", (long long)edge_base);
   d->edge_base = (uint32_t)edge_base;
   MMA_REQUIRE(mode >= MMA_DROP_NONE && mode <= MMA_DROP_EXPLICIT, "drop_mode %d unknown", mode);
@@ -669,7 +673,8 @@ extern "C" int mma_nc_fused_fwd(
     const int32_t* items, int64_t n_items, int64_t n_wave_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots, float* m, float* m_sum, int64_t ldms, float* T, uint8_t* sel, int64_t ldt,
     int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* kind_host, const uint8_t* act_host,
-    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, int64_t drop_edge_base, const uint8_t* keep, void* stream) {
+    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, int64_t drop_edge_base, const uint8_t* keep,
+    void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31), "N=%lld E=%lld out of int32 range", (long long)N, (long long)E);
   MMA_REQUIRE(H >= 1 && K >= 1 && K <= MMA_MAX_K, "H=%d K=%d unsupported (1<=K<=%d)", H, K, MMA_MAX_K);
   MMA_REQUIRE(ldx >= H && ldp >= (int64_t)K * H && ldq >= (int64_t)K * H, "row pitch too small: ldx=%lld ldp=%lld ldq=%lld",
@@ -687,7 +692,7 @@ extern "C" int mma_nc_fused_fwd(
   uint32_t kinds, acts;
   if (int rc = pack_codes(kind_host, act_host, K, &kinds, &acts)) return rc;
   NcFwdParams p{};
-  if (int rc = make_drop(drop_mode, drop_thr, seed, drop_edge_base, keep, E, &p.drop)) return rc;
+  if (int rc = make_drop(drop_mode, drop_thr, seed, seed_dev, drop_edge_base, keep, E, &p.drop)) return rc;
   const bool drop = drop_mode != MMA_DROP_NONE && !(drop_mode == MMA_DROP_HASH && drop_thr == 0);
   const bool save = T != nullptr;
   const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldp % 4 == 0) && (ldq % 4 == 0) && (!save || ldt % 4 == 0) && aligned16(x) &&
@@ -775,7 +780,8 @@ extern "C" int mma_nc_fused_bwd(
     const int32_t* items, int64_t n_items, int64_t n_wave_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots, float* gQ, int64_t ldgq, float* gx, int64_t ldgxo,
     int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* act_host,
-    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, int64_t drop_edge_base, const uint8_t* keep, void* stream) {
+    int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, int64_t drop_edge_base, const uint8_t* keep,
+    void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31), "N=%lld E=%lld out of int32 range", (long long)N, (long long)E);
   MMA_REQUIRE(H >= 1 && K >= 1 && K <= MMA_MAX_K, "H=%d K=%d unsupported (1<=K<=%d)", H, K, MMA_MAX_K);
   MMA_REQUIRE(ldx >= H && ldp >= (int64_t)K * H && ldq >= (int64_t)K * H && (!gs || ldg >= (int64_t)K * H) && ldgq >= (int64_t)K * H &&
@@ -790,7 +796,7 @@ extern "C" int mma_nc_fused_bwd(
   uint32_t kinds, acts;
   if (int rc = pack_codes(gs ? nullptr : kind_host, act_host, K, &kinds, &acts)) return rc;
   NcBwdParams p{};
-  if (int rc = make_drop(drop_mode, drop_thr, seed, drop_edge_base, keep, E, &p.drop)) return rc;
+  if (int rc = make_drop(drop_mode, drop_thr, seed, seed_dev, drop_edge_base, keep, E, &p.drop)) return rc;
   const bool drop = drop_mode != MMA_DROP_NONE && !(drop_mode == MMA_DROP_HASH && drop_thr == 0);
   const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldp % 4 == 0) && (ldq % 4 == 0) && (ldgx % 4 == 0) && (ldgq % 4 == 0) &&
                   (gs ? (ldg % 4 == 0 && aligned16(gs)) : (ldaux % 4 == 0 && aligned16(aux))) &&

@@ -38,11 +38,12 @@ class DropoutSpec:
     HASH mode quantises p to thr/256 (exact for the reference default 0.5); `keep` (K,E,H) uint8 switches to an
     explicit mask (parity tests)."""
 
-    def __init__(self, p=0.0, seed=None, keep=None):
+    def __init__(self, p=0.0, seed=None, keep=None, seed_tensor=None):
         self.p = float(p)
         if not (0.0 <= self.p < 1.0):
             raise ValueError("dropout probability has to be in [0, 1), but got %r" % p)
         self.keep = keep
+        self.seed_tensor = seed_tensor      # (1,) int64 GPU tensor: the kernels read the seed from it (hipGraph-safe)
         if keep is not None:
             self.mode, self.thr = DROP_EXPLICIT, int(round(self.p * 256))
             if self.thr / 256.0 != self.p:
@@ -53,11 +54,11 @@ class DropoutSpec:
             self.mode, self.thr = DROP_HASH, min(255, max(1, int(round(self.p * 256))))
         if seed is None:
             # drawn from torch's CPU generator so torch.manual_seed() controls it; no GPU sync
-            seed = int(torch.empty((), dtype=torch.int64).random_().item()) if self.mode == DROP_HASH else 0
+            seed = int(torch.empty((), dtype=torch.int64).random_().item()) if (self.mode == DROP_HASH and seed_tensor is None) else 0
         self.seed = seed & 0xFFFFFFFFFFFFFFFF
 
     def args(self):
-        return self.mode, self.thr, self.seed, ptr(self.keep)
+        return self.mode, self.thr, self.seed, ptr(self.seed_tensor), ptr(self.keep)
 
 
 def nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, save):
@@ -77,13 +78,13 @@ def nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, save):
     if drop.keep is not None:
         assert drop.keep.dtype == torch.uint8 and drop.keep.is_contiguous() and drop.keep.is_cuda and \
             tuple(drop.keep.shape) == (K, graph.E, H), "explicit keep mask must be a contiguous (K,E,H) uint8 GPU tensor"
-    mode, thr, seed, keep = drop.args()
+    mode, thr, seed, seed_dev, keep = drop.args()
     with _span("nc_fused_fwd"):
         call("mma_nc_fused_fwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
              ptr(graph.rowptr), ptr(graph.col), ptr(graph.items), graph.items.shape[0], graph.n_wave_items,
              ptr(graph.hubs) if graph.n_slots else None, graph.hubs.shape[0], ptr(partial), graph.n_slots,
              ptr(m), ptr(msum), H, ptr(T), ptr(sel), K * H, N, graph.E, H, K, host_codes(kinds), host_codes(acts),
-             mode, thr, seed, graph.edge_base, keep, stream_ptr())
+             mode, thr, seed, seed_dev, graph.edge_base, keep, stream_ptr())
     return (msum if reduce_k else m), T, sel
 
 
@@ -114,13 +115,13 @@ def nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, dr
     S, H = x_src.shape
     items, n_wave, hubs = part if part is not None else (graph.t_items, graph.t_n_wave_items, graph.t_hubs)
     shared = gs is None
-    mode, thr, seed, keep = drop.args()
+    mode, thr, seed, seed_dev, keep = drop.args()
     with _span("nc_fused_bwd"):
         call("mma_nc_fused_bwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
              ptr(gs), K * H, ptr(aux), ldaux, host_codes(kinds) if shared else None, ptr(gxs), H,
              ptr(graph.t_col), ptr(graph.t_eid), ptr(items), items.shape[0], n_wave,
              ptr(hubs) if hubs.shape[0] else None, hubs.shape[0], ptr(partial), graph.t_n_slots if hubs.shape[0] else 0,
-             ptr(gQ), gQ.stride(0), ptr(gx), H, S, graph.E, H, K, host_codes(acts), mode, thr, seed, graph.edge_base, keep,
+             ptr(gQ), gQ.stride(0), ptr(gx), H, S, graph.E, H, K, host_codes(acts), mode, thr, seed, seed_dev, graph.edge_base, keep,
              stream_ptr())
 
 
@@ -263,7 +264,6 @@ def csr_spmm(B, bias, sg, K=1):
 # ---- graph-regression path (K3/K4/K6) ----------------------------------------------------------------------
 GR_AGGR = {"sum": 0, "mean": 1, "min": 2, "max": 3, "var": 4, "std": 5}
 GR_SCALER = {"identity": 0, "amplification": 1, "attenuation": 2, "linear": 3, "inverse_linear": 4}
-_csr_ws = {}
 
 
 class DeviceCSR:
@@ -282,9 +282,7 @@ class DeviceCSR:
         nbytes = _lib.lib().mma_csr_workspace_bytes(E, N)
         if nbytes < 0:
             raise _lib.MMALibraryError("graph too large for int32 CSR: E=%d N=%d" % (E, N))
-        ws = _csr_ws.get(dev)
-        if ws is None or ws.numel() < nbytes:
-            ws = _csr_ws[dev] = torch.empty(int(nbytes * 1.5) + 1024, dtype=torch.uint8, device=dev)
+        ws = torch.empty(int(nbytes) + 1024, dtype=torch.uint8, device=dev)   # per call: cheap (caching allocator), capture-safe
         with _span("csr_build"):
             call("mma_build_csr", ptr(key), ptr(other.contiguous()) if other is not None else None, E, N, ptr(self.rowptr),
                  ptr(self.perm), ptr(self.other) if other is not None else None, ptr(ws), ws.numel(), stream_ptr())
@@ -311,7 +309,7 @@ def _gr_call(fn, csr, U, V, Z, inputs, extra, N, E, T, F, aggr, scalers, avg_log
     lduv = U.stride(0) if U is not None else 0
     call(fn, ptr(csr.rowptr), ptr(csr.other), ptr(csr.perm), ptr(U), ptr(V), lduv, ptr(Z), Z.stride(0) if Z is not None else 0,
          ptr(inputs), D if inputs is not None else 0, *extra, N, E, T, F, host_codes(aggr), len(aggr), host_codes(scalers),
-         len(scalers), float(avg_log), float(avg_lin), drop.mode, drop.thr, drop.seed, stream_ptr())
+         len(scalers), float(avg_log), float(avg_lin), drop.mode, drop.thr, drop.seed, ptr(drop.seed_tensor), stream_ptr())
 
 
 class _GRAggregate(torch.autograd.Function):

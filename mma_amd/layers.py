@@ -108,6 +108,10 @@ class MMA(Module):
         self._graph = add_all if isinstance(add_all, NCGraph) else None
         self._sg = None         # (adj object, SpmmGraph) cache for the tail spmm
         self.drop_override = None   # tests: a DropoutSpec (explicit keep mask / fixed seed) used instead of p
+        # hipGraph capture (torch.cuda.graph) of the layer: the dropout seed then lives in a device buffer that is re-drawn
+        # by a captured random_() on every replay, instead of being baked into the kernel arguments at capture time
+        self.graph_capturable = False
+        self._seed_buf = None
 
     def reset_parameters(self):
         stdv = 1. / math.sqrt(self.weight.size(0))
@@ -138,9 +142,14 @@ class MMA(Module):
             acts.append(Fn.ACT_RAW if (rawq and self.activation == "new_sigmoid") else Fn.ACT_SIGMOID)
         return kinds, acts
 
-    def _drop(self, names):
+    def _drop(self, names, device=None):
         if self.drop_override is not None:
             return self.drop_override
+        if self.graph_capturable and self.dropout > 0 and device is not None:
+            if self._seed_buf is None or self._seed_buf.device != device:
+                self._seed_buf = torch.zeros(1, dtype=torch.int64, device=device)
+            self._seed_buf.random_()
+            return Fn.DropoutSpec(self.dropout, seed_tensor=self._seed_buf)
         return Fn.DropoutSpec(self.dropout)
 
     def _aggregate(self, names, input, drop=None, reduce_k=False):
@@ -153,18 +162,19 @@ class MMA(Module):
         wtop, wbot = torch.cat([w[:H] for w in masks], 1), torch.cat([w[H:] for w in masks], 1)      # (H, K*H) each
         graph = self.graph(input.device)
         if reduce_k:
-            return Fn.nc_local_layer(input, wtop, wbot, graph, kinds, acts, drop or self._drop(names))
-        return Fn.nc_fused_aggregate(input, mm(input, wtop), mm(input, wbot), graph, kinds, acts, drop or self._drop(names))
+            return Fn.nc_local_layer(input, wtop, wbot, graph, kinds, acts, drop or self._drop(names, input.device))
+        return Fn.nc_fused_aggregate(input, mm(input, wtop), mm(input, wbot), graph, kinds, acts,
+                                     drop or self._drop(names, input.device))
 
     def _aggregate_all(self, names, input, reduce_k=False):
         outs = []
-        base = self._drop(names)
+        base = self._drop(names, input.device)
         for g0 in range(0, len(names), 8):
             grp = names[g0:g0 + 8]
             drop = base
             if base.keep is not None:   # explicit (K,E,H) mask: hand each group its slice
                 drop = Fn.DropoutSpec(base.p, keep=base.keep[g0:g0 + 8].contiguous())
-            elif g0:
+            elif g0 and base.seed_tensor is None:
                 drop = Fn.DropoutSpec(base.p, seed=base.seed + g0)
             outs.append(self._aggregate(grp, input, drop, reduce_k))
         if reduce_k:

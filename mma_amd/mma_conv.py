@@ -85,6 +85,8 @@ class MMAConv(torch.nn.Module):
 
         self._graph_cache = None      # (edge_index tensor, version, N) -> GRGraph
         self.drop_override = None     # tests: a functional.DropoutSpec with a fixed seed
+        self.graph_capturable = False  # True: the dropout seed is re-drawn on the device each call (hipGraph replays)
+        self._seed_buf = None
 
     def reset_parameters(self):
         if self.edge_dim is not None:
@@ -113,8 +115,15 @@ class MMAConv(torch.nn.Module):
     def _fusable(self):
         return self.pre_layers == 1 and self.mask != "no_linear"
 
-    def _drop(self):
-        return self.drop_override if self.drop_override is not None else Fn.DropoutSpec(self.dropout)
+    def _drop(self, device=None):
+        if self.drop_override is not None:
+            return self.drop_override
+        if self.graph_capturable and device is not None:
+            if self._seed_buf is None or self._seed_buf.device != device:
+                self._seed_buf = torch.zeros(1, dtype=torch.int64, device=device)
+            self._seed_buf.random_()
+            return Fn.DropoutSpec(self.dropout, seed_tensor=self._seed_buf)
+        return Fn.DropoutSpec(self.dropout)
 
     # ---- forward ------------------------------------------------------------------------------------------
     def forward(self, x: Tensor, edge_index, edge_attr: Optional[Tensor] = None) -> Tensor:
@@ -147,7 +156,7 @@ class MMAConv(torch.nn.Module):
                 We = torch.stack([l.weight[:, 2 * Fi:] for l in lins])
                 Z = self.edge_encoder(edge_attr) @ We.reshape(T * Fi, Fi).t()   # (E, T*F)
             out = Fn.gr_fused_conv(U, V, Z, graph, T, Fi, self.aggregators, self.scalers,
-                                   self.avg_deg['log'], self.avg_deg['lin'], self._drop())
+                                   self.avg_deg['log'], self.avg_deg['lin'], self._drop(x.device))
         else:
             src, dst = edge_index[0], edge_index[1]
             hs = self.message(x.index_select(0, dst), x.index_select(0, src), edge_attr)

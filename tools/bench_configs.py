@@ -25,6 +25,25 @@ from mma_amd import functional as Fn  # noqa: E402
 DEV = "cuda:0"
 
 
+def graph_replay_ms(step, n=50):
+    """Capture `step` (layer forward+backward on static tensors) into a hipGraph and time replays."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    g.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
 def wall(fn, n):
     fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -53,11 +72,14 @@ def nc_config(tag, npz, H, names, C, reps=50):
     for _ in range(reps):
         step()
     spans = t.summary(); Fn.TIMER = None
+    layer.graph_capturable = True
+    gms = graph_replay_ms(step)
     ab = bench.algorithmic_bytes(N, E, H, K)
     k = {n: {"avg_us": tot / c * 1e3, **({"algorithmic_bytes": ab[n], "GBs": ab[n] / (tot / c * 1e-3) / 1e9} if n in ab else {})}
          for n, (c, tot) in spans.items()}
     print(json.dumps({"config": tag, "nodes": N, "edges": E, "H": H, "K": K, "ms_per_layer_fwd_bwd": ms,
-                      "edges_per_s": E / ms * 1e3, "kernels": k}), flush=True)
+                      "ms_per_layer_fwd_bwd_hipgraph": gms, "edges_per_s": E / ms * 1e3, "edges_per_s_hipgraph": E / gms * 1e3,
+                      "kernels": k}), flush=True)
 
 
 def gr_config(tag, n_graphs, reps=20):
@@ -82,13 +104,16 @@ def gr_config(tag, n_graphs, reps=20):
     for _ in range(reps):
         step()
     spans = t.summary(); Fn.TIMER = None
+    conv.graph_capturable = True
+    gms = graph_replay_ms(step, 20)
     D = T * F
     ab = {"gr_fused_fwd": 4 * (E * (2 + 2 * D) + N * (1 + D + T * K * S * F)),
           "gr_fused_bwd": 4 * (E * (2 + D) + N * (1 + T * K * S * F + 2 * D))}
     k = {n: {"avg_us": tot / c * 1e3, **({"algorithmic_bytes": ab[n], "GBs": ab[n] / (tot / c * 1e-3) / 1e9} if n in ab else {})}
          for n, (c, tot) in spans.items()}
     print(json.dumps({"config": tag, "graphs": n_graphs, "nodes": N, "edges": E, "towers": T, "F": F,
-                      "ms_per_layer_fwd_bwd": ms, "edges_per_s": E / ms * 1e3, "kernels": k}), flush=True)
+                      "ms_per_layer_fwd_bwd": ms, "ms_per_layer_fwd_bwd_hipgraph": gms, "edges_per_s": E / ms * 1e3,
+                      "edges_per_s_hipgraph": E / gms * 1e3, "kernels": k}), flush=True)
 
 
 if __name__ == "__main__":
