@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 7
+#define MMA_ABI_VERSION 8
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -182,11 +182,12 @@ enum { MMA_SC_IDENTITY = 0, MMA_SC_AMPLIFICATION = 1, MMA_SC_ATTENUATION = 2, MM
  *   out[n, t, s*K*F + k*F + f] = aggr_k over {h_e[t*F+f] : target(e) = n}, times the running product of scalers 0..s.
  * U,V: (N,T*F) with U = x @ W_i^T + b, V = x @ W_j^T; Z: (E,T*F) = enc(edge_attr) @ W_e^T or NULL.
  * Saved for backward when non-NULL: amin/amax (N,T*F) original edge position of the extremum (-1: empty target,
- * ties -> lowest position), mean/var (N,T*F). */
+ * ties -> lowest position), mean/var, all with row pitch ldsave >= T*F.  When every operand's pitch is T*F rounded up to a
+ * multiple of 4 (zero padding columns) and 16-byte aligned, a lane moves one dwordx4 per row; otherwise one dword. */
 int mma_gr_fused_fwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
-    float* out, int32_t* amin, int32_t* amax, float* mean, float* var,
+    float* out, int32_t* amin, int32_t* amax, float* mean, float* var, int64_t ldsave,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
@@ -196,7 +197,7 @@ int mma_gr_fused_fwd(
 int mma_gr_fused_bwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
-    const float* gout, const int32_t* amin, const int32_t* amax, const float* mean, const float* var,
+    const float* gout, const int32_t* amin, const int32_t* amax, const float* mean, const float* var, int64_t ldsave,
     float* gmsg, int64_t ldg,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream);

@@ -23,7 +23,7 @@ struct GrParams {
   const float* U; const float* V; int64_t lduv; const float* Z; int64_t ldz;   // fused-message mode
   const float* inputs; int64_t ldi;                                              // given-messages mode (E,D)
   float* out; const float* gout;                                                 // (N, T, S*K*F)
-  int32_t* amin; int32_t* amax; float* mean; float* var;                         // (N,D) saved for backward (may be NULL)
+  int32_t* amin; int32_t* amax; float* mean; float* var; int64_t ldsave;        // (N,ldsave>=D) saved for backward (may be NULL)
   float* gmsg; int64_t ldg;                                                      // backward: (E,D) by original edge id
   int N, D, T, F, K, S, lpr_log;
   uint8_t aggr[MMA_MAX_K]; uint8_t scaler[8];
@@ -41,24 +41,38 @@ __device__ __forceinline__ float scaler_factor(int code, float deg, float avg_lo
   }
 }
 
-__device__ __forceinline__ float gr_message(const GrParams& p, const DropParams& dp, bool fused, float u, int j, uint32_t e, int cc) {
-  if (!fused) return p.inputs[(size_t)e * p.ldi + cc];
-  float h = u + p.V[(size_t)j * p.lduv + cc];
-  if (p.Z) h += p.Z[(size_t)e * p.ldz + cc];
+// the VEC messages h_e[c..c+VEC) of edge e (fused: drop(U[i] + V[j] + Z[e]); given: inputs[e])
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> gr_message(const GrParams& p, const DropParams& dp, bool fused, const Vec<VEC>& u, int j,
+                                               uint32_t e, int cc) {
+  if (!fused) return ldv<VEC>(p.inputs + (size_t)e * p.ldi + cc);
+  Vec<VEC> h = ldv<VEC>(p.V + (size_t)j * p.lduv + cc);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) h.v[i] += u.v[i];
+  if (p.Z) {
+    const Vec<VEC> z = ldv<VEC>(p.Z + (size_t)e * p.ldz + cc);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) h.v[i] += z.v[i];
+  }
   if (dp.mode != MMA_DROP_NONE) {
-    float f[1];
-    drop_factors<1>(dp, e, 0, cc, p.D, 0, f);
-    h *= f[0];
+    float f[VEC];
+    drop_factors<VEC>(dp, e, 0, cc, p.D, 0, f);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) h.v[i] *= f[i];
   }
   return h;
 }
 
+// VEC = 4 (F % 4 == 0 and 16-byte aligned rows everywhere): a lane owns 4 consecutive columns of one tower and moves one
+// dwordx4 per row, also for the (N,T,S*K*F) output.  Otherwise (e.g. ZINC's F = 75) VEC = 1: lanes own consecutive
+// columns, so all accesses are still coalesced 4-byte ones.
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void gr_fwd_kernel(const GrParams p) {
   const DropParams dp = drop_resolve(p.drop);
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log, epg = kWave >> p.lpr_log;
   const int sub = lane >> p.lpr_log;
-  const int c = (int)blockIdx.y * lpr + (lane & (lpr - 1));
+  const int c = ((int)blockIdx.y * lpr + (lane & (lpr - 1))) * VEC;
   const bool valid = c < p.D;
   const int cc = valid ? c : 0;
   const bool fused = p.inputs == nullptr;
@@ -66,9 +80,11 @@ __global__ __launch_bounds__(kBlock) void gr_fwd_kernel(const GrParams p) {
   for (int64_t n0 = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); n0 < p.N; n0 += stride) {
     const int node = __builtin_amdgcn_readfirstlane((int)n0);
     const int ebeg = p.rowptr[node], eend = p.rowptr[node + 1];
-    const float u = fused ? p.U[(size_t)node * p.lduv + cc] : 0.f;
-    float sum = 0.f, sq = 0.f, mn = INFINITY, mx = -INFINITY;
-    int an = INT_MAX, ax = INT_MAX;
+    const Vec<VEC> u = fused ? ldv<VEC>(p.U + (size_t)node * p.lduv + cc) : vzero<VEC>();
+    float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
+    int an[VEC], ax[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { sum[i] = 0.f; sq[i] = 0.f; mn[i] = INFINITY; mx[i] = -INFINITY; an[i] = INT_MAX; ax[i] = INT_MAX; }
     for (int base = ebeg; base < eend; base += kWave) {
       const int cnt = min(kWave, eend - base);
       const int myj = (lane < cnt) ? p.src[base + lane] : 0;
@@ -80,61 +96,89 @@ __global__ __launch_bounds__(kBlock) void gr_fwd_kernel(const GrParams p) {
         const bool ev = t < cnt;
         const int j = ev ? j_ : node;
         const int e = ev ? e_ : mye;       // any valid edge id of this segment
-        const float h = gr_message(p, dp, fused, u, j, (uint32_t)e, cc);
+        const Vec<VEC> h = gr_message<VEC>(p, dp, fused, u, j, (uint32_t)e, cc);
         if (ev) {
-          sum += h; sq += h * h;
-          if (h < mn) { mn = h; an = e; }   // strict: the first (lowest position) extremal edge wins
-          if (h > mx) { mx = h; ax = e; }
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            sum[i] += h.v[i]; sq[i] += h.v[i] * h.v[i];
+            if (h.v[i] < mn[i]) { mn[i] = h.v[i]; an[i] = e; }   // strict: the first (lowest position) extremal edge wins
+            if (h.v[i] > mx[i]) { mx[i] = h.v[i]; ax[i] = e; }
+          }
         }
       }
     }
     for (int off = kWave / 2; off >= lpr; off >>= 1) {
-      sum += __shfl_xor(sum, off, kWave);
-      sq += __shfl_xor(sq, off, kWave);
-      const float omn = __shfl_xor(mn, off, kWave); const int oan = __shfl_xor(an, off, kWave);
-      const float omx = __shfl_xor(mx, off, kWave); const int oax = __shfl_xor(ax, off, kWave);
-      if (omn < mn || (omn == mn && oan < an)) { mn = omn; an = oan; }
-      if (omx > mx || (omx == mx && oax < ax)) { mx = omx; ax = oax; }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        sum[i] += __shfl_xor(sum[i], off, kWave);
+        sq[i] += __shfl_xor(sq[i], off, kWave);
+        const float omn = __shfl_xor(mn[i], off, kWave); const int oan = __shfl_xor(an[i], off, kWave);
+        const float omx = __shfl_xor(mx[i], off, kWave); const int oax = __shfl_xor(ax[i], off, kWave);
+        if (omn < mn[i] || (omn == mn[i] && oan < an[i])) { mn[i] = omn; an[i] = oan; }
+        if (omx > mx[i] || (omx == mx[i] && oax < ax[i])) { mx[i] = omx; ax[i] = oax; }
+      }
     }
     if (sub == 0 && valid) {
       const int cnt = eend - ebeg;
       const float deg = (float)max(cnt, 1);                       // degree(...).clamp_(1), mma_conv.py:178-179
-      const float mean = sum / deg;                               // scatter mean: sum / clamp(count, 1)
-      const float var = sq / deg - mean * mean;                   // mma_conv.py:167-170
+      float fac[8];
+      for (int s = 0; s < p.S; ++s) fac[s] = scaler_factor(p.scaler[s], deg, p.avg_log, p.avg_lin);
+      // VEC == 4 is only launched when F % 4 == 0: the 4 columns of a lane then sit in one tower, 16-byte aligned in `out`
       const int t = c / p.F, f = c - t * p.F;
       float* o = p.out + ((size_t)node * p.T + t) * ((size_t)p.S * p.K * p.F) + f;
+      float mean[VEC], var[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        mean[i] = sum[i] / deg;                                   // scatter mean: sum / clamp(count, 1)
+        var[i] = sq[i] / deg - mean[i] * mean[i];                 // mma_conv.py:167-170
+      }
       for (int k = 0; k < p.K; ++k) {
-        float b;
-        switch (p.aggr[k]) {
-          case GR_SUM: b = sum; break;
-          case GR_MEAN: b = mean; break;
-          case GR_MIN: b = cnt ? mn : 0.f; break;                 // empty target -> 0 (torch_scatter)
-          case GR_MAX: b = cnt ? mx : 0.f; break;
-          case GR_VAR: b = var; break;
-          default: b = sqrtf(fmaxf(var, 0.f) + 1e-5f); break;
+        Vec<VEC> run;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          switch (p.aggr[k]) {
+            case GR_SUM: run.v[i] = sum[i]; break;
+            case GR_MEAN: run.v[i] = mean[i]; break;
+            case GR_MIN: run.v[i] = cnt ? mn[i] : 0.f; break;    // empty target -> 0 (torch_scatter)
+            case GR_MAX: run.v[i] = cnt ? mx[i] : 0.f; break;
+            case GR_VAR: run.v[i] = var[i]; break;
+            default: run.v[i] = sqrtf(fmaxf(var[i], 0.f) + 1e-5f); break;
+          }
         }
-        float run = b;
         for (int s = 0; s < p.S; ++s) {                           // compounding (G7)
-          run = run * scaler_factor(p.scaler[s], deg, p.avg_log, p.avg_lin);
-          o[(size_t)(s * p.K + k) * p.F] = run;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) run.v[i] = run.v[i] * fac[s];
+          stv<VEC>(o + (size_t)(s * p.K + k) * p.F, run);
         }
       }
-      const size_t so = (size_t)node * p.D + c;
-      if (p.amin) p.amin[so] = cnt ? an : -1;
-      if (p.amax) p.amax[so] = cnt ? ax : -1;
-      if (p.mean) p.mean[so] = mean;
-      if (p.var) p.var[so] = var;
+      const size_t so = (size_t)node * p.ldsave + c;
+      if (p.amin) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) p.amin[so + i] = cnt ? an[i] : -1;
+      }
+      if (p.amax) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) p.amax[so + i] = cnt ? ax[i] : -1;
+      }
+      if (p.mean) {
+        Vec<VEC> mv, vv;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { mv.v[i] = mean[i]; vv.v[i] = var[i]; }
+        stv<VEC>(p.mean + so, mv);
+        stv<VEC>(p.var + so, vv);
+      }
     }
   }
 }
 
 // K4: gradient w.r.t. every edge message, written by original edge id (each edge has exactly one target: no conflicts)
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void gr_bwd_kernel(const GrParams p) {
   const DropParams dp = drop_resolve(p.drop);
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log, epg = kWave >> p.lpr_log;
   const int sub = lane >> p.lpr_log;
-  const int c = (int)blockIdx.y * lpr + (lane & (lpr - 1));
+  const int c = ((int)blockIdx.y * lpr + (lane & (lpr - 1))) * VEC;
   const bool valid = c < p.D;
   const int cc = valid ? c : 0;
   const bool fused = p.inputs == nullptr;
@@ -144,33 +188,52 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_kernel(const GrParams p) {
     const int ebeg = p.rowptr[node], eend = p.rowptr[node + 1];
     if (ebeg == eend) continue;
     const float deg = (float)(eend - ebeg);
-    const int t = cc / p.F, f = cc - t * p.F;
-    const float* go = p.gout + ((size_t)node * p.T + t) * ((size_t)p.S * p.K * p.F) + f;
-    const size_t so = (size_t)node * p.D + cc;
-    float c_all = 0.f, c_min = 0.f, c_max = 0.f, c_var = 0.f;   // coefficients of: 1, [e==amin], [e==amax], (h - mean)
+    float fac[8];
+    for (int s = 0; s < p.S; ++s) fac[s] = scaler_factor(p.scaler[s], deg, p.avg_log, p.avg_lin);
+    float c_all[VEC], c_min[VEC], c_max[VEC], c_var[VEC], mean[VEC];   // coefficients of 1, [e==amin], [e==amax], (h - mean)
+    int an[VEC], ax[VEC];
     bool need_h = false;
-    for (int k = 0; k < p.K; ++k) {
-      float gb = 0.f, run = 1.f;
-      for (int s = 0; s < p.S; ++s) {
-        run = run * scaler_factor(p.scaler[s], deg, p.avg_log, p.avg_lin);
-        gb = fmaf(go[(size_t)(s * p.K + k) * p.F], run, gb);
+    {
+      const int t = cc / p.F, f = cc - t * p.F;                   // VEC == 4 only with F % 4 == 0 (one tower per lane)
+      const float* go = p.gout + ((size_t)node * p.T + t) * ((size_t)p.S * p.K * p.F) + f;
+      const size_t so = (size_t)node * p.ldsave + cc;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) c_all[i] = c_min[i] = c_max[i] = c_var[i] = 0.f;
+      for (int k = 0; k < p.K; ++k) {
+        float gb[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gb[i] = 0.f;
+        float run = 1.f;
+        for (int s = 0; s < p.S; ++s) {
+          run = run * fac[s];
+          const Vec<VEC> gv = ldv<VEC>(go + (size_t)(s * p.K + k) * p.F);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) gb[i] = fmaf(gv.v[i], run, gb[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          switch (p.aggr[k]) {
+            case GR_SUM: c_all[i] += gb[i]; break;
+            case GR_MEAN: c_all[i] += gb[i] / deg; break;
+            case GR_MIN: c_min[i] += gb[i]; break;
+            case GR_MAX: c_max[i] += gb[i]; break;
+            case GR_VAR: c_var[i] += gb[i] * 2.f / deg; need_h = true; break;
+            default: {
+              const float v = p.var[so + i];
+              if (v > 0.f) c_var[i] += gb[i] / (2.f * sqrtf(v + 1e-5f)) * 2.f / deg;   // relu'(v) = [v > 0]
+              need_h = true;
+            } break;
+          }
+        }
       }
-      switch (p.aggr[k]) {
-        case GR_SUM: c_all += gb; break;
-        case GR_MEAN: c_all += gb / deg; break;
-        case GR_MIN: c_min += gb; break;
-        case GR_MAX: c_max += gb; break;
-        case GR_VAR: c_var += gb * 2.f / deg; need_h = true; break;
-        default: {
-          const float v = p.var[so];
-          if (v > 0.f) c_var += gb / (2.f * sqrtf(v + 1e-5f)) * 2.f / deg;   // relu'(v) = [v > 0]
-          need_h = true;
-        } break;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        an[i] = p.amin ? p.amin[so + i] : -1;
+        ax[i] = p.amax ? p.amax[so + i] : -1;
+        mean[i] = need_h ? p.mean[so + i] : 0.f;
       }
     }
-    const int an = p.amin ? p.amin[so] : -1, ax = p.amax ? p.amax[so] : -1;
-    const float mean = need_h ? p.mean[so] : 0.f;
-    const float u = (fused && need_h) ? p.U[(size_t)node * p.lduv + cc] : 0.f;
+    const Vec<VEC> u = (fused && need_h) ? ldv<VEC>(p.U + (size_t)node * p.lduv + cc) : vzero<VEC>();
     for (int base = ebeg; base < eend; base += kWave) {
       const int cnt = min(kWave, eend - base);
       const int myj = (lane < cnt) ? p.src[base + lane] : 0;
@@ -180,14 +243,22 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_kernel(const GrParams p) {
         const int j_ = __shfl(myj, tt & (kWave - 1), kWave);
         const int e_ = __shfl(mye, tt & (kWave - 1), kWave);
         if (tt < cnt && valid) {
-          float g = c_all + (e_ == an ? c_min : 0.f) + (e_ == ax ? c_max : 0.f);
-          if (need_h) g += c_var * (gr_message(p, dp, fused, u, j_, (uint32_t)e_, cc) - mean);
-          if (fused && dp.mode != MMA_DROP_NONE) {
-            float fd[1];
-            drop_factors<1>(dp, (uint32_t)e_, 0, cc, p.D, 0, fd);
-            g *= fd[0];
+          Vec<VEC> g;
+          Vec<VEC> h = vzero<VEC>();
+          if (need_h) h = gr_message<VEC>(p, dp, fused, u, j_, (uint32_t)e_, cc);
+          float fd[VEC];
+          if (fused && dp.mode != MMA_DROP_NONE) drop_factors<VEC>(dp, (uint32_t)e_, 0, cc, p.D, 0, fd);
+          else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) fd[i] = 1.f;
           }
-          p.gmsg[(size_t)e_ * p.ldg + cc] = g;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            float gi = c_all[i] + (e_ == an[i] ? c_min[i] : 0.f) + (e_ == ax[i] ? c_max[i] : 0.f);
+            if (need_h) gi += c_var[i] * (h.v[i] - mean[i]);
+            g.v[i] = gi * fd[i];
+          }
+          stv<VEC>(p.gmsg + (size_t)e_ * p.ldg + cc, g);
         }
       }
     }
@@ -231,9 +302,36 @@ static int fill_codes(const uint8_t* aggr_host, int K, const uint8_t* scaler_hos
   return 0;
 }
 
-static dim3 gr_grid(int64_t N, int D, int* lpr_log) {
-  *lpr_log = min(ilog2_ceil(D), 6);
-  const int chunks = (D + (1 << *lpr_log) - 1) >> *lpr_log;
+// 16-byte row access is possible when every message operand has a pitch that is a multiple of 4 covering D rounded up,
+// 16-byte aligned bases, and the saved arrays are padded the same way
+static bool gr_vec4(const GrParams& p) {
+  if (p.F % 4 != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(p.out ? (const void*)p.out : (const void*)p.gout) & 15) != 0) return false;
+  const int Dp = p.D;
+  auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (p.inputs) {
+    if (!(p.ldi % 4 == 0 && p.ldi >= Dp && al(p.inputs))) return false;
+  } else {
+    if (!(p.lduv % 4 == 0 && p.lduv >= Dp && al(p.U) && al(p.V))) return false;
+    if (p.Z && !(p.ldz % 4 == 0 && p.ldz >= Dp && al(p.Z))) return false;
+  }
+  if ((p.amin || p.amax || p.mean || p.var) && p.ldsave < Dp) return false;
+  return true;
+}
+
+static dim3 gr_grid(int64_t N, int D, int vec, int* lpr_log) {
+  const int per_row = (D + vec - 1) / vec;
+  // lanes per row: the power of two in {64,32,16} that wastes the fewest lanes (94 quads -> 3 x 32, not 2 x 64)
+  int best = min(ilog2_ceil(per_row), 6);
+  if (per_row > 16) {
+    int best_waste = 1 << 30;
+    for (int lg = 6; lg >= 4; --lg) {
+      const int waste = ((per_row + (1 << lg) - 1) >> lg << lg) - per_row;
+      if (waste < best_waste) { best_waste = waste; best = lg; }
+    }
+  }
+  *lpr_log = best;
+  const int chunks = (per_row + (1 << *lpr_log) - 1) >> *lpr_log;
   int64_t blocks = (N + 3) / 4;
   if (blocks > kMaxGrid) blocks = kMaxGrid;
   if (blocks < 1) blocks = 1;
@@ -285,7 +383,7 @@ extern "C" int mma_build_csr(const int64_t* key, const int64_t* other, int64_t E
 extern "C" int mma_gr_fused_fwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
-    float* out, int32_t* amin, int32_t* amax, float* mean, float* var,
+    float* out, int32_t* amin, int32_t* amax, float* mean, float* var, int64_t ldsave,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31) && T >= 1 && F >= 1, "N=%lld E=%lld T=%d F=%d unsupported",
@@ -301,20 +399,23 @@ extern "C" int mma_gr_fused_fwd(
   MMA_REQUIRE(drop_mode == MMA_DROP_NONE || drop_mode == MMA_DROP_HASH, "GR dropout: NONE or HASH");
   MMA_REQUIRE(drop_mode == MMA_DROP_NONE || drop_thr < 256, "drop_thr out of range");
   p.rowptr = rowptr; p.src = src; p.perm = perm; p.U = U; p.V = V; p.lduv = lduv; p.Z = Z; p.ldz = ldz;
-  p.inputs = inputs; p.ldi = ldi; p.out = out; p.amin = amin; p.amax = amax; p.mean = mean; p.var = var;
+  p.inputs = inputs; p.ldi = ldi; p.out = out; p.amin = amin; p.amax = amax; p.mean = mean; p.var = var; p.ldsave = ldsave;
+  MMA_REQUIRE(!(amin || amax || mean || var) || ldsave >= D, "ldsave=%lld < T*F", (long long)ldsave);
   p.N = (int)N; p.D = D; p.T = T; p.F = F; p.avg_log = avg_log; p.avg_lin = avg_lin;
   p.drop.mode = (drop_mode == MMA_DROP_HASH && drop_thr > 0 && !inputs) ? MMA_DROP_HASH : MMA_DROP_NONE;
   p.drop.thr = drop_thr; p.drop.scale = 256.f / (256.f - (float)drop_thr);
   p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.seed_dev = seed_dev; p.drop.keep = nullptr; p.drop.E = E; p.drop.edge_base = 0;
-  const dim3 grid = gr_grid(N, D, &p.lpr_log);
-  hipLaunchKernelGGL(gr_fwd_kernel, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
+  const bool v4 = gr_vec4(p);
+  const dim3 grid = gr_grid(N, D, v4 ? 4 : 1, &p.lpr_log);
+  if (v4) hipLaunchKernelGGL((gr_fwd_kernel<4>), grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL((gr_fwd_kernel<1>), grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
   return check_launch("gr_fwd_kernel");
 }
 
 extern "C" int mma_gr_fused_bwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
-    const float* gout, const int32_t* amin, const int32_t* amax, const float* mean, const float* var,
+    const float* gout, const int32_t* amin, const int32_t* amax, const float* mean, const float* var, int64_t ldsave,
     float* gmsg, int64_t ldg,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
@@ -335,12 +436,15 @@ extern "C" int mma_gr_fused_bwd(
   p.rowptr = rowptr; p.src = src; p.perm = perm; p.U = U; p.V = V; p.lduv = lduv; p.Z = Z; p.ldz = ldz;
   p.inputs = inputs; p.ldi = ldi; p.gout = gout; p.amin = const_cast<int32_t*>(need_min ? amin : nullptr);
   p.amax = const_cast<int32_t*>(need_max ? amax : nullptr); p.mean = const_cast<float*>(mean); p.var = const_cast<float*>(var);
-  p.gmsg = gmsg; p.ldg = ldg;
+  p.gmsg = gmsg; p.ldg = ldg; p.ldsave = ldsave;
+  MMA_REQUIRE(!(need_min || need_max || need_stats) || ldsave >= D, "ldsave=%lld < T*F", (long long)ldsave);
   p.N = (int)N; p.D = D; p.T = T; p.F = F; p.avg_log = avg_log; p.avg_lin = avg_lin;
   p.drop.mode = (drop_mode == MMA_DROP_HASH && drop_thr > 0 && !inputs) ? MMA_DROP_HASH : MMA_DROP_NONE;
   p.drop.thr = drop_thr; p.drop.scale = 256.f / (256.f - (float)drop_thr);
   p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.seed_dev = seed_dev; p.drop.keep = nullptr; p.drop.E = E; p.drop.edge_base = 0;
-  const dim3 grid = gr_grid(N, D, &p.lpr_log);
-  hipLaunchKernelGGL(gr_bwd_kernel, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
+  const bool v4 = gr_vec4(p) && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(gmsg) & 15) == 0;
+  const dim3 grid = gr_grid(N, D, v4 ? 4 : 1, &p.lpr_log);
+  if (v4) hipLaunchKernelGGL((gr_bwd_kernel<4>), grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL((gr_bwd_kernel<1>), grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
   return check_launch("gr_bwd_kernel");
 }

@@ -314,7 +314,9 @@ def _gr_call(fn, csr, U, V, Z, inputs, extra, N, E, T, F, aggr, scalers, avg_log
 
 class _GRAggregate(torch.autograd.Function):
     """K aggregators + compounding degree scalers over target segments (mma_conv.py:159-196), messages either given
-    (`inputs`, the public aggregate() API) or formed in-kernel as drop(U[i] + V[j] + Z[e]) (fused forward)."""
+    (`inputs`, the public aggregate() API) or formed in-kernel as drop(U[i] + V[j] + Z[e]) (fused forward).
+    Fused mode: U, V (N,Dp) and Z (E,Dp) may carry zero padding columns (Dp = T*F rounded up to 4) so that every row is
+    16-byte aligned; the gradients come back in the same padded shape."""
 
     @staticmethod
     def forward(ctx, inputs, U, V, Z, graph, T, F, aggr, scalers, avg_log, avg_lin, drop):
@@ -328,54 +330,56 @@ class _GRAggregate(torch.autograd.Function):
         if fused:
             U, V = U.contiguous(), V.contiguous()
             Z = Z.contiguous() if Z is not None else None
-            assert U.shape == (N, D) and V.shape == (N, D) and (Z is None or Z.shape == (E, D))
+            Dp = U.shape[1]
+            assert Dp >= D and U.shape == (N, Dp) and V.shape == (N, Dp) and (Z is None or Z.shape == (E, Dp))
         else:
             inputs = inputs.contiguous()
             assert inputs.shape == (E, T, F)
+            Dp = D
         out = torch.empty((N, T, S * K * F), device=dev, dtype=torch.float32)
         need = any(ctx.needs_input_grad[:4])
-        amin = torch.empty((N, D), dtype=torch.int32, device=dev) if need and 2 in aggr else None
-        amax = torch.empty((N, D), dtype=torch.int32, device=dev) if need and 3 in aggr else None
+        amin = torch.empty((N, Dp), dtype=torch.int32, device=dev) if need and 2 in aggr else None
+        amax = torch.empty((N, Dp), dtype=torch.int32, device=dev) if need and 3 in aggr else None
         stats = need and (4 in aggr or 5 in aggr)
-        mean = torch.empty((N, D), device=dev) if stats else None
-        var = torch.empty((N, D), device=dev) if stats else None
+        mean = torch.empty((N, Dp), device=dev) if stats else None
+        var = torch.empty((N, Dp), device=dev) if stats else None
+        ctx.cfg = (graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, Z is not None, Dp)
         if E == 0:          # nothing to aggregate: every target is empty -> 0 (and a zero gradient)
             out.zero_()
-            ctx.cfg = (graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, Z is not None)
             ctx.save_for_backward(inputs, U, V, Z, None, None, None, None)
             return out
         with _span("gr_fused_fwd"):
-            _gr_call("mma_gr_fused_fwd", csr, U, V, Z, inputs, (ptr(out), ptr(amin), ptr(amax), ptr(mean), ptr(var)),
+            _gr_call("mma_gr_fused_fwd", csr, U, V, Z, inputs, (ptr(out), ptr(amin), ptr(amax), ptr(mean), ptr(var), Dp),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
-        ctx.cfg = (graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, Z is not None)
         ctx.save_for_backward(inputs, U, V, Z, amin, amax, mean, var)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, has_z = ctx.cfg
+        graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, has_z, Dp = ctx.cfg
         inputs, U, V, Z, amin, amax, mean, var = ctx.saved_tensors
         csr = graph.by_target
         N, E, D = graph.N, graph.E, T * F
         gout = gout.contiguous()
-        gmsg = torch.empty((E, D), device=gout.device, dtype=torch.float32)
+        gmsg = torch.empty((E, Dp), device=gout.device, dtype=torch.float32)
         if E == 0:
             if not fused:
                 return (gmsg.view(E, T, F),) + (None,) * 11
-            z = torch.zeros((N, D), device=gout.device, dtype=torch.float32)
+            z = torch.zeros((N, Dp), device=gout.device, dtype=torch.float32)
             return (None, z, z.clone(), gmsg if has_z else None) + (None,) * 8
         with _span("gr_fused_bwd"):
-            _gr_call("mma_gr_fused_bwd", csr, U, V, Z, inputs, (ptr(gout), ptr(amin), ptr(amax), ptr(mean), ptr(var), ptr(gmsg), D),
+            _gr_call("mma_gr_fused_bwd", csr, U, V, Z, inputs,
+                     (ptr(gout), ptr(amin), ptr(amax), ptr(mean), ptr(var), Dp, ptr(gmsg), Dp),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
         if not fused:
             return (gmsg.view(E, T, F),) + (None,) * 11
         # dU[i] = sum of its target segment, dV[j] = sum over the edges leaving j: two segment sums (K5 kernel)
-        gU = torch.empty((N, D), device=gout.device, dtype=torch.float32)
-        gV = torch.empty((N, D), device=gout.device, dtype=torch.float32)
+        gU = torch.empty((N, Dp), device=gout.device, dtype=torch.float32)
+        gV = torch.empty((N, Dp), device=gout.device, dtype=torch.float32)
         cs = graph.by_source
         with _span("gr_segsum"):
-            call("mma_csr_spmm", ptr(csr.rowptr), ptr(csr.perm), None, ptr(gmsg), D, E, 1, None, ptr(gU), D, N, D, stream_ptr())
-            call("mma_csr_spmm", ptr(cs.rowptr), ptr(cs.perm), None, ptr(gmsg), D, E, 1, None, ptr(gV), D, N, D, stream_ptr())
+            call("mma_csr_spmm", ptr(csr.rowptr), ptr(csr.perm), None, ptr(gmsg), Dp, E, 1, None, ptr(gU), Dp, N, Dp, stream_ptr())
+            call("mma_csr_spmm", ptr(cs.rowptr), ptr(cs.perm), None, ptr(gmsg), Dp, E, 1, None, ptr(gV), Dp, N, Dp, stream_ptr())
         return (None, gU, gV, gmsg if has_z else None) + (None,) * 8
 
 
