@@ -24,11 +24,9 @@ namespace mma {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int kKC = 128;                 // k per chunk
-constexpr int kRowPitch = kKC * 2 + 16;  // bytes per LDS row: 128 bf16 + 16 B pad
-constexpr int kPiece = 32 * kRowPitch;   // one piece of one 32-column tile
-constexpr int kSlab = 3 * kPiece;        // 26112 B
-
+constexpr int kKC = 128;                 // k per chunk when the A chunk is the only thing kept in registers (K == 128 form)
+constexpr int kKCPersist = 64;           // k per chunk when up to 4 accumulator tiles persist (K > 128 form): 48 instead of
+                                         // 96 A registers, so that two workgroups fit a CU
 struct GemmParams {
   const float* A; int64_t lda;
   const __bf16* Bt;          // (3, N, K) bf16: piece p of B^T, k contiguous
@@ -46,28 +44,48 @@ __device__ __forceinline__ Bf3 split3(const float v) {
   return r;
 }
 
-// One thread moves 6 of the 1536 16-byte pieces of a 3 x 32 x 128 bf16 slab.  Six scalars, not an array: an indexed
+template <int KC> struct SlabGeom {
+  static constexpr int kRowPitch = KC * 2 + 16;   // bytes per LDS row: KC bf16 + 16 B pad (conflict-free ds_read_b128)
+  static constexpr int kPiece = 32 * kRowPitch;   // one piece of one 32-column tile
+  static constexpr int kSlab = 3 * kPiece;
+  static constexpr int kCpr = KC / 8;             // 16-byte chunks per row
+  static constexpr int kPerThread = 3 * 32 * kCpr / kBlock;   // 6 (KC = 128) or 3 (KC = 64)
+};
+
+// One thread moves kPerThread of the 16-byte chunks of a 3 x 32 x KC bf16 slab.  Scalars, not an array: an indexed
 // register array that is written and read under run-time conditions stays in scratch memory.
 struct SlabRegs { uint4 r0, r1, r2, r3, r4, r5; };
+template <int KC>
 __device__ __forceinline__ const uint4* slab_src(const GemmParams& p, int q, int kc, int ct) {
-  const int piece = q >> 9, rem = q & 511, col = rem >> 4, kq = rem & 15;
-  return reinterpret_cast<const uint4*>(p.Bt + ((size_t)piece * p.N + (size_t)(ct * 32 + col)) * p.K + kc * kKC + kq * 8);
+  constexpr int cpr = SlabGeom<KC>::kCpr;
+  const int piece = q / (32 * cpr), rem = q % (32 * cpr), col = rem / cpr, kq = rem % cpr;
+  return reinterpret_cast<const uint4*>(p.Bt + ((size_t)piece * p.N + (size_t)(ct * 32 + col)) * p.K + kc * KC + kq * 8);
 }
+template <int KC>
 __device__ __forceinline__ uint4* slab_dst(unsigned char* dst, int q) {
-  const int piece = q >> 9, rem = q & 511, col = rem >> 4, kq = rem & 15;
-  return reinterpret_cast<uint4*>(dst + piece * kPiece + col * kRowPitch + kq * 16);
+  constexpr int cpr = SlabGeom<KC>::kCpr;
+  const int piece = q / (32 * cpr), rem = q % (32 * cpr), col = rem / cpr, kq = rem % cpr;
+  return reinterpret_cast<uint4*>(dst + piece * SlabGeom<KC>::kPiece + col * SlabGeom<KC>::kRowPitch + kq * 16);
 }
+template <int KC>
 __device__ __forceinline__ SlabRegs slab_load(const GemmParams& p, int tid, int kc, int ct) {
   SlabRegs s;
-  s.r0 = *slab_src(p, tid, kc, ct);              s.r1 = *slab_src(p, tid + kBlock, kc, ct);
-  s.r2 = *slab_src(p, tid + 2 * kBlock, kc, ct); s.r3 = *slab_src(p, tid + 3 * kBlock, kc, ct);
-  s.r4 = *slab_src(p, tid + 4 * kBlock, kc, ct); s.r5 = *slab_src(p, tid + 5 * kBlock, kc, ct);
+  s.r0 = *slab_src<KC>(p, tid, kc, ct);              s.r1 = *slab_src<KC>(p, tid + kBlock, kc, ct);
+  s.r2 = *slab_src<KC>(p, tid + 2 * kBlock, kc, ct);
+  if (SlabGeom<KC>::kPerThread > 3) {
+    s.r3 = *slab_src<KC>(p, tid + 3 * kBlock, kc, ct);
+    s.r4 = *slab_src<KC>(p, tid + 4 * kBlock, kc, ct); s.r5 = *slab_src<KC>(p, tid + 5 * kBlock, kc, ct);
+  }
   return s;
 }
+template <int KC>
 __device__ __forceinline__ void slab_store(unsigned char* dst, int tid, const SlabRegs& s) {
-  *slab_dst(dst, tid) = s.r0;              *slab_dst(dst, tid + kBlock) = s.r1;
-  *slab_dst(dst, tid + 2 * kBlock) = s.r2; *slab_dst(dst, tid + 3 * kBlock) = s.r3;
-  *slab_dst(dst, tid + 4 * kBlock) = s.r4; *slab_dst(dst, tid + 5 * kBlock) = s.r5;
+  *slab_dst<KC>(dst, tid) = s.r0;              *slab_dst<KC>(dst, tid + kBlock) = s.r1;
+  *slab_dst<KC>(dst, tid + 2 * kBlock) = s.r2;
+  if (SlabGeom<KC>::kPerThread > 3) {
+    *slab_dst<KC>(dst, tid + 3 * kBlock) = s.r3;
+    *slab_dst<KC>(dst, tid + 4 * kBlock) = s.r4; *slab_dst<KC>(dst, tid + 5 * kBlock) = s.r5;
+  }
 }
 
 // NCT > 0: K > 128, the NCT (= N/32 <= 4) accumulator tiles persist across the K chunks (compile-time indices only).
@@ -75,13 +93,16 @@ __device__ __forceinline__ void slab_store(unsigned char* dst, int tid, const Sl
 // FULL: every row of the block exists (no guards: the C stores are unconditional, so the compiler can count them in
 // vmcnt and never waits for a store); the last partial block is a separate guarded launch.
 template <int NCT, bool FULL>
-__global__ __launch_bounds__(kBlock, (NCT >= 3 ? 1 : 2)) void gemm_x3_kernel(const GemmParams p, int64_t blk0, int64_t n_blocks) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kSlab];
+__global__ __launch_bounds__(kBlock, 2) void gemm_x3_kernel(const GemmParams p, int64_t blk0, int64_t n_blocks) {
   constexpr bool PERSIST = NCT > 0;
+  constexpr int KC = PERSIST ? kKCPersist : kKC;
+  constexpr int KSTEPS = KC / 16;
+  constexpr int kRowPitch = SlabGeom<KC>::kRowPitch, kPiece = SlabGeom<KC>::kPiece, kSlab = SlabGeom<KC>::kSlab;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kSlab];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r31 = lane & 31, h = lane >> 5;
-  const int n_kc = p.K / kKC, n_ct = PERSIST ? NCT : p.N / 32;
+  const int n_kc = p.K / KC, n_ct = PERSIST ? NCT : p.N / 32;
   const int n_it = n_kc * n_ct;
 
   for (int64_t blk = blk0 + blockIdx.x; blk < blk0 + n_blocks; blk += gridDim.x) {
@@ -95,12 +116,12 @@ __global__ __launch_bounds__(kBlock, (NCT >= 3 ? 1 : 2)) void gemm_x3_kernel(con
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    SlabRegs nxt = slab_load(p, tid, 0, 0);                  // slab prefetch registers: 6 x 16 B per thread
-    slab_store(lds, tid, nxt);
-    if (n_it > 1) nxt = slab_load(p, tid, 1 / n_ct, 1 % n_ct);
+    SlabRegs nxt = slab_load<KC>(p, tid, 0, 0);              // slab prefetch registers: 3 or 6 x 16 B per thread
+    slab_store<KC>(lds, tid, nxt);
+    if (n_it > 1) nxt = slab_load<KC>(p, tid, 1 / n_ct, 1 % n_ct);
     __syncthreads();
 
-    bf16x8 af[8][3];
+    bf16x8 af[KSTEPS][3];
     int it = 0;
 // one 32-column tile of one K chunk: prefetch the next slab, 8 k-steps x 6 piece products, (last chunk) the C store,
 // publish the prefetched slab.  A macro, not a lambda: register arrays captured by a closure end up in scratch.
@@ -110,7 +131,7 @@ __global__ __launch_bounds__(kBlock, (NCT >= 3 ? 1 : 2)) void gemm_x3_kernel(con
 #define MMA_X3_TILE(C_, CT_, LAST_)                                                                          \
     {                                                                                                        \
       const unsigned char* sb = lds + (it & 1) * kSlab + r31 * kRowPitch + h * 16;                           \
-      _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                             \
+      _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                                \
         const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 0 * kPiece + ks * 32);                       \
         const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(sb + 1 * kPiece + ks * 32);                       \
         const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(sb + 2 * kPiece + ks * 32);                       \
@@ -121,10 +142,10 @@ __global__ __launch_bounds__(kBlock, (NCT >= 3 ? 1 : 2)) void gemm_x3_kernel(con
         C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1], b1, C_, 0, 0, 0);                            \
         C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], b1, C_, 0, 0, 0);                            \
       }                                                                                                      \
-      if (it + 1 < n_it) slab_store(lds + ((it + 1) & 1) * kSlab, tid, nxt);                                 \
+      if (it + 1 < n_it) slab_store<KC>(lds + ((it + 1) & 1) * kSlab, tid, nxt);                             \
       if (it + 2 < n_it) {                                                                                   \
         const int nk = (it + 2) / n_ct;                                                                      \
-        nxt = slab_load(p, tid, nk, it + 2 - nk * n_ct);                                                     \
+        nxt = slab_load<KC>(p, tid, nk, it + 2 - nk * n_ct);                                                 \
       }                                                                                                      \
       if (LAST_) { /* acc reg r holds row (r&3) + 8*(r>>2) + 4*h, column r31 of the tile */   \
         float* cp = p.C + (size_t)((CT_) * 32 + r31);                                                        \
@@ -143,9 +164,9 @@ __global__ __launch_bounds__(kBlock, (NCT >= 3 ? 1 : 2)) void gemm_x3_kernel(con
     for (int kc = 0; kc < n_kc; ++kc) {
       // this wave's 32 rows x 128 k of A: load, split into three bf16 pieces, keep in registers for all column tiles
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const float4 lo = *reinterpret_cast<const float4*>(ap + kc * kKC + ks * 16);
-        const float4 hi = *reinterpret_cast<const float4*>(ap + kc * kKC + ks * 16 + 4);
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const float4 lo = *reinterpret_cast<const float4*>(ap + kc * KC + ks * 16);
+        const float4 hi = *reinterpret_cast<const float4*>(ap + kc * KC + ks * 16 + 4);
         { const Bf3 t = split3(lo.x); af[ks][0][0] = t.a; af[ks][1][0] = t.b; af[ks][2][0] = t.c; }
         { const Bf3 t = split3(lo.y); af[ks][0][1] = t.a; af[ks][1][1] = t.b; af[ks][2][1] = t.c; }
         { const Bf3 t = split3(lo.z); af[ks][0][2] = t.a; af[ks][1][2] = t.b; af[ks][2][2] = t.c; }
