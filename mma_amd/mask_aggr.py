@@ -1,14 +1,16 @@
-"""Drop-in `MaskAggregateLinear` (reference graph_regression/mask_aggr.py:7-68).
+"""Drop-in `MaskAggregateLinear` (behaviour of the reference's graph_regression/mask_aggr.py:7-68).
 
-Same constructor and behaviour, quirks included: it subclasses `Linear` but never uses the inherited weight (G12);
-the K per-aggregation Linears live in a plain dict, so they are NOT registered parameters (absent from
-state_dict/parameters(), never trained, not moved by .to()) and are moved to the GPU eagerly (G2);
-an unknown aggregation raises ValueError (mask_aggr.py:64); mask == "no_linear" returns the input."""
+Quirks kept on purpose: the class derives from `Linear` but its own weight is never applied (G12);
+the per-aggregation Linears sit in a plain dict, i.e. they are NOT registered (missing from parameters()/state_dict(),
+never trained, ignored by .to()) and are therefore placed on the GPU at construction (G2); an aggregation name that is not
+in the list raises ValueError at call time (mask_aggr.py:64); mask == "no_linear" makes the module the identity."""
 from typing import List, Optional
 
 import torch
 
 from .pyg_compat import Linear
+
+_NO_LINEAR = "no_linear"
 
 
 class MaskAggregateLinear(Linear):
@@ -17,25 +19,23 @@ class MaskAggregateLinear(Linear):
                  bias_initializer: Optional[str] = None):
         super().__init__(in_channels, out_channels, bias, weight_initializer, bias_initializer)
         self.device = 'cuda' if torch.cuda.is_available() else 'cpu'
-        self.mask = mask
-        self.aggregation = aggregation
-        self.aggregation_layers = {}
-        for i, aggr in enumerate(aggregation_list):
-            aggregation_name = "{}".format(aggr)
-            if self.mask == "no_linear":
-                self.aggregation_layers[aggregation_name] = None
-            else:
-                linear = Linear(in_channels, out_channels, bias, weight_initializer, bias_initializer).to(self.device)
-                self.aggregation_layers[aggregation_name] = linear
+        self.mask, self.aggregation = mask, aggregation
+
+        def one_linear():
+            if mask == _NO_LINEAR:
+                return None
+            return Linear(in_channels, out_channels, bias, weight_initializer, bias_initializer).to(self.device)
+
+        # a dict on purpose: keeps the K Linears out of the module's registered parameters, as in the reference
+        self.aggregation_layers = {str(name): one_linear() for name in aggregation_list}
 
     def active_linear(self):
         """The Linear that forward() applies (None for mask == "no_linear")."""
-        if self.aggregation not in self.aggregation_layers:
-            raise ValueError("Invalid aggregation type: {}".format(self.aggregation))
-        return self.aggregation_layers[self.aggregation]
+        try:
+            return self.aggregation_layers[self.aggregation]
+        except KeyError:
+            raise ValueError("Invalid aggregation type: {}".format(self.aggregation)) from None
 
     def forward(self, input):
-        lin = self.active_linear()
-        if self.mask == "no_linear":
-            return input
-        return lin(input).to(self.device)
+        layer = self.active_linear()
+        return input if self.mask == _NO_LINEAR else layer(input).to(self.device)

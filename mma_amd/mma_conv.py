@@ -33,53 +33,29 @@ class MMAConv(torch.nn.Module):
                  mask: bool = True, divide_input: bool = False, **kwargs):
         kwargs.setdefault('aggr', None)      # accepted for signature compatibility with MessagePassing(node_dim=0, **kwargs)
         super().__init__()
-        if divide_input:
-            assert in_channels % towers == 0
         assert out_channels % towers == 0
-
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.aggregators = aggregators
-        self.scalers = scalers
-        self.edge_dim = edge_dim
-        self.towers = towers
-        self.divide_input = divide_input
-        self.dropout = 0.5
-        self.mask = mask
+        assert not divide_input or in_channels % towers == 0
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.aggregators, self.scalers = aggregators, scalers
+        self.edge_dim, self.towers, self.divide_input = edge_dim, towers, divide_input
+        self.mask, self.dropout = mask, 0.5                                     # G4
         self.pre_layers, self.post_layers = pre_layers, post_layers
-
         self.F_in = in_channels // towers if divide_input else in_channels
-        self.F_out = self.out_channels // towers
+        self.F_out = out_channels // towers
 
-        deg = deg.to(torch.float)
-        self.avg_deg: Dict[str, float] = {
-            'lin': deg.mean().item(),
-            'log': (deg + 1).log().mean().item(),
-            'exp': deg.exp().mean().item(),
-        }
-
-        if self.edge_dim is not None:
+        hist = deg.to(torch.float)                                              # G8: statistics of the histogram VALUES
+        self.avg_deg: Dict[str, float] = {'lin': float(hist.mean()), 'log': float(torch.log(hist + 1).mean()),
+                                          'exp': float(torch.exp(hist).mean())}
+        if edge_dim is not None:
             self.edge_encoder = Linear(edge_dim, self.F_in)
 
-        self.pre_nns = {}
-        for i, aggr in enumerate(aggregators):
-            self.pre_nns[aggr] = ModuleList()
-
+        # module creation order = the reference's (tower-major: K pre stacks, then the tower's post stack)
+        self.pre_nns = {aggr: ModuleList() for aggr in aggregators}             # plain dict (G2)
         self.post_nns = ModuleList()
         for _ in range(towers):
             for aggr in aggregators:
-                modules = [MaskAggregateLinear((3 if edge_dim else 2) * self.F_in, self.F_in, aggregators, aggr, mask=self.mask)]
-                for _ in range(pre_layers - 1):
-                    modules += [ReLU()]
-                    modules += [MaskAggregateLinear(self.F_in, self.F_in, aggregators, aggr, mask=self.mask)]
-                self.pre_nns[aggr].append(Sequential(*modules))
-            in_channels = (len(aggregators) * len(scalers) + 1) * self.F_in
-            modules = [Linear(in_channels, self.F_out)]
-            for _ in range(post_layers - 1):
-                modules += [ReLU()]
-                modules += [Linear(self.F_out, self.F_out)]
-            self.post_nns.append(Sequential(*modules))
-
+                self.pre_nns[aggr].append(self._pre_stack(aggr))
+            self.post_nns.append(self._post_stack())
         self.lin = Linear(out_channels, out_channels)
         self.reset_parameters()
 
@@ -88,14 +64,31 @@ class MMAConv(torch.nn.Module):
         self.graph_capturable = False  # True: the dropout seed is re-drawn on the device each call (hipGraph replays)
         self._seed_buf = None
 
+    def _pre_stack(self, aggr):
+        """Sequential(MaskAggregateLinear([x_i|x_j|e] -> F_in), (ReLU, MaskAggregateLinear) x (pre_layers-1))."""
+        def mal(width):
+            return MaskAggregateLinear(width, self.F_in, self.aggregators, aggr, mask=self.mask)
+        blocks = [mal((3 if self.edge_dim else 2) * self.F_in)]
+        for _ in range(1, self.pre_layers):
+            blocks.extend((ReLU(), mal(self.F_in)))
+        return Sequential(*blocks)
+
+    def _post_stack(self):
+        """Sequential(Linear([x | K*S aggregates] -> F_out), (ReLU, Linear) x (post_layers-1))."""
+        width = (1 + len(self.aggregators) * len(self.scalers)) * self.F_in
+        blocks = [Linear(width, self.F_out)]
+        for _ in range(1, self.post_layers):
+            blocks.extend((ReLU(), Linear(self.F_out, self.F_out)))
+        return Sequential(*blocks)
+
     def reset_parameters(self):
         if self.edge_dim is not None:
             self.edge_encoder.reset_parameters()
-        for aggr in self.pre_nns:       # iterates the KEYS (strings): a no-op, as in the reference (G3)
-            for nn in aggr:
-                reset(nn)
-        for nn in self.post_nns:
-            reset(nn)
+        for key in self.pre_nns:        # the KEYS are strings; walking their characters resets nothing (G3)
+            for ch in key:
+                reset(ch)
+        for stack in self.post_nns:
+            reset(stack)
         self.lin.reset_parameters()
 
     # ---- graph plan ---------------------------------------------------------------------------------------
@@ -106,10 +99,8 @@ class MMAConv(torch.nn.Module):
         return self._graph_cache[1]
 
     def _check_aggregators(self):
-        for aggregator in self.aggregators:
-            if not aggregator.startswith(('sum', 'mean', 'min', 'max')):
-                raise ValueError(f'Unknown aggregator "{aggregator}".')        # mma_conv.py:153-154
-            if aggregator not in _SCATTER_REDUCE:                               # torch_scatter rejects e.g. "sum2" (G5)
+        for aggregator in self.aggregators:     # mma_conv.py:153-154 accepts a prefix match, torch_scatter then rejects
+            if aggregator not in _SCATTER_REDUCE:   # anything but the four exact names (G5): same ValueError either way
                 raise ValueError(f'Unknown aggregator "{aggregator}".')
 
     def _fusable(self):
@@ -183,20 +174,16 @@ class MMAConv(torch.nn.Module):
 
     def message(self, x_i: Tensor, x_j: Tensor, edge_attr: Optional[Tensor]) -> Tensor:
         """mma_conv.py:138-157 with dense torch ops (only used when the fused path does not apply)."""
-        h: Tensor = x_i
+        parts = [x_i, x_j]
         if edge_attr is not None:
-            edge_attr = self.edge_encoder(edge_attr)
-            edge_attr = edge_attr.view(-1, 1, self.F_in)
-            edge_attr = edge_attr.repeat(1, self.towers, 1)
-            h = torch.cat([x_i, x_j, edge_attr], dim=-1)
-        else:
-            h = torch.cat([x_i, x_j], dim=-1)
-        for aggregator in self.aggregators:
-            if aggregator.startswith(('sum', 'mean', 'min', 'max')):
-                hs = [nn(h[:, i]) for i, nn in enumerate(self.pre_nns[aggregator])]
-            else:
+            enc = self.edge_encoder(edge_attr)
+            parts.append(enc.unsqueeze(1).expand(-1, self.towers, -1))
+        h = torch.cat(parts, dim=-1)                                            # (E, T, 2F|3F)
+        hs = None
+        for aggregator in self.aggregators:                                     # every pass overwrites hs: the last wins (G1)
+            if not aggregator.startswith(_SCATTER_REDUCE):
                 raise ValueError(f'Unknown aggregator "{aggregator}".')
-        hs = torch.stack(hs, dim=1)
+            hs = torch.stack([stack(h[:, t]) for t, stack in enumerate(self.pre_nns[aggregator])], dim=1)
         return F.dropout(hs, self.dropout)
 
     def aggregate(self, inputs: Tensor, index: Tensor, dim_size: Optional[int] = None, _graph=None) -> Tensor:

@@ -10,7 +10,8 @@ import torch
 
 
 def parse_index_file(filename):
-    return [int(line.strip()) for line in open(filename)]
+    with open(filename) as f:
+        return [int(tok) for tok in f.read().split()]
 
 
 def adjacency_from_dict_of_lists(graph, n=None):
@@ -33,55 +34,57 @@ def load_graph(dataset, data_dir="data"):
     return adj, [adj.indices[adj.indptr[i]:adj.indptr[i + 1]] for i in range(adj.shape[0])]
 
 
+_TRAIN_EXTRA = {'cora': 1068, 'citeseer': 1707, 'pubmed': 18157}      # utils.py:80-94: train = labelled + this many more
+
+
+def _unpickle(path):
+    with open(path, 'rb') as f:
+        return pickle.load(f, encoding='latin1')
+
+
 def load_data(dataset, data_dir="data"):
-    """utils.py:33-119.  Returns add_all, adj (torch sparse COO), features, labels, idx_train, idx_val, idx_test."""
-    names = ['x', 'y', 'tx', 'ty', 'allx', 'ally']
-    objects = []
-    for name in names:
-        with open("{}/ind.{}.{}".format(data_dir, dataset, name), 'rb') as f:
-            objects.append(pickle.load(f, encoding='latin1'))
-    x, y, tx, ty, allx, ally = tuple(objects)
-    test_idx_reorder = parse_index_file("{}/ind.{}.test.index".format(data_dir, dataset))
-    test_idx_range = np.sort(test_idx_reorder)
-    if dataset == 'citeseer':       # isolated test nodes become zero rows (utils.py:56-65)
-        full = list(range(min(test_idx_reorder), max(test_idx_reorder) + 1))
-        tx_extended = sp.lil_matrix((len(full), x.shape[1]))
-        tx_extended[test_idx_range - min(test_idx_range), :] = tx
-        tx = tx_extended
-        ty_extended = np.zeros((len(full), y.shape[1]))
-        ty_extended[test_idx_range - min(test_idx_range), :] = ty
-        ty = ty_extended
-    features = sp.vstack((allx, tx)).tolil()
-    features[test_idx_reorder, :] = features[test_idx_range, :]
+    """The reference's Planetoid loader (utils.py:33-119) -> add_all, adj (torch sparse COO), features, labels,
+    idx_train, idx_val, idx_test, with the same fixed splits."""
+    part = {n: _unpickle("{}/ind.{}.{}".format(data_dir, dataset, n)) for n in ('x', 'y', 'tx', 'ty', 'allx', 'ally')}
+    test_order = np.asarray(parse_index_file("{}/ind.{}.test.index".format(data_dir, dataset)))
+    test_sorted = np.sort(test_order)
+    tx, ty = part['tx'], part['ty']
+    if dataset == 'citeseer':       # test ids with no node: zero feature / label rows keep the index range dense
+        lo, span = test_order.min(), test_order.max() - test_order.min() + 1
+        tx_full = sp.lil_matrix((span, part['x'].shape[1]))
+        tx_full[test_sorted - lo, :] = tx
+        ty_full = np.zeros((span, part['y'].shape[1]))
+        ty_full[test_sorted - lo, :] = ty
+        tx, ty = tx_full, ty_full
+    feats = sp.vstack((part['allx'], tx)).tolil()
+    feats[test_order, :] = feats[test_sorted, :]
+    onehot = np.vstack((part['ally'], ty))
+    onehot[test_order, :] = onehot[test_sorted, :]
     adj, add_all = load_graph(dataset, data_dir)
-    labels = np.vstack((ally, ty))
-    labels[test_idx_reorder, :] = labels[test_idx_range, :]
-    idx_test = test_idx_range.tolist()
-    extra = {'cora': 1068, 'citeseer': 1707, 'pubmed': 18157}[dataset]        # utils.py:80-94
-    idx_train = range(len(y) + extra)
-    idx_val = range(len(y) + extra, len(y) + extra + 500)
-    features = torch.FloatTensor(np.array(features.todense()))
-    if dataset == "citeseer":
-        labels = torch.LongTensor([int(np.where(l == 1)[0][0]) if l.any() else 0 for l in labels])
+    n_lab = len(part['y'])
+    n_train = n_lab + _TRAIN_EXTRA[dataset]
+    if dataset == "citeseer":       # rows without a label become class 0
+        cls = np.where(onehot.any(1), onehot.argmax(1), 0)
     else:
-        labels = torch.LongTensor(np.where(labels)[1])
-    return (add_all, sparse_mx_to_torch_sparse_tensor(adj), features, labels, torch.LongTensor(idx_train),
-            torch.LongTensor(idx_val), torch.LongTensor(idx_test))
+        cls = np.where(onehot)[1]
+    return (add_all, sparse_mx_to_torch_sparse_tensor(adj), torch.FloatTensor(np.asarray(feats.todense())),
+            torch.LongTensor(cls), torch.arange(n_train), torch.arange(n_train, n_train + 500),
+            torch.LongTensor(test_sorted.tolist()))
 
 
 def normalize(mx):
-    rowsum = np.array(mx.sum(1))
-    r_inv = np.power(rowsum, -1.0).flatten()
-    r_inv[np.isinf(r_inv)] = 0.
-    return sp.diags(r_inv).dot(mx)
+    """Row-normalise (the reference defines it, utils.py:122-129, but never calls it)."""
+    with np.errstate(divide='ignore'):
+        inv = 1.0 / np.asarray(mx.sum(1), dtype=np.float64).ravel()
+    inv[~np.isfinite(inv)] = 0.0
+    return sp.diags(inv) @ mx
 
 
 def accuracy(output, labels):
-    preds = output.max(1)[1].type_as(labels)
-    return preds.eq(labels).double().sum() / len(labels)
+    return (output.argmax(1) == labels).double().mean()
 
 
 def sparse_mx_to_torch_sparse_tensor(sparse_mx):
-    m = sparse_mx.tocoo().astype(np.float32)
-    indices = torch.from_numpy(np.vstack((m.row, m.col)).astype(np.int64))
-    return torch.sparse_coo_tensor(indices, torch.from_numpy(m.data), torch.Size(m.shape))
+    coo = sparse_mx.tocoo()
+    idx = torch.from_numpy(np.stack([coo.row, coo.col]).astype(np.int64))
+    return torch.sparse_coo_tensor(idx, torch.from_numpy(coo.data.astype(np.float32)), tuple(coo.shape))
