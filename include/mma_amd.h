@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 8
+#define MMA_ABI_VERSION 9
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -159,6 +159,15 @@ int mma_pack_rows(const float* src, int64_t lds, const int32_t* idx, int64_t n_i
                   float* dst, int64_t ldd, int32_t width, void* stream);
 int mma_unpack_add_rows(const float* src, int64_t lds, const int32_t* idx, int64_t n_idx,
                         float* dst, int64_t ldd, int32_t width, void* stream);
+
+/* ---- K8: column sums of a tall row-major matrix (bias gradients) ----------------------------------------
+ * out[c] = sum_r g[r*ldg + c], r < R, c < C, in a fixed order (two passes over ~2*sqrt(R)-row blocks, no atomics).
+ * Replaces the `grad_output.sum(0)` that autograd runs for the bias of every Linear on the path (mma_conv.py:82,99-105,
+ * mask_aggr.py:50, layers.py:48,865): torch's column reduction takes 2-7 ms on (2e5..4e5) x 375 because 375 % 4 != 0.
+ * ws: mma_col_sum_workspace_floats(R, C) floats (0 => may be NULL). */
+int64_t mma_col_sum_workspace_floats(int64_t R, int32_t C);
+int mma_col_sum(const float* g, int64_t ldg, int64_t R, int32_t C, float* out, float* ws, int64_t ws_floats,
+                void* stream);
 
 /* ---- K6: CSR by key, built on the device (graph-regression batches change every call) ----------------
  * Stable radix sort (rocPRIM) of edge positions by key[e] (int64 node ids as PyG's edge_index holds them):

@@ -1,5 +1,6 @@
-// K5 (CSR SpMM over a K-times column-stacked adjacency: reference layers.py:861-865, layers.py:41) and
-// K7 (halo row pack / unpack-add for the node-sharded multi-GPU path).
+// K5 (CSR SpMM over a K-times column-stacked adjacency: reference layers.py:861-865, layers.py:41),
+// K7 (halo row pack / unpack-add for the node-sharded multi-GPU path) and
+// K8 (column sums of a tall matrix = the bias gradients of the dense transforms around the fused kernels).
 #include "common.h"
 
 namespace mma {
@@ -153,6 +154,44 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(const RowsParams p) {
   }
 }
 
+// K8: out[rb, c] = sum of g[r, c] over the rows of row block rb.  A workgroup is 64 columns x 4 row lanes (one wave reads 256
+// contiguous bytes of a row), each thread keeps four independent accumulation chains; fixed order => deterministic.
+struct ColSumParams { const float* g; int64_t ldg; int64_t R; int C; float* out; int64_t rows_per_block; };
+
+__global__ __launch_bounds__(kBlock) void col_sum_kernel(const ColSumParams p) {
+  __shared__ float red[4][kWave];
+  const int cl = threadIdx.x & (kWave - 1), rl = threadIdx.x >> 6;
+  const int c = (int)blockIdx.x * kWave + cl;
+  const int64_t r0 = (int64_t)blockIdx.y * p.rows_per_block;
+  const int64_t r1 = min(p.R, r0 + p.rows_per_block);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < p.C) {
+    const float* q = p.g + c;
+    int64_t r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {
+      a0 += q[r * p.ldg];
+      a1 += q[(r + 4) * p.ldg];
+      a2 += q[(r + 8) * p.ldg];
+      a3 += q[(r + 12) * p.ldg];
+    }
+    for (; r < r1; r += 4) a0 += q[r * p.ldg];
+  }
+  red[rl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rl == 0 && c < p.C) p.out[(int64_t)blockIdx.y * p.C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+static int64_t col_sum_rows_per_block(int64_t R) {      // ~2*sqrt(R), a power of two in [64, 4096]: both passes stay short
+  int64_t rpb = 64;
+  while (rpb < 4096 && rpb * rpb < 4 * R) rpb *= 2;
+  return rpb;
+}
+static int64_t col_sum_row_blocks(int64_t R) {
+  if (R <= 1024) return 1;
+  const int64_t rpb = col_sum_rows_per_block(R);
+  return (R + rpb - 1) / rpb;
+}
+
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace mma
@@ -242,4 +281,32 @@ extern "C" int mma_pack_rows(const float* src, int64_t lds, const int32_t* idx, 
 extern "C" int mma_unpack_add_rows(const float* src, int64_t lds, const int32_t* idx, int64_t n_idx, float* dst, int64_t ldd,
                                    int32_t width, void* stream) {
   return rows_call(true, src, lds, idx, n_idx, dst, ldd, width, stream);
+}
+
+extern "C" int64_t mma_col_sum_workspace_floats(int64_t R, int32_t C) {
+  const int64_t nrb = col_sum_row_blocks(R);
+  return nrb > 1 ? nrb * (int64_t)C : 0;
+}
+
+extern "C" int mma_col_sum(const float* g, int64_t ldg, int64_t R, int32_t C, float* out, float* ws, int64_t ws_floats,
+                           void* stream) {
+  MMA_REQUIRE(R >= 0 && C >= 1 && ldg >= C, "R=%lld C=%d ldg=%lld unsupported", (long long)R, C, (long long)ldg);
+  MMA_REQUIRE(out && (g || R == 0), "NULL argument");
+  const int64_t nrb = col_sum_row_blocks(R);
+  MMA_REQUIRE(nrb == 1 || (ws && ws_floats >= nrb * (int64_t)C), "workspace too small: %lld floats, need %lld",
+              (long long)ws_floats, (long long)(nrb * (int64_t)C));
+  MMA_REQUIRE(nrb < 65536, "R=%lld too large", (long long)R);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned cb = (unsigned)((C + kWave - 1) / kWave);
+  if (nrb == 1) {
+    ColSumParams p{g, ldg, R, C, out, R > 0 ? R : 1};
+    hipLaunchKernelGGL(col_sum_kernel, dim3(cb, 1), dim3(kBlock), 0, st, p);
+    return check_launch("col_sum_kernel");
+  }
+  ColSumParams p1{g, ldg, R, C, ws, col_sum_rows_per_block(R)};
+  hipLaunchKernelGGL(col_sum_kernel, dim3(cb, (unsigned)nrb), dim3(kBlock), 0, st, p1);
+  if (int rc = check_launch("col_sum_kernel")) return rc;
+  ColSumParams p2{ws, C, nrb, C, out, nrb};
+  hipLaunchKernelGGL(col_sum_kernel, dim3(cb, 1), dim3(kBlock), 0, st, p2);
+  return check_launch("col_sum_kernel");
 }

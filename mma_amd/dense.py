@@ -7,6 +7,7 @@ for the (128,N)@(N,16) tail).  Splitting the reduction into ~N/8192 batches (str
 batch) fills the chip: 140 TFLOP/s, 89 % of the fp32 MFMA peak (0.97 ms instead of 2.7 ms per mask-weight half)."""
 import torch
 
+from . import _lib
 from ._lib import call, ptr, stream_ptr
 
 _ROWS_PER_BATCH = 8192
@@ -103,3 +104,63 @@ def xt_g(x, g):
 def mm(x, w):
     """x @ w with the split-reduction weight gradient."""
     return _MM.apply(x, w)
+
+
+def col_sum(g):
+    """g.sum(0) of a tall (R,C) fp32 matrix on the K8 kernel (fixed summation order).  torch's own column reduction
+    falls off a cliff when C % 4 != 0 (3.2 ms for 204552 x 375 on MI355X; this kernel: HBM rate)."""
+    _lib.require_gpu(g)
+    assert g.dim() == 2 and g.dtype == torch.float32
+    if g.stride(1) != 1:
+        g = g.contiguous()
+    R, C = g.shape
+    out = torch.empty((C,), device=g.device, dtype=torch.float32)
+    n_ws = int(_lib.lib().mma_col_sum_workspace_floats(R, C))
+    ws = torch.empty((n_ws,), device=g.device, dtype=torch.float32) if n_ws else None
+    call("mma_col_sum", ptr(g), g.stride(0) if R > 1 else C, R, C, ptr(out), ptr(ws), n_ws, stream_ptr())
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b over the last dimension (torch_geometric Linear / F.linear: mma_conv.py:82,99-105, mask_aggr.py:50).
+    Forward is the library GEMM; backward replaces autograd's two weak spots for tall inputs: the weight gradient is the
+    split-reduction GEMM (xt_g) and the bias gradient the K8 column sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.mm(g2, weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            gw = xt_g(g2, x.reshape(-1, x.shape[-1]))                   # (out, in)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = col_sum(g2)
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    """F.linear with the tall-input backward (GPU tensors only)."""
+    return _Linear.apply(x, weight, bias)
+
+
+class _BiasAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, b):
+        return y + b
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, (col_sum(g.reshape(-1, g.shape[-1])) if ctx.needs_input_grad[1] else None)
+
+
+def bias_add(y, b):
+    """y (..., C) + b (C,) whose bias gradient is the K8 column sum."""
+    return _BiasAdd.apply(y, b)

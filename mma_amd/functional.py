@@ -315,82 +315,83 @@ def _gr_call(fn, csr, U, V, Z, inputs, extra, N, E, T, F, aggr, scalers, avg_log
 class _GRAggregate(torch.autograd.Function):
     """K aggregators + compounding degree scalers over target segments (mma_conv.py:159-196), messages either given
     (`inputs`, the public aggregate() API) or formed in-kernel as drop(U[i] + V[j] + Z[e]) (fused forward).
-    Fused mode: U, V (N,Dp) and Z (E,Dp) may carry zero padding columns (Dp = T*F rounded up to 4) so that every row is
-    16-byte aligned; the gradients come back in the same padded shape."""
+    Fused mode: UV (N, 2*T*F) holds U in its left and V in its right column half (one GEMM made both), Z is (E, T*F)
+    or None; the gradient of UV comes back as one buffer whose halves the two segment sums fill."""
 
     @staticmethod
-    def forward(ctx, inputs, U, V, Z, graph, T, F, aggr, scalers, avg_log, avg_lin, drop):
+    def forward(ctx, inputs, UV, Z, graph, T, F, aggr, scalers, avg_log, avg_lin, drop):
         fused = inputs is None
         csr = graph.by_target
         N, E, D = graph.N, graph.E, T * F
         K, S = len(aggr), len(scalers)
-        ref = U if fused else inputs
+        ref = UV if fused else inputs
         require_gpu(ref)
         dev = ref.device
+        U = V = None
         if fused:
-            U, V = U.contiguous(), V.contiguous()
+            UV = UV.contiguous()
             Z = Z.contiguous() if Z is not None else None
-            Dp = U.shape[1]
-            assert Dp >= D and U.shape == (N, Dp) and V.shape == (N, Dp) and (Z is None or Z.shape == (E, Dp))
+            assert UV.shape == (N, 2 * D) and (Z is None or Z.shape == (E, D))
+            U, V = UV[:, :D], UV[:, D:]
         else:
             inputs = inputs.contiguous()
             assert inputs.shape == (E, T, F)
-            Dp = D
         out = torch.empty((N, T, S * K * F), device=dev, dtype=torch.float32)
-        need = any(ctx.needs_input_grad[:4])
-        amin = torch.empty((N, Dp), dtype=torch.int32, device=dev) if need and 2 in aggr else None
-        amax = torch.empty((N, Dp), dtype=torch.int32, device=dev) if need and 3 in aggr else None
+        need = any(ctx.needs_input_grad[:3])
+        amin = torch.empty((N, D), dtype=torch.int32, device=dev) if need and 2 in aggr else None
+        amax = torch.empty((N, D), dtype=torch.int32, device=dev) if need and 3 in aggr else None
         stats = need and (4 in aggr or 5 in aggr)
-        mean = torch.empty((N, Dp), device=dev) if stats else None
-        var = torch.empty((N, Dp), device=dev) if stats else None
-        ctx.cfg = (graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, Z is not None, Dp)
+        mean = torch.empty((N, D), device=dev) if stats else None
+        var = torch.empty((N, D), device=dev) if stats else None
+        ctx.cfg = (graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, Z is not None)
         if E == 0:          # nothing to aggregate: every target is empty -> 0 (and a zero gradient)
             out.zero_()
-            ctx.save_for_backward(inputs, U, V, Z, None, None, None, None)
+            ctx.save_for_backward(inputs, UV, Z, None, None, None, None)
             return out
         with _span("gr_fused_fwd"):
-            _gr_call("mma_gr_fused_fwd", csr, U, V, Z, inputs, (ptr(out), ptr(amin), ptr(amax), ptr(mean), ptr(var), Dp),
+            _gr_call("mma_gr_fused_fwd", csr, U, V, Z, inputs, (ptr(out), ptr(amin), ptr(amax), ptr(mean), ptr(var), D),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
-        ctx.save_for_backward(inputs, U, V, Z, amin, amax, mean, var)
+        ctx.save_for_backward(inputs, UV, Z, amin, amax, mean, var)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, has_z, Dp = ctx.cfg
-        inputs, U, V, Z, amin, amax, mean, var = ctx.saved_tensors
+        graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, has_z = ctx.cfg
+        inputs, UV, Z, amin, amax, mean, var = ctx.saved_tensors
         csr = graph.by_target
         N, E, D = graph.N, graph.E, T * F
         gout = gout.contiguous()
-        gmsg = torch.empty((E, Dp), device=gout.device, dtype=torch.float32)
+        gmsg = torch.empty((E, D), device=gout.device, dtype=torch.float32)
         if E == 0:
             if not fused:
-                return (gmsg.view(E, T, F),) + (None,) * 11
-            z = torch.zeros((N, Dp), device=gout.device, dtype=torch.float32)
-            return (None, z, z.clone(), gmsg if has_z else None) + (None,) * 8
+                return (gmsg.view(E, T, F),) + (None,) * 10
+            return (None, torch.zeros((N, 2 * D), device=gout.device, dtype=torch.float32), gmsg if has_z else None) + (None,) * 8
+        U, V = (UV[:, :D], UV[:, D:]) if fused else (None, None)
         with _span("gr_fused_bwd"):
             _gr_call("mma_gr_fused_bwd", csr, U, V, Z, inputs,
-                     (ptr(gout), ptr(amin), ptr(amax), ptr(mean), ptr(var), Dp, ptr(gmsg), Dp),
+                     (ptr(gout), ptr(amin), ptr(amax), ptr(mean), ptr(var), D, ptr(gmsg), D),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
         if not fused:
-            return (gmsg.view(E, T, F),) + (None,) * 11
-        # dU[i] = sum of its target segment, dV[j] = sum over the edges leaving j: two segment sums (K5 kernel)
-        gU = torch.empty((N, Dp), device=gout.device, dtype=torch.float32)
-        gV = torch.empty((N, Dp), device=gout.device, dtype=torch.float32)
+            return (gmsg.view(E, T, F),) + (None,) * 10
+        # dU[i] = sum of its target segment, dV[j] = sum over the edges leaving j: two segment sums (K5 kernel) into the
+        # halves of one (N, 2D) buffer
+        gUV = torch.empty((N, 2 * D), device=gout.device, dtype=torch.float32)
         cs = graph.by_source
         with _span("gr_segsum"):
-            call("mma_csr_spmm", ptr(csr.rowptr), ptr(csr.perm), None, ptr(gmsg), Dp, E, 1, None, ptr(gU), Dp, N, Dp, stream_ptr())
-            call("mma_csr_spmm", ptr(cs.rowptr), ptr(cs.perm), None, ptr(gmsg), Dp, E, 1, None, ptr(gV), Dp, N, Dp, stream_ptr())
-        return (None, gU, gV, gmsg if has_z else None) + (None,) * 8
+            call("mma_csr_spmm", ptr(csr.rowptr), ptr(csr.perm), None, ptr(gmsg), D, E, 1, None, ptr(gUV), 2 * D, N, D, stream_ptr())
+            call("mma_csr_spmm", ptr(cs.rowptr), ptr(cs.perm), None, ptr(gmsg), D, E, 1, None, ptr(gUV[:, D:]), 2 * D, N, D,
+                 stream_ptr())
+        return (None, gUV, gmsg if has_z else None) + (None,) * 8
 
 
 def gr_aggregate(inputs, graph, aggregators, scalers, avg_log, avg_lin):
     """aggregate() on given messages (E,T,F) -> (N,T,S*K*F)."""
     E, T, F = inputs.shape
-    return _GRAggregate.apply(inputs, None, None, None, graph, T, F, tuple(GR_AGGR[a] for a in aggregators),
+    return _GRAggregate.apply(inputs, None, None, graph, T, F, tuple(GR_AGGR[a] for a in aggregators),
                               tuple(GR_SCALER[s] for s in scalers), avg_log, avg_lin, DropoutSpec(0.0))
 
 
-def gr_fused_conv(U, V, Z, graph, T, F, aggregators, scalers, avg_log, avg_lin, drop):
-    """message + aggregate fused: messages drop(U[i] + V[j] + Z[e]) never materialise."""
-    return _GRAggregate.apply(None, U, V, Z, graph, T, F, tuple(GR_AGGR[a] for a in aggregators),
+def gr_fused_conv(UV, Z, graph, T, F, aggregators, scalers, avg_log, avg_lin, drop):
+    """message + aggregate fused: messages drop(U[i] + V[j] + Z[e]) never materialise.  UV = [U | V] (N, 2*T*F)."""
+    return _GRAggregate.apply(None, UV, Z, graph, T, F, tuple(GR_AGGR[a] for a in aggregators),
                               tuple(GR_SCALER[s] for s in scalers), avg_log, avg_lin, drop)

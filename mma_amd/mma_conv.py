@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from torch import Tensor
 from torch.nn import ModuleList, ReLU, Sequential
 
+from . import dense
 from . import functional as Fn
 from ._lib import require_gpu
 from .mask_aggr import MaskAggregateLinear
@@ -130,23 +131,25 @@ class MMAConv(torch.nn.Module):
             self._check_aggregators()
             last = self.aggregators[-1]                                         # G1
             lins = [seq[0].active_linear() for seq in self.pre_nns[last]]       # T Linears (F_in, 3F|2F)
+            TF = T * Fi
             Wi = torch.stack([l.weight[:, :Fi] for l in lins])                  # (T, F, F_in)
             Wj = torch.stack([l.weight[:, Fi:2 * Fi] for l in lins])
-            b = torch.stack([l.bias for l in lins]).reshape(1, T * Fi) if lins[0].bias is not None else None
+            has_b = lins[0].bias is not None
+            b = torch.cat([l.bias for l in lins]) if has_b else None            # (T*F,), lands in U only
             if self.divide_input:
-                U = torch.einsum('ntf,tgf->ntg', x, Wi).reshape(N, T * Fi)
-                V = torch.einsum('ntf,tgf->ntg', x, Wj).reshape(N, T * Fi)
-            else:                                                               # G11: towers share x -> one GEMM each
-                x0 = x[:, 0]
-                U = x0 @ Wi.reshape(T * Fi, Fi).t()
-                V = x0 @ Wj.reshape(T * Fi, Fi).t()
-            if b is not None:
-                U = U + b
+                U = torch.einsum('ntf,tgf->ntg', x, Wi).reshape(N, TF)
+                V = torch.einsum('ntf,tgf->ntg', x, Wj).reshape(N, TF)
+                UV = torch.cat([dense.bias_add(U, b) if has_b else U, V], 1)
+            else:                                                               # G11: towers share x -> ONE GEMM for U | V
+                Wuv = torch.cat([Wi.reshape(TF, Fi), Wj.reshape(TF, Fi)])       # (2*T*F, F_in)
+                UV = dense.linear(x[:, 0], Wuv, torch.cat([b, torch.zeros_like(b)]) if has_b else None)
             Z = None
             if edge_attr is not None:
-                We = torch.stack([l.weight[:, 2 * Fi:] for l in lins])
-                Z = self.edge_encoder(edge_attr) @ We.reshape(T * Fi, Fi).t()   # (E, T*F)
-            out = Fn.gr_fused_conv(U, V, Z, graph, T, Fi, self.aggregators, self.scalers,
+                # enc(e) W_e^T = e (W_e W_enc)^T + W_e b_enc: the (E,F) encoding never materialises (mma_conv.py:141-146)
+                We = torch.stack([l.weight[:, 2 * Fi:] for l in lins]).reshape(TF, Fi)
+                enc = self.edge_encoder
+                Z = dense.linear(edge_attr, We @ enc.weight, We @ enc.bias if enc.bias is not None else None)   # (E, T*F)
+            out = Fn.gr_fused_conv(UV, Z, graph, T, Fi, self.aggregators, self.scalers,
                                    self.avg_deg['log'], self.avg_deg['lin'], self._drop(x.device))
         else:
             src, dst = edge_index[0], edge_index[1]
@@ -157,15 +160,14 @@ class MMAConv(torch.nn.Module):
             # post_nns[t](cat[x_t, out_t]) = x_t Wx_t^T + out_t Wo_t^T + b_t  (mma_conv.py:132-134) as ONE strided-batched
             # GEMM over the towers: neither the (N,T,(K*S+1)*F) concatenation nor the per-tower slices are materialised.
             Wp = torch.stack([seq[0].weight for seq in self.post_nns])                   # (T, F_out, (K*S+1)*F_in)
-            bp = torch.stack([seq[0].bias for seq in self.post_nns])                     # (T, F_out)
+            bp = torch.cat([seq[0].bias for seq in self.post_nns])                       # (T*F_out,)
             Wx, Wo = Wp[:, :, :Fi], Wp[:, :, Fi:]
-            y = torch.bmm(out.transpose(0, 1), Wo.transpose(1, 2))                       # (T, N, F_out), no copy of `out`
+            y = torch.bmm(out.transpose(0, 1), Wo.transpose(1, 2)).transpose(0, 1)       # (N, T, F_out), no copy of `out`
             if self.divide_input:
-                y = y + torch.bmm(x.transpose(0, 1), Wx.transpose(1, 2))
-                y = y.transpose(0, 1)
-            else:
-                y = y.transpose(0, 1) + (x[:, 0] @ Wx.reshape(T * self.F_out, Fi).t()).view(N, T, self.F_out)
-            out = (y + bp).reshape(N, T * self.F_out)
+                y = y + torch.bmm(x.transpose(0, 1), Wx.transpose(1, 2)).transpose(0, 1)
+                out = dense.bias_add(y.reshape(N, T * self.F_out), bp)
+            else:                                                                        # bias rides on the shared-x GEMM
+                out = y.reshape(N, T * self.F_out) + dense.linear(x[:, 0], Wx.reshape(T * self.F_out, Fi), bp)
         else:
             out = torch.cat([x, out], dim=-1)
             outs = [nn(out[:, i]) for i, nn in enumerate(self.post_nns)]

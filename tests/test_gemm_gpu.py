@@ -43,3 +43,36 @@ def test_mm_autograd_uses_x3_and_matches():
     for a, b, name in ((y, yr, "y"), (gx, gxr, "gx"), (gw, gwr, "gw")):
         err = (a.double() - b).abs().max().item() / b.abs().max().item()
         assert err < 1e-5, (name, err)
+
+
+@pytest.mark.parametrize("R,C,pad", [(0, 7, 0), (1, 1, 0), (3, 75, 0), (1000, 375, 0), (1025, 64, 0), (204552, 375, 0),
+                                     (427376, 75, 0), (50000, 15, 5), (300001, 130, 2)])
+def test_col_sum(R, C, pad):
+    """K8 column sums: fixed-order (bitwise repeatable), fp32-accurate against an fp64 sum, strided rows, ragged sizes."""
+    from mma_amd import dense
+    rng = np.random.default_rng(R + C)
+    full = torch.from_numpy(rng.standard_normal((R, C + pad)).astype(np.float32)).to(DEV)
+    g = full[:, :C] if pad else full
+    got = dense.col_sum(g)
+    ref = g.double().sum(0)
+    tol = 1e-6 * g.double().abs().sum(0) + 1e-30
+    assert got.shape == (C,) and bool(((got.double() - ref).abs() <= tol).all())
+    assert torch.equal(dense.col_sum(g), got)
+
+
+def test_linear_backward_matches_torch():
+    """dense.linear / bias_add: same forward as F.linear, gradients through the split-reduction dW and the K8 column sum."""
+    from mma_amd import dense
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.standard_normal((70001, 75)).astype(np.float32)).to(DEV).requires_grad_(True)
+    w = torch.from_numpy((rng.standard_normal((375, 75)) * 0.1).astype(np.float32)).to(DEV).requires_grad_(True)
+    b = torch.from_numpy(rng.standard_normal(375).astype(np.float32)).to(DEV).requires_grad_(True)
+    cot = torch.from_numpy(rng.standard_normal((70001, 375)).astype(np.float32)).to(DEV)
+    y = dense.bias_add(dense.linear(x, w, b), b)
+    got = torch.autograd.grad((y * cot).sum(), [x, w, b])
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yd = torch.nn.functional.linear(xd, wd, bd) + bd
+    ref = torch.autograd.grad((yd * cot.double()).sum(), [xd, wd, bd])
+    assert torch.allclose(y.double(), yd, rtol=1e-5, atol=1e-5)
+    for g_, r_ in zip(got, ref):
+        assert (g_.double() - r_).abs().max().item() <= 2e-6 * r_.abs().max().item() + 1e-6 * 70001 ** 0.5
