@@ -121,47 +121,49 @@ class MMAConv(torch.nn.Module):
     def forward(self, x: Tensor, edge_index, edge_attr: Optional[Tensor] = None) -> Tensor:
         require_gpu(x)
         T, Fi = self.towers, self.F_in
-        if self.divide_input:
-            x = x.view(-1, T, Fi)
-        else:
-            x = x.view(-1, 1, Fi).repeat(1, T, 1)
+        # G11: without divide_input every tower sees the same x; a stride-0 view stands in for the reference's repeat()
+        x = x.view(-1, T, Fi) if self.divide_input else x.view(-1, 1, Fi).expand(-1, T, -1)
         N = x.shape[0]
         graph = self._graph(edge_index, N)
+        Fw = Fi                     # width of one aggregate block inside `out`
         if self._fusable():
             self._check_aggregators()
+            Fw = self.fused_width()
             last = self.aggregators[-1]                                         # G1
             lins = [seq[0].active_linear() for seq in self.pre_nns[last]]       # T Linears (F_in, 3F|2F)
-            TF = T * Fi
-            Wi = torch.stack([l.weight[:, :Fi] for l in lins])                  # (T, F, F_in)
-            Wj = torch.stack([l.weight[:, Fi:2 * Fi] for l in lins])
+            TF = T * Fw
+
+            def rows(lo, hi):       # the T per-tower (F, hi-lo) weight blocks as rows of one (T*Fw, hi-lo) matrix
+                return self._pad_dim(torch.stack([l.weight[:, lo:hi] for l in lins]), 1, Fw).reshape(TF, hi - lo)
+            Wi, Wj = rows(0, Fi), rows(Fi, 2 * Fi)
             has_b = lins[0].bias is not None
-            b = torch.cat([l.bias for l in lins]) if has_b else None            # (T*F,), lands in U only
+            b = self._pad_dim(torch.stack([l.bias for l in lins]), 1, Fw).reshape(TF) if has_b else None   # lands in U only
             if self.divide_input:
-                U = torch.einsum('ntf,tgf->ntg', x, Wi).reshape(N, TF)
-                V = torch.einsum('ntf,tgf->ntg', x, Wj).reshape(N, TF)
+                U = torch.einsum('ntf,tgf->ntg', x, Wi.view(T, Fw, Fi)).reshape(N, TF)
+                V = torch.einsum('ntf,tgf->ntg', x, Wj.view(T, Fw, Fi)).reshape(N, TF)
                 UV = torch.cat([dense.bias_add(U, b) if has_b else U, V], 1)
-            else:                                                               # G11: towers share x -> ONE GEMM for U | V
-                Wuv = torch.cat([Wi.reshape(TF, Fi), Wj.reshape(TF, Fi)])       # (2*T*F, F_in)
-                UV = dense.linear(x[:, 0], Wuv, torch.cat([b, torch.zeros_like(b)]) if has_b else None)
+            else:                                                               # towers share x -> ONE GEMM for U | V
+                UV = dense.linear(x[:, 0], torch.cat([Wi, Wj]), torch.cat([b, torch.zeros_like(b)]) if has_b else None)
             Z = None
             if edge_attr is not None:
                 # enc(e) W_e^T = e (W_e W_enc)^T + W_e b_enc: the (E,F) encoding never materialises (mma_conv.py:141-146)
-                We = torch.stack([l.weight[:, 2 * Fi:] for l in lins]).reshape(TF, Fi)
-                enc = self.edge_encoder
-                Z = dense.linear(edge_attr, We @ enc.weight, We @ enc.bias if enc.bias is not None else None)   # (E, T*F)
-            out = Fn.gr_fused_conv(UV, Z, graph, T, Fi, self.aggregators, self.scalers,
+                We, enc = rows(2 * Fi, 3 * Fi), self.edge_encoder
+                Z = dense.linear(edge_attr, We @ enc.weight, We @ enc.bias if enc.bias is not None else None)   # (E, T*Fw)
+            out = Fn.gr_fused_conv(UV, Z, graph, T, Fw, self.aggregators, self.scalers,
                                    self.avg_deg['log'], self.avg_deg['lin'], self._drop(x.device))
         else:
             src, dst = edge_index[0], edge_index[1]
             hs = self.message(x.index_select(0, dst), x.index_select(0, src), edge_attr)
             out = self.aggregate(hs, dst, N, _graph=graph)
 
+        KS = len(self.aggregators) * len(self.scalers)
         if self.post_layers == 1:
             # post_nns[t](cat[x_t, out_t]) = x_t Wx_t^T + out_t Wo_t^T + b_t  (mma_conv.py:132-134) as ONE strided-batched
             # GEMM over the towers: neither the (N,T,(K*S+1)*F) concatenation nor the per-tower slices are materialised.
             Wp = torch.stack([seq[0].weight for seq in self.post_nns])                   # (T, F_out, (K*S+1)*F_in)
             bp = torch.cat([seq[0].bias for seq in self.post_nns])                       # (T*F_out,)
-            Wx, Wo = Wp[:, :, :Fi], Wp[:, :, Fi:]
+            Wx = Wp[:, :, :Fi]
+            Wo = self._pad_dim(Wp[:, :, Fi:].reshape(T, self.F_out, KS, Fi), 3, Fw).reshape(T, self.F_out, KS * Fw)
             y = torch.bmm(out.transpose(0, 1), Wo.transpose(1, 2)).transpose(0, 1)       # (N, T, F_out), no copy of `out`
             if self.divide_input:
                 y = y + torch.bmm(x.transpose(0, 1), Wx.transpose(1, 2)).transpose(0, 1)
@@ -169,10 +171,28 @@ class MMAConv(torch.nn.Module):
             else:                                                                        # bias rides on the shared-x GEMM
                 out = y.reshape(N, T * self.F_out) + dense.linear(x[:, 0], Wx.reshape(T * self.F_out, Fi), bp)
         else:
+            if Fw != Fi:
+                out = out.view(N, T, KS, Fw)[..., :Fi].reshape(N, T, KS * Fi)
             out = torch.cat([x, out], dim=-1)
             outs = [nn(out[:, i]) for i, nn in enumerate(self.post_nns)]
             out = torch.cat(outs, dim=1)
         return self.lin(out)
+
+    def fused_width(self):
+        """Per-tower feature width inside the fused path: F_in rounded up to 4 floats so that every (node|edge, tower) row
+        segment is 16-byte aligned (ZINC's F=75 -> 76).  The pad columns carry zero weights, hence zero messages, zero
+        aggregates and zero gradients; `out`'s pad columns meet zero rows of the post-NN weight.  The counter-hash dropout
+        stream is indexed by the padded column t*fused_width()+f."""
+        return -(-self.F_in // 4) * 4
+
+    @staticmethod
+    def _pad_dim(t, dim, size):
+        extra = size - t.shape[dim]
+        if extra == 0:
+            return t
+        pad = [0, 0] * (t.dim() - dim)
+        pad[-1] = extra
+        return F.pad(t, pad)
 
     def message(self, x_i: Tensor, x_j: Tensor, edge_attr: Optional[Tensor]) -> Tensor:
         """mma_conv.py:138-157 with dense torch ops (only used when the fused path does not apply)."""

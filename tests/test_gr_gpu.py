@@ -140,7 +140,8 @@ def test_mmaconv_forward_backward_vs_oracle(cfg, p):
     conv.drop_override = Fn.DropoutSpec(p, seed=seed)
     keep = None
     if p > 0:
-        keep = torch.from_numpy(keep_mask(seed, int(p * 256), 1, E, T * F)[0].reshape(E, T, F).astype(np.float32))
+        Fw = conv.fused_width()      # the kernel's dropout stream is indexed by the 16-byte-aligned column t*Fw + f
+        keep = torch.from_numpy(keep_mask(seed, int(p * 256), 1, E, T * Fw)[0].reshape(E, T, Fw)[:, :, :F].astype(np.float32))
     # oracle
     xo = torch.from_numpy(x).requires_grad_(True)
     eo = torch.from_numpy(ea).requires_grad_(True) if ea is not None else None
