@@ -26,6 +26,8 @@ struct GrParams {
   int32_t* amin; int32_t* amax; float* mean; float* var; int64_t ldsave;        // (N,ldsave>=D) saved for backward (may be NULL)
   float* gmsg; int64_t ldg;                                                      // backward: (E,D) by original edge id
   int N, D, T, F, K, S, lpr_log;
+  int wave_min_deg;                                  // wave-per-node pass: skip segments shorter than this
+  bool need_sum, need_sq, need_min, need_max, need_mean;   // which running reductions the aggregator list uses
   uint8_t aggr[MMA_MAX_K]; uint8_t scaler[8];
   float avg_log, avg_lin;
   DropParams drop;
@@ -63,205 +65,436 @@ __device__ __forceinline__ Vec<VEC> gr_message(const GrParams& p, const DropPara
   return h;
 }
 
+// Saved per-column edge ids (argmin / argmax): VEC consecutive int32, one 16-byte access when VEC == 4.
+template <int VEC> __device__ __forceinline__ void ldi(const int32_t* q, int (&a)[VEC]);
+template <> __device__ __forceinline__ void ldi<4>(const int32_t* q, int (&a)[4]) {
+  const int4 t = *reinterpret_cast<const int4*>(q);
+  a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w;
+}
+template <> __device__ __forceinline__ void ldi<1>(const int32_t* q, int (&a)[1]) { a[0] = *q; }
+template <int VEC> __device__ __forceinline__ void sti(int32_t* q, const int (&a)[VEC]);
+template <> __device__ __forceinline__ void sti<4>(int32_t* q, const int (&a)[4]) {
+  *reinterpret_cast<int4*>(q) = make_int4(a[0], a[1], a[2], a[3]);
+}
+template <> __device__ __forceinline__ void sti<1>(int32_t* q, const int (&a)[1]) { *q = a[0]; }
+
+// Two launch shapes share the node-level code below.
+//  * wave-per-node: the 64/lpr sub-rows of a wave split one node's edge segment and meet in a butterfly (any degree);
+//  * group-per-node: every lpr-lane group owns its own node and walks its (short) segment alone - no cross-lane
+//    traffic, and one VALU instruction works for 64/lpr nodes.  These kernels are INSTRUCTION bound on molecule batches
+//    (a wave64 VALU op occupies its SIMD for 4 cycles; ~600 of them per node and 128-column chunk), so this is what
+//    halves their time.  Nodes above kGroupMaxDeg edges are left to a wave-per-node pass over the same arrays.
+// Either way a wave walks its nodes (grid stride) through a two-deep software pipeline: while node n is reduced, the
+// segment bounds of node n+2 and the edge indices + U row of node n+1 are already in flight.
+constexpr int kGroupMaxDeg = 64;
+
+struct Seg { int b, e; };        // [b, e): positions of one node's target-sorted edges
+struct SegIdx { int j, e; };     // per lane: source node and original edge id at position b + lane
+struct Idx4 { int j[4], e[4]; }; // group mode: the first four edges of the group's node
+
+__device__ __forceinline__ Seg seg_load(const GrParams& p, int node) {       // beyond N: empty
+  Seg s{0, 0};
+  if (node < p.N) { s.b = p.rowptr[node]; s.e = p.rowptr[node + 1]; }
+  return s;
+}
+__device__ __forceinline__ SegIdx idx_load(const GrParams& p, int base, int end, int lane) {
+  SegIdx r{0, 0};
+  if (base + lane < end) { r.j = p.src[base + lane]; r.e = p.perm[base + lane]; }
+  return r;
+}
+__device__ __forceinline__ Idx4 idx4_load(const GrParams& p, Seg s) {
+  Idx4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.j[i] = 0; r.e[i] = 0;
+    if (s.b + i < s.e) { r.j[i] = p.src[s.b + i]; r.e[i] = p.perm[s.b + i]; }
+  }
+  return r;
+}
+
+struct GrLane { int lane, sub, lpr, epg, c, cc; bool valid, fused; };
+
+__device__ __forceinline__ GrLane gr_lane(const GrParams& p, int vec) {
+  GrLane l;
+  l.lane = threadIdx.x & (kWave - 1);
+  l.lpr = 1 << p.lpr_log; l.epg = kWave >> p.lpr_log;
+  l.sub = l.lane >> p.lpr_log;
+  l.c = ((int)blockIdx.y * l.lpr + (l.lane & (l.lpr - 1))) * vec;
+  l.valid = l.c < p.D;
+  l.cc = l.valid ? l.c : 0;
+  l.fused = p.inputs == nullptr;
+  return l;
+}
+
+// running reductions of one (node, VEC columns): only what the aggregator list needs is updated (wave-uniform flags)
+template <int VEC>
+struct GrAcc {
+  float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
+  int an[VEC], ax[VEC];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { sum[i] = 0.f; sq[i] = 0.f; mn[i] = INFINITY; mx[i] = -INFINITY; an[i] = INT_MAX; ax[i] = INT_MAX; }
+  }
+  __device__ __forceinline__ void take(const GrParams& p, const Vec<VEC>& h, int e) {
+    if (p.need_sum) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) sum[i] += h.v[i];
+    }
+    if (p.need_sq) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) sq[i] += h.v[i] * h.v[i];
+    }
+    if (p.need_min) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) if (h.v[i] < mn[i]) { mn[i] = h.v[i]; an[i] = e; }   // strict: the first extremal edge wins
+    }
+    if (p.need_max) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) if (h.v[i] > mx[i]) { mx[i] = h.v[i]; ax[i] = e; }
+    }
+  }
+};
+
+// degree scalers, K aggregates, final layout and the state saved for backward, for the lanes that own columns
+template <int VEC>
+__device__ __forceinline__ void gr_fwd_store(const GrParams& p, const GrLane& l, int node, int cnt, GrAcc<VEC>& a,
+                                             const float (&fac)[8]) {
+  const float deg = (float)max(cnt, 1);                       // degree(...).clamp_(1), mma_conv.py:178-179
+  // VEC == 4 is only launched when F % 4 == 0: the 4 columns of a lane then sit in one tower, 16-byte aligned in `out`
+  const int t = l.c / p.F, f = l.c - t * p.F;
+  float* o = p.out + ((size_t)node * p.T + t) * ((size_t)p.S * p.K * p.F) + f;
+  float mean[VEC], var[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { mean[i] = 0.f; var[i] = 0.f; }
+  if (p.need_mean) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) mean[i] = a.sum[i] / deg;   // scatter mean: sum / clamp(count, 1)
+  }
+  if (p.need_sq) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) var[i] = a.sq[i] / deg - mean[i] * mean[i];   // mma_conv.py:167-170
+  }
+  for (int k = 0; k < p.K; ++k) {
+    Vec<VEC> run;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      switch (p.aggr[k]) {
+        case GR_SUM: run.v[i] = a.sum[i]; break;
+        case GR_MEAN: run.v[i] = mean[i]; break;
+        case GR_MIN: run.v[i] = cnt ? a.mn[i] : 0.f; break;  // empty target -> 0 (torch_scatter)
+        case GR_MAX: run.v[i] = cnt ? a.mx[i] : 0.f; break;
+        case GR_VAR: run.v[i] = var[i]; break;
+        default: run.v[i] = sqrtf(fmaxf(var[i], 0.f) + 1e-5f); break;
+      }
+    }
+    for (int q = 0; q < p.S; ++q) {                           // compounding (G7)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) run.v[i] = run.v[i] * fac[q];
+      stv<VEC>(o + (size_t)(q * p.K + k) * p.F, run);
+    }
+  }
+  const size_t so = (size_t)node * p.ldsave + l.c;
+  if (p.amin) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) a.an[i] = cnt ? a.an[i] : -1;
+    sti<VEC>(p.amin + so, a.an);
+  }
+  if (p.amax) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) a.ax[i] = cnt ? a.ax[i] : -1;
+    sti<VEC>(p.amax + so, a.ax);
+  }
+  if (p.mean) {
+    Vec<VEC> mv, vv;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { mv.v[i] = mean[i]; vv.v[i] = var[i]; }
+    stv<VEC>(p.mean + so, mv);
+    stv<VEC>(p.var + so, vv);
+  }
+}
+
+__device__ __forceinline__ void gr_factors(const GrParams& p, float deg, float (&fac)[8]) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) fac[q] = q < p.S ? scaler_factor(p.scaler[q], deg, p.avg_log, p.avg_lin) : 1.f;
+}
+
+// the scaler factors of every degree a group-mode node can have, once per workgroup (logf and the divisions cost ~100
+// VALU instructions, which is a sixth of a molecule node's whole budget)
+__device__ __forceinline__ void gr_factor_table(const GrParams& p, float (*tab)[8]) {
+  for (int d = threadIdx.x; d <= kGroupMaxDeg; d += blockDim.x) {
+    float fac[8];
+    gr_factors(p, (float)max(d, 1), fac);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tab[d][q] = fac[q];
+  }
+  __syncthreads();
+}
+
 // VEC = 4 (F % 4 == 0 and 16-byte aligned rows everywhere): a lane owns 4 consecutive columns of one tower and moves one
-// dwordx4 per row, also for the (N,T,S*K*F) output.  Otherwise (e.g. ZINC's F = 75) VEC = 1: lanes own consecutive
-// columns, so all accesses are still coalesced 4-byte ones.
+// dwordx4 per row, also for the (N,T,S*K*F) output.  Otherwise VEC = 1: lanes own consecutive columns, so all accesses
+// are still coalesced 4-byte ones.  (MMAConv pads ZINC's F = 75 to 76 to stay on the VEC = 4 path.)
+template <int VEC>
+__device__ __forceinline__ void gr_node_fwd(const GrParams& p, const DropParams& dp, const GrLane& l, int node, Seg s,
+                                            SegIdx first, const Vec<VEC>& u) {
+  if (s.e - s.b < p.wave_min_deg) return;                      // second pass behind the group kernel: long segments only
+  GrAcc<VEC> a;
+  a.init();
+  for (int base = s.b; base < s.e; base += kWave) {
+    const int cnt = min(kWave, s.e - base);
+    SegIdx my = first;
+    if (base != s.b) my = idx_load(p, base, s.e, l.lane);
+    for (int t0 = 0; t0 < cnt; t0 += 2 * l.epg) {            // two edge steps in flight
+      const int ta = t0 + l.sub, tb = ta + l.epg;
+      const bool two = t0 + l.epg < cnt;                     // wave-uniform
+      // cross-lane reads stay outside divergent control flow: ds_bpermute returns 0 from inactive lanes
+      const int ja = __shfl(my.j, ta & (kWave - 1), kWave), ea = __shfl(my.e, ta & (kWave - 1), kWave);
+      const int jb = __shfl(my.j, tb & (kWave - 1), kWave), eb = __shfl(my.e, tb & (kWave - 1), kWave);
+      const bool va = ta < cnt, vb = tb < cnt;
+      // lanes past the segment end read a valid row (this node's own / edge 0) and drop the value
+      const Vec<VEC> ha = gr_message<VEC>(p, dp, l.fused, u, va ? ja : node, (uint32_t)(va ? ea : 0), l.cc);
+      Vec<VEC> hb = vzero<VEC>();
+      if (two) hb = gr_message<VEC>(p, dp, l.fused, u, vb ? jb : node, (uint32_t)(vb ? eb : 0), l.cc);
+      if (va) a.take(p, ha, ea);
+      if (two && vb) a.take(p, hb, eb);
+    }
+  }
+  for (int off = kWave / 2; off >= l.lpr; off >>= 1) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      a.sum[i] += __shfl_xor(a.sum[i], off, kWave);
+      a.sq[i] += __shfl_xor(a.sq[i], off, kWave);
+      const float omn = __shfl_xor(a.mn[i], off, kWave); const int oan = __shfl_xor(a.an[i], off, kWave);
+      const float omx = __shfl_xor(a.mx[i], off, kWave); const int oax = __shfl_xor(a.ax[i], off, kWave);
+      if (omn < a.mn[i] || (omn == a.mn[i] && oan < a.an[i])) { a.mn[i] = omn; a.an[i] = oan; }
+      if (omx > a.mx[i] || (omx == a.mx[i] && oax < a.ax[i])) { a.mx[i] = omx; a.ax[i] = oax; }
+    }
+  }
+  if (l.sub != 0 || !l.valid) return;
+  float fac[8];
+  gr_factors(p, (float)max(s.e - s.b, 1), fac);
+  gr_fwd_store<VEC>(p, l, node, s.e - s.b, a, fac);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void gr_fwd_kernel(const GrParams p) {
   const DropParams dp = drop_resolve(p.drop);
-  const int lane = threadIdx.x & (kWave - 1);
-  const int lpr = 1 << p.lpr_log, epg = kWave >> p.lpr_log;
-  const int sub = lane >> p.lpr_log;
-  const int c = ((int)blockIdx.y * lpr + (lane & (lpr - 1))) * VEC;
-  const bool valid = c < p.D;
-  const int cc = valid ? c : 0;
-  const bool fused = p.inputs == nullptr;
-  const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave);
-  for (int64_t n0 = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); n0 < p.N; n0 += stride) {
-    const int node = __builtin_amdgcn_readfirstlane((int)n0);
-    const int ebeg = p.rowptr[node], eend = p.rowptr[node + 1];
-    const Vec<VEC> u = fused ? ldv<VEC>(p.U + (size_t)node * p.lduv + cc) : vzero<VEC>();
-    float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
-    int an[VEC], ax[VEC];
+  const GrLane l = gr_lane(p, VEC);
+  const int stride = (int)gridDim.x * (kBlock / kWave);
+  int n = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)));
+  if (n >= p.N) return;
+  Seg s0 = seg_load(p, n), s1 = seg_load(p, n + stride);
+  SegIdx i0{0, 0};
+  Vec<VEC> u0 = vzero<VEC>();
+  if (s0.e - s0.b >= p.wave_min_deg) {
+    i0 = idx_load(p, s0.b, s0.e, l.lane);
+    if (l.fused) u0 = ldv<VEC>(p.U + (size_t)n * p.lduv + l.cc);
+  }
+  for (;;) {
+    const int n1 = n + stride;                               // the host keeps N + 2*stride inside int32
+    const Seg s2 = seg_load(p, n1 + stride);
+    const bool live1 = n1 < p.N && s1.e - s1.b >= p.wave_min_deg;     // wave-uniform; a skipped node prefetches nothing
+    SegIdx i1{0, 0};
+    Vec<VEC> u1 = vzero<VEC>();
+    if (live1) {
+      i1 = idx_load(p, s1.b, s1.e, l.lane);
+      if (l.fused) u1 = ldv<VEC>(p.U + (size_t)n1 * p.lduv + l.cc);
+    }
+    gr_node_fwd<VEC>(p, dp, l, n, s0, i0, u0);
+    if (n1 >= p.N) break;
+    n = n1; s0 = s1; s1 = s2; i0 = i1; u0 = u1;
+  }
+}
+
+// group-per-node forward: the lpr lanes of a group own one node; no cross-lane operation anywhere, so the node loop
+// may diverge between the groups of a wave
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gr_fwd_group_kernel(const GrParams p) {
+  __shared__ float fac_tab[kGroupMaxDeg + 1][8];
+  gr_factor_table(p, fac_tab);
+  const DropParams dp = drop_resolve(p.drop);
+  const GrLane l = gr_lane(p, VEC);
+  const int stride = (int)gridDim.x * (kBlock / kWave) * l.epg;
+  int n = ((int)blockIdx.x * (kBlock / kWave) + (int)(threadIdx.x >> 6)) * l.epg + l.sub;
+  Seg s0 = seg_load(p, n), s1 = seg_load(p, n + stride);
+  Idx4 i0 = idx4_load(p, s0);
+  Vec<VEC> u0 = (l.fused && n < p.N) ? ldv<VEC>(p.U + (size_t)n * p.lduv + l.cc) : vzero<VEC>();
+  while (n < p.N) {
+    const int n1 = n + stride;
+    const Seg s2 = seg_load(p, n1 + stride);
+    const Idx4 i1 = idx4_load(p, s1);
+    Vec<VEC> u1 = vzero<VEC>();
+    if (l.fused && n1 < p.N) u1 = ldv<VEC>(p.U + (size_t)n1 * p.lduv + l.cc);
+    const int deg = s0.e - s0.b;
+    if (deg <= kGroupMaxDeg) {
+      GrAcc<VEC> a;
+      a.init();
+      Vec<VEC> h[4];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { sum[i] = 0.f; sq[i] = 0.f; mn[i] = INFINITY; mx[i] = -INFINITY; an[i] = INT_MAX; ax[i] = INT_MAX; }
-    for (int base = ebeg; base < eend; base += kWave) {
-      const int cnt = min(kWave, eend - base);
-      const int myj = (lane < cnt) ? p.src[base + lane] : 0;
-      const int mye = (lane < cnt) ? p.perm[base + lane] : 0;
-      for (int t0 = 0; t0 < cnt; t0 += epg) {
-        const int t = t0 + sub;
-        const int j_ = __shfl(myj, t & (kWave - 1), kWave);
-        const int e_ = __shfl(mye, t & (kWave - 1), kWave);
-        const bool ev = t < cnt;
-        const int j = ev ? j_ : node;
-        const int e = ev ? e_ : mye;       // any valid edge id of this segment
-        const Vec<VEC> h = gr_message<VEC>(p, dp, fused, u, j, (uint32_t)e, cc);
-        if (ev) {
+      for (int i = 0; i < 4; ++i) {                           // up to four edges' rows in flight before the first use
+        h[i] = vzero<VEC>();
+        if (i < deg) h[i] = gr_message<VEC>(p, dp, l.fused, u0, i0.j[i], (uint32_t)i0.e[i], l.cc);
+      }
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            sum[i] += h.v[i]; sq[i] += h.v[i] * h.v[i];
-            if (h.v[i] < mn[i]) { mn[i] = h.v[i]; an[i] = e; }   // strict: the first (lowest position) extremal edge wins
-            if (h.v[i] > mx[i]) { mx[i] = h.v[i]; ax[i] = e; }
-          }
-        }
+      for (int i = 0; i < 4; ++i) if (i < deg) a.take(p, h[i], i0.e[i]);
+      for (int t = s0.b + 4; t < s0.e; ++t) {                 // ascending positions: ties keep the lowest edge
+        const int j = p.src[t], e = p.perm[t];
+        a.take(p, gr_message<VEC>(p, dp, l.fused, u0, j, (uint32_t)e, l.cc), e);
+      }
+      if (l.valid) {
+        float fac[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) fac[q] = fac_tab[deg][q];
+        gr_fwd_store<VEC>(p, l, n, deg, a, fac);
       }
     }
-    for (int off = kWave / 2; off >= lpr; off >>= 1) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        sum[i] += __shfl_xor(sum[i], off, kWave);
-        sq[i] += __shfl_xor(sq[i], off, kWave);
-        const float omn = __shfl_xor(mn[i], off, kWave); const int oan = __shfl_xor(an[i], off, kWave);
-        const float omx = __shfl_xor(mx[i], off, kWave); const int oax = __shfl_xor(ax[i], off, kWave);
-        if (omn < mn[i] || (omn == mn[i] && oan < an[i])) { mn[i] = omn; an[i] = oan; }
-        if (omx > mx[i] || (omx == mx[i] && oax < ax[i])) { mx[i] = omx; ax[i] = oax; }
-      }
-    }
-    if (sub == 0 && valid) {
-      const int cnt = eend - ebeg;
-      const float deg = (float)max(cnt, 1);                       // degree(...).clamp_(1), mma_conv.py:178-179
-      float fac[8];
-      for (int s = 0; s < p.S; ++s) fac[s] = scaler_factor(p.scaler[s], deg, p.avg_log, p.avg_lin);
-      // VEC == 4 is only launched when F % 4 == 0: the 4 columns of a lane then sit in one tower, 16-byte aligned in `out`
-      const int t = c / p.F, f = c - t * p.F;
-      float* o = p.out + ((size_t)node * p.T + t) * ((size_t)p.S * p.K * p.F) + f;
-      float mean[VEC], var[VEC];
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        mean[i] = sum[i] / deg;                                   // scatter mean: sum / clamp(count, 1)
-        var[i] = sq[i] / deg - mean[i] * mean[i];                 // mma_conv.py:167-170
-      }
-      for (int k = 0; k < p.K; ++k) {
-        Vec<VEC> run;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          switch (p.aggr[k]) {
-            case GR_SUM: run.v[i] = sum[i]; break;
-            case GR_MEAN: run.v[i] = mean[i]; break;
-            case GR_MIN: run.v[i] = cnt ? mn[i] : 0.f; break;    // empty target -> 0 (torch_scatter)
-            case GR_MAX: run.v[i] = cnt ? mx[i] : 0.f; break;
-            case GR_VAR: run.v[i] = var[i]; break;
-            default: run.v[i] = sqrtf(fmaxf(var[i], 0.f) + 1e-5f); break;
-          }
-        }
-        for (int s = 0; s < p.S; ++s) {                           // compounding (G7)
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) run.v[i] = run.v[i] * fac[s];
-          stv<VEC>(o + (size_t)(s * p.K + k) * p.F, run);
-        }
-      }
-      const size_t so = (size_t)node * p.ldsave + c;
-      if (p.amin) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) p.amin[so + i] = cnt ? an[i] : -1;
-      }
-      if (p.amax) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) p.amax[so + i] = cnt ? ax[i] : -1;
-      }
-      if (p.mean) {
-        Vec<VEC> mv, vv;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) { mv.v[i] = mean[i]; vv.v[i] = var[i]; }
-        stv<VEC>(p.mean + so, mv);
-        stv<VEC>(p.var + so, vv);
-      }
-    }
+    n = n1; s0 = s1; s1 = s2; i0 = i1; u0 = u1;
   }
 }
 
 // K4: gradient w.r.t. every edge message, written by original edge id (each edge has exactly one target: no conflicts)
 template <int VEC>
+struct GrCoef {       // d(out)/d(h_e) = c_all + [e == amin] c_min + [e == amax] c_max + c_var (h_e - mean), per column
+  float c_all[VEC], c_min[VEC], c_max[VEC], c_var[VEC], mean[VEC];
+  int an[VEC], ax[VEC];
+  bool need_h;
+};
+
+template <int VEC>
+__device__ __forceinline__ void gr_bwd_coef(const GrParams& p, const GrLane& l, int node, float deg, const float (&fac)[8],
+                                            GrCoef<VEC>& k_) {
+  const int t = l.cc / p.F, f = l.cc - t * p.F;              // VEC == 4 only with F % 4 == 0 (one tower per lane)
+  const float* go = p.gout + ((size_t)node * p.T + t) * ((size_t)p.S * p.K * p.F) + f;
+  const size_t so = (size_t)node * p.ldsave + l.cc;
+  k_.need_h = false;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { k_.c_all[i] = k_.c_min[i] = k_.c_max[i] = k_.c_var[i] = 0.f; k_.an[i] = k_.ax[i] = -1; k_.mean[i] = 0.f; }
+  if (p.amin) ldi<VEC>(p.amin + so, k_.an);
+  if (p.amax) ldi<VEC>(p.amax + so, k_.ax);
+  for (int k = 0; k < p.K; ++k) {
+    float gb[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) gb[i] = 0.f;
+    float run = 1.f;
+    for (int q = 0; q < p.S; ++q) {
+      run = run * fac[q];
+      const Vec<VEC> gv = ldv<VEC>(go + (size_t)(q * p.K + k) * p.F);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) gb[i] = fmaf(gv.v[i], run, gb[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      switch (p.aggr[k]) {
+        case GR_SUM: k_.c_all[i] += gb[i]; break;
+        case GR_MEAN: k_.c_all[i] += gb[i] / deg; break;
+        case GR_MIN: k_.c_min[i] += gb[i]; break;
+        case GR_MAX: k_.c_max[i] += gb[i]; break;
+        case GR_VAR: k_.c_var[i] += gb[i] * 2.f / deg; k_.need_h = true; break;
+        default: {
+          const float v = p.var[so + i];
+          if (v > 0.f) k_.c_var[i] += gb[i] / (2.f * sqrtf(v + 1e-5f)) * 2.f / deg;   // relu'(v) = [v > 0]
+          k_.need_h = true;
+        } break;
+      }
+    }
+  }
+  if (k_.need_h) {
+    const Vec<VEC> mv = ldv<VEC>(p.mean + so);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) k_.mean[i] = mv.v[i];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void gr_bwd_edge(const GrParams& p, const DropParams& dp, const GrLane& l, const GrCoef<VEC>& k_,
+                                            const Vec<VEC>& u, int j, int e) {
+  Vec<VEC> g;
+  Vec<VEC> h = vzero<VEC>();
+  if (k_.need_h) h = gr_message<VEC>(p, dp, l.fused, u, j, (uint32_t)e, l.cc);
+  float fd[VEC];
+  if (l.fused && dp.mode != MMA_DROP_NONE) drop_factors<VEC>(dp, (uint32_t)e, 0, l.cc, p.D, 0, fd);
+  else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) fd[i] = 1.f;
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    float gi = k_.c_all[i] + (e == k_.an[i] ? k_.c_min[i] : 0.f) + (e == k_.ax[i] ? k_.c_max[i] : 0.f);
+    if (k_.need_h) gi += k_.c_var[i] * (h.v[i] - k_.mean[i]);
+    g.v[i] = gi * fd[i];
+  }
+  stv<VEC>(p.gmsg + (size_t)e * p.ldg + l.cc, g);
+}
+
+template <int VEC>
+__device__ __forceinline__ void gr_node_bwd(const GrParams& p, const DropParams& dp, const GrLane& l, int node, Seg s,
+                                            SegIdx first) {
+  if (s.b == s.e || s.e - s.b < p.wave_min_deg) return;
+  const float deg = (float)(s.e - s.b);
+  float fac[8];
+  gr_factors(p, deg, fac);
+  GrCoef<VEC> k_;
+  gr_bwd_coef<VEC>(p, l, node, deg, fac, k_);
+  const Vec<VEC> u = (l.fused && k_.need_h) ? ldv<VEC>(p.U + (size_t)node * p.lduv + l.cc) : vzero<VEC>();
+  for (int base = s.b; base < s.e; base += kWave) {
+    const int cnt = min(kWave, s.e - base);
+    SegIdx my = first;
+    if (base != s.b) my = idx_load(p, base, s.e, l.lane);
+    for (int t0 = 0; t0 < cnt; t0 += l.epg) {
+      const int tt = t0 + l.sub;
+      const int j_ = __shfl(my.j, tt & (kWave - 1), kWave);
+      const int e_ = __shfl(my.e, tt & (kWave - 1), kWave);
+      if (tt < cnt && l.valid) gr_bwd_edge<VEC>(p, dp, l, k_, u, j_, e_);
+    }
+  }
+}
+
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void gr_bwd_kernel(const GrParams p) {
   const DropParams dp = drop_resolve(p.drop);
-  const int lane = threadIdx.x & (kWave - 1);
-  const int lpr = 1 << p.lpr_log, epg = kWave >> p.lpr_log;
-  const int sub = lane >> p.lpr_log;
-  const int c = ((int)blockIdx.y * lpr + (lane & (lpr - 1))) * VEC;
-  const bool valid = c < p.D;
-  const int cc = valid ? c : 0;
-  const bool fused = p.inputs == nullptr;
-  const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave);
-  for (int64_t n0 = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); n0 < p.N; n0 += stride) {
-    const int node = __builtin_amdgcn_readfirstlane((int)n0);
-    const int ebeg = p.rowptr[node], eend = p.rowptr[node + 1];
-    if (ebeg == eend) continue;
-    const float deg = (float)(eend - ebeg);
-    float fac[8];
-    for (int s = 0; s < p.S; ++s) fac[s] = scaler_factor(p.scaler[s], deg, p.avg_log, p.avg_lin);
-    float c_all[VEC], c_min[VEC], c_max[VEC], c_var[VEC], mean[VEC];   // coefficients of 1, [e==amin], [e==amax], (h - mean)
-    int an[VEC], ax[VEC];
-    bool need_h = false;
-    {
-      const int t = cc / p.F, f = cc - t * p.F;                   // VEC == 4 only with F % 4 == 0 (one tower per lane)
-      const float* go = p.gout + ((size_t)node * p.T + t) * ((size_t)p.S * p.K * p.F) + f;
-      const size_t so = (size_t)node * p.ldsave + cc;
+  const GrLane l = gr_lane(p, VEC);
+  const int stride = (int)gridDim.x * (kBlock / kWave);
+  int n = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)));
+  if (n >= p.N) return;
+  Seg s0 = seg_load(p, n), s1 = seg_load(p, n + stride);
+  SegIdx i0 = idx_load(p, s0.b, s0.e, l.lane);
+  for (;;) {
+    const int n1 = n + stride;
+    const Seg s2 = seg_load(p, n1 + stride);
+    SegIdx i1{0, 0};
+    if (s1.e - s1.b >= p.wave_min_deg) i1 = idx_load(p, s1.b, s1.e, l.lane);      // wave-uniform
+    gr_node_bwd<VEC>(p, dp, l, n, s0, i0);
+    if (n1 >= p.N) break;
+    n = n1; s0 = s1; s1 = s2; i0 = i1;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gr_bwd_group_kernel(const GrParams p) {
+  __shared__ float fac_tab[kGroupMaxDeg + 1][8];
+  gr_factor_table(p, fac_tab);
+  const DropParams dp = drop_resolve(p.drop);
+  const GrLane l = gr_lane(p, VEC);
+  const int stride = (int)gridDim.x * (kBlock / kWave) * l.epg;
+  int n = ((int)blockIdx.x * (kBlock / kWave) + (int)(threadIdx.x >> 6)) * l.epg + l.sub;
+  Seg s0 = seg_load(p, n), s1 = seg_load(p, n + stride);
+  Idx4 i0 = idx4_load(p, s0);
+  while (n < p.N) {
+    const int n1 = n + stride;
+    const Seg s2 = seg_load(p, n1 + stride);
+    const Idx4 i1 = idx4_load(p, s1);
+    const int deg = s0.e - s0.b;
+    if (deg > 0 && deg <= kGroupMaxDeg && l.valid) {
+      float fac[8];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) c_all[i] = c_min[i] = c_max[i] = c_var[i] = 0.f;
-      for (int k = 0; k < p.K; ++k) {
-        float gb[VEC];
+      for (int q = 0; q < 8; ++q) fac[q] = fac_tab[deg][q];
+      GrCoef<VEC> k_;
+      gr_bwd_coef<VEC>(p, l, n, (float)deg, fac, k_);
+      const Vec<VEC> u = (l.fused && k_.need_h) ? ldv<VEC>(p.U + (size_t)n * p.lduv + l.cc) : vzero<VEC>();
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) gb[i] = 0.f;
-        float run = 1.f;
-        for (int s = 0; s < p.S; ++s) {
-          run = run * fac[s];
-          const Vec<VEC> gv = ldv<VEC>(go + (size_t)(s * p.K + k) * p.F);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) gb[i] = fmaf(gv.v[i], run, gb[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          switch (p.aggr[k]) {
-            case GR_SUM: c_all[i] += gb[i]; break;
-            case GR_MEAN: c_all[i] += gb[i] / deg; break;
-            case GR_MIN: c_min[i] += gb[i]; break;
-            case GR_MAX: c_max[i] += gb[i]; break;
-            case GR_VAR: c_var[i] += gb[i] * 2.f / deg; need_h = true; break;
-            default: {
-              const float v = p.var[so + i];
-              if (v > 0.f) c_var[i] += gb[i] / (2.f * sqrtf(v + 1e-5f)) * 2.f / deg;   // relu'(v) = [v > 0]
-              need_h = true;
-            } break;
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        an[i] = p.amin ? p.amin[so + i] : -1;
-        ax[i] = p.amax ? p.amax[so + i] : -1;
-        mean[i] = need_h ? p.mean[so + i] : 0.f;
-      }
+      for (int i = 0; i < 4; ++i) if (i < deg) gr_bwd_edge<VEC>(p, dp, l, k_, u, i0.j[i], i0.e[i]);
+      for (int t = s0.b + 4; t < s0.e; ++t) gr_bwd_edge<VEC>(p, dp, l, k_, u, p.src[t], p.perm[t]);
     }
-    const Vec<VEC> u = (fused && need_h) ? ldv<VEC>(p.U + (size_t)node * p.lduv + cc) : vzero<VEC>();
-    for (int base = ebeg; base < eend; base += kWave) {
-      const int cnt = min(kWave, eend - base);
-      const int myj = (lane < cnt) ? p.src[base + lane] : 0;
-      const int mye = (lane < cnt) ? p.perm[base + lane] : 0;
-      for (int t0 = 0; t0 < cnt; t0 += epg) {
-        const int tt = t0 + sub;
-        const int j_ = __shfl(myj, tt & (kWave - 1), kWave);
-        const int e_ = __shfl(mye, tt & (kWave - 1), kWave);
-        if (tt < cnt && valid) {
-          Vec<VEC> g;
-          Vec<VEC> h = vzero<VEC>();
-          if (need_h) h = gr_message<VEC>(p, dp, fused, u, j_, (uint32_t)e_, cc);
-          float fd[VEC];
-          if (fused && dp.mode != MMA_DROP_NONE) drop_factors<VEC>(dp, (uint32_t)e_, 0, cc, p.D, 0, fd);
-          else {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) fd[i] = 1.f;
-          }
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            float gi = c_all[i] + (e_ == an[i] ? c_min[i] : 0.f) + (e_ == ax[i] ? c_max[i] : 0.f);
-            if (need_h) gi += c_var[i] * (h.v[i] - mean[i]);
-            g.v[i] = gi * fd[i];
-          }
-          stv<VEC>(p.gmsg + (size_t)e_ * p.ldg + cc, g);
-        }
-      }
-    }
+    n = n1; s0 = s1; s1 = s2; i0 = i1;
   }
 }
 
@@ -299,6 +532,14 @@ static int fill_codes(const uint8_t* aggr_host, int K, const uint8_t* scaler_hos
     p->scaler[s] = scaler_host[s];
   }
   p->K = K; p->S = S;
+  for (int k = 0; k < K; ++k) {
+    const int a = p->aggr[k];
+    p->need_sum |= a == GR_SUM || a == GR_MEAN || a >= GR_VAR;
+    p->need_mean |= a == GR_MEAN || a >= GR_VAR;
+    p->need_sq |= a >= GR_VAR;
+    p->need_min |= a == GR_MIN;
+    p->need_max |= a == GR_MAX;
+  }
   return 0;
 }
 
@@ -315,7 +556,8 @@ static bool gr_vec4(const GrParams& p) {
     if (!(p.lduv % 4 == 0 && p.lduv >= Dp && al(p.U) && al(p.V))) return false;
     if (p.Z && !(p.ldz % 4 == 0 && p.ldz >= Dp && al(p.Z))) return false;
   }
-  if ((p.amin || p.amax || p.mean || p.var) && p.ldsave < Dp) return false;
+  if ((p.amin || p.amax || p.mean || p.var) && (p.ldsave < Dp || p.ldsave % 4 != 0)) return false;
+  if (!(al(p.amin) && al(p.amax) && al(p.mean) && al(p.var))) return false;
   return true;
 }
 
@@ -336,6 +578,16 @@ static dim3 gr_grid(int64_t N, int D, int vec, int* lpr_log) {
   if (blocks > kMaxGrid) blocks = kMaxGrid;
   if (blocks < 1) blocks = 1;
   return dim3((unsigned)blocks, (unsigned)chunks);
+}
+
+// group-per-node pays when a wave holds at least two groups and segments are short on average
+static bool gr_group_mode(const GrParams& p, int64_t E) { return p.lpr_log <= 5 && E <= 16 * (int64_t)p.N; }
+static dim3 gr_group_grid(int64_t N, dim3 wave_grid, int lpr_log) {
+  const int64_t per_block = (int64_t)(kBlock / kWave) * (kWave >> lpr_log);
+  int64_t blocks = (N + per_block - 1) / per_block;
+  if (blocks > kMaxGrid) blocks = kMaxGrid;
+  if (blocks < 1) blocks = 1;
+  return dim3((unsigned)blocks, wave_grid.y);
 }
 
 }  // namespace mma
@@ -386,8 +638,8 @@ extern "C" int mma_gr_fused_fwd(
     float* out, int32_t* amin, int32_t* amax, float* mean, float* var, int64_t ldsave,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
-  MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31) && T >= 1 && F >= 1, "N=%lld E=%lld T=%d F=%d unsupported",
-              (long long)N, (long long)E, T, F);
+  MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) - (1 << 20) && E < (1LL << 31) && T >= 1 && F >= 1,
+              "N=%lld E=%lld T=%d F=%d unsupported", (long long)N, (long long)E, T, F);
   GrParams p{};
   if (int rc = fill_codes(aggr_host, K, scaler_host, S, &p)) return rc;
   if (N == 0) return 0;
@@ -407,8 +659,16 @@ extern "C" int mma_gr_fused_fwd(
   p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.seed_dev = seed_dev; p.drop.keep = nullptr; p.drop.E = E; p.drop.edge_base = 0;
   const bool v4 = gr_vec4(p);
   const dim3 grid = gr_grid(N, D, v4 ? 4 : 1, &p.lpr_log);
-  if (v4) hipLaunchKernelGGL((gr_fwd_kernel<4>), grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
-  else hipLaunchKernelGGL((gr_fwd_kernel<1>), grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (gr_group_mode(p, E)) {      // short segments: group-per-node kernel, then the wave-per-node pass for the few long ones
+    const dim3 gg = gr_group_grid(N, grid, p.lpr_log);
+    if (v4) hipLaunchKernelGGL((gr_fwd_group_kernel<4>), gg, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((gr_fwd_group_kernel<1>), gg, dim3(kBlock), 0, st, p);
+    if (int rc = check_launch("gr_fwd_group_kernel")) return rc;
+    p.wave_min_deg = kGroupMaxDeg + 1;
+  }
+  if (v4) hipLaunchKernelGGL((gr_fwd_kernel<4>), grid, dim3(kBlock), 0, st, p);
+  else hipLaunchKernelGGL((gr_fwd_kernel<1>), grid, dim3(kBlock), 0, st, p);
   return check_launch("gr_fwd_kernel");
 }
 
@@ -419,8 +679,8 @@ extern "C" int mma_gr_fused_bwd(
     float* gmsg, int64_t ldg,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
-  MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31) && T >= 1 && F >= 1, "N=%lld E=%lld T=%d F=%d unsupported",
-              (long long)N, (long long)E, T, F);
+  MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) - (1 << 20) && E < (1LL << 31) && T >= 1 && F >= 1,
+              "N=%lld E=%lld T=%d F=%d unsupported", (long long)N, (long long)E, T, F);
   GrParams p{};
   if (int rc = fill_codes(aggr_host, K, scaler_host, S, &p)) return rc;
   if (N == 0 || E == 0) return 0;
@@ -444,7 +704,15 @@ extern "C" int mma_gr_fused_bwd(
   p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.seed_dev = seed_dev; p.drop.keep = nullptr; p.drop.E = E; p.drop.edge_base = 0;
   const bool v4 = gr_vec4(p) && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(gmsg) & 15) == 0;
   const dim3 grid = gr_grid(N, D, v4 ? 4 : 1, &p.lpr_log);
-  if (v4) hipLaunchKernelGGL((gr_bwd_kernel<4>), grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
-  else hipLaunchKernelGGL((gr_bwd_kernel<1>), grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (gr_group_mode(p, E)) {
+    const dim3 gg = gr_group_grid(N, grid, p.lpr_log);
+    if (v4) hipLaunchKernelGGL((gr_bwd_group_kernel<4>), gg, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((gr_bwd_group_kernel<1>), gg, dim3(kBlock), 0, st, p);
+    if (int rc = check_launch("gr_bwd_group_kernel")) return rc;
+    p.wave_min_deg = kGroupMaxDeg + 1;
+  }
+  if (v4) hipLaunchKernelGGL((gr_bwd_kernel<4>), grid, dim3(kBlock), 0, st, p);
+  else hipLaunchKernelGGL((gr_bwd_kernel<1>), grid, dim3(kBlock), 0, st, p);
   return check_launch("gr_bwd_kernel");
 }

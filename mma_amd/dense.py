@@ -93,9 +93,9 @@ def xt_g(x, g):
     if B < 4:
         return torch.mm(x.t(), g)
     n = B * _ROWS_PER_BATCH
-    x = x.contiguous()
-    g = g.contiguous()
-    out = torch.bmm(x[:n].view(B, _ROWS_PER_BATCH, -1).transpose(1, 2), g[:n].view(B, _ROWS_PER_BATCH, -1)).sum(0)
+    x = x if x.stride(1) == 1 else x.contiguous()            # row-strided operands (column blocks of a wider buffer) are
+    g = g if g.stride(1) == 1 else g.contiguous()            # fine: the row blocks stay strided-batched GEMM operands
+    out = torch.bmm(x[:n].unflatten(0, (B, _ROWS_PER_BATCH)).transpose(1, 2), g[:n].unflatten(0, (B, _ROWS_PER_BATCH))).sum(0)
     if n < N:
         out = out + torch.mm(x[n:].t(), g[n:])
     return out
@@ -164,3 +164,31 @@ class _BiasAdd(torch.autograd.Function):
 def bias_add(y, b):
     """y (..., C) + b (C,) whose bias gradient is the K8 column sum."""
     return _BiasAdd.apply(y, b)
+
+
+class _TowerLinear(torch.autograd.Function):
+    """y[n,t,:] = a[n,t,:] @ W[t]^T for a (N,T,C), W (T,O,C): the per-tower post-NN Linear of MMAConv (mma_conv.py:132-134)
+    on the aggregates, without slicing towers apart.  Backward writes the gradient of `a` tower by tower straight into
+    its (N,T,C) layout (autograd's batched GEMM returns it tower-major and costs a 1.9 GB re-layout copy at C2L) and takes
+    the weight gradients as split-reduction GEMMs over the row-strided tower slices."""
+
+    @staticmethod
+    def forward(ctx, a, W):
+        ctx.save_for_backward(a, W)
+        return torch.bmm(a.transpose(0, 1), W.transpose(1, 2)).transpose(0, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, W = ctx.saved_tensors
+        T = W.shape[0]
+        ga = gW = None
+        if ctx.needs_input_grad[0]:
+            ga = torch.empty_like(a, memory_format=torch.contiguous_format)
+            torch.bmm(g.transpose(0, 1), W, out=ga.transpose(0, 1))          # strided-batched: ldc = T*C, batch stride C
+        if ctx.needs_input_grad[1]:
+            gW = torch.stack([xt_g(g[:, t], a[:, t]) for t in range(T)])
+        return ga, gW
+
+
+def tower_linear(a, W):
+    return _TowerLinear.apply(a, W)

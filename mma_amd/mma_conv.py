@@ -164,7 +164,7 @@ class MMAConv(torch.nn.Module):
             bp = torch.cat([seq[0].bias for seq in self.post_nns])                       # (T*F_out,)
             Wx = Wp[:, :, :Fi]
             Wo = self._pad_dim(Wp[:, :, Fi:].reshape(T, self.F_out, KS, Fi), 3, Fw).reshape(T, self.F_out, KS * Fw)
-            y = torch.bmm(out.transpose(0, 1), Wo.transpose(1, 2)).transpose(0, 1)       # (N, T, F_out), no copy of `out`
+            y = dense.tower_linear(out, Wo)                                              # (N, T, F_out), no copy of `out`
             if self.divide_input:
                 y = y + torch.bmm(x.transpose(0, 1), Wx.transpose(1, 2)).transpose(0, 1)
                 out = dense.bias_add(y.reshape(N, T * self.F_out), bp)
