@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 9
+#define MMA_ABI_VERSION 10
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -150,6 +150,13 @@ int mma_csr_spmm_items(
 int mma_split_bf16x3(const float* in, int64_t n, void* out_3n_bf16, void* stream);
 int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, float* C, int64_t ldc,
                     int64_t M, int32_t N, int32_t K, void* stream);
+/* TN form for the weight gradients (autograd's x^T g of layers.py:215-216's torch.mm): C (KA,NC) = X^T G with X (M,KA),
+ * G (M,NC) fp32 row-major, C contiguous.  KA in {32,64,96,128}, NC % 32 == 0.  Both operands are split to bf16x3 on the
+ * fly; the reduction over M runs in fixed row ranges whose partial tiles (ws) are summed in a fixed order.
+ * ws: mma_gemm_bf16x3_tn_workspace_floats(M, KA, NC) floats (0 => may be NULL). */
+int64_t mma_gemm_bf16x3_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC);
+int mma_gemm_bf16x3_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, float* C, float* ws, int64_t ws_floats,
+                       int64_t M, int32_t KA, int32_t NC, void* stream);
 
 /* ---- K7: halo pack / unpack for the 1-D node-sharded multi-GPU path --------------------------------
  * pack:   dst[r,:] = src[idx[r],:]            (send buffer for the all-to-all of halo rows)

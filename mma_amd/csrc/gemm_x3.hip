@@ -200,6 +200,203 @@ __global__ void split3_kernel(const float* in, int64_t n, __bf16* out) {
   }
 }
 
+
+// ---- TN form: C (KA, NC) = X^T G for X (M, KA), G (M, NC), M >> KA, NC: the weight gradients x^T [gP | gQ] -----------
+// Both operands are fp32 activations whose reduction index is the ROW, and the MFMA wants 8 consecutive k per lane.
+// No transpose is needed for that: a lane simply loads its 8 k values from 8 different rows (each load instruction
+// still reads 128 contiguous bytes of one row across 32 lanes).  X fragments go straight to registers (wave w owns the
+// X columns [32w, 32w+32)); the G tile (32 rows x 128 columns per chunk) is split once per workgroup and staged
+// k-contiguous through a double-buffered LDS slab, so its 6.5 VALU ops per value are paid once, not per wave.
+// The reduction over M is cut into `splits` row ranges (grid.y) whose partial tiles are summed by the K8 kernel in a
+// fixed order: no atomics, bitwise repeatable.
+struct TnParams {
+  const float* X; int64_t ldx; const float* G; int64_t ldg;
+  float* part;                 // (splits, KA, NC)
+  int64_t M, rows_per_split; int KA, NC, splits;
+};
+
+constexpr int kTnKC = 32;                        // rows of X / G per chunk
+constexpr int kTnPitch = kTnKC * 2 + 16;         // bytes per (piece, column) LDS row: 32 bf16 + 16 B pad
+constexpr int kTnPiece = 128 * kTnPitch;
+constexpr int kTnSlab = 3 * kTnPiece;            // 30 KB; double buffered => two workgroups per CU
+
+__device__ __forceinline__ void split3x8(const float (&v)[16], int o, bf16x8& a, bf16x8& b, bf16x8& c) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const Bf3 t = split3(v[o + i]);
+    a[i] = t.a; b[i] = t.b; c[i] = t.c;
+  }
+}
+
+// FULLCT: all four 32-column tiles of the block exist (NC % 128 == 0): the MFMA phase is then one branch-free block.
+template <bool FULLCT>
+__global__ __launch_bounds__(kBlock, 2) void gemm_x3_tn_kernel(const TnParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kTnSlab];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r31 = lane & 31, h = lane >> 5;
+  // Workgroups are dealt round-robin to the 8 XCDs (private L2 each).  The column blocks of one row range all read the same
+  // X rows, so they are given ids that land on ONE XCD back to back: X then comes from HBM once, not once per column block.
+  const int n_cb = (p.NC + 127) / 128;
+  int cb, split;
+  if (p.splits % 8 == 0) {
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    cb = slot % n_cb;
+    split = (slot / n_cb) * 8 + xcd;
+  } else {
+    cb = (int)blockIdx.x % n_cb;
+    split = (int)blockIdx.x / n_cb;
+  }
+  const int gcol0 = cb * 128;
+  const int n_ct = FULLCT ? 4 : min(4, (p.NC - gcol0) / 32);
+  const int64_t r0 = (int64_t)split * p.rows_per_split;
+  const int64_t r1 = min(p.M, r0 + p.rows_per_split);
+  const int n_chunks = r1 > r0 ? (int)((r1 - r0 + kTnKC - 1) / kTnKC) : 0;
+  const bool wave_active = wave * 32 < p.KA;
+  // staging role: column sn of the block's 128, k-groups skg and skg + 2 (8 rows each)
+  const int sn = tid & 127, skg = tid >> 7;
+  const int scol = gcol0 + sn < p.NC ? sn : 0;       // columns past NC belong to tiles that are never multiplied
+  const int xcol = min(wave * 32, p.KA - 32) + r31;
+  const int ldg_b = (int)p.ldg * 4, ldx_b = (int)p.ldx * 4;                    // row pitches in bytes
+  const int rows = (int)(r1 > r0 ? r1 - r0 : 0);
+  const int64_t rbase = r1 > r0 ? r0 : 0;                                      // an empty split still gets a valid base
+  const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G + rbase * p.ldg + gcol0), 0,
+                                                        rows ? (rows - 1) * ldg_b + min(128, p.NC - gcol0) * 4 : 0, 0x00020000);
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + rbase * p.ldx), 0,
+                                                        rows ? (rows - 1) * ldx_b + p.KA * 4 : 0, 0x00020000);
+  const int g_voff = skg * 8 * ldg_b + scol * 4;     // per lane: first row of its k-group, its column
+  const int x_voff = 8 * h * ldx_b + xcol * 4;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // two raw (fp32) chunk sets: chunk c+1 waits to be split while chunk c+2 is still on its way from HBM (one MFMA phase,
+  // ~0.8 us, is shorter than the loaded memory latency; with a single set every wave sat idle for two thirds of a chunk)
+  float graw0[16], xraw0[16], graw1[16], xraw1[16];
+  bf16x8 af[2][3];
+
+// Buffer loads: one descriptor per operand covering exactly this split's rows (wave-uniform base and size), a 32-bit
+// per-lane offset and no address arithmetic in VGPR pairs; rows past the end of the split are out of range and read as 0
+// (hardware range check on voffset), so the ragged last chunk needs no guard.
+#define MMA_TN_LOAD(C_, GR_, XR_)                                                              \
+  {                                                                                            \
+    int gv = g_voff + (C_) * (kTnKC * ldg_b);                                                  \
+    int xv = x_voff + (C_) * (kTnKC * ldx_b);                                                  \
+    /* opaque: otherwise the 32 loop-invariant sums voff + row*pitch are hoisted into 32 VGPRs (and spilled) */ \
+    asm volatile("" : "+v"(gv), "+v"(xv));                                                     \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g)                                              \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                            \
+        GR_[g * 8 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rsrc, gv + (g * 16 + i) * ldg_b, 0, 0)); \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                            \
+        XR_[ks * 8 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, xv + (ks * 16 + i) * ldx_b, 0, 0)); \
+  }
+// split a raw chunk: G pieces into LDS buffer B_ ([piece][column][k], k contiguous), X pieces into af
+#define MMA_TN_PUBLISH(B_, GR_, XR_)                                                           \
+  {                                                                                            \
+    unsigned char* d = lds + (B_) * kTnSlab + sn * kTnPitch;                                   \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                            \
+      bf16x8 a, b, c;                                                                          \
+      split3x8(GR_, g * 8, a, b, c);                                                           \
+      *reinterpret_cast<bf16x8*>(d + 0 * kTnPiece + (skg + 2 * g) * 16) = a;                   \
+      *reinterpret_cast<bf16x8*>(d + 1 * kTnPiece + (skg + 2 * g) * 16) = b;                   \
+      *reinterpret_cast<bf16x8*>(d + 2 * kTnPiece + (skg + 2 * g) * 16) = c;                   \
+    }                                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) split3x8(XR_, ks * 8, af[ks][0], af[ks][1], af[ks][2]); \
+  }
+// One chunk.  Its four groups of twelve MFMAs (k-step x pair of column tiles) are interleaved IN PROGRAM ORDER with the split of the
+// next chunk's G values (a wave issues in order: VALU work only hides in an MFMA's 32-cycle shadow if it sits between the
+// MFMAs), the B fragments of group m+1 are read while group m multiplies, and every group is fenced so the scheduler keeps
+// that order.  Then: next chunk's X pieces into af | refill the raw set with chunk C_+3 | raw barrier (__syncthreads()
+// would also drain vmcnt, i.e. wait for the prefetches that were just issued).  The publish goes to the other LDS buffer,
+// last read before the previous barrier.  Everything is unconditional: chunks past the end of the split are out of the
+// descriptors' range and read as zeros (a conditional prefetch also makes the compiler's vmcnt bookkeeping fall back to
+// "wait for everything"), and waves beyond KA multiply clamped columns that are never stored.
+#define MMA_TN_STEP(C_, B_, GR_, XR_)                                                          \
+  {                                                                                            \
+    const unsigned char* sb = lds + (B_) * kTnSlab + r31 * kTnPitch + h * 16;                  \
+    unsigned char* pd = lds + (1 - (B_)) * kTnSlab + sn * kTnPitch + skg * 16;                 \
+    bf16x8 bq[2][2][3], ga, gb, gc;      /* [parity][tile of the pair][piece] */               \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                              \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q)                                            \
+        bq[0][t][q] = *reinterpret_cast<const bf16x8*>(sb + t * 32 * kTnPitch + q * kTnPiece); \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) {       /* group m: k-step m>>1, column tiles 2*(m&1), 2*(m&1)+1 */ \
+      const int ks = m >> 1, c0 = 2 * (m & 1), c1 = c0 + 1, pa = m & 1;                        \
+      if (m + 1 < 4) {                                                                         \
+        const unsigned char* qn = sb + (2 * ((m + 1) & 1)) * 32 * kTnPitch + ((m + 1) >> 1) * 32; \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                          \
+          _Pragma("unroll") for (int q = 0; q < 3; ++q)                                        \
+            bq[1 - pa][t][q] = *reinterpret_cast<const bf16x8*>(qn + t * 32 * kTnPitch + q * kTnPiece); \
+      }                                                                                        \
+      /* the two tiles' chains alternate, so consecutive MFMAs never depend on each other */   \
+      const bool t0 = FULLCT || c0 < n_ct, t1 = FULLCT || c1 < n_ct;                           \
+      if (t0) acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], bq[pa][0][2], acc[c0], 0, 0, 0); \
+      if (t1) acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], bq[pa][1][2], acc[c1], 0, 0, 0); \
+      if (t0) acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1], bq[pa][0][1], acc[c0], 0, 0, 0); \
+      if (t1) acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1], bq[pa][1][1], acc[c1], 0, 0, 0); \
+      if (t0) acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][2], bq[pa][0][0], acc[c0], 0, 0, 0); \
+      if (t1) acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][2], bq[pa][1][0], acc[c1], 0, 0, 0); \
+      if (t0) acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], bq[pa][0][1], acc[c0], 0, 0, 0); \
+      if (t1) acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], bq[pa][1][1], acc[c1], 0, 0, 0); \
+      if (t0) acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1], bq[pa][0][0], acc[c0], 0, 0, 0); \
+      if (t1) acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1], bq[pa][1][0], acc[c1], 0, 0, 0); \
+      if (t0) acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], bq[pa][0][0], acc[c0], 0, 0, 0); \
+      if (t1) acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], bq[pa][1][0], acc[c1], 0, 0, 0); \
+      _Pragma("unroll") for (int j = 4 * m; j < 4 * m + 4; j += 2) { /* values j, j+1 of the next chunk's G set */ \
+        const Bf3 u0 = split3(GR_[j]), u1 = split3(GR_[j + 1]);                                \
+        ga[j & 7] = u0.a; gb[j & 7] = u0.b; gc[j & 7] = u0.c;                                  \
+        ga[(j + 1) & 7] = u1.a; gb[(j + 1) & 7] = u1.b; gc[(j + 1) & 7] = u1.c;                \
+      }                                                                                        \
+      if (m & 1) { /* a k-group of 8 rows is complete: [piece][column][k] rows, k contiguous */ \
+        *reinterpret_cast<bf16x8*>(pd + 0 * kTnPiece + (m >> 1) * 32) = ga;                    \
+        *reinterpret_cast<bf16x8*>(pd + 1 * kTnPiece + (m >> 1) * 32) = gb;                    \
+        *reinterpret_cast<bf16x8*>(pd + 2 * kTnPiece + (m >> 1) * 32) = gc;                    \
+      }                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+    }                                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) split3x8(XR_, ks * 8, af[ks][0], af[ks][1], af[ks][2]); \
+    MMA_TN_LOAD((C_) + 3, GR_, XR_)                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+    __builtin_amdgcn_s_barrier();                                                              \
+    asm volatile("" ::: "memory");                                                             \
+  }
+
+  MMA_TN_LOAD(0, graw0, xraw0)
+  MMA_TN_PUBLISH(0, graw0, xraw0)
+  MMA_TN_LOAD(1, graw1, xraw1)
+  MMA_TN_LOAD(2, graw0, xraw0)
+  __syncthreads();
+  for (int c = 0; c < n_chunks; c += 2) {                      // an odd count runs one all-zero chunk at the end
+    MMA_TN_STEP(c, 0, graw1, xraw1)                            // even chunk: buffer 0; chunk c+1 waits in raw set 1
+    MMA_TN_STEP(c + 1, 1, graw0, xraw0)
+  }
+#undef MMA_TN_STEP
+#undef MMA_TN_LOAD
+#undef MMA_TN_PUBLISH
+
+  if (wave_active) {   // acc reg r holds X column 32*wave + (r&3) + 8*(r>>2) + 4*h, G column gcol0 + 32*ct + r31
+    float* out = p.part + ((size_t)split * p.KA + (size_t)wave * 32) * p.NC + gcol0 + r31;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      if (ct < n_ct) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * p.NC + ct * 32] = acc[ct][r];
+      }
+    }
+  }
+}
+
+static int tn_splits(int64_t M, int NC) {
+  const int64_t n_cb = (NC + 127) / 128;
+  int64_t s = 512 / n_cb;                               // ~2 workgroups per CU in total
+  const int64_t max_s = (M + 8 * kTnKC - 1) / (8 * kTnKC);   // at least 8 chunks per split
+  if (s > max_s) s = max_s;
+  if (s >= 8) s = s / 8 * 8;                            // multiples of 8: the XCD-local id mapping of the kernel
+  return (int)(s < 1 ? 1 : s);
+}
+
 }  // namespace mma
 
 using namespace mma;
@@ -246,4 +443,34 @@ extern "C" int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, flo
 #undef MMA_X3_LAUNCH
   }
   return check_launch("gemm_x3_kernel");
+}
+
+extern "C" int64_t mma_gemm_bf16x3_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC) {
+  if (M <= 0 || KA <= 0 || NC <= 0) return 0;
+  const int s = tn_splits(M, NC);
+  return s > 1 ? (int64_t)s * KA * NC : 0;
+}
+
+extern "C" int mma_col_sum(const float* g, int64_t ldg, int64_t R, int32_t C, float* out, float* ws, int64_t ws_floats, void* stream);
+
+extern "C" int mma_gemm_bf16x3_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, float* C, float* ws, int64_t ws_floats,
+                                  int64_t M, int32_t KA, int32_t NC, void* stream) {
+  MMA_REQUIRE(M >= 1 && KA >= 32 && KA <= 128 && KA % 32 == 0 && NC >= 32 && NC % 32 == 0 && (int64_t)KA * NC < (1LL << 31),
+              "M=%lld KA=%d NC=%d: need KA in {32,64,96,128}, NC %% 32 == 0", (long long)M, KA, NC);
+  MMA_REQUIRE(X && G && C && ldx >= KA && ldg >= NC && ldx < (1 << 24) && ldg < (1 << 24), "NULL argument or row pitch out of range");
+  MMA_REQUIRE((reinterpret_cast<uintptr_t>(X) & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & 3) == 0, "misaligned argument");
+  const int s = tn_splits(M, NC);
+  MMA_REQUIRE(s == 1 || (ws && ws_floats >= (int64_t)s * KA * NC), "workspace too small: %lld floats, need %lld",
+              (long long)ws_floats, (long long)s * KA * NC);
+  int64_t rps = (M + s - 1) / s;
+  rps = (rps + kTnKC - 1) / kTnKC * kTnKC;
+  MMA_REQUIRE((rps + kTnKC) * (ldx > ldg ? ldx : ldg) * 4 < (1LL << 31), "row range of one split exceeds a 2 GB buffer window");
+  TnParams p{X, ldx, G, ldg, s == 1 ? C : ws, M, rps, KA, NC, s};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(((NC + 127) / 128) * s));
+  if (NC % 128 == 0) hipLaunchKernelGGL(gemm_x3_tn_kernel<true>, grid, dim3(kBlock), 0, st, p);
+  else hipLaunchKernelGGL(gemm_x3_tn_kernel<false>, grid, dim3(kBlock), 0, st, p);
+  if (int rc = check_launch("gemm_x3_tn_kernel")) return rc;
+  if (s == 1) return 0;
+  return mma_col_sum(ws, (int64_t)KA * NC, s, KA * NC, C, nullptr, 0, stream);      // s <= 512 rows: one pass, fixed order
 }

@@ -86,8 +86,26 @@ class _MM(torch.autograd.Function):
         return gx, gw
 
 
+def _x3_tn_ok(x, g):
+    return (USE_BF16X3 and x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32 and x.shape[0] >= _MIN_ROWS_X3
+            and x.shape[1] in (32, 64, 96, 128) and g.shape[1] % 32 == 0 and x.stride(1) == 1 and g.stride(1) == 1)
+
+
+def gemm_bf16x3_tn(x, g):
+    """x^T @ g (in,out) for tall fp32 x (N,in), g (N,out) on the bf16x3 TN kernel (row-strided operands are fine)."""
+    N, KA = x.shape
+    NC = g.shape[1]
+    out = torch.empty((KA, NC), device=x.device, dtype=torch.float32)
+    n_ws = int(_lib.lib().mma_gemm_bf16x3_tn_workspace_floats(N, KA, NC))
+    ws = torch.empty((n_ws,), device=x.device, dtype=torch.float32) if n_ws else None
+    call("mma_gemm_bf16x3_tn", ptr(x), x.stride(0), ptr(g), g.stride(0), ptr(out), ptr(ws), n_ws, N, KA, NC, stream_ptr())
+    return out
+
+
 def xt_g(x, g):
-    """x^T @ g for tall x (N,in), g (N,out): split-N batched GEMM + sum."""
+    """x^T @ g for tall x (N,in), g (N,out): the bf16x3 TN kernel where the shape allows, else split-N batched GEMM + sum."""
+    if _x3_tn_ok(x, g):
+        return gemm_bf16x3_tn(x, g)
     N = x.shape[0]
     B = N // _ROWS_PER_BATCH
     if B < 4:

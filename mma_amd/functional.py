@@ -254,7 +254,8 @@ class _CsrSpmm(torch.autograd.Function):
         with _span("csr_spmm_bwd"):
             _spmm_call(sg.t_rowptr, sg.t_col, sg.t_val, sg.t_items, sg.t_hubs, sg.t_n_slots, g, sg.n_rows, 1, None, gB1, sg.n_cols, C)
         gB = gB1 if K == 1 else gB1.unsqueeze(0).expand(K, -1, -1).reshape(K * sg.n_cols, C)  # every k-block sees the same A^T g
-        return gB, (g.sum(0) if ctx.has_bias else None), None, None
+        from .dense import col_sum
+        return gB, (col_sum(g) if ctx.has_bias else None), None, None
 
 
 def csr_spmm(B, bias, sg, K=1):

@@ -76,3 +76,22 @@ def test_linear_backward_matches_torch():
     assert torch.allclose(y.double(), yd, rtol=1e-5, atol=1e-5)
     for g_, r_ in zip(got, ref):
         assert (g_.double() - r_).abs().max().item() <= 2e-6 * r_.abs().max().item() + 1e-6 * 70001 ** 0.5
+
+
+@pytest.mark.parametrize("M,KA,NC,padx,padg", [(5000, 128, 1024, 0, 0), (4097, 64, 96, 0, 32), (70001, 128, 512, 128, 0),
+                                               (33, 32, 32, 0, 0), (262144 + 17, 96, 160, 0, 0)])
+def test_gemm_bf16x3_tn_accuracy(M, KA, NC, padx, padg):
+    """x^T g on the TN kernel: error at the level of an fp32 GEMM's against fp64, repeatable, row-strided operands."""
+    from mma_amd import dense
+    rng = np.random.default_rng(M + KA + NC)
+    xf = torch.from_numpy((rng.standard_normal((M, KA + padx)) * np.exp(rng.uniform(-3, 3, (M, 1)))).astype(np.float32)).to(DEV)
+    gf = torch.from_numpy(rng.standard_normal((M, NC + padg)).astype(np.float32)).to(DEV)
+    x, g = xf[:, padx:], gf[:, :NC]
+    got = dense.gemm_bf16x3_tn(x, g)
+    ref = x.double().t() @ g.double()
+    f32 = x.t() @ g
+    scale = x.double().abs().t() @ g.double().abs()
+    e_got = ((got.double() - ref).abs() / scale).max().item()
+    e_f32 = ((f32.double() - ref).abs() / scale).max().item()
+    assert got.shape == (KA, NC) and e_got < 5e-7 and e_got < 1.5 * e_f32 + 1e-7, (e_got, e_f32)
+    assert torch.equal(dense.gemm_bf16x3_tn(x, g), got)
