@@ -22,8 +22,10 @@ def _x3_ok(a, w):
 
 
 def gemm_bf16x3(a, w, out=None):
-    """a (M,K) @ w (K,N) with fp32 accuracy on the bf16 MFMA path (three-piece split of both operands)."""
-    a = a.contiguous()
+    """a (M,K) @ w (K,N) with fp32 accuracy on the bf16 MFMA path (three-piece split of both operands).  `a` may be a
+    row-strided view (a column block of a wider buffer)."""
+    if a.stride(1) != 1 or a.stride(0) % 4 or a.data_ptr() % 16:
+        a = a.contiguous()
     M, K = a.shape
     N = w.shape[1]
     wt = w.t().contiguous()                                  # (N,K): B^T, k contiguous

@@ -188,31 +188,38 @@ class _ShardedAggregate(torch.autograd.Function):
             call("mma_pack_rows", ptr(x_own), H, ptr(mod.send_idx), n_send, ptr(send), H, H, stream_ptr())
         h = all_to_all_rows_start(send, plan.send_counts, plan.recv_counts, plan.group, out=x_src[n:])
         x_src[:n].copy_(x_own)
-        P = torch.empty((n, K * H), device=dev, dtype=torch.float32)
-        Q = torch.empty((S, K * H), device=dev, dtype=torch.float32)
-        mm_into(x_own, wtop, P)
-        mm_into(x_own, wbot, Q[:n])
+        # one (S, 2KH) buffer: row i = [P_i | Q_i]; own rows come out of ONE GEMM with [Wtop | Wbot], halo rows only get
+        # their Q half (their P half is never read).  K1/K2b take P and Q as strided views of it.
+        KH = K * H
+        PQ = torch.empty((S, 2 * KH), device=dev, dtype=torch.float32)
+        wcat = torch.cat([wtop, wbot], 1)                                   # (H, 2KH)
+        mm_into(x_own, wcat, PQ[:n])
         with Fn._span("halo_wait"):
             h.wait()
-        mm_into(x_src[n:], wbot, Q[n:])
+        mm_into(x_src[n:], wbot, PQ[n:, KH:])
+        P, Q = PQ[:n, :KH], PQ[:, KH:]
         need = any(ctx.needs_input_grad[:3])
         msum, T, sel = Fn.nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, True, need)
         ctx.mod, ctx.kinds, ctx.acts, ctx.drop = mod, kinds, acts, drop
-        ctx.save_for_backward(x_src, P, Q, T, sel, wtop, wbot)
+        ctx.save_for_backward(x_src, PQ, T, sel, wcat)
         return msum
 
     @staticmethod
     def backward(ctx, g):
         mod, kinds, acts, drop = ctx.mod, ctx.kinds, ctx.acts, ctx.drop
         plan, graph = mod.plan, mod.graph
-        x_src, P, Q, T, sel, wtop, wbot = ctx.saved_tensors
+        x_src, PQ, T, sel, wcat = ctx.saved_tensors
         n, S, H = plan.n_own, plan.n_src, x_src.shape[1]
         K = len(kinds)
+        KH = K * H
+        P, Q = PQ[:n, :KH], PQ[:, KH:]
+        wbot = wcat[:, KH:]
         dev = g.device
         g = g.contiguous()
         shared = Fn.SHARED_GRAD_BWD
-        gs, aux, ldaux, gP, gxs = Fn.nc_bwd_node_launch(g, True, sel, T, graph, kinds, H, shared)
-        gQ = torch.empty((S, K * H), device=dev, dtype=torch.float32)
+        gPQ = torch.empty((S, 2 * KH), device=dev, dtype=torch.float32)          # [dL/dP | dL/dQ], halo rows: Q half only
+        gs, aux, ldaux, gP, gxs = Fn.nc_bwd_node_launch(g, True, sel, T, graph, kinds, H, shared, gP=gPQ[:n, :KH])
+        gQ = gPQ[:, KH:]
         gx = torch.empty((S, H), device=dev, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32) if graph.t_n_slots else None)
         back = None
@@ -224,9 +231,13 @@ class _ShardedAggregate(torch.autograd.Function):
             Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, own_part)
         else:
             Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial)
-        gx_own = gx[:n] + rows_mm(gP, wtop.t()) + rows_mm(gQ[:n], wbot.t())
-        gwtop = xt_g(x_src[:n], gP) if ctx.needs_input_grad[1] else None
-        gwbot = xt_g(x_src, gQ) if ctx.needs_input_grad[2] else None
+        gx_own = gx[:n] + rows_mm(gPQ[:n], wcat.t())             # direct + through P and Q of the own rows in one GEMM
+        gwtop = gwbot = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gw = xt_g(x_src[:n], gPQ[:n])                        # (H, 2KH) = [dL/dWtop | own part of dL/dWbot]
+            gwtop, gwbot = gw[:, :KH], gw[:, KH:]
+            if S > n:
+                gwbot = gwbot + xt_g(x_src[n:], gQ[n:])
         if back is not None:
             with Fn._span("halo_wait"):
                 rows = back.wait()                                                       # (n_send, H)
