@@ -1,0 +1,94 @@
+"""the reference's node-classification training step (train.py:72-86: forward, nll_loss on idx_train,
+backward, Adam) captured as one hipGraph (mma_amd/train_step.py).  With dropout off the captured step must walk the same
+parameter trajectory as the eager loop; with the reference's always-on dropout it must train and be faster than eager
+(the step is launch-bound on Cora-sized graphs)."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _cora_problem(dropout, seed=0):
+    import scipy.sparse as sp
+    from mma_amd.models import MMAConv
+    from mma_amd.utils import sparse_mx_to_torch_sparse_tensor
+    z = np.load(os.path.join(HERE, "golden", "cora_h64.npz"))
+    rowptr, col = z["rowptr"].astype(np.int64), z["col"].astype(np.int64)
+    N, C, nfeat = len(rowptr) - 1, 7, 96
+    add_all = [col[rowptr[i]:rowptr[i + 1]] for i in range(N)]
+    adj_sp = sp.csr_matrix((np.ones(len(col), np.float32), col, rowptr), shape=(N, N))
+    rng = np.random.default_rng(seed)
+    labels = rng.integers(0, C, N)
+    feats = (np.eye(C)[labels] @ rng.standard_normal((C, nfeat)) + 2.0 * rng.standard_normal((N, nfeat))).astype(np.float32)
+    torch.manual_seed(42)
+    model = MMAConv(add_all, "new_sigmoid", 2, nfeat, 64, C, dropout, ["mean", "mean2"], DEV).to(DEV)
+    for p in model.parameters():                               # the reference leaves init to the layers; unused masks too
+        if p.dim() == 2 and not torch.isfinite(p).all():
+            torch.nn.init.uniform_(p, -0.1, 0.1)
+    adj = sparse_mx_to_torch_sparse_tensor(adj_sp).to(DEV)
+    x, y = torch.from_numpy(feats).to(DEV), torch.from_numpy(labels).to(DEV)
+    idx_train = torch.arange(0, 1500, device=DEV)
+    return model, adj, x, y, idx_train
+
+
+def _used(model):
+    return [p for p in model.parameters() if p.requires_grad]
+
+
+def test_graphed_step_matches_eager_without_dropout():
+    from mma_amd.train_step import GraphedTrainStep
+    finals = []
+    for graphed in (False, True):
+        model, adj, x, y, idx = _cora_problem(0.0)
+        model.train()
+        opt = torch.optim.Adam(_used(model), lr=0.01, weight_decay=5e-4, capturable=True)
+        loss_fn = lambda: F.nll_loss(model(x, adj)[idx], y[idx])
+        if graphed:
+            step = GraphedTrainStep(model, opt, loss_fn, warmup=3)      # 3 eager warm-up steps (capture records, it does not run)
+            losses = [step().item() for _ in range(6)]
+        else:
+            losses = []
+            for _ in range(9):
+                opt.zero_grad(set_to_none=False)
+                loss = loss_fn(); loss.backward(); opt.step()
+                losses.append(loss.item())
+        finals.append((losses[-1], [p.detach().clone() for p in (model.weight0, model.weight1, model.weight_mean, model.bias1)]))
+    (le, pe), (lg, pg) = finals
+    assert abs(le - lg) <= 1e-4 * abs(le), (le, lg)                    # 9 optimizer steps either way
+    for a, b in zip(pe, pg):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_graphed_step_trains_and_beats_eager_launch_overhead():
+    from mma_amd.train_step import GraphedTrainStep
+    model, adj, x, y, idx = _cora_problem(0.5)
+    model.train()
+    opt = torch.optim.Adam(_used(model), lr=0.01, weight_decay=5e-4, capturable=True)
+    loss_fn = lambda: F.nll_loss(model(x, adj)[idx], y[idx])
+
+    def eager():
+        opt.zero_grad(set_to_none=False)
+        loss = loss_fn(); loss.backward(); opt.step()
+        return loss
+    first = [eager().item() for _ in range(5)]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20):
+        eager()
+    torch.cuda.synchronize(); t_eager = (time.perf_counter() - t0) / 20
+    step = GraphedTrainStep(model, opt, loss_fn)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(100):
+        loss = step()
+    torch.cuda.synchronize(); t_graph = (time.perf_counter() - t0) / 100
+    last = [step().item() for _ in range(5)]
+    print("train step on Cora structure: eager %.3f ms, hipGraph replay %.3f ms" % (t_eager * 1e3, t_graph * 1e3))
+    assert np.isfinite(last).all() and np.mean(last) < 0.8 * np.mean(first), (first, last)
+    assert len({round(v, 6) for v in last}) > 1                        # fresh dropout bits per replay
+    assert t_graph < 0.7 * t_eager, (t_eager, t_graph)
