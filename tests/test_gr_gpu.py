@@ -166,6 +166,43 @@ def test_mmaconv_forward_backward_vs_oracle(cfg, p):
     assert all(g is not None for g in gg)
 
 
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_mmaconv_fused_hub_and_medium_degrees(p):
+    """Fused message path on a graph that exercises every segment shape of the group-per-node kernels and the wave-per-node
+    pass behind them: one target with 200 in-edges (> 64: wave pass), degrees 5..24 (in-loop index loads), empty targets."""
+    from mma_amd import functional as Fn
+    from oracle import gr_oracle as G
+    from oracle.dropout_rng import keep_mask
+    rng = np.random.default_rng(11)
+    N, T, F = 300, 2, 8
+    deg = rng.integers(0, 25, N); deg[7] = 200; deg[-5:] = 0
+    dst = np.repeat(np.arange(N), deg)
+    src = rng.integers(0, N, len(dst))
+    perm = rng.permutation(len(dst))                       # unsorted edge list, as PyG hands it over
+    ei = np.stack([src[perm], dst[perm]])
+    E = ei.shape[1]
+    assert E <= 16 * N
+    conv = make_conv(["min", "max", "sum", "mean"], ["identity", "attenuation"], towers=T, F=F, edge_dim=5)
+    x = rng.standard_normal((N, conv.in_channels)).astype(np.float32)
+    ea = rng.standard_normal((E, 5)).astype(np.float32)
+    cot = rng.standard_normal((N, conv.out_channels)).astype(np.float32)
+    seed = 0xABCDEF0123
+    conv.drop_override = Fn.DropoutSpec(p, seed=seed)
+    keep = None
+    if p > 0:
+        Fw = conv.fused_width()
+        keep = torch.from_numpy(keep_mask(seed, int(p * 256), 1, E, T * Fw)[0].reshape(E, T, Fw)[:, :, :F].astype(np.float32))
+    xo = torch.from_numpy(x).requires_grad_(True)
+    want = G.conv_forward(xo, torch.from_numpy(ei), torch.from_numpy(ea), conv_params(conv), conv.aggregators, conv.scalers,
+                          conv.avg_deg, T, False, keep, p)
+    gw, = torch.autograd.grad((want * torch.from_numpy(cot)).sum(), [xo])
+    xg = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    got = conv(xg, torch.from_numpy(ei).to(DEV), torch.from_numpy(ea).to(DEV))
+    gg, = torch.autograd.grad((got * torch.from_numpy(cot).to(DEV)).sum(), [xg])
+    check_close(got, want.detach().numpy(), None, None, what="hub conv out", signed_sum=True)
+    check_close(gg, gw.numpy(), None, None, what="hub conv gx", signed_sum=True)
+
+
 def test_only_last_aggregators_mask_is_used():     # G1
     conv = make_conv(["min", "max"], ["identity"], towers=2, F=4, edge_dim=3)
     from mma_amd import functional as Fn
