@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Turn the raw rocprofv3 output of scratch/prof_all.sh (gpurun_out/prof_stats, prof_fetch, prof_write, bench_default.log)
-and scratch/prof_gr.sh (gpurun_out/prof_gr) into the committed summaries under profiles/:
+"""Turn the raw rocprofv3 output of tools/profile_round.sh (gpurun_out/prof_stats, prof_fetch, prof_write, prof_gr, bench_default.log)
+into the committed summaries under profiles/:
 
     python tools/make_profiles.py <tag>          # e.g. r01_v4
 
@@ -78,7 +78,7 @@ def main():
     except SystemExit:
         return
     ms = stats_table(g, 35, "rocprofv3 --kernel-trace --stats, GR layer on the 10 000-graph batch (C2L), round %s, build %s" % (rnd[1:], ver),
-                     "rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_gr -- python scratch/gr_prof.py  (= tools/bench_configs.gr_config('C2L', 10000))",
+                     "rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_gr -- python tools/gr_c2l_step.py",
                      "Workload: MMAConv 75->75, towers=5, edge_dim=50, aggregators [min,max], scalers [identity,amplification,linear] on 10 000 "
                      "ZINC-like molecules (204,552 nodes / 427,376 edges); 35 layer forward+backward calls.",
                      os.path.join(P, "%s_gr_c2l_kernel_stats_%s.md" % (rnd, ver)))
