@@ -6,7 +6,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMA_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "libmma_amd.so")   # override: A/B builds in development
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c = ctypes
 _P, _I64, _I32, _U32, _U64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_uint64
@@ -31,6 +31,7 @@ PROTOTYPES = {
     "mma_unpack_add_rows": [_P, _I64, _P, _I64, _P, _I64, _I32, _P],
     "mma_col_sum": [_P, _I64, _I64, _I32, _P, _P, _I64, _P],
     "mma_gemm_bf16x3_tn": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P],
+    "mma_tower_linear_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P],
 }
 
 _lib = None
@@ -57,6 +58,7 @@ def lib():
         L.mma_csr_workspace_bytes.argtypes, L.mma_csr_workspace_bytes.restype = [_I64, _I64], _I64
         L.mma_col_sum_workspace_floats.argtypes, L.mma_col_sum_workspace_floats.restype = [_I64, _I32], _I64
         L.mma_gemm_bf16x3_tn_workspace_floats.argtypes, L.mma_gemm_bf16x3_tn_workspace_floats.restype = [_I64, _I32, _I32], _I64
+        L.mma_tower_linear_bwd_blocks.argtypes, L.mma_tower_linear_bwd_blocks.restype = [_I64], _I64
         for name, args in PROTOTYPES.items():
             fn = getattr(L, name)  # AttributeError if a declared symbol is missing
             fn.argtypes, fn.restype = args, _I32

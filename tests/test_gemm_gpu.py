@@ -95,3 +95,24 @@ def test_gemm_bf16x3_tn_accuracy(M, KA, NC, padx, padg):
     e_f32 = ((f32.double() - ref).abs() / scale).max().item()
     assert got.shape == (KA, NC) and e_got < 5e-7 and e_got < 1.5 * e_f32 + 1e-7, (e_got, e_f32)
     assert torch.equal(dense.gemm_bf16x3_tn(x, g), got)
+
+
+@pytest.mark.parametrize("N,T,O,C", [(1, 1, 1, 4), (7, 2, 3, 12), (1000, 5, 15, 456), (70001, 3, 16, 260), (513, 1, 15, 456)])
+def test_tower_linear_backward(N, T, O, C):
+    """K9: both gradients of y[n,t,:] = a[n,t,:] W[t]^T in one pass over `a`, against an fp64 einsum; repeatable."""
+    from mma_amd import dense
+    rng = np.random.default_rng(N + T + O + C)
+    a = torch.from_numpy(rng.standard_normal((N, T, C)).astype(np.float32)).to(DEV).requires_grad_(True)
+    W = torch.from_numpy((rng.standard_normal((T, O, C)) * 0.1).astype(np.float32)).to(DEV).requires_grad_(True)
+    cot = torch.from_numpy(rng.standard_normal((N, T, O)).astype(np.float32)).to(DEV)
+    y = dense.tower_linear(a, W)
+    ga, gW = torch.autograd.grad((y * cot).sum(), [a, W])
+    yd = torch.einsum('ntc,toc->nto', a.double(), W.double())
+    assert torch.allclose(y.double(), yd, rtol=1e-5, atol=1e-5)
+    ga_ref = torch.einsum('nto,toc->ntc', cot.double(), W.double())
+    gW_ref = torch.einsum('nto,ntc->toc', cot.double(), a.double())
+    assert (ga.double() - ga_ref).abs().max().item() <= 1e-6 * (cot.double().abs().unsqueeze(-1) * W.double().abs().unsqueeze(0)).sum(2).max().item() + 1e-30
+    scale = torch.einsum('nto,ntc->toc', cot.double().abs(), a.double().abs())
+    assert bool(((gW.double() - gW_ref).abs() <= 2e-6 * scale + 1e-30).all())
+    ga2, gW2 = torch.autograd.grad((dense.tower_linear(a, W) * cot).sum(), [a, W])
+    assert torch.equal(ga, ga2) and torch.equal(gW, gW2)
