@@ -6,8 +6,8 @@
 //     10 000-molecule batch (rocBLAS reaches ~15 TFLOP/s on them), while the data is 1.9 GB in and 1.9 GB out.
 // A thread owns 4 consecutive columns c of one tower and keeps W[t, :, c..c+3] (O x 4 floats) and its gW partial (O x 4)
 // in registers; per node it reads 16 B of `a`, the wave reads the node's O gradient values with ONE 64-byte load and hands
-// them out with v_readlane (SGPR operands), 2 x O x 4 FMAs, one 16-byte store.  The 4 waves of a workgroup walk different
-// nodes of the same (tower, column chunk) and fold their partials in wave order through LDS (deterministic).
+// them out with v_readlane (SGPR operands), 2 x O x 4 FMAs, one 16-byte store.  The 4 waves of a workgroup take adjacent
+// (tower, column chunk) pieces of the same nodes; the node blocks' partial gW tiles are summed by K8 in a fixed order.
 #include "common.h"
 
 namespace mma {
@@ -21,11 +21,14 @@ struct TowerParams {
 };
 
 __global__ __launch_bounds__(kBlock) void tower_bwd_kernel(const TowerParams p) {
-  __shared__ float4 fold[kTowerMaxO][kWave];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int chunks = (p.C / 4 + kWave - 1) / kWave;
-  const int t = (int)blockIdx.y / chunks, chunk = (int)blockIdx.y % chunks;
+  // the 4 waves of a workgroup take 4 consecutive (tower, 256-column chunk) pieces of the SAME nodes: together they stream
+  // 4 KB of contiguous memory per node instead of four 1 KB pieces that are T*C floats apart
+  const int piece = (int)blockIdx.y * (kBlock / kWave) + wave;
+  if (piece >= p.T * chunks) return;
+  const int t = piece / chunks, chunk = piece % chunks;
   const int c = (chunk * kWave + lane) * 4;
   const bool valid = c < p.C;
   const int cc = valid ? c : 0;
@@ -39,53 +42,55 @@ __global__ __launch_bounds__(kBlock) void tower_bwd_kernel(const TowerParams p) 
   const int64_t n1 = min(p.N, n0 + p.nodes_per_block);
   const size_t row = (size_t)p.T * p.C, grow = (size_t)p.T * p.O;
   const float* ap = p.a + (size_t)t * p.C + cc;
-  const float* gp = p.gy + (size_t)t * p.O + (lane < p.O ? lane : 0);
   float* op = p.ga + (size_t)t * p.C + cc;
-  // one node ahead: its loads are in flight while the current node's FMAs issue
-  int64_t n = n0 + wave;
-  float gv = 0.f;
-  float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (n < n1) { gv = gp[n * grow]; av = *reinterpret_cast<const float4*>(ap + n * row); }
-  for (; n < n1; n += kBlock / kWave) {
-    const int64_t nn = n + kBlock / kWave;
-    float gnext = 0.f;
-    float4 anext = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nn < n1) { gnext = gp[nn * grow]; anext = *reinterpret_cast<const float4*>(ap + nn * row); }
-    const float gl = lane < p.O ? gv : 0.f;
-    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* gp = p.gy + (size_t)t * p.O + (lane < p.O ? lane : 0);
+  // kU nodes per step and one step ahead: 2 x kU 16-byte loads per lane in flight (one node at a time left the kernel
+  // latency-bound at 3.2 TB/s).  A node's O gradient values arrive with ONE 64-byte load and are handed out by v_readlane.
+  constexpr int kU = 4, kStride = 1;
+  float gv[kU];
+  float4 av[kU];
 #pragma unroll
-    for (int o = 0; o < kTowerMaxO; ++o) {     // lanes >= O hold 0 and their w rows are 0: the unused steps add exact zeros
-      const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), o));   // the builtin is typed int
-      out.x = fmaf(g, w[o].x, out.x); out.y = fmaf(g, w[o].y, out.y); out.z = fmaf(g, w[o].z, out.z); out.w = fmaf(g, w[o].w, out.w);
-      acc[o].x = fmaf(g, av.x, acc[o].x); acc[o].y = fmaf(g, av.y, acc[o].y);
-      acc[o].z = fmaf(g, av.z, acc[o].z); acc[o].w = fmaf(g, av.w, acc[o].w);
-    }
-    if (valid) *reinterpret_cast<float4*>(op + n * row) = out;
-    gv = gnext; av = anext;
+  for (int u = 0; u < kU; ++u) {
+    const int64_t m = n0 + (int64_t)u * kStride;
+    gv[u] = 0.f; av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < n1) { gv[u] = gp[m * grow]; av[u] = *reinterpret_cast<const float4*>(ap + m * row); }
   }
-  // fold the four waves' partials in wave order (fixed => bitwise repeatable), then one partial tile per workgroup
-  for (int wv = 0; wv < kBlock / kWave; ++wv) {
-    if (wave == wv) {
+  for (int64_t n = n0; n < n1; n += (int64_t)kU * kStride) {
+    float gnext[kU];
+    float4 anext[kU];
 #pragma unroll
-      for (int o = 0; o < kTowerMaxO; ++o) {
-        if (wv == 0) fold[o][lane] = acc[o];
-        else {
-          float4 f = fold[o][lane];
-          f.x += acc[o].x; f.y += acc[o].y; f.z += acc[o].z; f.w += acc[o].w;
-          fold[o][lane] = f;
+    for (int u = 0; u < kU; ++u) {
+      const int64_t m = n + (int64_t)(kU + u) * kStride;
+      gnext[u] = 0.f; anext[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < n1) { gnext[u] = gp[m * grow]; anext[u] = *reinterpret_cast<const float4*>(ap + m * row); }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t m = n + (int64_t)u * kStride;
+      if (m < n1) {                                   // wave-uniform
+        const float gl = lane < p.O ? gv[u] : 0.f;
+        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < kTowerMaxO; ++o) {       // lanes >= O hold 0 and their w rows are 0: the unused steps add exact zeros
+          const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), o));   // the builtin is typed int
+          out.x = fmaf(g, w[o].x, out.x); out.y = fmaf(g, w[o].y, out.y); out.z = fmaf(g, w[o].z, out.z); out.w = fmaf(g, w[o].w, out.w);
+          acc[o].x = fmaf(g, av[u].x, acc[o].x); acc[o].y = fmaf(g, av[u].y, acc[o].y);
+          acc[o].z = fmaf(g, av[u].z, acc[o].z); acc[o].w = fmaf(g, av[u].w, acc[o].w);
         }
+        if (valid) *reinterpret_cast<float4*>(op + m * row) = out;
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { gv[u] = gnext[u]; av[u] = anext[u]; }
   }
-  if (wave == 0 && valid) {
+  if (valid) {       // one partial tile per (node block, piece); K8 sums the node blocks in a fixed order
     float* q = p.part + ((size_t)blockIdx.x * p.T + t) * p.O * p.C + c;
-    for (int o = 0; o < p.O; ++o) *reinterpret_cast<float4*>(q + (size_t)o * p.C) = fold[o][lane];
+    for (int o = 0; o < p.O; ++o) *reinterpret_cast<float4*>(q + (size_t)o * p.C) = acc[o];
   }
 }
 
 static int64_t tower_blocks(int64_t N) {
-  int64_t b = (N + 255) / 256;            // at least 64 nodes per wave
+  int64_t b = (N + 63) / 64;              // at least 64 nodes per wave
   if (b > 512) b = 512;
   return b < 1 ? 1 : b;
 }
@@ -108,7 +113,7 @@ extern "C" int mma_tower_linear_bwd(const float* gy, const float* a, const float
   TowerParams p{gy, a, W, ga, part, N, (N + n_blocks - 1) / n_blocks, T, O, C};
   const int chunks = (C / 4 + kWave - 1) / kWave;
   MMA_REQUIRE((int64_t)T * chunks < 65536, "T * column chunks too large");
-  hipLaunchKernelGGL(tower_bwd_kernel, dim3((unsigned)n_blocks, (unsigned)(T * chunks)), dim3(kBlock), 0,
+  hipLaunchKernelGGL(tower_bwd_kernel, dim3((unsigned)n_blocks, (unsigned)((T * chunks + 3) / 4)), dim3(kBlock), 0,
                      static_cast<hipStream_t>(stream), p);
   return check_launch("tower_bwd_kernel");
 }
