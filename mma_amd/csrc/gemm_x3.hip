@@ -7,10 +7,14 @@
 // piece products that matter,   a b ~= a1b3 + a2b2 + a3b1 + a1b2 + a2b1 + a1b1   (dropped terms < 2^-24 |ab|),
 // every piece product being exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  The result is as accurate as
 // an fp32 GEMM (measured max error 2.4e-7 vs 3.0e-7 for the fp32 library GEMM, both relative to sum|a||b| against
-// fp64) at 6/16 of its matrix-core time.  Measured (C4, M = 2^20): 1.06 ms per (M,128)x(128,512) or (M,512)x(512,128)
-// product vs 1.3-1.45 ms for rocBLAS fp32; PMC: MFMA pipe 51 % busy at a 1.6 GHz effective clock - the A load/split,
-// MFMA and C-store phases of a workgroup still run back to back (ablation: 0.2 + 0.5 + 0.35 ms), which is the next
-// thing to fix (LDS-DMA slabs to free 24 VGPRs for a second accumulator so stores drain under the next tile's MFMAs).
+// fp64) at 6/16 of its matrix-core time.  Measured in situ (C4, M = 2^20): 1.60 ms for (M,128)x(128,1024), 1.55 ms for
+// (M,1024)x(1024,128), vs 2.1-2.6 ms for rocBLAS fp32; matrix pipe ~50 % busy.
+// What was measured about the remaining half (round 1, so that the next attempt does not repeat it): s_memtime stamps put
+// 26 % of a tile in the issue of the 16 C stores and 23 % in the issue of the 6 slab loads queued behind them (K == 128
+// form); turning the tile through LDS into 4 dwordx4 stores changes nothing (the wait is the write bandwidth, 4.3 GB, not
+// the instruction count: without any store the kernel still takes 1.43 ms); prefetching the next K chunk of A in the
+// persistent form changes nothing; -fno-slp-vectorize changes nothing; two independent workgroups per CU beat one 8-wave
+// workgroup with explicit multiply / split roles.
 //
 // Layout: one workgroup = 4 waves = 128 rows of A; a wave keeps its 32 rows x 128 k of A in registers, already split
 // (3 x 8 k-steps x 8 bf16 = 96 VGPRs) and walks the 32-column tiles of B; the three bf16 pieces of the B tile
