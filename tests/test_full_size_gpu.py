@@ -88,3 +88,48 @@ def test_c4_full_size_properties_and_sample_parity():
     assert gx[mask].abs().max().item() == 0.0
     for n, a, b in zip(names, grads[1:], go[1:]):
         check_close(a, b.numpy(), None, None, what="C4 sample gW/" + n, signed_sum=True)
+
+
+def test_c2l_full_batch_properties_and_sample_parity():
+    """The GR layer at full scale (the whole ZINC-subset split as ONE batch: 10 000 molecules, ~2e5 nodes / ~4.3e5 edges,
+    MMAConv 75->75, towers=5, edge_dim=50, [min,max] x [identity,amplification,linear], always-on dropout): bitwise
+    repeatable, and - molecules being independent components laid out one after the other - the rows of the first 40
+    molecules must equal the CPU oracle run on those 40 molecules alone (same edge positions => same dropout bits),
+    forward and backward."""
+    import mma_amd
+    from mma_amd import functional as Fn
+    from oracle import gr_oracle as G
+    from oracle.dropout_rng import keep_mask
+    from test_gr_gpu import conv_params, molecule_batch
+    rng = np.random.default_rng(5)
+    ei, N, sizes = molecule_batch(rng, 10000, return_sizes=True)
+    E = ei.shape[1]
+    T, F, p, seed = 5, 75, 0.5, 0x2121ABCD77
+    hist = np.bincount(np.bincount(ei[1], minlength=N), minlength=5)
+    torch.manual_seed(3)
+    conv = mma_amd.MMAConv(75, 75, ["min", "max"], ["identity", "amplification", "linear"], torch.tensor(hist), edge_dim=50,
+                           towers=T).to(DEV)
+    conv.drop_override = Fn.DropoutSpec(p, seed=seed)
+    x = rng.standard_normal((N, 75)).astype(np.float32)
+    ea = rng.standard_normal((E, 50)).astype(np.float32)
+    cot = rng.standard_normal((N, 75)).astype(np.float32)
+    xg = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    eig, eag, cg = torch.from_numpy(ei).to(DEV), torch.from_numpy(ea).to(DEV), torch.from_numpy(cot).to(DEV)
+    out = conv(xg, eig, eag)
+    gx, = torch.autograd.grad((out * cg).sum(), [xg])
+    out2 = conv(xg, eig, eag)
+    gx2, = torch.autograd.grad((out2 * cg).sum(), [xg])
+    assert torch.equal(out, out2) and torch.equal(gx, gx2)                 # no atomics, fixed reduction orders
+    assert torch.isfinite(out).all() and torch.isfinite(gx).all()
+    # the first 40 molecules as their own batch on the CPU oracle
+    n_s = int(sizes[:40].sum())
+    e_s = int((ei[1] < n_s).sum())
+    assert (ei[:, :e_s] < n_s).all() and (ei[:, e_s:] >= n_s).all()       # components are laid out one after the other
+    Fw = conv.fused_width()
+    keep = torch.from_numpy(keep_mask(seed, int(p * 256), 1, e_s, T * Fw)[0].reshape(e_s, T, Fw)[:, :, :F].astype(np.float32))
+    xo = torch.from_numpy(x[:n_s]).requires_grad_(True)
+    want = G.conv_forward(xo, torch.from_numpy(ei[:, :e_s]), torch.from_numpy(ea[:e_s]), conv_params(conv), conv.aggregators,
+                          conv.scalers, conv.avg_deg, T, False, keep, p)
+    gw, = torch.autograd.grad((want * torch.from_numpy(cot[:n_s])).sum(), [xo])
+    check_close(out[:n_s], want.detach().numpy(), None, None, what="C2L sample out", signed_sum=True)
+    check_close(gx[:n_s], gw.numpy(), None, None, what="C2L sample gx", signed_sum=True)
