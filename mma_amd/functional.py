@@ -1,6 +1,5 @@
 """autograd wrappers over the C ABI (include/mma_amd.h).  Tensors are plumbing: every FLOP and byte of the
 hot path moves inside libmma_amd.so; torch only owns the memory, the stream and the autograd tape."""
-import math
 
 import torch
 

@@ -13,7 +13,6 @@ Parameters stay owned by the caller (models.py:17-60 creates them and the optimi
 """
 import math
 
-import numpy as np
 import torch
 from torch.nn.modules.module import Module
 

@@ -19,7 +19,6 @@ line on top of the PUBLISHED semantics of the third-party calls at the reference
 It is anchored by hand-computed known-answer tests (tests/test_gr_oracle.py): ties -> lowest edge id, empty target -> 0,
 compounding scalers, avg_deg from the histogram tensor itself, only the LAST aggregator's pre-Linear applied.
 """
-import math
 
 import torch
 
