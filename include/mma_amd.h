@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 11
+#define MMA_ABI_VERSION 12
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -149,7 +149,7 @@ int mma_csr_spmm_items(
  * matrix.  Requires N % 32 == 0, K % 128 == 0 and (K == 128 or N <= 128). */
 int mma_split_bf16x3(const float* in, int64_t n, void* out_3n_bf16, void* stream);
 int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, float* C, int64_t ldc,
-                    int64_t M, int32_t N, int32_t K, void* stream);
+                    int64_t M, int32_t N, int32_t K, int32_t accumulate /* 0: C = A B, 1: C += A B */, void* stream);
 /* TN form for the weight gradients (autograd's x^T g of layers.py:215-216's torch.mm): C (KA,NC) = X^T G with X (M,KA),
  * G (M,NC) fp32 row-major, C contiguous.  KA in {32,64,96,128}, NC % 32 == 0.  Both operands are split to bf16x3 on the
  * fly; the reduction over M runs in fixed row ranges whose partial tiles (ws) are summed in a fixed order.

@@ -36,6 +36,7 @@ struct GemmParams {
   const __bf16* Bt;          // (3, N, K) bf16: piece p of B^T, k contiguous
   float* C; int64_t ldc;
   int64_t M; int N, K;
+  int accumulate;            // C += A B instead of C = A B (the tile's old values are fetched before its MFMAs start)
 };
 
 struct Bf3 { __bf16 a, b, c; };
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_kernel(const GemmParams p, 
         float* cp = p.C + (size_t)((CT_) * 32 + r31);                                                        \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                     \
           const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;                                         \
-          if (FULL || row < p.M) cp[row * p.ldc] = C_[r];                                                    \
+          if (FULL || row < p.M) cp[row * p.ldc] = p.accumulate ? cp[row * p.ldc] + C_[r] : C_[r];           \
         }                                                                                                    \
       }                                                                                                      \
       /* raw barrier: __syncthreads() would also drain vmcnt, i.e. wait for the C stores to reach memory */         \
@@ -424,7 +425,7 @@ extern "C" int mma_split_bf16x3(const float* in, int64_t n, void* out, void* str
 }
 
 extern "C" int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, float* C, int64_t ldc, int64_t M, int32_t N, int32_t K,
-                               void* stream) {
+                               int32_t accumulate, void* stream) {
   MMA_REQUIRE(M >= 0 && N >= 32 && K >= kKC && N % 32 == 0 && K % kKC == 0, "M=%lld N=%d K=%d: need N %% 32 == 0, K %% 128 == 0",
               (long long)M, N, K);
   MMA_REQUIRE(K == kKC || N <= 128, "either K == 128 or N <= 128 (accumulator tiles live in registers)");
@@ -432,7 +433,7 @@ extern "C" int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, flo
   if (M == 0) return 0;
   MMA_REQUIRE(A && Bt3 && C && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt3) & 15) == 0,
               "NULL or misaligned argument");
-  GemmParams p{A, lda, static_cast<const __bf16*>(Bt3), C, ldc, M, N, K};
+  GemmParams p{A, lda, static_cast<const __bf16*>(Bt3), C, ldc, M, N, K, accumulate ? 1 : 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nct = K == kKC ? 0 : N / 32;
   const int64_t n_full = M / 128;

@@ -21,9 +21,9 @@ def _x3_ok(a, w):
             and N % 32 == 0 and K % 128 == 0 and (K == 128 or N <= 128))
 
 
-def gemm_bf16x3(a, w, out=None):
+def gemm_bf16x3(a, w, out=None, accumulate=False):
     """a (M,K) @ w (K,N) with fp32 accuracy on the bf16 MFMA path (three-piece split of both operands).  `a` may be a
-    row-strided view (a column block of a wider buffer)."""
+    row-strided view (a column block of a wider buffer); accumulate=True adds the product to `out`."""
     if a.stride(1) != 1 or a.stride(0) % 4 or a.data_ptr() % 16:
         a = a.contiguous()
     M, K = a.shape
@@ -31,10 +31,11 @@ def gemm_bf16x3(a, w, out=None):
     wt = w.t().contiguous()                                  # (N,K): B^T, k contiguous
     bt3 = torch.empty((3, N, K), device=a.device, dtype=torch.bfloat16)
     call("mma_split_bf16x3", ptr(wt), N * K, ptr(bt3), stream_ptr())
+    assert out is not None or not accumulate
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
-    call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(bt3), ptr(out), out.stride(0), M, N, K, stream_ptr())
+    call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(bt3), ptr(out), out.stride(0), M, N, K, 1 if accumulate else 0, stream_ptr())
     return out
 
 
@@ -50,6 +51,15 @@ def mm_into(a, w, out):
 def rows_mm(a, w):
     """a @ w for tall a, no autograd (bf16x3 kernel or row-batched library GEMM)."""
     return _rows_mm(a, w)
+
+
+def rows_mm_add_(acc, a, w):
+    """acc += a @ w in place (no autograd): the bf16x3 kernel folds the addition into its epilogue."""
+    if a.shape[0] == 0:
+        return acc
+    if _x3_ok(a, w) and acc.stride(1) == 1:
+        return gemm_bf16x3(a, w, acc, accumulate=True)
+    return acc.add_(_rows_mm(a, w))
 
 
 def _rows_mm(a, w):

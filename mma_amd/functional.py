@@ -185,7 +185,7 @@ class _NCLocalLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        from .dense import rows_mm, xt_g
+        from .dense import rows_mm_add_, xt_g
         graph, kinds, acts, drop = ctx.graph, ctx.kinds, ctx.acts, ctx.drop
         x, PQ, T, sel, wcat = ctx.saved_tensors
         N, H = x.shape
@@ -198,7 +198,7 @@ class _NCLocalLayer(torch.autograd.Function):
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=g.device, dtype=torch.float32)
                    if graph.t_n_slots else None)
         nc_bwd_edges_launch(x, PQ[:, :KH], PQ[:, KH:], gs, aux, ldaux, gxs, graph, kinds, acts, drop, gPQ[:, KH:], gx, partial)
-        gx = gx + rows_mm(gPQ, wcat.t())                                     # direct + through P and Q in one GEMM
+        rows_mm_add_(gx, gPQ, wcat.t())                                      # direct + through P and Q in one GEMM (C += A B)
         gw = xt_g(x, gPQ) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
         return gx, (gw[:, :KH] if gw is not None else None), (gw[:, KH:] if gw is not None else None), None, None, None, None
 

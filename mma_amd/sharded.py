@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import functional as Fn
-from .dense import mm, mm_into, rows_mm, xt_g
+from .dense import mm, mm_into, rows_mm_add_, xt_g
 from ._lib import call, ptr, require_gpu, stream_ptr
 from .graph import DEFAULT_CHUNK, NCGraph, SpmmGraph
 from .layers import _AGG
@@ -226,12 +226,12 @@ class _ShardedAggregate(torch.autograd.Function):
         if S > n:
             halo_part, own_part = graph.t_parts
             Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, halo_part)
-            gxh = gx[n:] + rows_mm(gQ[n:], wbot.t())          # dL/dx of the halo rows: direct + through Q = x Wbot
+            gxh = rows_mm_add_(gx[n:], gQ[n:], wbot.t())      # dL/dx of the halo rows: direct + through Q = x Wbot
             back = all_to_all_rows_start(gxh, plan.recv_counts, plan.send_counts, plan.group)
             Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, own_part)
         else:
             Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial)
-        gx_own = gx[:n] + rows_mm(gPQ[:n], wcat.t())             # direct + through P and Q of the own rows in one GEMM
+        gx_own = rows_mm_add_(gx[:n], gPQ[:n], wcat.t())         # direct + through P and Q of the own rows in one GEMM
         gwtop = gwbot = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             gw = xt_g(x_src[:n], gPQ[:n])                        # (H, 2KH) = [dL/dWtop | own part of dL/dWbot]

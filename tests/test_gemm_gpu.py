@@ -116,3 +116,20 @@ def test_tower_linear_backward(N, T, O, C):
     assert bool(((gW.double() - gW_ref).abs() <= 2e-6 * scale + 1e-30).all())
     ga2, gW2 = torch.autograd.grad((dense.tower_linear(a, W) * cot).sum(), [a, W])
     assert torch.equal(ga, ga2) and torch.equal(gW, gW2)
+
+
+@pytest.mark.parametrize("M,K,N", [(5000, 128, 512), (4099, 512, 128), (9001, 1024, 128)])
+def test_gemm_bf16x3_accumulate(M, K, N):
+    """accumulate=True: C += A B in the kernel epilogue (used for dL/dx = direct part + g [Wtop|Wbot]^T)."""
+    from mma_amd import dense
+    rng = np.random.default_rng(M + K + N + 1)
+    a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(DEV)
+    w = torch.from_numpy(((rng.random((K, N)) * 2 - 1) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    c0 = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV)
+    plain = dense.gemm_bf16x3(a, w)
+    acc = c0.clone()
+    got = dense.rows_mm_add_(acc, a, w)
+    assert got.data_ptr() == acc.data_ptr()
+    assert torch.equal(acc, c0 + plain)                       # one fp32 addition on top of the same product
+    ref = c0.double() + a.double() @ w.double()
+    assert (acc.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
