@@ -309,6 +309,11 @@ class ShardedMMA(torch.nn.Module):
         return Fn.csr_spmm(torch.cat([S, S_halo], 0), self.bias, self.sg, 1)
 
     def allreduce_grads(self):
-        for p in self.owned:
-            if p.grad is not None:
-                all_reduce_sum(p.grad, self.plan.group)
+        """Sum the parameter gradients over the ranks: ONE collective on a flat bucket (six tiny all-reduces cost six
+        collective latencies per step, which at 8 ranks is a tenth of the step)."""
+        grads = [p.grad for p in self.owned if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        all_reduce_sum(flat, self.plan.group)
+        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
