@@ -11,8 +11,8 @@
 // (M,1024)x(1024,128), vs 2.1-2.6 ms for rocBLAS fp32; matrix pipe ~50 % busy.
 // What was measured about the remaining half (round 1, so that the next attempt does not repeat it): s_memtime stamps put
 // 26 % of a tile in the issue of the 16 C stores and 23 % in the issue of the 6 slab loads queued behind them (K == 128
-// form); turning the tile through LDS into 4 dwordx4 stores changes nothing (the wait is the write bandwidth, 4.3 GB, not
-// the instruction count: without any store the kernel still takes 1.43 ms); prefetching the next K chunk of A in the
+// form); turning the tile through LDS into 4 dwordx4 stores changes nothing (the wait is the 4.3 GB themselves - 0.63 ms
+// at the 6.8 TB/s a plain fill reaches - not the instruction count; without any store the kernel still takes 1.43 ms); prefetching the next K chunk of A in the
 // persistent form changes nothing; -fno-slp-vectorize changes nothing; two independent workgroups per CU beat one 8-wave
 // workgroup with explicit multiply / split roles.
 //
