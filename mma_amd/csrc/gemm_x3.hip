@@ -218,7 +218,8 @@ __global__ void split3_kernel(const float* in, int64_t n, __bf16* out) {
 // (PMC; G once + X once thanks to the XCD-local ids), matrix pipe 53 % busy.  Ablations: MFMAs + fragment reads alone
 // 1.1 ms, loads + split alone 0.9 ms.  Tried and not faster: 8-wave workgroups whose two halves alternate multiply /
 // split roles (2.2 ms; LDS-bound once X is staged as well), 64 x 64 wave tiles with both operands through LDS and
-// dwordx4 loads (1.8 ms), -fno-slp-vectorize.  All three bf16x3 kernels of this file land at ~1.7 ms per 275 GFLOP:
+// dwordx4 loads (1.8 ms), dwordx2 G loads with interleaved column tiles (half the G load instructions: no change),
+// -fno-slp-vectorize.  All three bf16x3 kernels of this file land at ~1.7 ms per 275 GFLOP:
 // the per-value split (6.5 VALU ops, 4 issue cycles each, against 24 free issue cycles per 32-cycle MFMA) is what the
 // three-piece scheme costs on top of its 6x MFMA count.
 struct TnParams {
