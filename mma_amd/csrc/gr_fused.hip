@@ -2,7 +2,7 @@
 //
 // K3 fuses, for one target node per wavefront, what the reference does with ~K+12 launches:
 //   message  h_e = drop( U[i] + V[j] + Z[e] )            (= per-tower Linear([x_i || x_j || enc(e_ij)]) + dropout,
-//                                                          mma_conv.py:138-157, split as three dense GEMMs)
+//                                                          mma_conv.py:138-157, split into dense GEMMs)
 //   K x torch_scatter.scatter(h, index, reduce)           sum / mean / min(+arg) / max(+arg) / var / std  (:164-172)
 //   degree + compounding scalers + final layout           (:176-196)  out[n, t, s*K*F + k*F + f]
 // in ONE pass over the node's target-sorted edge segment.  Edges are sorted by target with a STABLE radix sort

@@ -2,9 +2,10 @@
 
 Same constructor, `forward(x, edge_index, edge_attr=None)`, `message`, `aggregate(inputs, index, dim_size=None)`,
 public `dropout` attribute and error behaviour, without torch_geometric / torch_scatter.  forward() runs the fused
-HIP path: three dense GEMMs (U = x W_i^T + b, V = x W_j^T, Z = enc(e) W_e^T) and ONE kernel that forms the per-edge
-message, applies the always-on dropout and reduces all K aggregators with their degree scalers (K3); `aggregate()`
-on given messages uses the same kernel.  Reference quirks kept:
+HIP path: two dense GEMMs ([U | V] = x [W_i | W_j]^T + [b | 0] for all towers at once, Z = e (W_e W_enc)^T + W_e b_enc with
+the edge encoder folded in) and ONE kernel that forms the per-edge message U[i] + V[j] + Z[e], applies the always-on
+dropout and reduces all K aggregators with their degree scalers (K3); the post-NN runs as one batched GEMM forward and
+the K9 kernel backward; `aggregate()` on given messages uses the same K3.  Reference quirks kept:
   G1  only the LAST aggregator's pre_nns is applied; all K aggregators reduce the same message;
   G2  pre_nns is a plain dict of ModuleLists => mask Linears are unregistered (not in parameters()/state_dict);
   G3  reset_parameters() iterates dict keys => no-op for pre_nns;   G4  dropout p=0.5 hard-coded, always on;
