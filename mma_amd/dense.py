@@ -16,9 +16,11 @@ _MIN_ROWS_X3 = 4096
 
 
 def _x3_ok(a, w):
+    """The kernel takes K == 128 with any N, or any K % 128 == 0 with N <= 128 (accumulator tiles live in registers); a
+    product with both K > 128 and N > 128 (hidden width 256: C5) is run as N/128 column blocks of the second form."""
     K, N = w.shape
     return (USE_BF16X3 and a.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32 and a.shape[0] >= _MIN_ROWS_X3
-            and N % 32 == 0 and K % 128 == 0 and (K == 128 or N <= 128))
+            and N % 32 == 0 and K % 128 == 0 and (K == 128 or N <= 128 or N % 128 == 0))
 
 
 def gemm_bf16x3(a, w, out=None, accumulate=False):
@@ -35,7 +37,13 @@ def gemm_bf16x3(a, w, out=None, accumulate=False):
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
-    call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(bt3), ptr(out), out.stride(0), M, N, K, 1 if accumulate else 0, stream_ptr())
+    acc = 1 if accumulate else 0
+    if K == 128 or N <= 128:
+        call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(bt3), ptr(out), out.stride(0), M, N, K, acc, stream_ptr())
+    else:                                                    # K > 128 and N > 128: one launch per 128-column block of the output
+        for j in range(0, N, 128):
+            blk = bt3[:, j:j + 128].contiguous()             # (3,128,K): the kernel's piece stride is its own N * K
+            call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(blk), ptr(out[:, j:j + 128]), out.stride(0), M, 128, K, acc, stream_ptr())
     return out
 
 
@@ -99,8 +107,10 @@ class _MM(torch.autograd.Function):
 
 
 def _x3_tn_ok(x, g):
+    """The kernel takes up to 128 x columns; wider x (hidden width 256: C5) runs as 128-column blocks of x."""
+    KA = x.shape[1]
     return (USE_BF16X3 and x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32 and x.shape[0] >= _MIN_ROWS_X3
-            and x.shape[1] in (32, 64, 96, 128) and g.shape[1] % 32 == 0 and x.stride(1) == 1 and g.stride(1) == 1)
+            and (KA in (32, 64, 96, 128) or KA % 128 == 0) and g.shape[1] % 32 == 0 and x.stride(1) == 1 and g.stride(1) == 1)
 
 
 def gemm_bf16x3_tn(x, g):
@@ -108,9 +118,12 @@ def gemm_bf16x3_tn(x, g):
     N, KA = x.shape
     NC = g.shape[1]
     out = torch.empty((KA, NC), device=x.device, dtype=torch.float32)
-    n_ws = int(_lib.lib().mma_gemm_bf16x3_tn_workspace_floats(N, KA, NC))
+    kb = KA if KA <= 128 else 128
+    n_ws = int(_lib.lib().mma_gemm_bf16x3_tn_workspace_floats(N, kb, NC))
     ws = torch.empty((n_ws,), device=x.device, dtype=torch.float32) if n_ws else None
-    call("mma_gemm_bf16x3_tn", ptr(x), x.stride(0), ptr(g), g.stride(0), ptr(out), ptr(ws), n_ws, N, KA, NC, stream_ptr())
+    for j in range(0, KA, kb):                               # one launch per 128-column block of x (= row block of the result)
+        call("mma_gemm_bf16x3_tn", ptr(x[:, j:j + kb]), x.stride(0), ptr(g), g.stride(0), ptr(out[j:j + kb]), ptr(ws), n_ws, N, kb,
+             NC, stream_ptr())
     return out
 
 

@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("M,K,N", [(5000, 128, 512), (4099, 512, 128), (9001, 256, 64), (4096, 128, 32), (70000, 384, 96)])
+@pytest.mark.parametrize("M,K,N", [(5000, 128, 512), (4099, 512, 128), (9001, 256, 64), (4096, 128, 32), (70000, 384, 96),
+                                   (5003, 256, 384), (4100, 1024, 256)])      # the last two: column-blocked (K > 128 and N > 128)
 def test_gemm_bf16x3_accuracy(M, K, N):
     from mma_amd import dense
     rng = np.random.default_rng(M + K + N)
@@ -79,7 +80,7 @@ def test_linear_backward_matches_torch():
 
 
 @pytest.mark.parametrize("M,KA,NC,padx,padg", [(5000, 128, 1024, 0, 0), (4097, 64, 96, 0, 32), (70001, 128, 512, 128, 0),
-                                               (33, 32, 32, 0, 0), (262144 + 17, 96, 160, 0, 0)])
+                                               (33, 32, 32, 0, 0), (262144 + 17, 96, 160, 0, 0), (6000, 256, 512, 0, 0)])
 def test_gemm_bf16x3_tn_accuracy(M, KA, NC, padx, padg):
     """x^T g on the TN kernel: error at the level of an fp32 GEMM's against fp64, repeatable, row-strided operands."""
     from mma_amd import dense
