@@ -41,9 +41,10 @@ def gemm_bf16x3(a, w, out=None, accumulate=False):
     if K == 128 or N <= 128:
         call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(bt3), ptr(out), out.stride(0), M, N, K, acc, stream_ptr())
     else:                                                    # K > 128 and N > 128: one launch per 128-column block of the output
-        for j in range(0, N, 128):
-            blk = bt3[:, j:j + 128].contiguous()             # (3,128,K): the kernel's piece stride is its own N * K
-            call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(blk), ptr(out[:, j:j + 128]), out.stride(0), M, 128, K, acc, stream_ptr())
+        blocks = bt3.view(3, N // 128, 128, K).permute(1, 0, 2, 3).contiguous()    # (N/128, 3, 128, K): a block's own three pieces
+        for b in range(N // 128):
+            call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(blocks[b]), ptr(out[:, 128 * b:128 * b + 128]), out.stride(0), M, 128, K,
+                 acc, stream_ptr())
     return out
 
 
