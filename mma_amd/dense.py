@@ -110,8 +110,15 @@ class _MM(torch.autograd.Function):
 def _x3_tn_ok(x, g):
     """The kernel takes up to 128 x columns; wider x (hidden width 256: C5) runs as 128-column blocks of x."""
     KA = x.shape[1]
-    return (USE_BF16X3 and x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32 and x.shape[0] >= _MIN_ROWS_X3
-            and (KA in (32, 64, 96, 128) or KA % 128 == 0) and g.shape[1] % 32 == 0 and x.stride(1) == 1 and g.stride(1) == 1)
+    ok = (USE_BF16X3 and x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32 and x.shape[0] >= _MIN_ROWS_X3
+          and (KA in (32, 64, 96, 128) or KA % 128 == 0) and g.shape[1] % 32 == 0 and x.stride(1) == 1 and g.stride(1) == 1)
+    if not ok:
+        return False
+    # the kernel addresses one row range through a 32-bit buffer window: (rows per split) x (row pitch) must stay < 2 GB
+    M, NC, kb = x.shape[0], g.shape[1], min(KA, 128)
+    splits = max(1, int(_lib.lib().mma_gemm_bf16x3_tn_workspace_floats(M, kb, NC)) // (kb * NC))
+    rows = -(-(-(-M // splits)) // 32) * 32
+    return (rows + 32) * max(x.stride(0), g.stride(0)) * 4 < 2 ** 31
 
 
 def gemm_bf16x3_tn(x, g):
