@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 12
+#define MMA_ABI_VERSION 13
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -218,12 +218,14 @@ int mma_gr_fused_fwd(
 
 /* ---- K4: backward of K3 w.r.t. every edge message: gmsg[e, :] (E,T*F) by original edge position ------
  * min/max route the gradient to the saved arg edge only (torch_scatter), mean divides by the count, var/std use the
- * saved mean/var; in fused-message mode the dropout factor of the edge is applied, so gmsg = dL/d(U[i]+V[j]+Z[e]). */
+ * saved mean/var; in fused-message mode the dropout factor of the edge is applied, so gmsg = dL/d(U[i]+V[j]+Z[e]).
+ * gU (may be NULL): (N, ldgu >= T*F) receives dL/dU[i] = the sum of gmsg over target i's segment (a zero row for an empty
+ * target) from the same pass - the kernel walks exactly those segments, so the separate segment sum is not needed. */
 int mma_gr_fused_bwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
     const float* gout, const int32_t* amin, const int32_t* amax, const float* mean, const float* var, int64_t ldsave,
-    float* gmsg, int64_t ldg,
+    float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream);
 

@@ -6,7 +6,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMA_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "libmma_amd.so")   # override: A/B builds in development
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c = ctypes
 _P, _I64, _I32, _U32, _U64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_uint64
@@ -22,7 +22,7 @@ PROTOTYPES = {
     "mma_build_csr": [_P, _P, _I64, _I64, _P, _P, _P, _P, _I64, _P],
     "mma_gr_fused_fwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64,
                          _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P, _P],
-    "mma_gr_fused_bwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64,
+    "mma_gr_fused_bwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64,
                          _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P, _P],
     "mma_csr_spmm_items": [_P, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _P],
     "mma_split_bf16x3": [_P, _I64, _P, _P],

@@ -25,6 +25,7 @@ struct GrParams {
   float* out; const float* gout;                                                 // (N, T, S*K*F)
   int32_t* amin; int32_t* amax; float* mean; float* var; int64_t ldsave;        // (N,ldsave>=D) saved for backward (may be NULL)
   float* gmsg; int64_t ldg;                                                      // backward: (E,D) by original edge id
+  float* gU; int64_t ldgu;                                                       // backward, optional: (N,D) sum of gmsg over each target's segment
   int N, D, T, F, K, S, lpr_log;
   int wave_min_deg;                                  // wave-per-node pass: skip segments shorter than this
   bool need_sum, need_sq, need_min, need_max, need_mean;   // which running reductions the aggregator list uses
@@ -405,8 +406,8 @@ __device__ __forceinline__ void gr_bwd_coef(const GrParams& p, const GrLane& l, 
 }
 
 template <int VEC>
-__device__ __forceinline__ void gr_bwd_edge(const GrParams& p, const DropParams& dp, const GrLane& l, const GrCoef<VEC>& k_,
-                                            const Vec<VEC>& u, int j, int e) {
+__device__ __forceinline__ Vec<VEC> gr_bwd_edge(const GrParams& p, const DropParams& dp, const GrLane& l, const GrCoef<VEC>& k_,
+                                                const Vec<VEC>& u, int j, int e) {
   Vec<VEC> g;
   Vec<VEC> h = vzero<VEC>();
   if (k_.need_h) h = gr_message<VEC>(p, dp, l.fused, u, j, (uint32_t)e, l.cc);
@@ -423,28 +424,43 @@ __device__ __forceinline__ void gr_bwd_edge(const GrParams& p, const DropParams&
     g.v[i] = gi * fd[i];
   }
   stv<VEC>(p.gmsg + (size_t)e * p.ldg + l.cc, g);
+  return g;
 }
 
 template <int VEC>
 __device__ __forceinline__ void gr_node_bwd(const GrParams& p, const DropParams& dp, const GrLane& l, int node, Seg s,
                                             SegIdx first) {
-  if (s.b == s.e || s.e - s.b < p.wave_min_deg) return;
-  const float deg = (float)(s.e - s.b);
-  float fac[8];
-  gr_factors(p, deg, fac);
-  GrCoef<VEC> k_;
-  gr_bwd_coef<VEC>(p, l, node, deg, fac, k_);
-  const Vec<VEC> u = (l.fused && k_.need_h) ? ldv<VEC>(p.U + (size_t)node * p.lduv + l.cc) : vzero<VEC>();
-  for (int base = s.b; base < s.e; base += kWave) {
-    const int cnt = min(kWave, s.e - base);
-    SegIdx my = first;
-    if (base != s.b) my = idx_load(p, base, s.e, l.lane);
-    for (int t0 = 0; t0 < cnt; t0 += l.epg) {
-      const int tt = t0 + l.sub;
-      const int j_ = __shfl(my.j, tt & (kWave - 1), kWave);
-      const int e_ = __shfl(my.e, tt & (kWave - 1), kWave);
-      if (tt < cnt && l.valid) gr_bwd_edge<VEC>(p, dp, l, k_, u, j_, e_);
+  if (s.e - s.b < p.wave_min_deg) return;                     // second pass behind the group kernel: long segments only
+  Vec<VEC> su = vzero<VEC>();                                 // dL/dU[node] = sum of the segment's message gradients
+  if (s.b != s.e) {
+    const float deg = (float)(s.e - s.b);
+    float fac[8];
+    gr_factors(p, deg, fac);
+    GrCoef<VEC> k_;
+    gr_bwd_coef<VEC>(p, l, node, deg, fac, k_);
+    const Vec<VEC> u = (l.fused && k_.need_h) ? ldv<VEC>(p.U + (size_t)node * p.lduv + l.cc) : vzero<VEC>();
+    for (int base = s.b; base < s.e; base += kWave) {
+      const int cnt = min(kWave, s.e - base);
+      SegIdx my = first;
+      if (base != s.b) my = idx_load(p, base, s.e, l.lane);
+      for (int t0 = 0; t0 < cnt; t0 += l.epg) {
+        const int tt = t0 + l.sub;
+        const int j_ = __shfl(my.j, tt & (kWave - 1), kWave);
+        const int e_ = __shfl(my.e, tt & (kWave - 1), kWave);
+        if (tt < cnt && l.valid) {
+          const Vec<VEC> g = gr_bwd_edge<VEC>(p, dp, l, k_, u, j_, e_);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) su.v[i] += g.v[i];
+        }
+      }
     }
+  }
+  if (p.gU) {                                                 // wave-uniform; an empty target gets a zero row
+    for (int off = kWave / 2; off >= l.lpr; off >>= 1) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) su.v[i] += __shfl_xor(su.v[i], off, kWave);
+    }
+    if (l.sub == 0 && l.valid) stv<VEC>(p.gU + (size_t)node * p.ldgu + l.c, su);
   }
 }
 
@@ -483,16 +499,30 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_group_kernel(const GrParams p) 
     const Seg s2 = seg_load(p, n1 + stride);
     const Idx4 i1 = idx4_load(p, s1);
     const int deg = s0.e - s0.b;
-    if (deg > 0 && deg <= kGroupMaxDeg && l.valid) {
-      float fac[8];
+    if (deg <= kGroupMaxDeg && l.valid) {
+      Vec<VEC> su = vzero<VEC>();                             // dL/dU[n]: the group walks the whole segment, so it is a local sum
+      if (deg > 0) {
+        float fac[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) fac[q] = fac_tab[deg][q];
-      GrCoef<VEC> k_;
-      gr_bwd_coef<VEC>(p, l, n, (float)deg, fac, k_);
-      const Vec<VEC> u = (l.fused && k_.need_h) ? ldv<VEC>(p.U + (size_t)n * p.lduv + l.cc) : vzero<VEC>();
+        for (int q = 0; q < 8; ++q) fac[q] = fac_tab[deg][q];
+        GrCoef<VEC> k_;
+        gr_bwd_coef<VEC>(p, l, n, (float)deg, fac, k_);
+        const Vec<VEC> u = (l.fused && k_.need_h) ? ldv<VEC>(p.U + (size_t)n * p.lduv + l.cc) : vzero<VEC>();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) if (i < deg) gr_bwd_edge<VEC>(p, dp, l, k_, u, i0.j[i], i0.e[i]);
-      for (int t = s0.b + 4; t < s0.e; ++t) gr_bwd_edge<VEC>(p, dp, l, k_, u, p.src[t], p.perm[t]);
+        for (int i = 0; i < 4; ++i) {
+          if (i < deg) {
+            const Vec<VEC> g = gr_bwd_edge<VEC>(p, dp, l, k_, u, i0.j[i], i0.e[i]);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) su.v[c] += g.v[c];
+          }
+        }
+        for (int t = s0.b + 4; t < s0.e; ++t) {
+          const Vec<VEC> g = gr_bwd_edge<VEC>(p, dp, l, k_, u, p.src[t], p.perm[t]);
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) su.v[c] += g.v[c];
+        }
+      }
+      if (p.gU) stv<VEC>(p.gU + (size_t)n * p.ldgu + l.c, su);
     }
     n = n1; s0 = s1; s1 = s2; i0 = i1;
   }
@@ -676,7 +706,7 @@ extern "C" int mma_gr_fused_bwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
     const float* gout, const int32_t* amin, const int32_t* amax, const float* mean, const float* var, int64_t ldsave,
-    float* gmsg, int64_t ldg,
+    float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) - (1 << 20) && E < (1LL << 31) && T >= 1 && F >= 1,
@@ -696,13 +726,15 @@ extern "C" int mma_gr_fused_bwd(
   p.rowptr = rowptr; p.src = src; p.perm = perm; p.U = U; p.V = V; p.lduv = lduv; p.Z = Z; p.ldz = ldz;
   p.inputs = inputs; p.ldi = ldi; p.gout = gout; p.amin = const_cast<int32_t*>(need_min ? amin : nullptr);
   p.amax = const_cast<int32_t*>(need_max ? amax : nullptr); p.mean = const_cast<float*>(mean); p.var = const_cast<float*>(var);
-  p.gmsg = gmsg; p.ldg = ldg; p.ldsave = ldsave;
+  p.gmsg = gmsg; p.ldg = ldg; p.ldsave = ldsave; p.gU = gU; p.ldgu = ldgu;
+  MMA_REQUIRE(!gU || ldgu >= D, "ldgu=%lld < T*F", (long long)ldgu);
   MMA_REQUIRE(!(need_min || need_max || need_stats) || ldsave >= D, "ldsave=%lld < T*F", (long long)ldsave);
   p.N = (int)N; p.D = D; p.T = T; p.F = F; p.avg_log = avg_log; p.avg_lin = avg_lin;
   p.drop.mode = (drop_mode == MMA_DROP_HASH && drop_thr > 0 && !inputs) ? MMA_DROP_HASH : MMA_DROP_NONE;
   p.drop.thr = drop_thr; p.drop.scale = 256.f / (256.f - (float)drop_thr);
   p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.seed_dev = seed_dev; p.drop.keep = nullptr; p.drop.E = E; p.drop.edge_base = 0;
-  const bool v4 = gr_vec4(p) && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(gmsg) & 15) == 0;
+  const bool v4 = gr_vec4(p) && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(gmsg) & 15) == 0 &&
+                  (!gU || (ldgu % 4 == 0 && (reinterpret_cast<uintptr_t>(gU) & 15) == 0));
   const dim3 grid = gr_grid(N, D, v4 ? 4 : 1, &p.lpr_log);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (gr_group_mode(p, E)) {

@@ -367,18 +367,17 @@ class _GRAggregate(torch.autograd.Function):
                 return (gmsg.view(E, T, F),) + (None,) * 10
             return (None, torch.zeros((N, 2 * D), device=gout.device, dtype=torch.float32), gmsg if has_z else None) + (None,) * 8
         U, V = (UV[:, :D], UV[:, D:]) if fused else (None, None)
+        # dU[i] = sum of its target segment: produced by K4 itself (it walks exactly those segments); dV[j] = sum over the
+        # edges leaving j: one segment sum (K5 kernel) over the by-source grouping.  Both land in the halves of one (N, 2D) buffer.
+        gUV = torch.empty((N, 2 * D), device=gout.device, dtype=torch.float32) if fused else None
         with _span("gr_fused_bwd"):
             _gr_call("mma_gr_fused_bwd", csr, U, V, Z, inputs,
-                     (ptr(gout), ptr(amin), ptr(amax), ptr(mean), ptr(var), D, ptr(gmsg), D),
+                     (ptr(gout), ptr(amin), ptr(amax), ptr(mean), ptr(var), D, ptr(gmsg), D, ptr(gUV), 2 * D if fused else 0),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
         if not fused:
             return (gmsg.view(E, T, F),) + (None,) * 10
-        # dU[i] = sum of its target segment, dV[j] = sum over the edges leaving j: two segment sums (K5 kernel) into the
-        # halves of one (N, 2D) buffer
-        gUV = torch.empty((N, 2 * D), device=gout.device, dtype=torch.float32)
         cs = graph.by_source
         with _span("gr_segsum"):
-            call("mma_csr_spmm", ptr(csr.rowptr), ptr(csr.perm), None, ptr(gmsg), D, E, 1, None, ptr(gUV), 2 * D, N, D, stream_ptr())
             call("mma_csr_spmm", ptr(cs.rowptr), ptr(cs.perm), None, ptr(gmsg), D, E, 1, None, ptr(gUV[:, D:]), 2 * D, N, D,
                  stream_ptr())
         return (None, gUV, gmsg if has_z else None) + (None,) * 8
