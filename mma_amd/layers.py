@@ -20,7 +20,7 @@ from . import functional as Fn
 from .dense import mm
 from ._lib import require_gpu
 from .graph import DEFAULT_CHUNK, NCGraph, SpmmGraph
-from .scalers import SCALERS, scaler_factors
+from .scalers import SCALERS, scaler_row_factor
 
 # aggregator name -> (combine kind, raw logits under activation == "new_sigmoid")   layers.py:201-728
 _AGG = {
@@ -188,8 +188,7 @@ class MMA(Module):
         #     sum_k A (c * m_k W)  ==  A (c * (sum_k m_k) W):
         # the fused kernel emits sum_k m_k (N,H) directly - K x fewer bytes through the GEMM and the SpMM.
         msum = self._aggregate_all(self.aggregator_names, input, reduce_k=True)
-        amp, att = scaler_factors(N, input.device)
-        support = mm(msum, self.weight) * (1.0 + amp + att)
+        support = mm(msum, self.weight) * scaler_row_factor(N, input.device)
         if self._sg is None or self._sg[0] is not adj:   # extension: a ready-made SpmmGraph is accepted as `adj`
             self._sg = (adj, adj if isinstance(adj, SpmmGraph) else SpmmGraph.from_torch_sparse(adj))
         return Fn.csr_spmm(support, self.bias, self._sg[1], 1)                  # layers.py:861-867

@@ -49,3 +49,19 @@ def scaler_factors(N, device):
     lg = torch.log(all_degrees + 1)
     avg = torch.mean(lg)
     return (lg / avg).unsqueeze(-1), (avg / lg).unsqueeze(-1)
+
+
+_ROW_FACTOR = {}
+
+
+def scaler_row_factor(N, device):
+    """1 + amplification + attenuation as ONE (1,1) tensor.  Every row of scaler_factors(N) holds the same value (all
+    "degrees" are N, quirk Q1), so it is evaluated once per (N, device) with exactly the operations above - the mean over N
+    equal logs included, whose rounding depends on N - and multiplied in by broadcast: bit-identical to the per-row form,
+    without six N-element kernels per forward."""
+    key = (int(N), str(device))
+    c = _ROW_FACTOR.get(key)
+    if c is None:
+        amp, att = scaler_factors(N, device)
+        c = _ROW_FACTOR[key] = (1.0 + amp[:1] + att[:1]).detach()
+    return c

@@ -25,7 +25,7 @@ from .dense import mm, mm_into, rows_mm_add_, xt_g
 from ._lib import call, ptr, require_gpu, stream_ptr
 from .graph import DEFAULT_CHUNK, NCGraph, SpmmGraph
 from .layers import _AGG
-from .scalers import scaler_factors
+from .scalers import scaler_row_factor
 
 
 def partition_bounds(rowptr, world):
@@ -301,8 +301,7 @@ class ShardedMMA(torch.nn.Module):
         ws = [self.masks[a] for a in self.names]
         msum = _ShardedAggregate.apply(x_own, torch.cat([w[:H] for w in ws], 1), torch.cat([w[H:] for w in ws], 1), self,
                                        tuple(kinds), tuple(acts), self._drop())                 # (n_own, H)
-        amp, att = scaler_factors(self.n_total or n, x_own.device)                          # Q1: identical rows
-        c3 = (1.0 + amp[:1] + att[:1])
+        c3 = scaler_row_factor(self.n_total or n, x_own.device)                             # Q1: identical rows
         # sum_k A (m_k W) == A ((sum_k m_k) W): only the (n,C) rows travel and enter the SpMM
         S = mm(msum, self.weight) * c3
         S_halo = _HaloExchange.apply(S, self.plan, self.send_idx)
