@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py - edges/sec (fwd+bwd) of the MMA layer on MI355X, one process per GPU.
+"""bench.py - edges/sec (fwd+bwd) of the MMA message-passing hot path on MI355X, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2l]
 
-Workload (BASELINE.json configs[3], the config the 1/2/4/8-GPU metric is quoted on; SURVEY 8d "C4"):
-synthetic R-MAT power-law graph, 2^20 nodes / ~10 M directed edges, hidden H=128, K=4 masks
-[sum, mean, max, min], activation new_sigmoid, mask dropout p=0.5, nclass C=16, fp32.
-One step = one forward + backward of the drop-in `mma_amd.MMA` layer (GEMM-pre, fused K-mask aggregate,
-GEMM-post, K-stacked SpMM, and their backward) with inputs resident in HBM.  N>1: the same graph is
-1-D node-sharded over the ranks (edge-balanced contiguous target ranges) with an RCCL all-to-all halo
-exchange per direction (strong scaling: total work fixed).
+N > 1 without a launcher (RANK unset): bench.py starts N child ranks itself (`python -m torch.distributed.run ...
+bench.py <same args>`) BEFORE anything touches the GPU, relays rank 0's JSON line and exits with the children's status.
+Under a launcher (RANK/WORLD_SIZE set, the driver's documented form) it is one of the ranks.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant fused kernel, HIP-event timed inside the timed
-region, algorithmic bytes from DESIGN.md) and `cpu_baseline` (the CPU oracle on a bounded sample).
+Workload `c4` (default; BASELINE.json configs[3], the config the 1/2/4/8-GPU metric is quoted on; SURVEY 8d "C4"):
+synthetic R-MAT power-law graph, 2^20 nodes / ~10.9 M directed edges, hidden H=128, K=4 masks [sum, mean, max, min],
+activation new_sigmoid, mask dropout p=0.5, nclass C=16, fp32.  One step = one forward + backward of the drop-in
+`mma_amd.MMA` layer (GEMM-pre, fused K-mask aggregate, GEMM-post, K-stacked SpMM, and their backward), inputs resident
+in HBM.  N>1: the same graph is 1-D node-sharded over the ranks (edge-balanced contiguous target ranges) with an RCCL
+all-to-all halo exchange per direction (strong scaling: total work fixed).  Rank 0 generates the graph once and shares
+it through /dev/shm; every rank materialises only its own rows of the features.
+Workload `c2l` (BASELINE configs[1] at ZINC-split scale): the drop-in `mma_amd.MMAConv` 75->75, towers=5, edge_dim=50,
+[min,max] x [identity,amplification,linear] on a 10 000-molecule batch; `roofline` is the fused GR kernel.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant fused kernel, HIP-event timed inside the timed region,
+algorithmic bytes from DESIGN.md) and `cpu_baseline` (the CPU oracle on a bounded sample); at N=1 `extra` holds the
+other BASELINE configs that fit one GPU (C1, C3, C2, C2L: layer fwd+bwd, eager and one-hipGraph replay).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,40 +34,26 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from tools.synth import feature_rows, golden_csr, molecule_batch, rmat_graph  # noqa: E402,F401
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured streaming copy)
+C4_DEFAULTS = dict(scale=20, edges=5_000_000, hidden=128, nclass=16, aggregators="sum,mean,max,min", dropout=0.5)
 
 
-# ---- synthetic graph ---------------------------------------------------------------------
-def rmat_graph(scale, n_undirected, seed=42, a=0.57, b=0.19, c=0.19):
-    """R-MAT -> symmetrised, de-duplicated, no self loops, isolated nodes attached to a random node.
-    Returns CSR by target (rowptr int64, col int64) with ascending neighbour order (utils.py:100)."""
-    rng = np.random.default_rng(seed)
-    N = 1 << scale
-    src = np.zeros(n_undirected, dtype=np.int64)
-    dst = np.zeros(n_undirected, dtype=np.int64)
-    for bit in range(scale):
-        r = rng.random(n_undirected, dtype=np.float32)
-        sb = (r >= a + b).astype(np.int64)                       # quadrants c,d set the source bit
-        db = (((r >= a) & (r < a + b)) | (r >= a + b + c)).astype(np.int64)   # quadrants b,d set the target bit
-        src |= sb << bit
-        dst |= db << bit
-    perm = rng.permutation(N)                                    # break the bit-pattern locality of raw R-MAT ids
-    src, dst = perm[src], perm[dst]
-    keep = src != dst
-    src, dst = src[keep], dst[keep]
-    key = np.unique(np.concatenate([src * N + dst, dst * N + src]))
-    row, col = key // N, key % N
-    deg = np.bincount(row, minlength=N)
-    iso = np.nonzero(deg == 0)[0]
-    if len(iso):                                                 # reference needs d >= 1 (Q12)
-        nb = rng.integers(0, N, len(iso))
-        nb = np.where(nb == iso, (nb + 1) % N, nb)
-        key = np.unique(np.concatenate([key, iso * N + nb, nb * N + iso]))
-        row, col = key // N, key % N
-    rowptr = np.zeros(N + 1, dtype=np.int64)
-    np.cumsum(np.bincount(row, minlength=N), out=rowptr[1:])
-    return rowptr, col
+# ---- self-launch -----------------------------------------------------------------------------------------
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` with no launcher: become the launcher.  Runs before any torch.cuda call - this process
+    never touches the GPU, it only starts N fresh children and waits (no exec of a GPU-initialised process)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // gpus)))
+    return subprocess.run(cmd, env=env).returncode
 
 
 class KernelTimer:
@@ -100,36 +95,53 @@ def algorithmic_bytes(N, E, H, K, n_sel=None):
     return {"nc_fused_fwd": fwd, "nc_fused_bwd": bwd}
 
 
-PMC_KERNEL = {"nc_fused_fwd": "mma::nc_fwd_", "nc_fused_bwd": "mma::nc_bwd_k"}   # fwd: kernel + finalize; bwd: kernel only (nc_bwd_node is K2a)
+def gr_algorithmic_bytes(N, E, T, F, K, S, has_z=True):
+    """SURVEY 8d, GR fused kernels: fwd 4[E(2 + TF + TF_Z) + N(1 + TF + TKSF)]; bwd reads the (N,T,K*S*F) gradient and
+    the saved state and writes one message gradient per edge + dU per node."""
+    D = T * F
+    fwd = 4 * (E * (2 + D + (D if has_z else 0)) + N * (1 + D + T * K * S * F))
+    bwd = 4 * (E * (2 + D) + N * (1 + T * K * S * F + 2 * D))
+    return {"gr_fused_fwd": fwd, "gr_fused_bwd": bwd}
 
 
-def pmc_traffic(name, N, E, H, K):
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes of THIS command
-    (profiles/r*_pmc_traffic.json, made by tools/pmc_summary.py); None when no profile matches the workload."""
+PMC_KERNEL = {"nc_fused_fwd": "mma::nc_fwd_", "nc_fused_bwd": "mma::nc_bwd_k",   # fwd: kernel + finalize; bwd: kernel only
+              "gr_fused_fwd": "mma::gr_fwd", "gr_fused_bwd": "mma::gr_bwd"}
+
+
+def pmc_traffic(name, workload):
+    """(HBM bytes per launch of the dominant kernel, source file) from the COMMITTED rocprofv3 PMC passes of this command
+    (profiles/r*_pmc_traffic*.json, made by tools/pmc_summary.py) - a recorded profile, not measured in this run;
+    (None, None) when no profile matches the workload."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload") != {"nodes": N, "edges": E, "hidden": H, "K": K}:
+        if d.get("workload") != workload:
             continue
         # one C-ABI call = up to two launches of the kernel (items run one per wavefront / grouped) + the hub finalize
         parts = [v["traffic_bytes"] for k, v in d["kernels"].items() if PMC_KERNEL.get(name, "?") in k]
         if parts:
-            return sum(parts)
-    return None
+            return sum(parts), os.path.relpath(f, ROOT)
+    return None, None
 
 
-def cpu_baseline(rowptr, col, H, names, activation, p, n_targets, seed):
-    """The CPU oracle (oracle/nc_oracle.py, torch-CPU vectorised restatement of layers.py) on a bounded sample:
-    the first n_targets target nodes with ALL their in-edges; fwd+bwd of the K aggregators + dense tail."""
-    from oracle import nc_oracle as O
+# ---- CPU baselines (the oracle is the checker/baseline, never the product path) ------------------------------
+def _threads():
     # the box gives one GPU job a share of the host (16 cores), whatever os.cpu_count() says
-    threads = min(len(os.sched_getaffinity(0)), 16)
-    torch.set_num_threads(threads)
+    n = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(n)
+    return n
+
+
+def cpu_baseline(rowptr, col, H, names, activation, p, n_targets, seed, label):
+    """Vectorised CPU oracle (oracle/nc_oracle.py, torch-CPU restatement of layers.py) on a bounded sample: the first
+    n_targets target nodes with ALL their in-edges; fwd+bwd of the K masked aggregators."""
+    from oracle import nc_oracle as O
+    threads = _threads()
     e_hi = int(rowptr[n_targets])
-    sub_col = col[:e_hi]
+    sub_col = np.asarray(col[:e_hi])
     nodes = np.unique(np.concatenate([np.arange(n_targets), sub_col]))      # targets first (they are 0..n_targets-1)
     remap = np.full(len(rowptr) - 1, -1, dtype=np.int64); remap[nodes] = np.arange(len(nodes))
     n_sub = len(nodes)
@@ -144,10 +156,178 @@ def cpu_baseline(rowptr, col, H, names, activation, p, n_targets, seed):
     loss = sum(m[:n_targets].sum() for m in ms)
     loss.backward()
     dt = time.perf_counter() - t0
-    return {"value": e_hi / dt, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": "first %d target nodes of the C4 graph with all their in-edges (%d edges, %d distinct rows), "
+    return {"value": e_hi / dt, "unit": "edges/s", "cores": threads, "kind": "port", "form": "vectorised",
+            "sample": "first %d target nodes of the %s graph with all their in-edges (%d edges, %d distinct rows), "
                       "fwd+bwd of the K=%d masked aggregators, torch-CPU vectorised oracle, %.1f s" % (
-                          n_targets, e_hi, n_sub, len(names), dt)}
+                          n_targets, label, e_hi, n_sub, len(names), dt)}
+
+
+def cpu_loop_baseline(tag, fixture, H, names, p, max_nodes, seed=42):
+    """Faithful-loop CPU oracle (oracle.nc_oracle.aggregate_loop: the per-node op sequence of layers.py:205-226) on the
+    Cora / Pubmed structure - SURVEY 8d "CPU baseline (i)"; expected ~ the reference's own speed (1.6-2.0 k
+    edges/s on 8 cores).  Bounded: the first max_nodes target nodes, fwd+bwd."""
+    from oracle import nc_oracle as O
+    threads = _threads()
+    rowptr, col = golden_csr(fixture)
+    N = len(rowptr) - 1
+    n = min(N, max_nodes)
+    e_hi = int(rowptr[n])
+    add_all = [col[rowptr[i]:rowptr[i + 1]] for i in range(n)]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.relu(torch.randn(N, H, generator=g)).requires_grad_(True)
+    Ws = {a: ((torch.rand(2 * H, H, generator=g) * 2 - 1) / np.sqrt(H)).requires_grad_(True) for a in names}
+    keeps = {a: (torch.rand(e_hi, H, generator=g) >= p).float() for a in names} if p > 0 else None
+    t0 = time.perf_counter()
+    ms = [O.aggregate_loop(a, x, Ws[a], add_all, "new_sigmoid", p, None if keeps is None else keeps[a]) for a in names]
+    sum(m.sum() for m in ms).backward()
+    dt = time.perf_counter() - t0
+    return {"config": tag, "value": e_hi / dt, "unit": "edges/s", "cores": threads, "kind": "port", "form": "faithful per-node loop",
+            "sample": "first %d of %d target nodes of the %s structure (%d edges), H=%d, aggregators %s, p=%g, fwd+bwd, %.1f s" % (
+                n, N, fixture, e_hi, H, ",".join(names), p, dt)}
+
+
+# ---- secondary configurations (N = 1 only; BASELINE configs that are not the headline) --------------------------
+def graph_replay_ms(step, n=50):
+    """Capture `step` (layer forward+backward on static tensors) into a hipGraph and time replays."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    g.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def wall_ms(fn, n):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def _kernel_table(spans, steps, ab):
+    kernels = {}
+    for name, (cnt, tot_ms) in spans.items():
+        avg = tot_ms / steps            # per step (a sharded backward issues the call twice: halo / own sources)
+        k = {"launches": cnt, "avg_ms": avg}
+        if name in ab:
+            k["algorithmic_bytes"] = ab[name]
+            k["achieved_GBs"] = ab[name] / (avg * 1e-3) / 1e9
+        kernels[name] = k
+    return kernels
+
+
+def nc_config(tag, fixture, H, names, C, p, dev, reps=50, replay=True):
+    """MMA layer fwd+bwd on a committed fixture graph (Cora / Pubmed structure): eager wall, per-kernel HIP-event times,
+    one-hipGraph replay."""
+    import mma_amd
+    from mma_amd import functional as Fn
+    rowptr, col = golden_csr(fixture)
+    N, E, K = len(rowptr) - 1, len(col), len(names)
+    graph = mma_amd.NCGraph(rowptr, col, dev)
+    layer = make_layer(mma_amd, graph, H, C, names, p, dev)
+    dst = np.repeat(np.arange(N), np.diff(rowptr))
+    adj = mma_amd.graph.SpmmGraph(dst, col, None, N, N, dev)
+    x = torch.relu(torch.randn(N, H, device=dev)).requires_grad_(True)
+    cot = torch.randn(N, C, device=dev)
+
+    def step():
+        x.grad = None
+        layer(x, adj).backward(cot)
+    ms = wall_ms(step, reps)
+    prev = Fn.TIMER
+    Fn.TIMER = t = KernelTimer(); t.enabled = True
+    for _ in range(reps):
+        step()
+    spans = t.summary(); Fn.TIMER = prev
+    n_sel = sum(1 for a in names if a.rstrip("234") in ("max", "min", "softmax", "softmin")) if Fn.SHARED_GRAD_BWD else None
+    r = {"config": tag, "nodes": N, "edges": E, "hidden": H, "K": K, "dropout": p, "ms_per_step_eager": ms, "edges_per_s_eager": E / ms * 1e3,
+         "kernels": _kernel_table(spans, reps, algorithmic_bytes(N, E, H, K, n_sel)),
+         "note": "launch-bound: the fused kernels move tens of MB (a few us at the HBM roofline)"}
+    if replay:
+        layer.graph_capturable = True
+        gms = graph_replay_ms(step)
+        r.update(ms_per_step_hipgraph=gms, edges_per_s_hipgraph=E / gms * 1e3)
+    return r
+
+
+def gr_setup(n_graphs, dev, seed=0):
+    import mma_amd
+    rng = np.random.default_rng(seed)
+    ei, N = molecule_batch(rng, n_graphs)
+    E = ei.shape[1]
+    hist = np.bincount(np.bincount(ei[1], minlength=N), minlength=5)
+    conv = mma_amd.MMAConv(75, 75, ["min", "max"], ["identity", "amplification", "linear"], torch.tensor(hist), edge_dim=50,
+                           towers=5).to(dev)
+    x = torch.randn(N, 75, device=dev, requires_grad=True)
+    ea = torch.randn(E, 50, device=dev)
+    eig = torch.from_numpy(ei).to(dev)
+    cot = torch.randn(N, 75, device=dev)
+
+    def step():
+        x.grad = None
+        conv(x, eig, ea).backward(cot)
+    return conv, step, N, E
+
+
+def gr_config(tag, n_graphs, dev, reps=20, replay=True):
+    """MMAConv (mma.py:92-95 shape) layer fwd+bwd on a ZINC-like batch of n_graphs molecules."""
+    from mma_amd import functional as Fn
+    conv, step, N, E = gr_setup(n_graphs, dev)
+    ms = wall_ms(step, reps)
+    prev = Fn.TIMER
+    Fn.TIMER = t = KernelTimer(); t.enabled = True
+    for _ in range(reps):
+        step()
+    spans = t.summary(); Fn.TIMER = prev
+    r = {"config": tag, "graphs": n_graphs, "nodes": N, "edges": E, "towers": 5, "F": 75, "ms_per_step_eager": ms,
+         "edges_per_s_eager": E / ms * 1e3, "kernels": _kernel_table(spans, reps, gr_algorithmic_bytes(N, E, 5, 75, 2, 3))}
+    if replay:
+        conv.graph_capturable = True
+        gms = graph_replay_ms(step, 20)
+        r.update(ms_per_step_hipgraph=gms, edges_per_s_hipgraph=E / gms * 1e3)
+    return r
+
+
+def extra_configs(dev):
+    out = {}
+    for key, fn in (("C1", lambda: nc_config("C1: Cora structure, H=64, mean,mean2, p=0.75", "cora_h64", 64, ["mean", "mean2"], 7, 0.75, dev)),
+                    ("C3", lambda: nc_config("C3: Pubmed structure, H=16, min,min2,min3,min4, p=0.5", "pubmed_h16", 16,
+                                             ["min", "min2", "min3", "min4"], 3, 0.5, dev)),
+                    ("C2", lambda: gr_config("C2: ZINC-like batch of 64 molecules, MMAConv T=5 F=75 min,max x id,amp,lin", 64, dev)),
+                    ("C2L", lambda: gr_config("C2L: the same layer on a 10 000-molecule batch", 10000, dev, reps=5))):
+        try:
+            out[key] = fn()
+        except Exception as e:      # a secondary entry must never take the headline line down with it
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+# ---- shared graph for the ranks of one node -----------------------------------------------------------------
+def shared_graph(args, rank, world, barrier):
+    """Rank 0 generates the R-MAT graph once and shares the CSR through /dev/shm; the others map it read-only (8 ranks
+    generating a scale-23 graph each would need 8x the host memory and time)."""
+    if world == 1:
+        return rmat_graph(args.scale, args.edges, seed=42)
+    tag = "/dev/shm/mma_bench_%d_%s_s%d_e%d" % (os.getuid(), os.environ.get("MASTER_PORT", "0"), args.scale, args.edges)
+    if rank == 0:
+        rowptr, col = rmat_graph(args.scale, args.edges, seed=42)
+        np.save(tag + "_rowptr.npy", rowptr)
+        np.save(tag + "_col.npy", col)
+    barrier()
+    rowptr = np.load(tag + "_rowptr.npy")
+    col = np.load(tag + "_col.npy", mmap_mode="r")
+    return rowptr, col, tag
 
 
 def main():
@@ -155,29 +335,51 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scale", type=int, default=20, help="R-MAT scale (2^scale nodes)")
-    ap.add_argument("--edges", type=int, default=5_000_000, help="undirected R-MAT edges before symmetrisation")
-    ap.add_argument("--hidden", type=int, default=128)
-    ap.add_argument("--nclass", type=int, default=16)
-    ap.add_argument("--aggregators", type=str, default="sum,mean,max,min")
-    ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2l"], help="c4: MMA layer on the R-MAT graph (headline); "
+                    "c2l: MMAConv on a 10 000-molecule ZINC-like batch (roofline = the fused GR kernel)")
+    ap.add_argument("--scale", type=int, default=C4_DEFAULTS["scale"], help="R-MAT scale (2^scale nodes)")
+    ap.add_argument("--edges", type=int, default=C4_DEFAULTS["edges"], help="undirected R-MAT edges before symmetrisation")
+    ap.add_argument("--hidden", type=int, default=C4_DEFAULTS["hidden"])
+    ap.add_argument("--nclass", type=int, default=C4_DEFAULTS["nclass"])
+    ap.add_argument("--aggregators", type=str, default=C4_DEFAULTS["aggregators"])
+    ap.add_argument("--dropout", type=float, default=C4_DEFAULTS["dropout"])
+    ap.add_argument("--true-degree-scalers", action="store_true", help="C5 option: the S=5 true-degree scalers of "
+                    "mma_conv.py:181-196 on the NC aggregates (strict_reference=False) instead of the reference's degenerate three")
+    ap.add_argument("--molecules", type=int, default=10000, help="c2l: molecules in the batch")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded (RCCL) path even at world size 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' (halo staged through the host) lets "
                     "several ranks share one GPU to rehearse the N>1 path on a 1-GPU box")
     ap.add_argument("--cpu-sample", type=int, default=150000, help="target nodes in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (C1, C3, C2, C2L) and the loop baseline")
+    ap.add_argument("--rendezvous-only", action="store_true", help="(tests) ranks meet, all-reduce their rank and leave: "
+                    "checks the launch path without a GPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    import torch.distributed as dist
+
+    if args.rendezvous_only:
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "world": world, "rank_sum": t.item()}), flush=True)
+        dist.destroy_process_group()
+        return
+
     if args.backend == "gloo":
         local_rank = 0                      # rehearsal: all ranks on cuda:0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
     if sharded:
-        import torch.distributed as dist
         if "RANK" not in os.environ:      # --force-sharded without a launcher
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
         if args.backend == "nccl":
@@ -185,28 +387,36 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    def barrier():
+        if sharded:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == "c2l":
+        assert not sharded, "c2l: molecule batches are independent - run replicas, there is no halo (DESIGN.md 5)"
+        return run_c2l(args, dev)
+
     import mma_amd
     from mma_amd import functional as Fn
 
     names = args.aggregators.split(",")
     K, H, C = len(names), args.hidden, args.nclass
-    rowptr, col = rmat_graph(args.scale, args.edges, seed=42)
+    g = shared_graph(args, rank, world, barrier)
+    rowptr, col, shm_tag = g if len(g) == 3 else (g[0], g[1], None)
     N, E = len(rowptr) - 1, int(rowptr[-1])
 
     timer = KernelTimer()
     Fn.TIMER = timer
     torch.manual_seed(42)
-    gen = torch.Generator(device="cpu").manual_seed(42)
-    x_full = torch.relu(torch.randn(N, H, generator=gen))
-    cot_full = torch.randn(N, C, generator=gen)
+    extra_kw = dict(strict_reference=False) if args.true_degree_scalers else {}
 
     if not sharded:
         graph = mma_amd.NCGraph(rowptr, col, dev)
-        layer = make_layer(mma_amd, graph, H, C, names, args.dropout, dev)
+        layer = make_layer(mma_amd, graph, H, C, names, args.dropout, dev, **extra_kw)
         dst = np.repeat(np.arange(N, dtype=np.int64), np.diff(rowptr))
         adj = mma_amd.graph.SpmmGraph(dst, col, None, N, N, dev)
-        x = x_full.to(dev).requires_grad_(True)
-        cot = cot_full.to(dev)
+        x = torch.from_numpy(feature_rows(0, N, H, 42)).to(dev).requires_grad_(True)
+        cot = torch.from_numpy(feature_rows(0, N, C, 43, relu=False)).to(dev)
 
         def step():
             x.grad = None
@@ -217,9 +427,9 @@ def main():
         local_edges, n_local = E, N
     else:
         from mma_amd.sharded import ShardedMMA
-        sh = ShardedMMA.build(rowptr, col, rank, world, dev, H, C, names, args.dropout)
-        x = x_full[sh.lo:sh.hi].to(dev).requires_grad_(True)
-        cot = cot_full[sh.lo:sh.hi].to(dev)
+        sh = ShardedMMA.build(rowptr, col, rank, world, dev, H, C, names, args.dropout, **extra_kw)
+        x = torch.from_numpy(feature_rows(sh.lo, sh.hi, H, 42)).to(dev).requires_grad_(True)
+        cot = torch.from_numpy(feature_rows(sh.lo, sh.hi, C, 43, relu=False)).to(dev)
 
         def step():
             x.grad = None
@@ -229,12 +439,10 @@ def main():
             out.backward(cot)
             sh.allreduce_grads()
         local_edges, n_local = sh.local_edges, sh.hi - sh.lo
-    del x_full, cot_full
-
-    def barrier():
-        if sharded:
-            dist.barrier()
-        torch.cuda.synchronize()
+        barrier()
+        if rank == 0 and shm_tag:
+            for suf in ("_rowptr.npy", "_col.npy"):
+                os.unlink(shm_tag + suf)
 
     for _ in range(args.warmup):
         step()
@@ -257,46 +465,120 @@ def main():
         value = E * args.steps / dt
         n_sel = sum(1 for a in names if a.rstrip("234") in ("max", "min", "softmax", "softmin")) if Fn.SHARED_GRAD_BWD else None
         ab = algorithmic_bytes(n_local, local_edges, H, K, n_sel)
-        kernels = {}
-        for name, (cnt, tot_ms) in spans.items():
-            avg = tot_ms / args.steps           # per step (a sharded backward issues the call twice: halo / own sources)
-            k = {"launches": cnt, "avg_ms": avg}
-            if name in ab:
-                k["algorithmic_bytes"] = ab[name]
-                k["achieved_GBs"] = ab[name] / (avg * 1e-3) / 1e9
-            kernels[name] = k
+        kernels = _kernel_table(spans, args.steps, ab)
         dom = max((n for n in kernels if n in ab), key=lambda n: kernels[n]["avg_ms"])
+        traffic, src = (None, None) if sharded else pmc_traffic(dom, {"nodes": N, "edges": E, "hidden": H, "K": K})
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dom, N, E, H, K) if not sharded else None}
+                "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": ("recorded rocprofv3 PMC passes of this command, " + src) if src else None}
+        is_c4 = all(getattr(args, k) == v for k, v in C4_DEFAULTS.items()) and not args.true_degree_scalers
+        label = "C4" if is_c4 else "custom (not a BASELINE config)"
         cpu = None
-        if args.cpu_sample and not sharded:
-            cpu = cpu_baseline(rowptr, col, H, names, "new_sigmoid", args.dropout, min(args.cpu_sample, N), 42)
+        extra = None
+        if not sharded:
+            if args.cpu_sample:
+                cpu = cpu_baseline(rowptr, col, H, names, "new_sigmoid", args.dropout, min(args.cpu_sample, N), 42,
+                                   "%s R-MAT" % label.split()[0])
+            if not args.no_extra:
+                if cpu is not None:
+                    cpu["loop"] = [cpu_loop_baseline("C1", "cora_h64", 64, ["mean", "mean2"], 0.75, 2708),
+                                   cpu_loop_baseline("C3", "pubmed_h16", 16, ["min", "min2", "min3", "min4"], 0.5, 2000)]
+                Fn.TIMER = None
+                extra = extra_configs(dev)
         line = {
             "metric": "aggregated edges/sec (fwd+bwd) MultiMaskConv", "value": value, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C4: synthetic R-MAT power-law graph, %d nodes / %d directed edges, feat=%d, "
-                                   "K=%d masks [%s], nclass=%d, mask dropout p=%g, MMA layer fwd+bwd" % (
-                                       N, E, H, K, ",".join(names), C, args.dropout),
+            "config": {"workload": "%s: synthetic R-MAT power-law graph (scale %d), %d nodes / %d directed edges, feat=%d, "
+                                   "K=%d masks [%s], nclass=%d, mask dropout p=%g, %sMMA layer fwd+bwd" % (
+                                       label, args.scale, N, E, H, K, ",".join(names), C, args.dropout,
+                                       "S=5 true-degree scalers, " if args.true_degree_scalers else ""),
                        "nodes": N, "edges": E, "hidden": H, "K": K, "nclass": C,
                        "parallelism": "1-D node shard x%d, RCCL all-to-all halo" % world if world > 1 else "single GPU"},
             "masked_edges_per_s": value * K,
-            "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(line), flush=True)
     if sharded:
         dist.destroy_process_group()
 
 
-def make_layer(mma_amd, graph, H, C, names, p, dev):
+def run_c2l(args, dev):
+    """`--workload c2l`: MMAConv fwd+bwd on a molecule batch; roofline = the fused GR kernels (K3/K4)."""
+    from mma_amd import functional as Fn
+    conv, step, N, E = gr_setup(args.molecules, dev)
+    timer = KernelTimer()
+    Fn.TIMER = timer
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    T, F, K, S = 5, 75, 2, 3
+    ab = gr_algorithmic_bytes(N, E, T, F, K, S)
+    kernels = _kernel_table(timer.summary(), args.steps, ab)
+    roofs = {}
+    for n in ("gr_fused_fwd", "gr_fused_bwd"):
+        traffic, src = pmc_traffic(n, {"workload": "c2l", "nodes": N, "edges": E})
+        roofs[n] = {"bound": "hbm", "kernel": n, "achieved": kernels[n]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": kernels[n]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": ("recorded rocprofv3 PMC passes of this command, " + src) if src else None}
+    dom = max(roofs, key=lambda n: kernels[n]["avg_ms"])
+    cpu = None
+    if args.cpu_sample:
+        cpu = gr_cpu_baseline(200)
+    line = {"metric": "aggregated edges/sec (fwd+bwd) MultiMaskConv", "value": E * args.steps / dt, "unit": "edges/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2L: ZINC-like batch of %d molecules (%d nodes / %d directed edges), MMAConv 75->75, towers=5, "
+                                   "edge_dim=50, aggregators min,max, scalers identity,amplification,linear, dropout 0.5, layer fwd+bwd" % (
+                                       args.molecules, N, E), "nodes": N, "edges": E, "towers": T, "F": F, "K": K, "S": S,
+                       "parallelism": "single GPU"},
+            "roofline": roofs[dom], "roofline_other": roofs[[n for n in roofs if n != dom][0]], "kernels": kernels, "cpu_baseline": cpu}
+    print(json.dumps(line), flush=True)
+
+
+def gr_cpu_baseline(n_graphs):
+    """The GR CPU oracle (oracle/gr_oracle.conv_forward, parity unpinned - see its header) fwd+bwd on a small batch."""
+    from oracle import gr_oracle as G
+    threads = _threads()
+    rng = np.random.default_rng(1)
+    ei, N = molecule_batch(rng, n_graphs)
+    E = ei.shape[1]
+    T, F = 5, 75
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.1
+    prm = {"enc_w": r(F, 50), "enc_b": r(F), "pre_w": [r(F, 3 * F) for _ in range(T)], "pre_b": [r(F) for _ in range(T)],
+           "post_w": [r(15, 7 * F) for _ in range(T)], "post_b": [r(15) for _ in range(T)], "lin_w": r(75, 75), "lin_b": r(75)}
+    x = torch.randn(N, F, generator=g).requires_grad_(True)
+    ea = torch.randn(E, 50, generator=g)
+    keep = (torch.rand(E, T, F, generator=g) >= 0.5).float()
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 10.0:
+        out = G.conv_forward(x, torch.from_numpy(ei), ea, prm, ["min", "max"], ["identity", "amplification", "linear"],
+                             {"lin": 2.0, "log": 1.0}, T, False, keep, 0.5)
+        out.sum().backward()
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": E * reps / dt, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": "%d-molecule batch (%d nodes / %d edges), MMAConv fwd+bwd on the torch-CPU GR oracle, %d passes in %.1f s" % (
+                n_graphs, N, E, reps, dt)}
+
+
+def make_layer(mma_amd, graph, H, C, names, p, dev, **kw):
     """The drop-in MMA layer with externally owned Parameters, as models.py:17-60 creates them."""
     from mma_amd.layers import _MASK_NAMES
     P = lambda *s: torch.nn.Parameter(torch.empty(*s, device=dev))
     # only the masks in use get a full (2H,H) tensor; the reference allocates all 21 (models.py:21-41)
     masks = {n: P(2 * H, H) if n in names else P(2, 1) for n in _MASK_NAMES}
     w, b = P(H, C), P(C)
-    layer = mma_amd.MMA(graph, "new_sigmoid", 2, H, C, w, b, *[masks[n] for n in _MASK_NAMES], p, names, dev)
+    layer = mma_amd.MMA(graph, "new_sigmoid", 2, H, C, w, b, *[masks[n] for n in _MASK_NAMES], p, names, dev, **kw)
     layer.owned = [w, b] + [masks[n] for n in names]
     return layer
 

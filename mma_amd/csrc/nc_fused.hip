@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_k
           tt[u] = t0 + u * epg + sub;
           ev[u] = tt[u] < cnt;
           const int j = __shfl(myj, gbase + (tt[u] & (G - 1)), kWave);
-          const int jj = ev[u] ? j : node;   // inactive sub-rows re-read the own row (cached), contribute 0
+          const int jj = ev[u] ? j : node;   // inactive sub-rows re-read the own row (cached) and are zeroed by SELECTS below
           xj[u] = ldv<VEC>(p.x + (size_t)jj * p.ldx + cc);
 #pragma unroll
           for (int k = 0; k < K; ++k)
@@ -164,24 +164,29 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_k
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const float on = ev[u] ? 1.f : 0.f;
+          // An inactive sub-row (past the end of its item) must contribute exactly 0 whatever it loaded: its neighbour
+          // row and its logits are replaced by 0 with selects - a multiplication by 0 would turn an inf/NaN of the row
+          // it happened to read into a NaN of this node's sums.
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) xj[u].v[i] = ev[u] ? xj[u].v[i] : 0.f;
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const bool raw = (p.acts >> (p.k_base + k)) & 1u;
             float f[VEC];
             if (DROP) {
-              drop_factors<VEC>(dp, (uint32_t)(ev[u] ? ebeg + base + tt[u] : ebeg), p.k_base + k, cc, p.H, p.HQ, f);
+              // inactive: edge 0 (any valid position; EXPLICIT mode reads keep[(k*E + e)*H + c], and ebeg may equal E)
+              drop_factors<VEC>(dp, (uint32_t)(ev[u] ? ebeg + base + tt[u] : 0), p.k_base + k, cc, p.H, p.HQ, f);
             } else {
 #pragma unroll
               for (int i = 0; i < VEC; ++i) f[i] = 1.f;
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-              const float z = pk[k].v[i] + qv[u][k].v[i];
+              const float z = ev[u] ? pk[k].v[i] + qv[u][k].v[i] : 0.f;
               float a, da;
               if (raw) { a = z; da = 1.f; }
               else { a = sigmoid_fast(z); da = a - a * a; }
-              const float w = f[i] * on * xj[u].v[i];
+              const float w = f[i] * xj[u].v[i];
               acc[k].v[i] = fmaf(a, w, acc[k].v[i]);
               if (SAVE) tac[k].v[i] = fmaf(da, w, tac[k].v[i]);
             }
@@ -443,11 +448,17 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const float on = ev[u] ? 1.f : 0.f;
+          // inactive sub-rows read target row 0: everything they loaded is replaced by 0 with selects (see nc_fwd_kernel)
+          if (SHARED) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) gv[u][0].v[i] = ev[u] ? gv[u][0].v[i] : 0.f;
+            idg[u] = ev[u] ? idg[u] : 0.f;
+          }
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const bool raw = (p.acts >> (p.k_base + k)) & 1u;
             const int kind = SHARED ? kind_of(p.kinds, p.k_base + k) : 0;
+            if (SHARED) codes[u][k] = ev[u] ? codes[u][k] : 0u;
             const float kscale = 0.5f * (kind == MMA_KIND_MEAN ? idg[u] : 1.f);   // the code byte holds TWICE dm/ds
             float f[VEC];
             if (DROP) {
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-              const float z = pv[u][k].v[i] + qk[k].v[i];
+              const float z = ev[u] ? pv[u][k].v[i] + qk[k].v[i] : 0.f;
               float a, da;
               if (raw) { a = z; da = 1.f; }
               else { a = sigmoid_fast(z); da = a - a * a; }
@@ -469,9 +480,9 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
                 if (kind >= MMA_KIND_SOFTMAX && tf == 255u) cf = __builtin_nanf("");   // exp overflow in the forward combine
                 gsv = gv[u][0].v[i] * (cf * kscale);
               } else {
-                gsv = gv[u][k].v[i];
+                gsv = ev[u] ? gv[u][k].v[i] : 0.f;
               }
-              const float w = f[i] * on * gsv;
+              const float w = f[i] * gsv;
               aq[k].v[i] = fmaf(da, w, aq[k].v[i]);
               ax.v[i] = fmaf(a, w, ax.v[i]);
             }

@@ -130,7 +130,9 @@ class SpmmGraph:
         self.t_items, self.t_hubs = i32(it), i32(hb)
 
     @classmethod
-    def from_torch_sparse(cls, adj):
+    def from_torch_sparse(cls, adj, device=None):
+        """`device`: where the plan lives (the layer passes its input's device: a CPU sparse adj next to GPU features must
+        not hand host pointers to the kernels)."""
         a = adj.coalesce()
         idx = a.indices().cpu().numpy()
-        return cls(idx[0], idx[1], a.values().cpu().numpy(), a.shape[0], a.shape[1], adj.device)
+        return cls(idx[0], idx[1], a.values().cpu().numpy(), a.shape[0], a.shape[1], adj.device if device is None else device)

@@ -54,7 +54,7 @@ class GraphConvolution(Module):
     def forward(self, input, adj):
         require_gpu(input)
         if self._sg is None or self._sg[0] is not adj:
-            self._sg = (adj, SpmmGraph.from_torch_sparse(adj))
+            self._sg = (adj, adj if isinstance(adj, SpmmGraph) else SpmmGraph.from_torch_sparse(adj, input.device))
         support = mm(input, self.weight)
         return Fn.csr_spmm(support, self.bias, self._sg[1], 1)
 
@@ -145,8 +145,9 @@ class MMA(Module):
         if self.drop_override is not None:
             return self.drop_override
         if self.graph_capturable and self.dropout > 0 and device is not None:
-            if self._seed_buf is None or self._seed_buf.device != device:
-                self._seed_buf = torch.zeros(1, dtype=torch.int64, device=device)
+            n_groups = -(-len(names) // 8)      # one device seed per 8-mask launch group: groups must not share dropout bits
+            if self._seed_buf is None or self._seed_buf.device != device or self._seed_buf.numel() != n_groups:
+                self._seed_buf = torch.zeros(n_groups, dtype=torch.int64, device=device)
             self._seed_buf.random_()
             return Fn.DropoutSpec(self.dropout, seed_tensor=self._seed_buf)
         return Fn.DropoutSpec(self.dropout)
@@ -173,6 +174,8 @@ class MMA(Module):
             drop = base
             if base.keep is not None:   # explicit (K,E,H) mask: hand each group its slice
                 drop = Fn.DropoutSpec(base.p, keep=base.keep[g0:g0 + 8].contiguous())
+            elif g0 and base.seed_tensor is not None and base.seed_tensor.numel() > g0 // 8:
+                drop = Fn.DropoutSpec(base.p, seed_tensor=base.seed_tensor[g0 // 8:])       # this group's own device seed
             elif g0 and base.seed_tensor is None:
                 drop = Fn.DropoutSpec(base.p, seed=base.seed + g0)
             outs.append(self._aggregate(grp, input, drop, reduce_k))
@@ -190,7 +193,7 @@ class MMA(Module):
         msum = self._aggregate_all(self.aggregator_names, input, reduce_k=True)
         support = mm(msum, self.weight) * scaler_row_factor(N, input.device)
         if self._sg is None or self._sg[0] is not adj:   # extension: a ready-made SpmmGraph is accepted as `adj`
-            self._sg = (adj, adj if isinstance(adj, SpmmGraph) else SpmmGraph.from_torch_sparse(adj))
+            self._sg = (adj, adj if isinstance(adj, SpmmGraph) else SpmmGraph.from_torch_sparse(adj, input.device))
         return Fn.csr_spmm(support, self.bias, self._sg[1], 1)                  # layers.py:861-867
 
     def __repr__(self):

@@ -128,6 +128,7 @@ class HaloPlan:
         dist.all_to_all_single(give, want, [int(c) for c in self.send_counts], [int(c) for c in self.recv_counts], group=group)
         give = give.cpu().numpy()
         assert len(give) == 0 or (give.min() >= self.lo and give.max() < self.hi), "peer asked for rows this rank does not own"
+        self.n_total = int(bounds[-1])                                   # global node count (the scalers' quirk Q1 uses N)
         self.send_idx = (give - self.lo).astype(np.int64)               # local row ids, concatenated per peer
         self.send_offsets = np.concatenate([[0], np.cumsum(self.send_counts)]).astype(np.int64)
 
@@ -222,6 +223,9 @@ class _ShardedAggregate(torch.autograd.Function):
         gQ = gPQ[:, KH:]
         gx = torch.empty((S, H), device=dev, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32) if graph.t_n_slots else None)
+        # The reverse exchange is a COLLECTIVE: every rank of a multi-rank plan joins it, also one that has no halo rows of
+        # its own (a directed graph, or an empty shard) - its peers may still owe it gradient rows (send_counts > 0), and a
+        # rank that skipped the call would leave them blocked or matched against its next collective.
         back = None
         if S > n:
             halo_part, own_part = graph.t_parts
@@ -230,6 +234,8 @@ class _ShardedAggregate(torch.autograd.Function):
             back = all_to_all_rows_start(gxh, plan.recv_counts, plan.send_counts, plan.group)
             Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, own_part)
         else:
+            if plan.world > 1:
+                back = all_to_all_rows_start(gx[n:], plan.recv_counts, plan.send_counts, plan.group)    # sends (0,H), still receives
             Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial)
         gx_own = rows_mm_add_(gx[:n], gPQ[:n], wcat.t())         # direct + through P and Q of the own rows in one GEMM
         gwtop = gwbot = None
@@ -268,7 +274,7 @@ class ShardedMMA(torch.nn.Module):
         self.weight, self.bias = weight, bias
         self.owned = [weight, bias] + [masks[n] for n in self.names]
         self.local_edges = int(plan.rowptr[-1])
-        self.n_total = None         # global node count (scalers quirk Q1 uses N); set by build()
+        self.n_total = plan.n_total  # global node count: the scalers' quirk Q1 evaluates its factor with N, on every rank alike
         self.drop_override = None
 
     @classmethod
@@ -286,9 +292,7 @@ class ShardedMMA(torch.nn.Module):
         P = lambda *s: torch.nn.Parameter(((torch.rand(*s, generator=g) * 2 - 1) * b).to(device))
         masks = {n: P(2 * H, H) for n in names}
         weight, bias = P(H, C), P(C)
-        mod = cls(plan, device, H, C, names, masks, weight, bias, dropout, edge_base=e0, chunk=chunk)
-        mod.n_total = len(rowptr) - 1
-        return mod
+        return cls(plan, device, H, C, names, masks, weight, bias, dropout, edge_base=e0, chunk=chunk)
 
     def _drop(self):
         return self.drop_override if self.drop_override is not None else Fn.DropoutSpec(self.dropout)
@@ -301,7 +305,7 @@ class ShardedMMA(torch.nn.Module):
         ws = [self.masks[a] for a in self.names]
         msum = _ShardedAggregate.apply(x_own, torch.cat([w[:H] for w in ws], 1), torch.cat([w[H:] for w in ws], 1), self,
                                        tuple(kinds), tuple(acts), self._drop())                 # (n_own, H)
-        c3 = scaler_row_factor(self.n_total or n, x_own.device)                             # Q1: identical rows
+        c3 = scaler_row_factor(self.n_total, x_own.device)                             # Q1: identical rows
         # sum_k A (m_k W) == A ((sum_k m_k) W): only the (n,C) rows travel and enter the SpMM
         S = mm(msum, self.weight) * c3
         S_halo = _HaloExchange.apply(S, self.plan, self.send_idx)

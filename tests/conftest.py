@@ -22,3 +22,25 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Dump the strict-bar (1e-5 + 1e-5|ref|) failure count of every parity comparison of this session."""
+    try:
+        import json
+        import golden_util
+        if not golden_util.REPORT:
+            return
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        import torch
+        tag = "gpu" if torch.cuda.is_available() else "cpu"
+        with open(os.path.join(out_dir, "parity_strict_report_%s.jsonl" % tag), "w") as f:
+            for r in golden_util.REPORT:
+                f.write(json.dumps(r) + "\n")
+        n = len(golden_util.REPORT)
+        bad = [r for r in golden_util.REPORT if r["strict_outside"]]
+        print("\n[parity] %d comparisons, %d with elements outside the strict 1e-5 bar (%d elements of %d)" % (
+            n, len(bad), sum(r["strict_outside"] for r in bad), sum(r["n"] for r in golden_util.REPORT)))
+    except Exception as e:      # reporting must never turn a green run red
+        print("[parity] report skipped:", e)

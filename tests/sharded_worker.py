@@ -27,11 +27,38 @@ def graph(seed, N, avg):
     return rowptr, col
 
 
-def close(a, b, what, tol=1e-5):
+def directed_graph(N, world):
+    """Edges only run from LOWER to higher node blocks: the rank owning the first block reads no remote row (no halo of its
+    own) while every other rank reads rows of it - the case in which a rank must still join the reverse exchange."""
+    rng = np.random.default_rng(11)
+    deg = rng.integers(1, 6, N)
+    blk = N // world
+    rows = []
+    for i in range(N):
+        hi = max(blk, (i // blk) * blk)           # sources below the start of the own block (block 0: inside itself)
+        rows.append(np.sort(rng.integers(0, hi, deg[i])))
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    return rowptr, np.concatenate(rows).astype(np.int64)
+
+
+def hub_first_graph(N):
+    """Node 0 holds ~70 % of all edges: an edge-balanced 3-way partition then has an EMPTY middle shard."""
+    rng = np.random.default_rng(12)
+    deg = rng.integers(1, 4, N)
+    deg[0] = 5 * int(deg[1:].sum()) // 2
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = np.concatenate([np.sort(rng.integers(0, N, d)) for d in deg]).astype(np.int64)
+    return rowptr, col
+
+
+def close(a, b, what, signed_sum=True):
+    """Same bars as tests/golden_util.check_close: strict 1e-5 + 1e-5|ref| element-wise; long signed sums get
+    atol = max(1e-5, 1e-6 * max|ref|)."""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    err = (a - b).abs().max().item()
-    scale = max(b.abs().max().item(), 1e-30)
-    assert err <= tol * scale + 1e-6, "%s: err %.3g vs scale %.3g" % (what, err, scale)
+    err = (a - b).abs()
+    atol = max(1e-5, 1e-6 * b.abs().max().item()) if (signed_sum and b.numel()) else 1e-5
+    bad = err > atol + 1e-5 * b.abs()
+    assert not bad.any(), "%s: max err %.3g (atol %.3g), %d/%d outside" % (what, err.max().item(), atol, int(bad.sum()), err.numel())
 
 
 def run_cpu(rank, world):
@@ -86,20 +113,29 @@ def run_cpu(rank, world):
     close(gx, gx_f[lo:hi], "sharded gx (rank %d)" % rank)
 
 
-def run_gpu(rank, world):
+def run_gpu(rank, world, variant="hub"):
     import mma_amd
     from mma_amd import functional as Fn
     from mma_amd.layers import _MASK_NAMES
-    from mma_amd.sharded import ShardedMMA
+    from mma_amd.sharded import ShardedMMA, partition_bounds
     dev = "cuda:0"
     N, H, C, names, p = 400, 32, 6, ["sum", "mean", "max", "min"], 0.5
-    rowptr, col = graph(5, N, 5)
+    if variant == "directed":
+        rowptr, col = directed_graph(N, world)
+    elif variant == "empty":
+        rowptr, col = hub_first_graph(N)
+        assert (np.diff(partition_bounds(rowptr, world)) == 0).any(), "variant 'empty' needs an empty shard"
+    else:
+        rowptr, col = graph(5, N, 5)
     g = torch.Generator().manual_seed(0)
     x = torch.relu(torch.randn(N, H, generator=g))
     cot = torch.randn(N, C, generator=g)
     sh = ShardedMMA.build(rowptr, col, rank, world, dev, H, C, names, p, seed=7, chunk=64)
     seed = 0xABCDEF1234
     sh.drop_override = Fn.DropoutSpec(p, seed=seed)
+    if variant == "directed":
+        assert (rank == 0) == (sh.plan.n_halo == 0) and (rank == 0 or sh.plan.send_counts.sum() >= 0)
+        assert rank != 0 or sh.plan.send_counts.sum() > 0            # rank 0: no halo, but its rows are read by the others
     xo = x[sh.lo:sh.hi].to(dev).requires_grad_(True)
     out = sh(xo)
     out.backward(cot[sh.lo:sh.hi].to(dev))
@@ -133,7 +169,10 @@ if __name__ == "__main__":
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     try:
-        (run_cpu if mode == "cpu" else run_gpu)(rank, world)
+        if mode == "cpu":
+            run_cpu(rank, world)
+        else:
+            run_gpu(rank, world, sys.argv[2] if len(sys.argv) > 2 else "hub")
         dist.barrier()
         if rank == 0:
             print("SHARDED_%s_OK world=%d" % (mode.upper(), world), flush=True)

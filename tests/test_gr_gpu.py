@@ -92,25 +92,7 @@ def conv_params(conv):
     return prm
 
 
-def molecule_batch(rng, n_graphs=12, return_sizes=False):
-    """ZINC-like: trees of ~23 nodes + ring closures, max degree 4, symmetrised."""
-    src, dst, off, sizes = [], [], 0, []
-    for _ in range(n_graphs):
-        n = int(rng.integers(12, 30))
-        deg = np.zeros(n, int)
-        for v in range(1, n):
-            cand = [u for u in range(v) if deg[u] < 3]
-            u = int(rng.choice(cand))
-            src += [off + u, off + v]; dst += [off + v, off + u]; deg[u] += 1; deg[v] += 1
-        for _ in range(int(rng.integers(1, 4))):
-            u, v = rng.choice(n, 2, replace=False)
-            if deg[u] < 4 and deg[v] < 4:
-                src += [off + u, off + v]; dst += [off + v, off + u]; deg[u] += 1; deg[v] += 1
-        off += n
-        sizes.append(n)
-    if return_sizes:
-        return np.array([src, dst]), off, np.array(sizes)
-    return np.array([src, dst]), off
+from tools.synth import molecule_batch  # noqa: E402,F401  (ZINC-like batches; shared with bench.py)
 
 
 CONV_CASES = [

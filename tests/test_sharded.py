@@ -14,15 +14,15 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _launch(mode, world):
+def _launch(mode, world, *extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "sharded_worker.py"), mode]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "sharded_worker.py"), mode, *extra]
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and ("SHARDED_%s_OK" % mode.upper()) in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_sharded_cpu_gloo(world):
     _launch("cpu", world)
 
@@ -30,6 +30,14 @@ def test_sharded_cpu_gloo(world):
 @pytest.mark.gpu
 def test_sharded_gpu_two_ranks_one_device():
     _launch("gpu", 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,world", [("directed", 2), ("empty", 3)])
+def test_sharded_gpu_rank_without_halo_still_joins_the_exchange(variant, world):
+    """a rank with no halo rows of its own (directed graph) or an empty shard must still take part in the
+    reverse all-to-all and receive its peers' dL/dx contributions."""
+    _launch("gpu", world, variant)
 
 
 def test_partition_bounds_balance():

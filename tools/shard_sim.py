@@ -50,6 +50,7 @@ def make_plan(rank, world):
     p.send_counts = np.array(sc, dtype=np.int64)
     p.send_idx = (np.concatenate(give) - p.lo).astype(np.int64) if give else np.zeros(0, np.int64)
     p.send_offsets = np.concatenate([[0], np.cumsum(p.send_counts)]).astype(np.int64)
+    p.n_total = N
     return p, e0
 
 def run(rank, world, steps=5):
@@ -58,7 +59,6 @@ def run(rank, world, steps=5):
     P = lambda *s: torch.nn.Parameter(((torch.rand(*s, generator=g) * 2 - 1) * b).to(dev))
     masks = {n: P(2 * H, H) for n in names}
     sh = S.ShardedMMA(plan, dev, H, C, names, masks, P(H, C), P(C), 0.5, edge_base=e0)
-    sh.n_total = N
     x = torch.relu(torch.randn(plan.n_own, H, device=dev)).requires_grad_(True)
     cot = torch.randn(plan.n_own, C, device=dev)
     def step():
