@@ -201,8 +201,19 @@ class MMA(Module):
 
 
 def _make_learnable(name):
-    def learnable(self, input, adj=None, *unused):
+    """learnable_<name>(input, adj): the public per-aggregator methods of layers.py:201-851, same signatures - the max* /
+    min* forms carry the reference's (unused) `min_value=-inf` / `max_value=inf` keyword (layers.py:430,540)."""
+    def run(self, input):
         return self._aggregate([name], input)[0]
+    if name.startswith("max"):
+        def learnable(self, input, adj, min_value=-math.inf):
+            return run(self, input)
+    elif name.startswith("min"):
+        def learnable(self, input, adj, max_value=math.inf):
+            return run(self, input)
+    else:
+        def learnable(self, input, adj):
+            return run(self, input)
     learnable.__name__ = "learnable_" + name
     learnable.__doc__ = "Fused HIP form of layers.py learnable_%s(input, adj) -> (N, H)." % name
     return learnable

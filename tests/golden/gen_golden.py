@@ -243,14 +243,14 @@ CASES = {
                                       single_aggs=("sum3", "mean3", "max4", "min2"), full_store=True),
     # BASELINE config 1 shape: Cora, H=64, mean,mean2 (README.md:70)
     "cora_h64": lambda: run_case("cora_h64", graph_from_pickle("cora"), 64, 7, 44,
-                                 agg_sets=[("mean", "mean2")], activations=["new_sigmoid"], p_list=[0.0]),
+                                 agg_sets=[("mean", "mean2")], activations=["new_sigmoid"], p_list=[0.0, 0.75]),   # --dropout=0.75
     "cora_h16": lambda: run_case("cora_h16", graph_from_pickle("cora"), 16, 7, 45,
                                  agg_sets=[("sum", "max", "min", "mean")], activations=["new_sigmoid"],
                                  p_list=[0.0, 0.5]),
     # BASELINE config 3 shape: Pubmed structure, H=16, min,min2,min3,min4 (README.md:58/64)
     "pubmed_h16": lambda: run_case("pubmed_h16", graph_from_pickle("pubmed"), 16, 3, 46,
                                    agg_sets=[("min", "min2", "min3", "min4")], activations=["new_sigmoid"],
-                                   p_list=[0.0]),
+                                   p_list=[0.0, 0.5]),                                                       # --dropout=0.5
 }
 
 if __name__ == "__main__":

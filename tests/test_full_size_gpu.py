@@ -70,24 +70,35 @@ def test_c4_full_size_properties_and_sample_parity():
     # edges must be listed in the sub-graph's target order (ascending remapped id == ascending global id)
     cj = remap[src]
     keep = keep_mask(seed, int(p * 256), K, len(seg), H, edge_ids=seg)
-    xo = x[nodes].clone().requires_grad_(True)
-    Wo = {n: Ws[n].clone().requires_grad_(True) for n in names}
-    mo = torch.stack([O.aggregate(n, xo, Wo[n], rp, cj, act, p, keep[k]) for k, n in enumerate(names)])
     tgt = torch.from_numpy(remap[sample])
     cot_sub = torch.zeros(K, n_sub, H); cot_sub[:, tgt] = cot[:, sample]
-    go = torch.autograd.grad((mo * cot_sub).sum(), [xo] + [Wo[n] for n in names])
+
+    def oracle(dtype):
+        """One aggregator at a time (the masks only meet in the sum over k of dL/dx): bounds the host memory of the
+        float64 pass to one mask's autograd tape."""
+        xo = x[nodes].to(dtype)
+        ms, gx, gws = [], torch.zeros_like(xo), []
+        for k, n in enumerate(names):
+            xk, wk = xo.clone().requires_grad_(True), Ws[n].to(dtype).requires_grad_(True)
+            mk = O.aggregate(n, xk, wk, rp, cj, act, p, keep[k])
+            a, b = torch.autograd.grad((mk * cot_sub[k].to(dtype)).sum(), [xk, wk])
+            ms.append(mk.detach()); gx += a; gws.append(b)
+            del mk
+        return torch.stack(ms), [gx] + gws
+    mo, go = oracle(torch.float32)
+    m64, g64 = oracle(torch.float64)        # exact value of the same formulas: sets the slack of the long signed sums
     # forward rows
     for k, n in enumerate(names):
         # raw-logit masks (max/min under "new_sigmoid") sum ~26 k SIGNED terms on the hubs: scale-relative bar there
-        check_close(m[k][torch.from_numpy(sample).to(DEV)], mo[k][tgt].detach().numpy(), None, None, what="C4 sample m/" + n,
-                    signed_sum=O.uses_raw_logits(n, act))
+        check_close(m[k][torch.from_numpy(sample).to(DEV)], mo[k][tgt].numpy(), None, None, what="C4 sample m/" + n,
+                    signed_sum=O.uses_raw_logits(n, act), truth=m64[k][tgt].numpy())
     # backward: gradient w.r.t. x on every involved node (0 elsewhere), and w.r.t. the mask weights
     gx = grads[0].cpu()
-    check_close(gx[torch.from_numpy(nodes)], go[0].numpy(), None, None, what="C4 sample gx", signed_sum=True)
+    check_close(gx[torch.from_numpy(nodes)], go[0].numpy(), None, None, what="C4 sample gx", signed_sum=True, truth=g64[0].numpy())
     mask = torch.ones(N, dtype=torch.bool); mask[torch.from_numpy(nodes)] = False
     assert gx[mask].abs().max().item() == 0.0
-    for n, a, b in zip(names, grads[1:], go[1:]):
-        check_close(a, b.numpy(), None, None, what="C4 sample gW/" + n, signed_sum=True)
+    for n, a, b, t in zip(names, grads[1:], go[1:], g64[1:]):
+        check_close(a, b.numpy(), None, None, what="C4 sample gW/" + n, signed_sum=True, truth=t.numpy())
 
 
 def test_c2l_full_batch_properties_and_sample_parity():
@@ -131,5 +142,10 @@ def test_c2l_full_batch_properties_and_sample_parity():
     want = G.conv_forward(xo, torch.from_numpy(ei[:, :e_s]), torch.from_numpy(ea[:e_s]), conv_params(conv), conv.aggregators,
                           conv.scalers, conv.avg_deg, T, False, keep, p)
     gw, = torch.autograd.grad((want * torch.from_numpy(cot[:n_s])).sum(), [xo])
-    check_close(out[:n_s], want.detach().numpy(), None, None, what="C2L sample out", signed_sum=True)
-    check_close(gx[:n_s], gw.numpy(), None, None, what="C2L sample gx", signed_sum=True)
+    from test_gr_gpu import to64
+    x64 = torch.from_numpy(x[:n_s]).double().requires_grad_(True)
+    w64 = G.conv_forward(x64, torch.from_numpy(ei[:, :e_s]), torch.from_numpy(ea[:e_s]).double(), to64(conv_params(conv)),
+                         conv.aggregators, conv.scalers, conv.avg_deg, T, False, keep, p)
+    g64, = torch.autograd.grad((w64 * torch.from_numpy(cot[:n_s]).double()).sum(), [x64])
+    check_close(out[:n_s], want.detach().numpy(), None, None, what="C2L sample out", signed_sum=True, truth=w64.detach().numpy())
+    check_close(gx[:n_s], gw.numpy(), None, None, what="C2L sample gx", signed_sum=True, truth=g64.numpy())

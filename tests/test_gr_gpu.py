@@ -92,6 +92,11 @@ def conv_params(conv):
     return prm
 
 
+def to64(prm):
+    """The oracle's parameter dict in float64 (truth passes of golden_util.check_close)."""
+    return {k: ([t.double() for t in v] if isinstance(v, list) else v.double()) for k, v in prm.items()}
+
+
 from tools.synth import molecule_batch  # noqa: E402,F401  (ZINC-like batches, SURVEY 8d C2; shared with bench.py)
 
 
@@ -130,6 +135,11 @@ def test_mmaconv_forward_backward_vs_oracle(cfg, p):
     want = G.conv_forward(xo, torch.from_numpy(ei), eo, conv_params(conv), cfg["aggregators"], cfg["scalers"], conv.avg_deg, T,
                           cfg.get("divide_input", False), keep, p)
     gw = torch.autograd.grad((want * torch.from_numpy(cot)).sum(), [xo] + ([eo] if eo is not None else []))
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    e64 = torch.from_numpy(ea).double().requires_grad_(True) if ea is not None else None
+    w64 = G.conv_forward(x64, torch.from_numpy(ei), e64, to64(conv_params(conv)), cfg["aggregators"], cfg["scalers"], conv.avg_deg, T,
+                         cfg.get("divide_input", False), keep, p)
+    g64 = torch.autograd.grad((w64 * torch.from_numpy(cot).double()).sum(), [x64] + ([e64] if e64 is not None else []))
     # HIP
     xg = torch.from_numpy(x).to(DEV).requires_grad_(True)
     eg = torch.from_numpy(ea).to(DEV).requires_grad_(True) if ea is not None else None
@@ -138,10 +148,10 @@ def test_mmaconv_forward_backward_vs_oracle(cfg, p):
     params = [p_ for p_ in conv.parameters()]
     gg = torch.autograd.grad((got * torch.from_numpy(cot).to(DEV)).sum(), [xg] + ([eg] if eg is not None else []) + params,
                              allow_unused=True)
-    check_close(got, want.detach().numpy(), None, None, what="conv out", signed_sum=True)
-    check_close(gg[0], gw[0].numpy(), None, None, what="conv gx", signed_sum=True)
+    check_close(got, want.detach().numpy(), None, None, what="conv out", signed_sum=True, truth=w64.detach().numpy())
+    check_close(gg[0], gw[0].numpy(), None, None, what="conv gx", signed_sum=True, truth=g64[0].numpy())
     if eg is not None:
-        check_close(gg[1], gw[1].numpy(), None, None, what="conv g(edge_attr)", signed_sum=True)
+        check_close(gg[1], gw[1].numpy(), None, None, what="conv g(edge_attr)", signed_sum=True, truth=g64[1].numpy())
     # G2: the mask Linears are unregistered => not among parameters(), every registered parameter got a gradient
     names = [n for n, _ in conv.named_parameters()]
     assert not any("pre_nns" in n or "aggregation_layers" in n for n in names)
@@ -178,11 +188,15 @@ def test_mmaconv_fused_hub_and_medium_degrees(p):
     want = G.conv_forward(xo, torch.from_numpy(ei), torch.from_numpy(ea), conv_params(conv), conv.aggregators, conv.scalers,
                           conv.avg_deg, T, False, keep, p)
     gw, = torch.autograd.grad((want * torch.from_numpy(cot)).sum(), [xo])
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    w64 = G.conv_forward(x64, torch.from_numpy(ei), torch.from_numpy(ea).double(), to64(conv_params(conv)), conv.aggregators,
+                         conv.scalers, conv.avg_deg, T, False, keep, p)
+    g64, = torch.autograd.grad((w64 * torch.from_numpy(cot).double()).sum(), [x64])
     xg = torch.from_numpy(x).to(DEV).requires_grad_(True)
     got = conv(xg, torch.from_numpy(ei).to(DEV), torch.from_numpy(ea).to(DEV))
     gg, = torch.autograd.grad((got * torch.from_numpy(cot).to(DEV)).sum(), [xg])
-    check_close(got, want.detach().numpy(), None, None, what="hub conv out", signed_sum=True)
-    check_close(gg, gw.numpy(), None, None, what="hub conv gx", signed_sum=True)
+    check_close(got, want.detach().numpy(), None, None, what="hub conv out", signed_sum=True, truth=w64.detach().numpy())
+    check_close(gg, gw.numpy(), None, None, what="hub conv gx", signed_sum=True, truth=g64.numpy())
 
 
 def test_only_last_aggregators_mask_is_used():     # G1

@@ -66,3 +66,31 @@ def test_avg_deg_uses_histogram_values():
     hist = torch.tensor([0, 10, 30, 50, 10])
     a = G.avg_deg_from_histogram(hist)
     assert math.isclose(a["lin"], 20.0) and math.isclose(a["log"], float(torch.log(hist.float() + 1).mean()), rel_tol=1e-6)
+
+
+def test_two_scatter_restatements_agree_on_ties_and_empty_targets():
+    """gr_oracle.scatter (scatter_reduce + arg trick) against the literal sequential-update loop (scatter_sequential):
+    values bit-equal; the gradient of min/max is exactly the one-hot of the sequential loop's arg (first extremal edge)."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for trial, (E, N, feat) in enumerate([(0, 3, (2,)), (1, 1, (1,)), (40, 7, (3,)), (300, 25, (2, 5)), (64, 64, (4,))]):
+        index = rng.integers(0, max(N - 2, 1), E)                       # the last two targets stay empty (when N > 2)
+        if E >= 40:
+            index[:20] = 1                                              # one long segment
+        vals = (rng.integers(-2, 3, (E,) + feat) * 0.5).astype(np.float32)   # 5 distinct values: ties everywhere
+        src = torch.from_numpy(vals).requires_grad_(True)
+        for red in ("sum", "mean", "min", "max"):
+            a = G.scatter(src, torch.from_numpy(index), N, red)
+            b, arg = G.scatter_sequential(vals, index, N, red)
+            if red in ("min", "max"):
+                assert np.array_equal(a.detach().numpy(), b), (trial, red)
+                ga = torch.autograd.grad(a.sum(), [src], allow_unused=True)[0] if a.requires_grad else None
+                onehot = np.zeros_like(vals)
+                it = np.nditer(arg, flags=["multi_index"])
+                for v in it:
+                    if int(v) >= 0:
+                        onehot[(int(v),) + it.multi_index[1:]] = 1.0
+                assert np.array_equal((ga if ga is not None else torch.zeros_like(src)).numpy(), onehot), (trial, red)
+                assert (arg[max(N - 2, 1):] == -1).all() and (b[max(N - 2, 1):] == 0).all()     # empty targets: 0, no arg
+            else:
+                assert np.allclose(a.detach().numpy(), b, rtol=1e-6, atol=1e-6), (trial, red)     # summation order differs

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import CASES, Golden, check_close
+from golden_util import CASES, Golden, check_close, nc_truth
 from oracle import nc_oracle as O
 
 
@@ -42,17 +42,18 @@ def test_forward_and_grads(gold):
         out, ms = O.mma_forward(aggs, x, Ws, weight, bias, gold.rowptr, gold.col,
                                 gold.z["adj_row"], gold.z["adj_col"], gold.z["adj_val"], act, p, keeps, return_m=True)
         z = gold.z
-        check_close(out, z[key + "/out"], gold.rows, z[key + "/out/stats"], what=key + "/out", signed_sum=True)
+        tr = nc_truth(gold, key)
+        check_close(out, z[key + "/out"], gold.rows, z[key + "/out/stats"], what=key + "/out", signed_sum=True, truth=tr["out"])
         for a, m in zip(aggs, ms):
             check_close(m, z[key + "/m/" + a], gold.rows, z[key + "/m/" + a + "/stats"], what=key + "/m/" + a)
         grads = torch.autograd.grad((out * cot).sum(), [x, weight, bias] + [Ws[a] for a in aggs])
-        def gclose(g, want, what, rows=None):
-            check_close(g, want, rows, None, what=what, signed_sum=True)
-        gclose(grads[0], z[key + "/gx"], key + "/gx", gold.rows)
-        gclose(grads[1], z[key + "/gweight"], key + "/gweight")
-        gclose(grads[2], z[key + "/gbias"], key + "/gbias")
+        def gclose(g, name, rows=None):
+            check_close(g, z[key + "/" + name], rows, None, what=key + "/" + name, signed_sum=True, truth=tr[name])
+        gclose(grads[0], "gx", gold.rows)
+        gclose(grads[1], "gweight")
+        gclose(grads[2], "gbias")
         for a, g in zip(aggs, grads[3:]):
-            gclose(g, z[key + "/gmask/" + a], key + "/gmask/" + a)
+            gclose(g, "gmask/" + a)
 
 
 def test_scalers_are_identity_quirk():
