@@ -408,7 +408,8 @@ def main():
     timer = KernelTimer()
     Fn.TIMER = timer
     torch.manual_seed(42)
-    extra_kw = dict(strict_reference=False) if args.true_degree_scalers else {}
+    extra_kw = dict(strict_reference=False, scalers=["identity", "amplification", "attenuation", "linear", "inverse_linear"],
+                    compound_scalers=True) if args.true_degree_scalers else {}
 
     if not sharded:
         graph = mma_amd.NCGraph(rowptr, col, dev)

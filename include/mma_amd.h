@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 13
+#define MMA_ABI_VERSION 14
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -202,30 +202,37 @@ enum { MMA_SC_IDENTITY = 0, MMA_SC_AMPLIFICATION = 1, MMA_SC_ATTENUATION = 2, MM
 /* ---- K3: fused message + K-aggregator scatter-reduce + degree scalers, graph-regression form --------
  * One pass over each target's edge segment replaces MMAConv.message + MMAConv.aggregate
  * (mma_conv.py:138-196: cat, per-tower Linear, dropout, K x torch_scatter.scatter, degree, compounding scalers, cat):
- *   h_e = drop(U[i] + V[j] + Z[e])      with i = target, j = src[p], e = perm[p]   (fused-message mode), or
+ *   h_e = drop(U[i] + V[j] + Z[r])      with i = target, j = src[p], e = perm[p]   (fused-message mode), or
  *   h_e = inputs[e]                                                                (given-messages mode = aggregate())
  *   out[n, t, s*K*F + k*F + f] = aggr_k over {h_e[t*F+f] : target(e) = n}, times the running product of scalers 0..s.
- * U,V: (N,T*F) with U = x @ W_i^T + b, V = x @ W_j^T; Z: (E,T*F) = enc(edge_attr) @ W_e^T or NULL.
- * Saved for backward when non-NULL: amin/amax (N,T*F) original edge position of the extremum (-1: empty target,
- * ties -> lowest position), mean/var, all with row pitch ldsave >= T*F.  When every operand's pitch is T*F rounded up to a
- * multiple of 4 (zero padding columns) and 16-byte aligned, a lane moves one dwordx4 per row; otherwise one dword. */
+ * U,V: (N,T*F) with U = x @ W_i^T + b, V = x @ W_j^T; Z: (E,T*F) = enc(edge_attr) @ W_e^T or NULL, its row r = the
+ * target-sorted POSITION p when by_pos != 0 (the caller permuted edge_attr by `perm` before its GEMM, so Z streams
+ * contiguously), the original edge id e otherwise.  The dropout bits are keyed by e in both cases.
+ * Saved for backward when non-NULL (row pitch ldsave >= T*F for all of them):
+ *   amin8/amax8 (N,ldsave) BYTES: offset of the extremal edge inside its target's segment (ties -> lowest position, the
+ *     torch_scatter CPU rule; 0xFF: none) for segments of < 256 edges; longer segments store int32 offsets in row
+ *     ceil(rowptr[n]/256) of amin_side/amax_side (mma_gr_arg_side_rows(E), ldsave) - both of a pair or neither;
+ *   mean/var (N,ldsave) floats for var/std.
+ * When every operand's pitch is T*F rounded up to a multiple of 4 (zero padding columns) and 16-byte aligned, a lane
+ * moves one dwordx4 per row; otherwise one dword. */
+int64_t mma_gr_arg_side_rows(int64_t E);
 int mma_gr_fused_fwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
-    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
-    float* out, int32_t* amin, int32_t* amax, float* mean, float* var, int64_t ldsave,
+    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
+    float* out, uint8_t* amin8, uint8_t* amax8, int32_t* amin_side, int32_t* amax_side, float* mean, float* var, int64_t ldsave,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
-/* ---- K4: backward of K3 w.r.t. every edge message: gmsg[e, :] (E,T*F) by original edge position ------
+/* ---- K4: backward of K3 w.r.t. every edge message: gmsg (E,T*F), row = position p (by_pos != 0) or original edge id ------
  * min/max route the gradient to the saved arg edge only (torch_scatter), mean divides by the count, var/std use the
- * saved mean/var; in fused-message mode the dropout factor of the edge is applied, so gmsg = dL/d(U[i]+V[j]+Z[e]).
+ * saved mean/var; in fused-message mode the dropout factor of the edge is applied, so gmsg = dL/d(U[i]+V[j]+Z[r]).
  * gU (may be NULL): (N, ldgu >= T*F) receives dL/dU[i] = the sum of gmsg over target i's segment (a zero row for an empty
  * target) from the same pass - the kernel walks exactly those segments, so the separate segment sum is not needed. */
 int mma_gr_fused_bwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
-    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
-    const float* gout, const int32_t* amin, const int32_t* amax, const float* mean, const float* var, int64_t ldsave,
-    float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
+    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
+    const float* gout, const uint8_t* amin8, const uint8_t* amax8, const int32_t* amin_side, const int32_t* amax_side,
+    const float* mean, const float* var, int64_t ldsave, float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream);
 

@@ -21,13 +21,19 @@ enum { SC_IDENTITY = 0, SC_AMPLIFICATION = 1, SC_ATTENUATION = 2, SC_LINEAR = 3,
 struct GrParams {
   const int32_t* rowptr; const int32_t* src; const int32_t* perm;
   const float* U; const float* V; int64_t lduv; const float* Z; int64_t ldz;   // fused-message mode
-  const float* inputs; int64_t ldi;                                              // given-messages mode (E,D)
+  const float* inputs; int64_t ldi;                                              // given-messages mode (E,D), rows by ORIGINAL edge id
   float* out; const float* gout;                                                 // (N, T, S*K*F)
-  int32_t* amin; int32_t* amax; float* mean; float* var; int64_t ldsave;        // (N,ldsave>=D) saved for backward (may be NULL)
-  float* gmsg; int64_t ldg;                                                      // backward: (E,D) by original edge id
+  // saved for backward (may be NULL): argmin / argmax as the edge's OFFSET inside its target segment - one byte per column
+  // for segments of < 256 edges (arg8), an int32 row per longer segment in a side table (row = ceil(rowptr[n] / 256): a
+  // segment of >= 256 positions contains exactly one first multiple of 256, so the rows are unique and (E >> 8) + 2 suffice)
+  uint8_t* amin8; uint8_t* amax8; int32_t* amin_side; int32_t* amax_side;
+  float* mean; float* var; int64_t ldsave;                                      // (N,ldsave>=D)
+  float* gmsg; int64_t ldg;                                                      // backward: (E,D) message gradients
   float* gU; int64_t ldgu;                                                       // backward, optional: (N,D) sum of gmsg over each target's segment
   int N, D, T, F, K, S, lpr_log;
+  int by_pos;                                        // 1: Z and gmsg rows are indexed by the target-sorted POSITION p, 0: by perm[p]
   int wave_min_deg;                                  // wave-per-node pass: skip segments shorter than this
+  int nb; uint32_t qd, qd_magic, f_magic;            // flat kernels: nodes per workgroup, lanes (VEC columns each) per row, 2^32/d magics
   bool need_sum, need_sq, need_min, need_max, need_mean;   // which running reductions the aggregator list uses
   uint8_t aggr[MMA_MAX_K]; uint8_t scaler[8];
   float avg_log, avg_lin;
@@ -44,29 +50,29 @@ __device__ __forceinline__ float scaler_factor(int code, float deg, float avg_lo
   }
 }
 
-// the VEC messages h_e[c..c+VEC) of edge e (fused: drop(U[i] + V[j] + Z[e]); given: inputs[e])
+// the VEC messages h_e[c..c+VEC) of the edge at target-sorted position pos with original id e and source j
+// (fused: drop(U[i] + V[j] + Z[e or pos]); given: inputs[e])
 template <int VEC>
 __device__ __forceinline__ Vec<VEC> gr_message(const GrParams& p, const DropParams& dp, bool fused, const Vec<VEC>& u, int j,
-                                               uint32_t e, int cc) {
+                                               uint32_t e, uint32_t pos, int cc) {
   if (!fused) return ldv<VEC>(p.inputs + (size_t)e * p.ldi + cc);
   Vec<VEC> h = ldv<VEC>(p.V + (size_t)j * p.lduv + cc);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) h.v[i] += u.v[i];
   if (p.Z) {
-    const Vec<VEC> z = ldv<VEC>(p.Z + (size_t)e * p.ldz + cc);
+    const Vec<VEC> z = ldv<VEC>(p.Z + (size_t)(p.by_pos ? pos : e) * p.ldz + cc);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) h.v[i] += z.v[i];
   }
   if (dp.mode != MMA_DROP_NONE) {
     float f[VEC];
-    drop_factors<VEC>(dp, e, 0, cc, p.D, 0, f);
+    drop_factors<VEC>(dp, e, 0, cc, p.D, 0, f);      // the keep bits are keyed by the ORIGINAL edge id (oracle/dropout_rng.py)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) h.v[i] *= f[i];
   }
   return h;
 }
 
-// Saved per-column edge ids (argmin / argmax): VEC consecutive int32, one 16-byte access when VEC == 4.
 template <int VEC> __device__ __forceinline__ void ldi(const int32_t* q, int (&a)[VEC]);
 template <> __device__ __forceinline__ void ldi<4>(const int32_t* q, int (&a)[4]) {
   const int4 t = *reinterpret_cast<const int4*>(q);
@@ -79,19 +85,48 @@ template <> __device__ __forceinline__ void sti<4>(int32_t* q, const int (&a)[4]
 }
 template <> __device__ __forceinline__ void sti<1>(int32_t* q, const int (&a)[1]) { *q = a[0]; }
 
-// Two launch shapes share the node-level code below.
+// saved arg = offset of the extremal edge inside the node's segment [segb, segb + cnt)
+__device__ __forceinline__ size_t arg_side_row(int segb) { return (size_t)((segb + 255) >> 8); }
+template <int VEC>
+__device__ __forceinline__ void arg_store(const GrParams& p, uint8_t* a8, int32_t* side, int node, int segb, int cnt, int c,
+                                          const int (&off)[VEC]) {
+  if (cnt < 256) {                                   // offsets 0..254; 0xFF = no edge selected (all-NaN column)
+    uint32_t w = 0;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) w |= ((uint32_t)off[i] & 0xFFu) << (8 * i);
+    stb<VEC>(a8 + (size_t)node * p.ldsave + c, w);
+  } else {
+    sti<VEC>(side + arg_side_row(segb) * p.ldsave + c, off);
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void arg_load(const GrParams& p, const uint8_t* a8, const int32_t* side, int node, int segb, int cnt, int c,
+                                         int (&off)[VEC]) {
+  if (cnt < 256) {
+    const uint32_t w = ldb<VEC>(a8 + (size_t)node * p.ldsave + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) off[i] = (int)((w >> (8 * i)) & 0xFFu);     // 255 never equals an offset of such a segment
+  } else {
+    ldi<VEC>(side + arg_side_row(segb) * p.ldsave + c, off);
+  }
+}
+
+// Three launch shapes share the node-level code below.
+//  * flat (short segments, E <= 16 N: molecule batches): a workgroup owns a CONTIGUOUS block of nb nodes and a lane one
+//    VEC-column piece of the flat (node, column) array of that block, looping over its own node's few edges alone.  U, out,
+//    the saved args, gout, gU and (with by_pos) Z and gmsg of consecutive nodes are then contiguous runs of the block -
+//    every store instruction of a wave covers whole lines whatever D = T*F is (ZINC: 380 floats per row, 456 per output
+//    tower), and a line is only ever shared between the two workgroups at a block boundary.  The round-1 shape (a wave
+//    per 2 nodes, column chunks in blockIdx.y, neighbouring nodes on different XCDs) left most 128-byte lines of `out`
+//    partially written by workgroups on different XCDs: 1.34x the algorithmic traffic, 0.34 of the HBM peak.
+//    Workgroup ids are dealt so that each XCD walks its own contiguous eighth of the node blocks (neighbour rows V[j] of a
+//    molecule then sit in the L2 of the XCD that needs them).
 //  * wave-per-node: the 64/lpr sub-rows of a wave split one node's edge segment and meet in a butterfly (any degree);
-//  * group-per-node: every lpr-lane group owns its own node and walks its (short) segment alone - no cross-lane
-//    traffic, and one VALU instruction works for 64/lpr nodes.  These kernels are INSTRUCTION bound on molecule batches
-//    (a wave64 VALU op occupies its SIMD for 4 cycles; ~600 of them per node and 128-column chunk), so this is what
-//    halves their time.  Nodes above kGroupMaxDeg edges are left to a wave-per-node pass over the same arrays.
-// Either way a wave walks its nodes (grid stride) through a two-deep software pipeline: while node n is reduced, the
-// segment bounds of node n+2 and the edge indices + U row of node n+1 are already in flight.
+//    behind the flat kernel it only takes the segments above kGroupMaxDeg edges.
 constexpr int kGroupMaxDeg = 64;
 
 struct Seg { int b, e; };        // [b, e): positions of one node's target-sorted edges
 struct SegIdx { int j, e; };     // per lane: source node and original edge id at position b + lane
-struct Idx4 { int j[4], e[4]; }; // group mode: the first four edges of the group's node
 
 __device__ __forceinline__ Seg seg_load(const GrParams& p, int node) {       // beyond N: empty
   Seg s{0, 0};
@@ -103,17 +138,8 @@ __device__ __forceinline__ SegIdx idx_load(const GrParams& p, int base, int end,
   if (base + lane < end) { r.j = p.src[base + lane]; r.e = p.perm[base + lane]; }
   return r;
 }
-__device__ __forceinline__ Idx4 idx4_load(const GrParams& p, Seg s) {
-  Idx4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    r.j[i] = 0; r.e[i] = 0;
-    if (s.b + i < s.e) { r.j[i] = p.src[s.b + i]; r.e[i] = p.perm[s.b + i]; }
-  }
-  return r;
-}
 
-struct GrLane { int lane, sub, lpr, epg, c, cc; bool valid, fused; };
+struct GrLane { int lane, sub, lpr, epg, c, cc, t, f; bool valid, fused; };
 
 __device__ __forceinline__ GrLane gr_lane(const GrParams& p, int vec) {
   GrLane l;
@@ -123,11 +149,13 @@ __device__ __forceinline__ GrLane gr_lane(const GrParams& p, int vec) {
   l.c = ((int)blockIdx.y * l.lpr + (l.lane & (l.lpr - 1))) * vec;
   l.valid = l.c < p.D;
   l.cc = l.valid ? l.c : 0;
+  l.t = l.cc / p.F; l.f = l.cc - l.t * p.F;       // VEC == 4 only with F % 4 == 0: the 4 columns of a lane sit in one tower
   l.fused = p.inputs == nullptr;
   return l;
 }
 
-// running reductions of one (node, VEC columns): only what the aggregator list needs is updated (wave-uniform flags)
+// running reductions of one (node, VEC columns): only what the aggregator list needs is updated (wave-uniform flags);
+// an / ax = OFFSET of the extremal edge inside the node's segment
 template <int VEC>
 struct GrAcc {
   float sum[VEC], sq[VEC], mn[VEC], mx[VEC];
@@ -136,7 +164,7 @@ struct GrAcc {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { sum[i] = 0.f; sq[i] = 0.f; mn[i] = INFINITY; mx[i] = -INFINITY; an[i] = INT_MAX; ax[i] = INT_MAX; }
   }
-  __device__ __forceinline__ void take(const GrParams& p, const Vec<VEC>& h, int e) {
+  __device__ __forceinline__ void take(const GrParams& p, const Vec<VEC>& h, int off) {
     if (p.need_sum) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) sum[i] += h.v[i];
@@ -147,23 +175,21 @@ struct GrAcc {
     }
     if (p.need_min) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) if (h.v[i] < mn[i]) { mn[i] = h.v[i]; an[i] = e; }   // strict: the first extremal edge wins
+      for (int i = 0; i < VEC; ++i) if (h.v[i] < mn[i]) { mn[i] = h.v[i]; an[i] = off; }   // strict: the first extremal edge wins
     }
     if (p.need_max) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) if (h.v[i] > mx[i]) { mx[i] = h.v[i]; ax[i] = e; }
+      for (int i = 0; i < VEC; ++i) if (h.v[i] > mx[i]) { mx[i] = h.v[i]; ax[i] = off; }
     }
   }
 };
 
 // degree scalers, K aggregates, final layout and the state saved for backward, for the lanes that own columns
 template <int VEC>
-__device__ __forceinline__ void gr_fwd_store(const GrParams& p, const GrLane& l, int node, int cnt, GrAcc<VEC>& a,
+__device__ __forceinline__ void gr_fwd_store(const GrParams& p, const GrLane& l, int node, int segb, int cnt, GrAcc<VEC>& a,
                                              const float (&fac)[8]) {
   const float deg = (float)max(cnt, 1);                       // degree(...).clamp_(1), mma_conv.py:178-179
-  // VEC == 4 is only launched when F % 4 == 0: the 4 columns of a lane then sit in one tower, 16-byte aligned in `out`
-  const int t = l.c / p.F, f = l.c - t * p.F;
-  float* o = p.out + ((size_t)node * p.T + t) * ((size_t)p.S * p.K * p.F) + f;
+  float* o = p.out + ((size_t)node * p.T + l.t) * ((size_t)p.S * p.K * p.F) + l.f;
   float mean[VEC], var[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { mean[i] = 0.f; var[i] = 0.f; }
@@ -194,18 +220,10 @@ __device__ __forceinline__ void gr_fwd_store(const GrParams& p, const GrLane& l,
       stv<VEC>(o + (size_t)(q * p.K + k) * p.F, run);
     }
   }
-  const size_t so = (size_t)node * p.ldsave + l.c;
-  if (p.amin) {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) a.an[i] = cnt ? a.an[i] : -1;
-    sti<VEC>(p.amin + so, a.an);
-  }
-  if (p.amax) {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) a.ax[i] = cnt ? a.ax[i] : -1;
-    sti<VEC>(p.amax + so, a.ax);
-  }
+  if (p.amin8) arg_store<VEC>(p, p.amin8, p.amin_side, node, segb, cnt, l.c, a.an);
+  if (p.amax8) arg_store<VEC>(p, p.amax8, p.amax_side, node, segb, cnt, l.c, a.ax);
   if (p.mean) {
+    const size_t so = (size_t)node * p.ldsave + l.c;
     Vec<VEC> mv, vv;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { mv.v[i] = mean[i]; vv.v[i] = var[i]; }
@@ -219,7 +237,7 @@ __device__ __forceinline__ void gr_factors(const GrParams& p, float deg, float (
   for (int q = 0; q < 8; ++q) fac[q] = q < p.S ? scaler_factor(p.scaler[q], deg, p.avg_log, p.avg_lin) : 1.f;
 }
 
-// the scaler factors of every degree a group-mode node can have, once per workgroup (logf and the divisions cost ~100
+// the scaler factors of every degree a flat-kernel node can have, once per workgroup (logf and the divisions cost ~100
 // VALU instructions, which is a sixth of a molecule node's whole budget)
 __device__ __forceinline__ void gr_factor_table(const GrParams& p, float (*tab)[8]) {
   for (int d = threadIdx.x; d <= kGroupMaxDeg; d += blockDim.x) {
@@ -237,7 +255,7 @@ __device__ __forceinline__ void gr_factor_table(const GrParams& p, float (*tab)[
 template <int VEC>
 __device__ __forceinline__ void gr_node_fwd(const GrParams& p, const DropParams& dp, const GrLane& l, int node, Seg s,
                                             SegIdx first, const Vec<VEC>& u) {
-  if (s.e - s.b < p.wave_min_deg) return;                      // second pass behind the group kernel: long segments only
+  if (s.e - s.b < p.wave_min_deg) return;                      // second pass behind the flat kernel: long segments only
   GrAcc<VEC> a;
   a.init();
   for (int base = s.b; base < s.e; base += kWave) {
@@ -251,12 +269,12 @@ __device__ __forceinline__ void gr_node_fwd(const GrParams& p, const DropParams&
       const int ja = __shfl(my.j, ta & (kWave - 1), kWave), ea = __shfl(my.e, ta & (kWave - 1), kWave);
       const int jb = __shfl(my.j, tb & (kWave - 1), kWave), eb = __shfl(my.e, tb & (kWave - 1), kWave);
       const bool va = ta < cnt, vb = tb < cnt;
-      // lanes past the segment end read a valid row (this node's own / edge 0) and drop the value
-      const Vec<VEC> ha = gr_message<VEC>(p, dp, l.fused, u, va ? ja : node, (uint32_t)(va ? ea : 0), l.cc);
+      // lanes past the segment end read a valid row (this node's own / the segment's first edge) and drop the value
+      const Vec<VEC> ha = gr_message<VEC>(p, dp, l.fused, u, va ? ja : node, (uint32_t)(va ? ea : 0), (uint32_t)(va ? base + ta : s.b), l.cc);
       Vec<VEC> hb = vzero<VEC>();
-      if (two) hb = gr_message<VEC>(p, dp, l.fused, u, vb ? jb : node, (uint32_t)(vb ? eb : 0), l.cc);
-      if (va) a.take(p, ha, ea);
-      if (two && vb) a.take(p, hb, eb);
+      if (two) hb = gr_message<VEC>(p, dp, l.fused, u, vb ? jb : node, (uint32_t)(vb ? eb : 0), (uint32_t)(vb ? base + tb : s.b), l.cc);
+      if (va) a.take(p, ha, base + ta - s.b);
+      if (two && vb) a.take(p, hb, base + tb - s.b);
     }
   }
   for (int off = kWave / 2; off >= l.lpr; off >>= 1) {
@@ -273,7 +291,7 @@ __device__ __forceinline__ void gr_node_fwd(const GrParams& p, const DropParams&
   if (l.sub != 0 || !l.valid) return;
   float fac[8];
   gr_factors(p, (float)max(s.e - s.b, 1), fac);
-  gr_fwd_store<VEC>(p, l, node, s.e - s.b, a, fac);
+  gr_fwd_store<VEC>(p, l, node, s.b, s.e - s.b, a, fac);
 }
 
 template <int VEC>
@@ -306,71 +324,90 @@ __global__ __launch_bounds__(kBlock) void gr_fwd_kernel(const GrParams p) {
   }
 }
 
-// group-per-node forward: the lpr lanes of a group own one node; no cross-lane operation anywhere, so the node loop
-// may diverge between the groups of a wave
+// ---- flat kernels -----------------------------------------------------------------------------------------------------
+// node block of workgroup-slot pb: the 8 XCDs (blocks b and b+8 share one: round-robin dispatch) each take a contiguous
+// eighth of the node blocks.  Speed only - any placement gives the same result.
+__device__ __forceinline__ int flat_node_block(int pb, int nblocks) {
+  const int per_xcd = (nblocks + 7) >> 3;
+  const int lb = (pb & 7) * per_xcd + (pb >> 3);
+  return lb < nblocks ? lb : -1;
+}
+
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void gr_fwd_group_kernel(const GrParams p) {
+__device__ __forceinline__ GrLane flat_lane(const GrParams& p, int q, bool fused) {
+  GrLane l;
+  l.lane = 0; l.sub = 0; l.lpr = 0; l.epg = 0;
+  l.c = q * VEC; l.cc = l.c; l.valid = true; l.fused = fused;
+  l.t = (int)__umulhi((uint32_t)l.c, p.f_magic); l.f = l.c - l.t * p.F;
+  return l;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gr_fwd_flat_kernel(const GrParams p) {
   __shared__ float fac_tab[kGroupMaxDeg + 1][8];
   gr_factor_table(p, fac_tab);
   const DropParams dp = drop_resolve(p.drop);
-  const GrLane l = gr_lane(p, VEC);
-  const int stride = (int)gridDim.x * (kBlock / kWave) * l.epg;
-  int n = ((int)blockIdx.x * (kBlock / kWave) + (int)(threadIdx.x >> 6)) * l.epg + l.sub;
-  Seg s0 = seg_load(p, n), s1 = seg_load(p, n + stride);
-  Idx4 i0 = idx4_load(p, s0);
-  Vec<VEC> u0 = (l.fused && n < p.N) ? ldv<VEC>(p.U + (size_t)n * p.lduv + l.cc) : vzero<VEC>();
-  while (n < p.N) {
-    const int n1 = n + stride;
-    const Seg s2 = seg_load(p, n1 + stride);
-    const Idx4 i1 = idx4_load(p, s1);
-    Vec<VEC> u1 = vzero<VEC>();
-    if (l.fused && n1 < p.N) u1 = ldv<VEC>(p.U + (size_t)n1 * p.lduv + l.cc);
-    const int deg = s0.e - s0.b;
-    if (deg <= kGroupMaxDeg) {
-      GrAcc<VEC> a;
-      a.init();
+  const bool fused = p.inputs == nullptr;
+  const int nblocks = (p.N + p.nb - 1) / p.nb;
+  const int slots = ((nblocks + 7) >> 3) << 3;
+  for (int pb = blockIdx.x; pb < slots; pb += gridDim.x) {      // gridDim.x is a multiple of 8: pb % 8 stays the XCD
+    const int lb = flat_node_block(pb, nblocks);
+    if (lb < 0) continue;
+    const int n0 = lb * p.nb;
+    const int items = min(p.nb, p.N - n0) * (int)p.qd;
+    for (int it = threadIdx.x; it < items; it += kBlock) {
+      const int dn = (int)__umulhi((uint32_t)it, p.qd_magic);   // it / qd
+      const int node = n0 + dn;
+      const GrLane l = flat_lane<VEC>(p, it - dn * (int)p.qd, fused);
+      const int b = p.rowptr[node], deg = p.rowptr[node + 1] - b;
+      if (deg > kGroupMaxDeg) continue;                         // left to the wave-per-node pass
+      const Vec<VEC> u = fused ? ldv<VEC>(p.U + (size_t)node * p.lduv + l.c) : vzero<VEC>();
+      int j[4], e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        j[i] = 0; e[i] = 0;
+        if (i < deg) { j[i] = p.src[b + i]; e[i] = p.perm[b + i]; }
+      }
       Vec<VEC> h[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {                           // up to four edges' rows in flight before the first use
+      for (int i = 0; i < 4; ++i) {                             // up to four edges' rows in flight before the first use
         h[i] = vzero<VEC>();
-        if (i < deg) h[i] = gr_message<VEC>(p, dp, l.fused, u0, i0.j[i], (uint32_t)i0.e[i], l.cc);
+        if (i < deg) h[i] = gr_message<VEC>(p, dp, fused, u, j[i], (uint32_t)e[i], (uint32_t)(b + i), l.c);
       }
+      GrAcc<VEC> a;
+      a.init();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) if (i < deg) a.take(p, h[i], i0.e[i]);
-      for (int t = s0.b + 4; t < s0.e; ++t) {                 // ascending positions: ties keep the lowest edge
-        const int j = p.src[t], e = p.perm[t];
-        a.take(p, gr_message<VEC>(p, dp, l.fused, u0, j, (uint32_t)e, l.cc), e);
+      for (int i = 0; i < 4; ++i) if (i < deg) a.take(p, h[i], i);
+      for (int t = 4; t < deg; ++t) {                           // ascending positions: ties keep the lowest edge
+        const int jj = p.src[b + t], ee = p.perm[b + t];
+        a.take(p, gr_message<VEC>(p, dp, fused, u, jj, (uint32_t)ee, (uint32_t)(b + t), l.c), t);
       }
-      if (l.valid) {
-        float fac[8];
+      float fac[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) fac[q] = fac_tab[deg][q];
-        gr_fwd_store<VEC>(p, l, n, deg, a, fac);
-      }
+      for (int q = 0; q < 8; ++q) fac[q] = fac_tab[deg][q];
+      gr_fwd_store<VEC>(p, l, node, b, deg, a, fac);
     }
-    n = n1; s0 = s1; s1 = s2; i0 = i1; u0 = u1;
   }
 }
 
-// K4: gradient w.r.t. every edge message, written by original edge id (each edge has exactly one target: no conflicts)
+// K4: gradient w.r.t. every edge message (each edge has exactly one target: no conflicts)
 template <int VEC>
-struct GrCoef {       // d(out)/d(h_e) = c_all + [e == amin] c_min + [e == amax] c_max + c_var (h_e - mean), per column
+struct GrCoef {       // d(out)/d(h_e) = c_all + [off == amin] c_min + [off == amax] c_max + c_var (h_e - mean), per column
   float c_all[VEC], c_min[VEC], c_max[VEC], c_var[VEC], mean[VEC];
   int an[VEC], ax[VEC];
   bool need_h;
 };
 
 template <int VEC>
-__device__ __forceinline__ void gr_bwd_coef(const GrParams& p, const GrLane& l, int node, float deg, const float (&fac)[8],
-                                            GrCoef<VEC>& k_) {
-  const int t = l.cc / p.F, f = l.cc - t * p.F;              // VEC == 4 only with F % 4 == 0 (one tower per lane)
-  const float* go = p.gout + ((size_t)node * p.T + t) * ((size_t)p.S * p.K * p.F) + f;
+__device__ __forceinline__ void gr_bwd_coef(const GrParams& p, const GrLane& l, int node, int segb, int cnt, float deg,
+                                            const float (&fac)[8], GrCoef<VEC>& k_) {
+  const float* go = p.gout + ((size_t)node * p.T + l.t) * ((size_t)p.S * p.K * p.F) + l.f;
   const size_t so = (size_t)node * p.ldsave + l.cc;
   k_.need_h = false;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { k_.c_all[i] = k_.c_min[i] = k_.c_max[i] = k_.c_var[i] = 0.f; k_.an[i] = k_.ax[i] = -1; k_.mean[i] = 0.f; }
-  if (p.amin) ldi<VEC>(p.amin + so, k_.an);
-  if (p.amax) ldi<VEC>(p.amax + so, k_.ax);
+  if (p.amin8) arg_load<VEC>(p, p.amin8, p.amin_side, node, segb, cnt, l.cc, k_.an);
+  if (p.amax8) arg_load<VEC>(p, p.amax8, p.amax_side, node, segb, cnt, l.cc, k_.ax);
   for (int k = 0; k < p.K; ++k) {
     float gb[VEC];
 #pragma unroll
@@ -405,12 +442,13 @@ __device__ __forceinline__ void gr_bwd_coef(const GrParams& p, const GrLane& l, 
   }
 }
 
+// gradient of the edge at position pos (offset off in its segment, original id e, source j); written to gmsg[pos or e]
 template <int VEC>
 __device__ __forceinline__ Vec<VEC> gr_bwd_edge(const GrParams& p, const DropParams& dp, const GrLane& l, const GrCoef<VEC>& k_,
-                                                const Vec<VEC>& u, int j, int e) {
+                                                const Vec<VEC>& u, int j, int e, int pos, int off) {
   Vec<VEC> g;
   Vec<VEC> h = vzero<VEC>();
-  if (k_.need_h) h = gr_message<VEC>(p, dp, l.fused, u, j, (uint32_t)e, l.cc);
+  if (k_.need_h) h = gr_message<VEC>(p, dp, l.fused, u, j, (uint32_t)e, (uint32_t)pos, l.cc);
   float fd[VEC];
   if (l.fused && dp.mode != MMA_DROP_NONE) drop_factors<VEC>(dp, (uint32_t)e, 0, l.cc, p.D, 0, fd);
   else {
@@ -419,25 +457,25 @@ __device__ __forceinline__ Vec<VEC> gr_bwd_edge(const GrParams& p, const DropPar
   }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    float gi = k_.c_all[i] + (e == k_.an[i] ? k_.c_min[i] : 0.f) + (e == k_.ax[i] ? k_.c_max[i] : 0.f);
+    float gi = k_.c_all[i] + (off == k_.an[i] ? k_.c_min[i] : 0.f) + (off == k_.ax[i] ? k_.c_max[i] : 0.f);
     if (k_.need_h) gi += k_.c_var[i] * (h.v[i] - k_.mean[i]);
     g.v[i] = gi * fd[i];
   }
-  stv<VEC>(p.gmsg + (size_t)e * p.ldg + l.cc, g);
+  stv<VEC>(p.gmsg + (size_t)(p.by_pos ? pos : e) * p.ldg + l.cc, g);
   return g;
 }
 
 template <int VEC>
 __device__ __forceinline__ void gr_node_bwd(const GrParams& p, const DropParams& dp, const GrLane& l, int node, Seg s,
                                             SegIdx first) {
-  if (s.e - s.b < p.wave_min_deg) return;                     // second pass behind the group kernel: long segments only
+  if (s.e - s.b < p.wave_min_deg) return;                     // second pass behind the flat kernel: long segments only
   Vec<VEC> su = vzero<VEC>();                                 // dL/dU[node] = sum of the segment's message gradients
   if (s.b != s.e) {
     const float deg = (float)(s.e - s.b);
     float fac[8];
     gr_factors(p, deg, fac);
     GrCoef<VEC> k_;
-    gr_bwd_coef<VEC>(p, l, node, deg, fac, k_);
+    gr_bwd_coef<VEC>(p, l, node, s.b, s.e - s.b, deg, fac, k_);
     const Vec<VEC> u = (l.fused && k_.need_h) ? ldv<VEC>(p.U + (size_t)node * p.lduv + l.cc) : vzero<VEC>();
     for (int base = s.b; base < s.e; base += kWave) {
       const int cnt = min(kWave, s.e - base);
@@ -448,7 +486,7 @@ __device__ __forceinline__ void gr_node_bwd(const GrParams& p, const DropParams&
         const int j_ = __shfl(my.j, tt & (kWave - 1), kWave);
         const int e_ = __shfl(my.e, tt & (kWave - 1), kWave);
         if (tt < cnt && l.valid) {
-          const Vec<VEC> g = gr_bwd_edge<VEC>(p, dp, l, k_, u, j_, e_);
+          const Vec<VEC> g = gr_bwd_edge<VEC>(p, dp, l, k_, u, j_, e_, base + tt, base + tt - s.b);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) su.v[i] += g.v[i];
         }
@@ -485,46 +523,43 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_kernel(const GrParams p) {
 }
 
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void gr_bwd_group_kernel(const GrParams p) {
+__global__ __launch_bounds__(kBlock) void gr_bwd_flat_kernel(const GrParams p) {
   __shared__ float fac_tab[kGroupMaxDeg + 1][8];
   gr_factor_table(p, fac_tab);
   const DropParams dp = drop_resolve(p.drop);
-  const GrLane l = gr_lane(p, VEC);
-  const int stride = (int)gridDim.x * (kBlock / kWave) * l.epg;
-  int n = ((int)blockIdx.x * (kBlock / kWave) + (int)(threadIdx.x >> 6)) * l.epg + l.sub;
-  Seg s0 = seg_load(p, n), s1 = seg_load(p, n + stride);
-  Idx4 i0 = idx4_load(p, s0);
-  while (n < p.N) {
-    const int n1 = n + stride;
-    const Seg s2 = seg_load(p, n1 + stride);
-    const Idx4 i1 = idx4_load(p, s1);
-    const int deg = s0.e - s0.b;
-    if (deg <= kGroupMaxDeg && l.valid) {
-      Vec<VEC> su = vzero<VEC>();                             // dL/dU[n]: the group walks the whole segment, so it is a local sum
+  const bool fused = p.inputs == nullptr;
+  const bool need_e = !p.by_pos || (fused && dp.mode != MMA_DROP_NONE) || !fused;   // original edge ids: gmsg rows / dropout key / inputs rows
+  const int nblocks = (p.N + p.nb - 1) / p.nb;
+  const int slots = ((nblocks + 7) >> 3) << 3;
+  for (int pb = blockIdx.x; pb < slots; pb += gridDim.x) {
+    const int lb = flat_node_block(pb, nblocks);
+    if (lb < 0) continue;
+    const int n0 = lb * p.nb;
+    const int items = min(p.nb, p.N - n0) * (int)p.qd;
+    for (int it = threadIdx.x; it < items; it += kBlock) {
+      const int dn = (int)__umulhi((uint32_t)it, p.qd_magic);
+      const int node = n0 + dn;
+      const GrLane l = flat_lane<VEC>(p, it - dn * (int)p.qd, fused);
+      const int b = p.rowptr[node], deg = p.rowptr[node + 1] - b;
+      if (deg > kGroupMaxDeg) continue;
+      Vec<VEC> su = vzero<VEC>();                             // dL/dU[node]: this lane walks the whole segment, so it is a local sum
       if (deg > 0) {
         float fac[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) fac[q] = fac_tab[deg][q];
         GrCoef<VEC> k_;
-        gr_bwd_coef<VEC>(p, l, n, (float)deg, fac, k_);
-        const Vec<VEC> u = (l.fused && k_.need_h) ? ldv<VEC>(p.U + (size_t)n * p.lduv + l.cc) : vzero<VEC>();
+        gr_bwd_coef<VEC>(p, l, node, b, deg, (float)deg, fac, k_);
+        const Vec<VEC> u = (fused && k_.need_h) ? ldv<VEC>(p.U + (size_t)node * p.lduv + l.c) : vzero<VEC>();
+        for (int t = 0; t < deg; ++t) {
+          const int jj = k_.need_h ? p.src[b + t] : 0;
+          const int ee = need_e ? p.perm[b + t] : 0;
+          const Vec<VEC> g = gr_bwd_edge<VEC>(p, dp, l, k_, u, jj, ee, b + t, t);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (i < deg) {
-            const Vec<VEC> g = gr_bwd_edge<VEC>(p, dp, l, k_, u, i0.j[i], i0.e[i]);
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) su.v[c] += g.v[c];
-          }
-        }
-        for (int t = s0.b + 4; t < s0.e; ++t) {
-          const Vec<VEC> g = gr_bwd_edge<VEC>(p, dp, l, k_, u, p.src[t], p.perm[t]);
-#pragma unroll
-          for (int c = 0; c < VEC; ++c) su.v[c] += g.v[c];
+          for (int cidx = 0; cidx < VEC; ++cidx) su.v[cidx] += g.v[cidx];
         }
       }
-      if (p.gU) stv<VEC>(p.gU + (size_t)n * p.ldgu + l.c, su);
+      if (p.gU) stv<VEC>(p.gU + (size_t)node * p.ldgu + l.c, su);
     }
-    n = n1; s0 = s1; s1 = s2; i0 = i1;
   }
 }
 
@@ -586,8 +621,8 @@ static bool gr_vec4(const GrParams& p) {
     if (!(p.lduv % 4 == 0 && p.lduv >= Dp && al(p.U) && al(p.V))) return false;
     if (p.Z && !(p.ldz % 4 == 0 && p.ldz >= Dp && al(p.Z))) return false;
   }
-  if ((p.amin || p.amax || p.mean || p.var) && (p.ldsave < Dp || p.ldsave % 4 != 0)) return false;
-  if (!(al(p.amin) && al(p.amax) && al(p.mean) && al(p.var))) return false;
+  if ((p.amin8 || p.amax8 || p.mean || p.var) && (p.ldsave < Dp || p.ldsave % 4 != 0)) return false;
+  if (!(al(p.amin8) && al(p.amax8) && al(p.amin_side) && al(p.amax_side) && al(p.mean) && al(p.var))) return false;
   return true;
 }
 
@@ -610,14 +645,22 @@ static dim3 gr_grid(int64_t N, int D, int vec, int* lpr_log) {
   return dim3((unsigned)blocks, (unsigned)chunks);
 }
 
-// group-per-node pays when a wave holds at least two groups and segments are short on average
-static bool gr_group_mode(const GrParams& p, int64_t E) { return p.lpr_log <= 5 && E <= 16 * (int64_t)p.N; }
-static dim3 gr_group_grid(int64_t N, dim3 wave_grid, int lpr_log) {
-  const int64_t per_block = (int64_t)(kBlock / kWave) * (kWave >> lpr_log);
-  int64_t blocks = (N + per_block - 1) / per_block;
-  if (blocks > kMaxGrid) blocks = kMaxGrid;
-  if (blocks < 1) blocks = 1;
-  return dim3((unsigned)blocks, wave_grid.y);
+// the flat kernels pay when segments are short on average (molecule batches); they leave segments above kGroupMaxDeg
+// edges to a wave-per-node pass.  Sets the flat geometry; false: run everything wave-per-node.
+constexpr int kFlatNodes = 16;       // nodes per workgroup: ZINC rows (95 quads) -> 1520 lanes of work, 5.9 sweeps of 256 threads
+static bool gr_flat_mode(GrParams* p, int64_t E, int vec) {
+  const int qd = (p->D + vec - 1) / vec;
+  if (!(E <= 16 * (int64_t)p->N) || qd > 4095 || p->D > 65535) return false;
+  p->nb = kFlatNodes; p->qd = (uint32_t)qd;
+  p->qd_magic = (uint32_t)((1ULL << 32) / (uint32_t)qd) + 1u;      // exact floor(n / qd) for n, qd < 2^16
+  p->f_magic = (uint32_t)((1ULL << 32) / (uint32_t)p->F) + 1u;
+  return true;
+}
+static dim3 gr_flat_grid(int64_t N) {
+  int64_t slots = ((N + kFlatNodes - 1) / kFlatNodes + 7) / 8 * 8;
+  if (slots > 4 * kMaxGrid) slots = 4 * kMaxGrid;                    // a multiple of 8: grid-stride keeps a slot's XCD
+  if (slots < 8) slots = 8;
+  return dim3((unsigned)slots);
 }
 
 }  // namespace mma
@@ -662,10 +705,32 @@ extern "C" int mma_build_csr(const int64_t* key, const int64_t* other, int64_t E
   return check_launch("csr build");
 }
 
+extern "C" int64_t mma_gr_arg_side_rows(int64_t E) { return E < 0 ? -1 : (E >> 8) + 2; }
+
+static int gr_fill_common(GrParams& p, const int32_t* rowptr, const int32_t* src, const int32_t* perm, const float* U, const float* V,
+                          int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
+                          uint8_t* amin8, uint8_t* amax8, int32_t* amin_side, int32_t* amax_side, float* mean, float* var,
+                          int64_t ldsave, int64_t N, int64_t E, int32_t T, int32_t F, float avg_log, float avg_lin, int32_t drop_mode,
+                          uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev) {
+  MMA_REQUIRE(drop_mode == MMA_DROP_NONE || drop_mode == MMA_DROP_HASH, "GR dropout: NONE or HASH");
+  MMA_REQUIRE(drop_mode == MMA_DROP_NONE || drop_thr < 256, "drop_thr out of range");
+  MMA_REQUIRE((amin8 == nullptr) == (amin_side == nullptr) && (amax8 == nullptr) == (amax_side == nullptr),
+              "arg8 (N,ldsave) bytes and arg_side (mma_gr_arg_side_rows(E), ldsave) int32 come in pairs");
+  p.rowptr = rowptr; p.src = src; p.perm = perm; p.U = U; p.V = V; p.lduv = lduv; p.Z = Z; p.ldz = ldz; p.by_pos = by_pos ? 1 : 0;
+  p.inputs = inputs; p.ldi = ldi; p.amin8 = amin8; p.amax8 = amax8; p.amin_side = amin_side; p.amax_side = amax_side;
+  p.mean = mean; p.var = var; p.ldsave = ldsave;
+  p.N = (int)N; p.D = T * F; p.T = T; p.F = F; p.avg_log = avg_log; p.avg_lin = avg_lin;
+  p.drop.mode = (drop_mode == MMA_DROP_HASH && drop_thr > 0 && !inputs) ? MMA_DROP_HASH : MMA_DROP_NONE;
+  p.drop.thr = drop_thr; p.drop.scale = 256.f / (256.f - (float)drop_thr);
+  p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.seed_dev = seed_dev; p.drop.keep = nullptr;
+  p.drop.E = E; p.drop.edge_base = 0;
+  return 0;
+}
+
 extern "C" int mma_gr_fused_fwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
-    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
-    float* out, int32_t* amin, int32_t* amax, float* mean, float* var, int64_t ldsave,
+    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
+    float* out, uint8_t* amin8, uint8_t* amax8, int32_t* amin_side, int32_t* amax_side, float* mean, float* var, int64_t ldsave,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) - (1 << 20) && E < (1LL << 31) && T >= 1 && F >= 1,
@@ -678,23 +743,18 @@ extern "C" int mma_gr_fused_fwd(
   MMA_REQUIRE(E == 0 || (src && perm), "NULL CSR arrays");
   MMA_REQUIRE((inputs != nullptr) != (U != nullptr && V != nullptr), "give either `inputs` or U and V");
   MMA_REQUIRE(inputs ? ldi >= D : (lduv >= D && (!Z || ldz >= D)), "row pitch too small");
-  MMA_REQUIRE(drop_mode == MMA_DROP_NONE || drop_mode == MMA_DROP_HASH, "GR dropout: NONE or HASH");
-  MMA_REQUIRE(drop_mode == MMA_DROP_NONE || drop_thr < 256, "drop_thr out of range");
-  p.rowptr = rowptr; p.src = src; p.perm = perm; p.U = U; p.V = V; p.lduv = lduv; p.Z = Z; p.ldz = ldz;
-  p.inputs = inputs; p.ldi = ldi; p.out = out; p.amin = amin; p.amax = amax; p.mean = mean; p.var = var; p.ldsave = ldsave;
-  MMA_REQUIRE(!(amin || amax || mean || var) || ldsave >= D, "ldsave=%lld < T*F", (long long)ldsave);
-  p.N = (int)N; p.D = D; p.T = T; p.F = F; p.avg_log = avg_log; p.avg_lin = avg_lin;
-  p.drop.mode = (drop_mode == MMA_DROP_HASH && drop_thr > 0 && !inputs) ? MMA_DROP_HASH : MMA_DROP_NONE;
-  p.drop.thr = drop_thr; p.drop.scale = 256.f / (256.f - (float)drop_thr);
-  p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.seed_dev = seed_dev; p.drop.keep = nullptr; p.drop.E = E; p.drop.edge_base = 0;
+  MMA_REQUIRE(!(amin8 || amax8 || mean || var) || ldsave >= D, "ldsave=%lld < T*F", (long long)ldsave);
+  if (int rc = gr_fill_common(p, rowptr, src, perm, U, V, lduv, Z, ldz, by_pos, inputs, ldi, amin8, amax8, amin_side, amax_side, mean,
+                              var, ldsave, N, E, T, F, avg_log, avg_lin, drop_mode, drop_thr, seed, seed_dev)) return rc;
+  p.out = out;
   const bool v4 = gr_vec4(p);
   const dim3 grid = gr_grid(N, D, v4 ? 4 : 1, &p.lpr_log);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (gr_group_mode(p, E)) {      // short segments: group-per-node kernel, then the wave-per-node pass for the few long ones
-    const dim3 gg = gr_group_grid(N, grid, p.lpr_log);
-    if (v4) hipLaunchKernelGGL((gr_fwd_group_kernel<4>), gg, dim3(kBlock), 0, st, p);
-    else hipLaunchKernelGGL((gr_fwd_group_kernel<1>), gg, dim3(kBlock), 0, st, p);
-    if (int rc = check_launch("gr_fwd_group_kernel")) return rc;
+  if (gr_flat_mode(&p, E, v4 ? 4 : 1)) {      // short segments: flat kernel, then the wave-per-node pass for the few long ones
+    const dim3 fg = gr_flat_grid(N);
+    if (v4) hipLaunchKernelGGL((gr_fwd_flat_kernel<4>), fg, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((gr_fwd_flat_kernel<1>), fg, dim3(kBlock), 0, st, p);
+    if (int rc = check_launch("gr_fwd_flat_kernel")) return rc;
     p.wave_min_deg = kGroupMaxDeg + 1;
   }
   if (v4) hipLaunchKernelGGL((gr_fwd_kernel<4>), grid, dim3(kBlock), 0, st, p);
@@ -704,9 +764,9 @@ extern "C" int mma_gr_fused_fwd(
 
 extern "C" int mma_gr_fused_bwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
-    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, const float* inputs, int64_t ldi,
-    const float* gout, const int32_t* amin, const int32_t* amax, const float* mean, const float* var, int64_t ldsave,
-    float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
+    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
+    const float* gout, const uint8_t* amin8, const uint8_t* amax8, const int32_t* amin_side, const int32_t* amax_side,
+    const float* mean, const float* var, int64_t ldsave, float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) - (1 << 20) && E < (1LL << 31) && T >= 1 && F >= 1,
@@ -720,28 +780,25 @@ extern "C" int mma_gr_fused_bwd(
   for (int k = 0; k < K; ++k) {
     need_min |= p.aggr[k] == GR_MIN; need_max |= p.aggr[k] == GR_MAX; need_stats |= p.aggr[k] >= GR_VAR;
   }
-  MMA_REQUIRE((!need_min || amin) && (!need_max || amax) && (!need_stats || (mean && var)), "saved forward state missing");
+  MMA_REQUIRE((!need_min || amin8) && (!need_max || amax8) && (!need_stats || (mean && var)), "saved forward state missing");
   MMA_REQUIRE(!need_stats || (inputs != nullptr) != (U != nullptr && V != nullptr), "var/std backward needs the messages");
-  MMA_REQUIRE(drop_mode == MMA_DROP_NONE || drop_mode == MMA_DROP_HASH, "GR dropout: NONE or HASH");
-  p.rowptr = rowptr; p.src = src; p.perm = perm; p.U = U; p.V = V; p.lduv = lduv; p.Z = Z; p.ldz = ldz;
-  p.inputs = inputs; p.ldi = ldi; p.gout = gout; p.amin = const_cast<int32_t*>(need_min ? amin : nullptr);
-  p.amax = const_cast<int32_t*>(need_max ? amax : nullptr); p.mean = const_cast<float*>(mean); p.var = const_cast<float*>(var);
-  p.gmsg = gmsg; p.ldg = ldg; p.ldsave = ldsave; p.gU = gU; p.ldgu = ldgu;
   MMA_REQUIRE(!gU || ldgu >= D, "ldgu=%lld < T*F", (long long)ldgu);
   MMA_REQUIRE(!(need_min || need_max || need_stats) || ldsave >= D, "ldsave=%lld < T*F", (long long)ldsave);
-  p.N = (int)N; p.D = D; p.T = T; p.F = F; p.avg_log = avg_log; p.avg_lin = avg_lin;
-  p.drop.mode = (drop_mode == MMA_DROP_HASH && drop_thr > 0 && !inputs) ? MMA_DROP_HASH : MMA_DROP_NONE;
-  p.drop.thr = drop_thr; p.drop.scale = 256.f / (256.f - (float)drop_thr);
-  p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.seed_dev = seed_dev; p.drop.keep = nullptr; p.drop.E = E; p.drop.edge_base = 0;
+  if (int rc = gr_fill_common(p, rowptr, src, perm, U, V, lduv, Z, ldz, by_pos, inputs, ldi,
+                              const_cast<uint8_t*>(need_min ? amin8 : nullptr), const_cast<uint8_t*>(need_max ? amax8 : nullptr),
+                              const_cast<int32_t*>(need_min ? amin_side : nullptr), const_cast<int32_t*>(need_max ? amax_side : nullptr),
+                              const_cast<float*>(mean), const_cast<float*>(var), ldsave, N, E, T, F, avg_log, avg_lin, drop_mode,
+                              drop_thr, seed, seed_dev)) return rc;
+  p.gout = gout; p.gmsg = gmsg; p.ldg = ldg; p.gU = gU; p.ldgu = ldgu;
   const bool v4 = gr_vec4(p) && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(gmsg) & 15) == 0 &&
                   (!gU || (ldgu % 4 == 0 && (reinterpret_cast<uintptr_t>(gU) & 15) == 0));
   const dim3 grid = gr_grid(N, D, v4 ? 4 : 1, &p.lpr_log);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (gr_group_mode(p, E)) {
-    const dim3 gg = gr_group_grid(N, grid, p.lpr_log);
-    if (v4) hipLaunchKernelGGL((gr_bwd_group_kernel<4>), gg, dim3(kBlock), 0, st, p);
-    else hipLaunchKernelGGL((gr_bwd_group_kernel<1>), gg, dim3(kBlock), 0, st, p);
-    if (int rc = check_launch("gr_bwd_group_kernel")) return rc;
+  if (gr_flat_mode(&p, E, v4 ? 4 : 1)) {
+    const dim3 fg = gr_flat_grid(N);
+    if (v4) hipLaunchKernelGGL((gr_bwd_flat_kernel<4>), fg, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((gr_bwd_flat_kernel<1>), fg, dim3(kBlock), 0, st, p);
+    if (int rc = check_launch("gr_bwd_flat_kernel")) return rc;
     p.wave_min_deg = kGroupMaxDeg + 1;
   }
   if (v4) hipLaunchKernelGGL((gr_bwd_kernel<4>), grid, dim3(kBlock), 0, st, p);

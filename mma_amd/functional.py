@@ -296,6 +296,8 @@ class GRGraph:
         self.edge_index, self.N, self.E = edge_index, int(N), int(edge_index.shape[1])
         self.by_target = DeviceCSR(edge_index[1], edge_index[0], N)
         self._by_source = None
+        self._inv_perm = None
+        self._by_source_pos = None
 
     @property
     def by_source(self):
@@ -303,23 +305,66 @@ class GRGraph:
             self._by_source = DeviceCSR(self.edge_index[0], None, self.N)
         return self._by_source
 
+    @property
+    def perm(self):
+        """(E,) int32: original edge id at each target-sorted position."""
+        return self.by_target.perm[:self.E]
 
-def _gr_call(fn, csr, U, V, Z, inputs, extra, N, E, T, F, aggr, scalers, avg_log, avg_lin, drop):
+    @property
+    def inv_perm(self):
+        """(E,) int64: target-sorted position of each original edge."""
+        if self._inv_perm is None:
+            inv = torch.empty(self.E, dtype=torch.int64, device=self.perm.device)
+            inv[self.perm.long()] = torch.arange(self.E, device=self.perm.device)
+            self._inv_perm = inv
+        return self._inv_perm
+
+    @property
+    def by_source_pos(self):
+        """(E,) int32: the by-source grouping expressed in target-sorted POSITIONS (rows of a by_pos message-gradient buffer)."""
+        if self._by_source_pos is None:
+            self._by_source_pos = self.inv_perm[self.by_source.perm[:self.E].long()].to(torch.int32)
+        return self._by_source_pos
+
+
+class _PermuteRows(torch.autograd.Function):
+    """rows[idx] for a PERMUTATION idx; backward gathers with the inverse permutation (deterministic, no index_add)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, inv):
+        ctx.inv = inv
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.index_select(0, ctx.inv), None, None
+
+
+def rows_by_position(x, graph):
+    """x (E, ...) by original edge id -> rows in target-sorted position order (so that a GEMM on it yields Z by position)."""
+    if graph.E == 0:
+        return x
+    return _PermuteRows.apply(x, graph.perm.long(), graph.inv_perm)
+
+
+def _gr_call(fn, csr, U, V, Z, by_pos, inputs, extra, N, E, T, F, aggr, scalers, avg_log, avg_lin, drop):
     D = T * F
     lduv = U.stride(0) if U is not None else 0
     call(fn, ptr(csr.rowptr), ptr(csr.other), ptr(csr.perm), ptr(U), ptr(V), lduv, ptr(Z), Z.stride(0) if Z is not None else 0,
-         ptr(inputs), D if inputs is not None else 0, *extra, N, E, T, F, host_codes(aggr), len(aggr), host_codes(scalers),
-         len(scalers), float(avg_log), float(avg_lin), drop.mode, drop.thr, drop.seed, ptr(drop.seed_tensor), stream_ptr())
+         1 if by_pos else 0, ptr(inputs), D if inputs is not None else 0, *extra, N, E, T, F, host_codes(aggr), len(aggr),
+         host_codes(scalers), len(scalers), float(avg_log), float(avg_lin), drop.mode, drop.thr, drop.seed, ptr(drop.seed_tensor),
+         stream_ptr())
 
 
 class _GRAggregate(torch.autograd.Function):
     """K aggregators + compounding degree scalers over target segments (mma_conv.py:159-196), messages either given
-    (`inputs`, the public aggregate() API) or formed in-kernel as drop(U[i] + V[j] + Z[e]) (fused forward).
+    (`inputs`, the public aggregate() API) or formed in-kernel as drop(U[i] + V[j] + Z[r]) (fused forward).
     Fused mode: UV (N, 2*T*F) holds U in its left and V in its right column half (one GEMM made both), Z is (E, T*F)
-    or None; the gradient of UV comes back as one buffer whose halves the two segment sums fill."""
+    or None - with by_pos its rows (and the rows of the gradient handed back for it) are in target-sorted position order;
+    the gradient of UV comes back as one buffer whose halves the kernel and the by-source segment sum fill."""
 
     @staticmethod
-    def forward(ctx, inputs, UV, Z, graph, T, F, aggr, scalers, avg_log, avg_lin, drop):
+    def forward(ctx, inputs, UV, Z, graph, T, F, aggr, scalers, avg_log, avg_lin, drop, by_pos):
         fused = inputs is None
         csr = graph.by_target
         N, E, D = graph.N, graph.E, T * F
@@ -336,61 +381,72 @@ class _GRAggregate(torch.autograd.Function):
         else:
             inputs = inputs.contiguous()
             assert inputs.shape == (E, T, F)
+            by_pos = False
         out = torch.empty((N, T, S * K * F), device=dev, dtype=torch.float32)
         need = any(ctx.needs_input_grad[:3])
-        amin = torch.empty((N, D), dtype=torch.int32, device=dev) if need and 2 in aggr else None
-        amax = torch.empty((N, D), dtype=torch.int32, device=dev) if need and 3 in aggr else None
+        # argmin / argmax: one BYTE per column (offset inside the target's segment) + an int32 side table for the rare
+        # segments of >= 256 edges (see include/mma_amd.h) - a quarter of the int32 edge ids round 1 wrote and re-read
+        side_rows = int(_lib.lib().mma_gr_arg_side_rows(E))
+        amin = torch.empty((N, D), dtype=torch.uint8, device=dev) if need and 2 in aggr else None
+        amax = torch.empty((N, D), dtype=torch.uint8, device=dev) if need and 3 in aggr else None
+        amin_s = torch.empty((side_rows, D), dtype=torch.int32, device=dev) if amin is not None else None
+        amax_s = torch.empty((side_rows, D), dtype=torch.int32, device=dev) if amax is not None else None
         stats = need and (4 in aggr or 5 in aggr)
         mean = torch.empty((N, D), device=dev) if stats else None
         var = torch.empty((N, D), device=dev) if stats else None
-        ctx.cfg = (graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, Z is not None)
+        ctx.cfg = (graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, Z is not None, by_pos)
         if E == 0:          # nothing to aggregate: every target is empty -> 0 (and a zero gradient)
             out.zero_()
-            ctx.save_for_backward(inputs, UV, Z, None, None, None, None)
+            ctx.save_for_backward(inputs, UV, Z, None, None, None, None, None, None)
             return out
         with _span("gr_fused_fwd"):
-            _gr_call("mma_gr_fused_fwd", csr, U, V, Z, inputs, (ptr(out), ptr(amin), ptr(amax), ptr(mean), ptr(var), D),
+            _gr_call("mma_gr_fused_fwd", csr, U, V, Z, by_pos, inputs,
+                     (ptr(out), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), ptr(mean), ptr(var), D),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
-        ctx.save_for_backward(inputs, UV, Z, amin, amax, mean, var)
+        ctx.save_for_backward(inputs, UV, Z, amin, amax, amin_s, amax_s, mean, var)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, has_z = ctx.cfg
-        inputs, UV, Z, amin, amax, mean, var = ctx.saved_tensors
+        graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, has_z, by_pos = ctx.cfg
+        inputs, UV, Z, amin, amax, amin_s, amax_s, mean, var = ctx.saved_tensors
         csr = graph.by_target
         N, E, D = graph.N, graph.E, T * F
         gout = gout.contiguous()
         gmsg = torch.empty((E, D), device=gout.device, dtype=torch.float32)
         if E == 0:
             if not fused:
-                return (gmsg.view(E, T, F),) + (None,) * 10
-            return (None, torch.zeros((N, 2 * D), device=gout.device, dtype=torch.float32), gmsg if has_z else None) + (None,) * 8
+                return (gmsg.view(E, T, F),) + (None,) * 11
+            return (None, torch.zeros((N, 2 * D), device=gout.device, dtype=torch.float32), gmsg if has_z else None) + (None,) * 9
         U, V = (UV[:, :D], UV[:, D:]) if fused else (None, None)
         # dU[i] = sum of its target segment: produced by K4 itself (it walks exactly those segments); dV[j] = sum over the
         # edges leaving j: one segment sum (K5 kernel) over the by-source grouping.  Both land in the halves of one (N, 2D) buffer.
         gUV = torch.empty((N, 2 * D), device=gout.device, dtype=torch.float32) if fused else None
         with _span("gr_fused_bwd"):
-            _gr_call("mma_gr_fused_bwd", csr, U, V, Z, inputs,
-                     (ptr(gout), ptr(amin), ptr(amax), ptr(mean), ptr(var), D, ptr(gmsg), D, ptr(gUV), 2 * D if fused else 0),
+            _gr_call("mma_gr_fused_bwd", csr, U, V, Z, by_pos, inputs,
+                     (ptr(gout), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), ptr(mean), ptr(var), D, ptr(gmsg), D, ptr(gUV),
+                      2 * D if fused else 0),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
         if not fused:
-            return (gmsg.view(E, T, F),) + (None,) * 10
+            return (gmsg.view(E, T, F),) + (None,) * 11
         cs = graph.by_source
+        rows = graph.by_source_pos if by_pos else cs.perm      # gmsg rows: positions (by_pos) or original edge ids
         with _span("gr_segsum"):
-            call("mma_csr_spmm", ptr(cs.rowptr), ptr(cs.perm), None, ptr(gmsg), D, E, 1, None, ptr(gUV[:, D:]), 2 * D, N, D,
+            call("mma_csr_spmm", ptr(cs.rowptr), ptr(rows), None, ptr(gmsg), D, E, 1, None, ptr(gUV[:, D:]), 2 * D, N, D,
                  stream_ptr())
-        return (None, gUV, gmsg if has_z else None) + (None,) * 8
+        return (None, gUV, gmsg if has_z else None) + (None,) * 9
 
 
 def gr_aggregate(inputs, graph, aggregators, scalers, avg_log, avg_lin):
     """aggregate() on given messages (E,T,F) -> (N,T,S*K*F)."""
     E, T, F = inputs.shape
     return _GRAggregate.apply(inputs, None, None, graph, T, F, tuple(GR_AGGR[a] for a in aggregators),
-                              tuple(GR_SCALER[s] for s in scalers), avg_log, avg_lin, DropoutSpec(0.0))
+                              tuple(GR_SCALER[s] for s in scalers), avg_log, avg_lin, DropoutSpec(0.0), False)
 
 
-def gr_fused_conv(UV, Z, graph, T, F, aggregators, scalers, avg_log, avg_lin, drop):
-    """message + aggregate fused: messages drop(U[i] + V[j] + Z[e]) never materialise.  UV = [U | V] (N, 2*T*F)."""
+def gr_fused_conv(UV, Z, graph, T, F, aggregators, scalers, avg_log, avg_lin, drop, z_by_pos=False):
+    """message + aggregate fused: messages drop(U[i] + V[j] + Z[r]) never materialise.  UV = [U | V] (N, 2*T*F).
+    z_by_pos: Z's rows are in target-sorted position order (made from rows_by_position(edge_attr, graph)): the kernels then
+    stream Z and the message gradients contiguously instead of gathering / scattering them by original edge id."""
     return _GRAggregate.apply(None, UV, Z, graph, T, F, tuple(GR_AGGR[a] for a in aggregators),
-                              tuple(GR_SCALER[s] for s in scalers), avg_log, avg_lin, drop)
+                              tuple(GR_SCALER[s] for s in scalers), avg_log, avg_lin, drop, bool(z_by_pos))

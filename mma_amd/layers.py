@@ -20,7 +20,7 @@ from . import functional as Fn
 from .dense import mm
 from ._lib import require_gpu
 from .graph import DEFAULT_CHUNK, NCGraph, SpmmGraph
-from .scalers import SCALERS, scaler_row_factor
+from .scalers import SCALERS, scaler_row_factor, true_degree_row_factor
 
 # aggregator name -> (combine kind, raw logits under activation == "new_sigmoid")   layers.py:201-728
 _AGG = {
@@ -70,7 +70,12 @@ class MMA(Module):
                  weight_mean2, weight_mean3, weight_mean4, weight_max, weight_max2, weight_max3,
                  weight_max4, weight_min, weight_min2, weight_min3, weight_min4, weight_softmax,
                  weight_softmin, weight_std, weight_normalized_mean, dropout, aggregator_list, device,
-                 chunk=DEFAULT_CHUNK):
+                 chunk=DEFAULT_CHUNK, strict_reference=True, scalers=None, compound_scalers=False, avg_d=None):
+        """Positional arguments: the reference's (layers.py:57-61).  Keyword extensions (defaults = reference behaviour):
+        strict_reference=False evaluates the degree scalers with the TRUE degrees len(add_all[i]) instead of the degenerate
+        factor 1.0 the reference computes (quirk Q1): `scalers` (default identity, amplification, attenuation - the
+        reference's three, scalers.py:64) may also name linear / inverse_linear, and compound_scalers=True chains them like
+        mma_conv.py:181-196 (BASELINE configs[4]: "K=8 aggregators + all scalers")."""
         super().__init__()
         self.activation = activation
         self.k = k
@@ -98,8 +103,15 @@ class MMA(Module):
         self.num_aggregators = len(self.aggregators)
 
         self.reset_parameters()
-        self.avg_d = None
+        self.avg_d = avg_d          # strict_reference=False: optional {'log','lin'} means (default: over this graph's degrees)
         self.self_loop = None
+
+        self.strict_reference = bool(strict_reference)
+        self.scaler_names = list(scalers) if scalers is not None else list(SCALERS)
+        self.compound_scalers = bool(compound_scalers)
+        if self.strict_reference and (scalers is not None or compound_scalers):
+            raise ValueError("scalers / compound_scalers are extensions: pass strict_reference=False to use them")
+        self._row_factor = None          # (device, (N,1) tensor) cache of the true-degree factor
 
         self._chunk = chunk
         # NCGraph, built once (the reference captures add_all at construction time).  Extension: a ready-made
@@ -128,6 +140,17 @@ class MMA(Module):
         if self._graph is None or self._graph.device != device:
             self._graph = NCGraph.from_add_all(self.add_all, device, chunk=self._chunk)
         return self._graph
+
+    def _scaler_factor(self, N, device):
+        """Row factor of the scaler stage (layers.py:856-860 with the weight stacked once per scaler): the reference's
+        degenerate constant (Q1), or - strict_reference=False - sum_s c_s(d_i) from the true degrees."""
+        if self.strict_reference:
+            return scaler_row_factor(N, device)
+        if self._row_factor is None or self._row_factor[0] != device:
+            g = self.graph(device)
+            deg = (g.rowptr[1:] - g.rowptr[:-1])
+            self._row_factor = (device, true_degree_row_factor(deg, self.scaler_names, self.compound_scalers, self.avg_d))
+        return self._row_factor[1]
 
     def _codes(self, names):
         kinds, acts = [], []
@@ -191,7 +214,7 @@ class MMA(Module):
         #     sum_k A (c * m_k W)  ==  A (c * (sum_k m_k) W):
         # the fused kernel emits sum_k m_k (N,H) directly - K x fewer bytes through the GEMM and the SpMM.
         msum = self._aggregate_all(self.aggregator_names, input, reduce_k=True)
-        support = mm(msum, self.weight) * scaler_row_factor(N, input.device)
+        support = mm(msum, self.weight) * self._scaler_factor(N, input.device)
         if self._sg is None or self._sg[0] is not adj:   # extension: a ready-made SpmmGraph is accepted as `adj`
             self._sg = (adj, adj if isinstance(adj, SpmmGraph) else SpmmGraph.from_torch_sparse(adj, input.device))
         return Fn.csr_spmm(support, self.bias, self._sg[1], 1)                  # layers.py:861-867

@@ -65,3 +65,30 @@ def scaler_row_factor(N, device):
         amp, att = scaler_factors(N, device)
         c = _ROW_FACTOR[key] = (1.0 + amp[:1] + att[:1]).detach()
     return c
+
+
+# ---- strict_reference=False: degree scalers evaluated with the TRUE degrees (extension, SURVEY 7 "Quirk fidelity vs. sanity")
+TRUE_DEGREE_SCALERS = ("identity", "amplification", "attenuation", "linear", "inverse_linear")   # mma_conv.py:181-192
+
+
+def true_degree_row_factor(deg, scalers, compound, avg_d=None):
+    """The per-row factor R(i) that the scaler stage reduces to when the layer weight is stacked once per scaler:
+        cat_s(c_s(i) * m[i]) @ [W; ...; W]  ==  (sum_s c_s(i)) * (m[i] @ W),
+    with c_s from the node's true degree d_i = len(add_all[i]) clamped to >= 1 (mma_conv.py:179):
+      compound=False  the node-classification scalers (scalers.py:22-62) as PNA meant them:  c_s = f_s(d_i);
+      compound=True   the graph-regression form (mma_conv.py:181-196, quirk G7):             c_s = prod_{q<=s} f_q(d_i),
+    f = 1 | log(d+1)/avg_log | avg_log/log(d+1) | d/avg_lin | avg_lin/d.   avg_d: {'log','lin'} (default: the means over
+    `deg`, i.e. PNA's delta; the sharded layer passes the GLOBAL means).  deg: (N,) tensor.  Returns (N,1) fp32."""
+    d = deg.to(torch.float32).clamp(min=1)
+    lg = torch.log(d + 1)
+    avg_log = lg.mean() if avg_d is None else torch.as_tensor(avg_d["log"], dtype=torch.float32, device=d.device)
+    avg_lin = d.mean() if avg_d is None else torch.as_tensor(avg_d["lin"], dtype=torch.float32, device=d.device)
+    f = {"identity": torch.ones_like(d), "amplification": lg / avg_log, "attenuation": avg_log / lg,
+         "linear": d / avg_lin, "inverse_linear": avg_lin / d}
+    total, run = torch.zeros_like(d), torch.ones_like(d)
+    for name in scalers:
+        if name not in f:
+            raise ValueError('Unknown scaler "%s".' % name)          # mma_conv.py:193-194
+        run = run * f[name] if compound else f[name]
+        total = total + run
+    return total.unsqueeze(-1)

@@ -25,7 +25,7 @@ from .dense import mm, mm_into, rows_mm_add_, xt_g
 from ._lib import call, ptr, require_gpu, stream_ptr
 from .graph import DEFAULT_CHUNK, NCGraph, SpmmGraph
 from .layers import _AGG
-from .scalers import scaler_row_factor
+from .scalers import scaler_row_factor, true_degree_row_factor
 
 
 def partition_bounds(rowptr, world):
@@ -260,8 +260,12 @@ class ShardedMMA(torch.nn.Module):
     """The MMA layer (layers.py:54-872 semantics, as mma_amd.MMA) on this rank's shard of the graph."""
 
     def __init__(self, plan, device, H, C, names, masks, weight, bias, dropout, activation="new_sigmoid", edge_base=0,
-                 chunk=DEFAULT_CHUNK, adj_val=None):
+                 chunk=DEFAULT_CHUNK, adj_val=None, strict_reference=True, scalers=None, compound_scalers=False, avg_d=None):
         super().__init__()
+        # strict_reference=False: true-degree scalers as in mma_amd.MMA; avg_d must then hold the GLOBAL means {'log','lin'}
+        self.strict_reference, self.scaler_names, self.compound_scalers, self.avg_d = strict_reference, scalers, compound_scalers, avg_d
+        assert strict_reference or avg_d is not None, "sharded true-degree scalers need the global degree means (avg_d)"
+        self._row_factor = None
         self.plan, self.names, self.activation, self.dropout = plan, list(names), activation, dropout
         self.H, self.C = H, C
         self.lo, self.hi = plan.lo, plan.hi
@@ -278,7 +282,8 @@ class ShardedMMA(torch.nn.Module):
         self.drop_override = None
 
     @classmethod
-    def build(cls, rowptr, col, rank, world, device, H, C, names, dropout, seed=42, chunk=DEFAULT_CHUNK, group=None):
+    def build(cls, rowptr, col, rank, world, device, H, C, names, dropout, seed=42, chunk=DEFAULT_CHUNK, group=None,
+              strict_reference=True, scalers=None, compound_scalers=False):
         """Convenience for bench/tests: every rank holds the full CSR and slices its shard; parameters are
         initialised identically on all ranks (layers.py:143-198 distributions)."""
         rowptr = np.asarray(rowptr, dtype=np.int64)
@@ -292,7 +297,12 @@ class ShardedMMA(torch.nn.Module):
         P = lambda *s: torch.nn.Parameter(((torch.rand(*s, generator=g) * 2 - 1) * b).to(device))
         masks = {n: P(2 * H, H) for n in names}
         weight, bias = P(H, C), P(C)
-        return cls(plan, device, H, C, names, masks, weight, bias, dropout, edge_base=e0, chunk=chunk)
+        avg_d = None
+        if not strict_reference:      # PNA's delta over the WHOLE graph (every rank holds the full rowptr here)
+            d = np.maximum(np.diff(rowptr), 1).astype(np.float32)
+            avg_d = {"log": float(torch.log(torch.from_numpy(d) + 1).mean()), "lin": float(torch.from_numpy(d).mean())}
+        return cls(plan, device, H, C, names, masks, weight, bias, dropout, edge_base=e0, chunk=chunk,
+                   strict_reference=strict_reference, scalers=scalers, compound_scalers=compound_scalers, avg_d=avg_d)
 
     def _drop(self):
         return self.drop_override if self.drop_override is not None else Fn.DropoutSpec(self.dropout)
@@ -305,7 +315,14 @@ class ShardedMMA(torch.nn.Module):
         ws = [self.masks[a] for a in self.names]
         msum = _ShardedAggregate.apply(x_own, torch.cat([w[:H] for w in ws], 1), torch.cat([w[H:] for w in ws], 1), self,
                                        tuple(kinds), tuple(acts), self._drop())                 # (n_own, H)
-        c3 = scaler_row_factor(self.n_total, x_own.device)                             # Q1: identical rows
+        if self.strict_reference:
+            c3 = scaler_row_factor(self.n_total, x_own.device)                         # Q1: identical rows
+        else:
+            if self._row_factor is None:
+                deg = self.graph.rowptr[1:] - self.graph.rowptr[:-1]                    # a rank owns ALL in-edges of its targets
+                names_ = self.scaler_names if self.scaler_names is not None else ["identity", "amplification", "attenuation"]
+                self._row_factor = true_degree_row_factor(deg, names_, self.compound_scalers, self.avg_d)
+            c3 = self._row_factor
         # sum_k A (m_k W) == A ((sum_k m_k) W): only the (n,C) rows travel and enter the SpMM
         S = mm(msum, self.weight) * c3
         S_halo = _HaloExchange.apply(S, self.plan, self.send_idx)

@@ -115,17 +115,55 @@ def scaler_factors(N):
     return (lg / avg).unsqueeze(-1), (avg / lg).unsqueeze(-1)   # amplification, attenuation: (N,1)
 
 
+def true_degree_scaled(m, rowptr, K, scalers, compound, avg_d=None):
+    """The scaler stage with TRUE degrees (the build's strict_reference=False extension; BASELINE configs[4] "all
+    scalers"): m (K*N,H) -> (K*N, S*H).  compound=False: each scaler applied to m on its own, as scalers.py:22-62 would
+    with add_all handed in (PNA); compound=True: the running product of mma_conv.py:181-196 (`out = out * ...`, every
+    stage appends the running `out`).  deg = len(add_all[i]).clamp(1) (mma_conv.py:179), tiled K times (scalers.py:33-40)."""
+    rp = torch.as_tensor(np.asarray(rowptr), dtype=torch.int64)
+    deg = (rp[1:] - rp[:-1]).clamp(min=1).to(torch.float32)
+    avg_log = torch.log(deg + 1).mean() if avg_d is None else avg_d["log"]
+    avg_lin = deg.mean() if avg_d is None else avg_d["lin"]
+    deg = torch.cat([deg] * K, 0).unsqueeze(-1)
+    outs, out = [], m
+    for scaler in scalers:
+        if scaler == "identity":
+            f = None
+        elif scaler == "amplification":
+            f = torch.log(deg + 1) / avg_log
+        elif scaler == "attenuation":
+            f = avg_log / torch.log(deg + 1)
+        elif scaler == "linear":
+            f = deg / avg_lin
+        elif scaler == "inverse_linear":
+            f = avg_lin / deg
+        else:
+            raise ValueError('Unknown scaler "%s".' % scaler)
+        if compound:
+            out = out if f is None else out * f
+            outs.append(out)
+        else:
+            outs.append(m if f is None else m * f)
+    return torch.cat(outs, 1)
+
+
 def mma_forward(names, x, Ws, weight, bias, rowptr, col, adj_row, adj_col, adj_val,
-                activation="new_sigmoid", p=0.0, keeps=None, return_m=False):
-    """MMA.forward (layers.py:853-867), literal op sequence."""
+                activation="new_sigmoid", p=0.0, keeps=None, return_m=False, true_degree_scalers=None, compound=False,
+                avg_d=None):
+    """MMA.forward (layers.py:853-867), literal op sequence.  true_degree_scalers: list of scaler names -> the
+    strict_reference=False extension (see true_degree_scaled) instead of the reference's degenerate three."""
     N = x.shape[0]
     K = len(names)
     ms = [aggregate(n, x, Ws[n], rowptr, col, activation, p, None if keeps is None else keeps[n]) for n in names]
     m = torch.cat(ms, 0)                                              # (K*N, H)
-    amp, att = scaler_factors(N)
-    amp, att = torch.cat([amp] * K, 0), torch.cat([att] * K, 0)
-    m3 = torch.cat([m, amp * m, att * m], 1)                          # identity, amplification, attenuation
-    w3 = torch.cat([weight, weight, weight], 0)
+    if true_degree_scalers is not None:
+        m3 = true_degree_scaled(m, rowptr, K, true_degree_scalers, compound, avg_d)
+        w3 = torch.cat([weight] * len(true_degree_scalers), 0)
+    else:
+        amp, att = scaler_factors(N)
+        amp, att = torch.cat([amp] * K, 0), torch.cat([att] * K, 0)
+        m3 = torch.cat([m, amp * m, att * m], 1)                      # identity, amplification, attenuation
+        w3 = torch.cat([weight, weight, weight], 0)
     support = m3 @ w3                                                 # (K*N, C)
     r = torch.as_tensor(np.asarray(adj_row), dtype=torch.int64)
     c = torch.as_tensor(np.asarray(adj_col), dtype=torch.int64)

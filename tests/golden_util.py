@@ -59,7 +59,10 @@ class Golden:
 #     formula on these inputs).  |want - truth| is the fp32 evaluation noise of the reference/oracle itself, element by
 #     element; rows share one summation structure, so a row's noise level is its max.  Bar:
 #         |got - want| <= 1e-5 + 1e-5*|want| + NOISE_C * rowmax|want - truth|        (NOISE_C = 8)
-#     i.e. the HIP path may differ from the reference by a few times what the reference differs from exact arithmetic.
+#     i.e. the HIP path may differ from the reference by a few times what the reference differs from exact arithmetic
+#     (measured on MI355X, round 2: the largest multiple any golden / small-graph comparison needs is 2.95, one element
+#     in 131 072 of the C5-shape mask-weight gradient - a sum over 2^20 rows at H=256 - needs 5.4; the fp32 CPU oracle
+#     itself needs 0.69 against the goldens).
 #   * no truth available:   atol = max(1e-5, SIGNED_SUM_ATOL * max|want|), SIGNED_SUM_ATOL = 1e-6
 #     (round 1 used 1e-5 * max|want| everywhere: 10x looser than this fallback, ~1000x looser than the truth-based bar).
 SIGNED_SUM_ATOL = 1e-6

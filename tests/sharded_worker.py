@@ -28,15 +28,14 @@ def graph(seed, N, avg):
 
 
 def directed_graph(N, world):
-    """Edges only run from LOWER to higher node blocks: the rank owning the first block reads no remote row (no halo of its
-    own) while every other rank reads rows of it - the case in which a rank must still join the reverse exchange."""
+    """All sources lie in the first half of the first rank's range: that rank reads no remote row (no halo of its own) while
+    every other rank reads rows of it - the case in which a rank must still join the reverse exchange."""
     rng = np.random.default_rng(11)
     deg = rng.integers(1, 6, N)
     blk = N // world
     rows = []
     for i in range(N):
-        hi = max(blk, (i // blk) * blk)           # sources below the start of the own block (block 0: inside itself)
-        rows.append(np.sort(rng.integers(0, hi, deg[i])))
+        rows.append(np.sort(rng.integers(0, blk // 2, deg[i])))      # every source sits well inside the first rank's range
     rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
     return rowptr, np.concatenate(rows).astype(np.int64)
 
@@ -169,10 +168,15 @@ if __name__ == "__main__":
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     try:
-        if mode == "cpu":
-            run_cpu(rank, world)
-        else:
-            run_gpu(rank, world, sys.argv[2] if len(sys.argv) > 2 else "hub")
+        try:
+            if mode == "cpu":
+                run_cpu(rank, world)
+            else:
+                run_gpu(rank, world, sys.argv[2] if len(sys.argv) > 2 else "hub")
+        except BaseException:
+            import traceback
+            print("RANK %d FAILED:\n%s" % (rank, traceback.format_exc()[-1800:]), flush=True)    # the launcher truncates stderr
+            raise
         dist.barrier()
         if rank == 0:
             print("SHARDED_%s_OK world=%d" % (mode.upper(), world), flush=True)

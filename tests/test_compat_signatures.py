@@ -16,7 +16,7 @@ COMPAT = os.path.join(ROOT, "mma_amd", "compat")
 FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_signatures.json")))
 
 # Deliberate, documented deviations from the reference surface:
-EXTRA_OK = {("layers", "MMA", "__init__"): {"chunk", "strict_reference", "scalers", "avg_d"},      # trailing keyword extensions
+EXTRA_OK = {("layers", "MMA", "__init__"): {"chunk", "strict_reference", "scalers", "compound_scalers", "avg_d"},      # trailing keyword extensions
             ("mma_conv", "MMAConv", "aggregate"): {"_graph"},                                   # private plan hand-over
             ("utils", "load_data"): {"data_dir"}}                                                # the reference hard-codes "data/"
 HELPERS_NOT_NEEDED = {("utils", "sample_mask"), ("utils", "normalize"), ("utils", "sparse_mx_to_torch_sparse_tensor")}

@@ -270,3 +270,60 @@ def test_degenerate_graphs(N, H, names, edges):
     check_close(gg, go.numpy(), None, None, what="degenerate gx", signed_sum=True, truth=g64.numpy())
     ms = Fn.nc_fused_aggregate(xg.detach(), P.detach(), Q.detach(), graph, kinds, acts, reduce_k=True)
     check_close(ms, mo.detach().sum(0).numpy(), None, None, what="degenerate msum", signed_sum=True, truth=m64.detach().sum(0).numpy())
+
+
+@pytest.mark.parametrize("compound,scalers", [(False, None), (True, ["identity", "amplification", "attenuation", "linear", "inverse_linear"]),
+                                              (True, ["amplification", "identity", "inverse_linear"])])
+def test_true_degree_scalers_vs_oracle(compound, scalers):
+    """strict_reference=False (BASELINE configs[4] "+ all scalers"): the layer with TRUE-degree scalers - the reference's
+    three as PNA meant them, or the compounding five of mma_conv.py:181-196 - against the oracle's literal restatement
+    (cat of the scaled blocks, mm with the stacked weight), forward and every gradient; the default stays the reference's
+    degenerate factor."""
+    import mma_amd
+    from mma_amd import functional as Fn
+    from mma_amd.layers import _MASK_NAMES
+    from oracle import nc_oracle as O
+    rng = np.random.default_rng(99)
+    N, H, C, names, act = 300, 32, 5, ["sum", "mean", "max", "min"], "new_sigmoid"
+    rowptr, col = random_graph(rng, N, 5, hub_deg=150)
+    dst = np.repeat(np.arange(N), np.diff(rowptr))
+    x = torch.from_numpy(np.maximum(rng.standard_normal((N, H)), 0).astype(np.float32))
+    cot = torch.from_numpy(rng.standard_normal((N, C)).astype(np.float32))
+    Ws, weight, bias = O.init_like_reference(H, C, names, 3)
+    sc = scalers if scalers is not None else ["identity", "amplification", "attenuation"]
+
+    def oracle(dtype):
+        xo, wo, bo = x.to(dtype).requires_grad_(True), weight.to(dtype).requires_grad_(True), bias.to(dtype).requires_grad_(True)
+        Wo = {n: Ws[n].to(dtype).requires_grad_(True) for n in names}
+        out = O.mma_forward(names, xo, Wo, wo, bo, rowptr, col, dst, col, np.ones(len(col), np.float32), act,
+                            true_degree_scalers=sc, compound=compound)
+        return out.detach(), torch.autograd.grad((out * cot.to(dtype)).sum(), [xo, wo, bo] + [Wo[n] for n in names])
+    want, gw = oracle(torch.float32)
+    w64, g64 = oracle(torch.float64)
+
+    P = lambda t: torch.nn.Parameter(t.clone().to(DEV))
+    mp = {n: P(Ws[n]) if n in names else P(torch.zeros(2, 1)) for n in _MASK_NAMES}
+    w, b = P(weight), P(bias)
+    add_all = [col[rowptr[i]:rowptr[i + 1]] for i in range(N)]
+    mod = mma_amd.MMA(add_all, act, 2, H, C, w, b, *[mp[n] for n in _MASK_NAMES], 0.0, names, DEV, chunk=64,
+                      strict_reference=False, scalers=scalers, compound_scalers=compound)
+    with torch.no_grad():
+        for n in names:
+            mp[n].copy_(Ws[n])
+        w.copy_(weight); b.copy_(bias)
+    adj = mma_amd.graph.SpmmGraph(dst, col, None, N, N, DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out = mod(xg, adj)
+    gg = torch.autograd.grad((out * cot.to(DEV)).sum(), [xg, w, b] + [mp[n] for n in names])
+    check_close(out, want.numpy(), None, None, what="true-degree out", signed_sum=True, truth=w64.numpy())
+    for name, a, r, t in zip(["gx", "gweight", "gbias"] + ["gmask/" + n for n in names], gg, gw, g64):
+        check_close(a, r.numpy(), None, None, what="true-degree " + name, signed_sum=True, truth=t.numpy())
+    # the extension is opt-in: the default module on the same inputs gives the reference's (different) result
+    ref = mma_amd.MMA(add_all, act, 2, H, C, w, b, *[mp[n] for n in _MASK_NAMES], 0.0, names, DEV, chunk=64)
+    with torch.no_grad():
+        for n in names:
+            mp[n].copy_(Ws[n])
+        w.copy_(weight); b.copy_(bias)
+    assert not torch.allclose(ref(xg, adj), out)
+    with pytest.raises(ValueError):
+        mma_amd.MMA(add_all, act, 2, H, C, w, b, *[mp[n] for n in _MASK_NAMES], 0.0, names, DEV, scalers=["linear"])

@@ -19,7 +19,7 @@ def _launch(mode, world, *extra):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "sharded_worker.py"), mode, *extra]
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and ("SHARDED_%s_OK" % mode.upper()) in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0 and ("SHARDED_%s_OK" % mode.upper()) in r.stdout, r.stdout[-6000:] + r.stderr[-1500:]
 
 
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
