@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 14
+#define MMA_ABI_VERSION 15
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -190,9 +190,14 @@ int mma_tower_linear_bwd(const float* gy, const float* a, const float* W, float*
  *   rowptr (N+1), perm (E) = original edge positions grouped by key, ascending inside a group (so min/max ties
  *   resolve to the lowest edge position, like torch_scatter), other_sorted[p] = other[perm[p]] (may be NULL).
  * Replaces the implicit grouping inside torch_scatter.scatter / PyG propagate (mma_conv.py:130,166). */
+/*   long_nodes (may be NULL): mma_gr_long_nodes_len(E) int32 = [count, ids of the nodes whose group holds more than
+ *   MMA_GR_LONG_SEGMENT entries ...] (ids in no particular order): K3/K4 hand exactly these segments to their
+ *   wave-per-node pass, everything shorter runs in the block kernels. */
+#define MMA_GR_LONG_SEGMENT 64
 int64_t mma_csr_workspace_bytes(int64_t E, int64_t N);
+int64_t mma_gr_long_nodes_len(int64_t E);
 int mma_build_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N,
-                  int32_t* rowptr, int32_t* perm, int32_t* other_sorted,
+                  int32_t* rowptr, int32_t* perm, int32_t* other_sorted, int32_t* long_nodes,
                   void* workspace, int64_t workspace_bytes, void* stream);
 
 /* aggregator / scaler codes of the graph-regression path (mma_conv.py:164-172, 181-194) */
@@ -220,6 +225,7 @@ int mma_gr_fused_fwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
     float* out, uint8_t* amin8, uint8_t* amax8, int32_t* amin_side, int32_t* amax_side, float* mean, float* var, int64_t ldsave,
+    const int32_t* long_nodes,                   /* from mma_build_csr, or NULL (the second pass then scans all N row pointers) */
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
@@ -232,7 +238,7 @@ int mma_gr_fused_bwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
     const float* gout, const uint8_t* amin8, const uint8_t* amax8, const int32_t* amin_side, const int32_t* amax_side,
-    const float* mean, const float* var, int64_t ldsave, float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
+    const float* mean, const float* var, int64_t ldsave, const int32_t* long_nodes, float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream);
 

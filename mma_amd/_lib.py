@@ -6,7 +6,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMA_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "libmma_amd.so")   # override: A/B builds in development
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _c = ctypes
 _P, _I64, _I32, _U32, _U64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_uint64
@@ -19,10 +19,10 @@ PROTOTYPES = {
     "mma_nc_fused_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64,
                          _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I32, _I32, _P, _I32, _U32, _U64, _P, _I64, _P, _P],
     "mma_csr_spmm": [_P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _I64, _I64, _I32, _P],
-    "mma_build_csr": [_P, _P, _I64, _I64, _P, _P, _P, _P, _I64, _P],
-    "mma_gr_fused_fwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64,
+    "mma_build_csr": [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _I64, _P],
+    "mma_gr_fused_fwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P,
                          _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P, _P],
-    "mma_gr_fused_bwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64,
+    "mma_gr_fused_bwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _I64,
                          _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P, _P],
     "mma_csr_spmm_items": [_P, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _P],
     "mma_split_bf16x3": [_P, _I64, _P, _P],
@@ -57,6 +57,7 @@ def lib():
         L.mma_nc_aux_row_floats.argtypes, L.mma_nc_aux_row_floats.restype = [_I32, _I32, _P], _I64
         L.mma_csr_workspace_bytes.argtypes, L.mma_csr_workspace_bytes.restype = [_I64, _I64], _I64
         L.mma_gr_arg_side_rows.argtypes, L.mma_gr_arg_side_rows.restype = [_I64], _I64
+        L.mma_gr_long_nodes_len.argtypes, L.mma_gr_long_nodes_len.restype = [_I64], _I64
         L.mma_col_sum_workspace_floats.argtypes, L.mma_col_sum_workspace_floats.restype = [_I64, _I32], _I64
         L.mma_gemm_bf16x3_tn_workspace_floats.argtypes, L.mma_gemm_bf16x3_tn_workspace_floats.restype = [_I64, _I32, _I32], _I64
         L.mma_tower_linear_bwd_blocks.argtypes, L.mma_tower_linear_bwd_blocks.restype = [_I64], _I64

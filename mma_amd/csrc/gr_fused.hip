@@ -34,11 +34,19 @@ struct GrParams {
   int by_pos;                                        // 1: Z and gmsg rows are indexed by the target-sorted POSITION p, 0: by perm[p]
   int wave_min_deg;                                  // wave-per-node pass: skip segments shorter than this
   int nb; uint32_t qd, qd_magic, f_magic;            // flat kernels: nodes per workgroup, lanes (VEC columns each) per row, 2^32/d magics
+  // block kernels: float4s per node / per tower / per aggregate block of `out`, with their magics; LDS byte offsets
+  uint32_t tskf4, m_tskf4, skf4, m_skf4, f4, m_f4, m_k;
+  uint32_t lds_agg, lds_arg, lds_bytes; int n_coef;
+  const int32_t* long_nodes;                         // optional [count, node ids...] of the segments above kGroupMaxDeg (mma_build_csr)
   bool need_sum, need_sq, need_min, need_max, need_mean;   // which running reductions the aggregator list uses
   uint8_t aggr[MMA_MAX_K]; uint8_t scaler[8];
+  uint32_t aggr_pack, scaler_pack;                   // the same codes, 4 bits each: a run-time index into a kernarg ARRAY is a vector-memory load
   float avg_log, avg_lin;
   DropParams drop;
 };
+
+// floor(n / d) for n, d < 2^16 through magic = floor(2^32 / d) + 1 (host: div_magic); d == 1 has no 32-bit magic: 0 stands for it
+__device__ __forceinline__ uint32_t udiv(uint32_t n, uint32_t magic) { return magic ? __umulhi(n, magic) : n; }
 
 __device__ __forceinline__ float scaler_factor(int code, float deg, float avg_log, float avg_lin) {
   switch (code) {
@@ -294,6 +302,23 @@ __device__ __forceinline__ void gr_node_fwd(const GrParams& p, const DropParams&
   gr_fwd_store<VEC>(p, l, node, s.b, s.e - s.b, a, fac);
 }
 
+// second pass behind the flat / block kernels when mma_build_csr listed the long segments: one wave per listed node
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gr_fwd_list_kernel(const GrParams p) {
+  const int count = p.long_nodes[0];
+  if (count == 0) return;
+  const DropParams dp = drop_resolve(p.drop);
+  const GrLane l = gr_lane(p, VEC);
+  const int stride = (int)gridDim.x * (kBlock / kWave);
+  for (int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6))); i < count; i += stride) {
+    const int n = __builtin_amdgcn_readfirstlane(p.long_nodes[1 + i]);
+    const Seg s = seg_load(p, n);
+    const SegIdx i0 = idx_load(p, s.b, s.e, l.lane);
+    const Vec<VEC> u0 = l.fused ? ldv<VEC>(p.U + (size_t)n * p.lduv + l.cc) : vzero<VEC>();
+    gr_node_fwd<VEC>(p, dp, l, n, s, i0, u0);
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void gr_fwd_kernel(const GrParams p) {
   const DropParams dp = drop_resolve(p.drop);
@@ -338,7 +363,7 @@ __device__ __forceinline__ GrLane flat_lane(const GrParams& p, int q, bool fused
   GrLane l;
   l.lane = 0; l.sub = 0; l.lpr = 0; l.epg = 0;
   l.c = q * VEC; l.cc = l.c; l.valid = true; l.fused = fused;
-  l.t = (int)__umulhi((uint32_t)l.c, p.f_magic); l.f = l.c - l.t * p.F;
+  l.t = (int)udiv((uint32_t)l.c, p.f_magic); l.f = l.c - l.t * p.F;
   return l;
 }
 
@@ -356,7 +381,7 @@ __global__ __launch_bounds__(kBlock) void gr_fwd_flat_kernel(const GrParams p) {
     const int n0 = lb * p.nb;
     const int items = min(p.nb, p.N - n0) * (int)p.qd;
     for (int it = threadIdx.x; it < items; it += kBlock) {
-      const int dn = (int)__umulhi((uint32_t)it, p.qd_magic);   // it / qd
+      const int dn = (int)udiv((uint32_t)it, p.qd_magic);   // it / qd
       const int node = n0 + dn;
       const GrLane l = flat_lane<VEC>(p, it - dn * (int)p.qd, fused);
       const int b = p.rowptr[node], deg = p.rowptr[node + 1] - b;
@@ -503,6 +528,20 @@ __device__ __forceinline__ void gr_node_bwd(const GrParams& p, const DropParams&
 }
 
 template <int VEC>
+__global__ __launch_bounds__(kBlock) void gr_bwd_list_kernel(const GrParams p) {
+  const int count = p.long_nodes[0];
+  if (count == 0) return;
+  const DropParams dp = drop_resolve(p.drop);
+  const GrLane l = gr_lane(p, VEC);
+  const int stride = (int)gridDim.x * (kBlock / kWave);
+  for (int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6))); i < count; i += stride) {
+    const int n = __builtin_amdgcn_readfirstlane(p.long_nodes[1 + i]);
+    const Seg s = seg_load(p, n);
+    gr_node_bwd<VEC>(p, dp, l, n, s, idx_load(p, s.b, s.e, l.lane));
+  }
+}
+
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void gr_bwd_kernel(const GrParams p) {
   const DropParams dp = drop_resolve(p.drop);
   const GrLane l = gr_lane(p, VEC);
@@ -537,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_flat_kernel(const GrParams p) {
     const int n0 = lb * p.nb;
     const int items = min(p.nb, p.N - n0) * (int)p.qd;
     for (int it = threadIdx.x; it < items; it += kBlock) {
-      const int dn = (int)__umulhi((uint32_t)it, p.qd_magic);
+      const int dn = (int)udiv((uint32_t)it, p.qd_magic);
       const int node = n0 + dn;
       const GrLane l = flat_lane<VEC>(p, it - dn * (int)p.qd, fused);
       const int b = p.rowptr[node], deg = p.rowptr[node + 1] - b;
@@ -563,6 +602,327 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_flat_kernel(const GrParams p) {
   }
 }
 
+// ---- block kernels: the fast path of the molecule-batch shape ----------------------------------------------------------
+// Same node-block mapping as the flat kernels, ONE workgroup per block of nb nodes, in two phases with LDS between them:
+//   A  loads only: a lane owns a (node, 4 columns) item and issues a FIXED batch of loads for it (three edge slots,
+//      duplicates clamped to the last edge - molecule degrees are 1..4 -, plus a rare conditional tail; backward: the K*S
+//      gradient blocks + the arg bytes) before any arithmetic, and leaves the K aggregates (forward) or the gradient
+//      coefficients (backward) in LDS;
+//   B  stores only: the block's region of `out` (forward) is ONE contiguous run - every lane writes one float4 of it, read
+//      back from LDS and scaled, so each store instruction is 1 KB of consecutive bytes whatever D, F and S*K are;
+//      backward writes the block's contiguous message-gradient rows and dL/dU rows.
+// Why two phases: CDNA has ONE in-order vmcnt for loads and stores, so an item loop that loads, stores, loads ... makes
+// every wait for the next item's rows also wait for the previous item's stores to reach memory (PMC on the flat kernel:
+// waves parked 83 % of their cycles, 850 VALU instructions per item mostly on run-time switches).  With the phases split a
+// workgroup never waits for a store; other workgroups of the CU fill the pipe meanwhile.  Message form, dropout and the
+// set of running reductions are template parameters.
+constexpr int kBlkCap = 256;         // edge positions of a block staged in LDS (src, perm); blocks with more read them from memory
+constexpr int kBlkMaxKS = 8;         // backward: gradient blocks (K*S) loaded per item in one batch
+enum { NEED_SUM = 1, NEED_MIN = 2, NEED_MAX = 4 };
+
+
+struct BlkLds {
+  float (*fac)[8]; float (*pre)[8]; int* rowptr; int* src; int* perm; float* agg; uint8_t* arg;
+};
+constexpr uint32_t kBlkHead = 2 * (kGroupMaxDeg + 1) * 32 + 32 * 4 + 2 * kBlkCap * 4;   // two scaler tables, row pointers, src, perm
+__device__ __forceinline__ BlkLds blk_lds(const GrParams& p, unsigned char* smem) {
+  BlkLds L;
+  L.fac = reinterpret_cast<float(*)[8]>(smem);
+  L.pre = reinterpret_cast<float(*)[8]>(smem + (kGroupMaxDeg + 1) * 32);
+  L.rowptr = reinterpret_cast<int*>(smem + 2 * (kGroupMaxDeg + 1) * 32);
+  L.src = L.rowptr + 32;
+  L.perm = L.src + kBlkCap;
+  L.agg = reinterpret_cast<float*>(smem + p.lds_agg);
+  L.arg = smem + p.lds_arg;
+  return L;
+}
+
+// stage the block's row pointers, edge indices and the scaler tables (fac[d][q] and its running product pre[d][q], in the
+// reference's multiplication order); returns false when the workgroup has no block
+__device__ __forceinline__ bool blk_stage(const GrParams& p, const BlkLds& L, int& n0, int& n_here, int& p0, int& p1, bool& staged) {
+  const int nblocks = (p.N + p.nb - 1) / p.nb;
+  const int lb = flat_node_block((int)blockIdx.x, nblocks);
+  if (lb < 0) return false;
+  n0 = lb * p.nb;
+  n_here = min(p.nb, p.N - n0);
+  p0 = p.rowptr[n0]; p1 = p.rowptr[n0 + n_here];            // wave-uniform addresses: scalar loads
+  staged = p1 - p0 <= kBlkCap;
+  const int tid = threadIdx.x;
+  if (tid <= n_here) L.rowptr[tid] = p.rowptr[n0 + tid];
+  if (staged) {
+    for (int i = tid; i < p1 - p0; i += kBlock) { L.src[i] = p.src[p0 + i]; L.perm[i] = p.perm[p0 + i]; }
+  }
+  for (int d = tid; d <= kGroupMaxDeg; d += kBlock) {
+    float run = 1.f;
+    for (int q = 0; q < p.S; ++q) {
+      const float f = scaler_factor((int)((p.scaler_pack >> (4 * q)) & 15u), (float)max(d, 1), p.avg_log, p.avg_lin);
+      run = run * f;
+      L.fac[d][q] = f; L.pre[d][q] = run;
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
+// keep multipliers of the GR dropout (HASH mode only; keyed by the original edge id, mask index 0)
+__device__ __forceinline__ void blk_drop(const DropParams& d, uint32_t e, int c, float (&f)[4]) {
+  const uint32_t r = drop_mix(drop_edge_key(e + d.edge_base, d.seed_lo) ^ drop_col_key((uint32_t)(c >> 2), d.seed_hi));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = ((r >> (8 * i)) & 0xFFu) >= d.thr ? d.scale : 0.f;
+}
+
+template <int NEEDS>
+struct BlkAcc {
+  float sum[4], mn[4], mx[4]; int an[4], ax[4];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sum[i] = 0.f; mn[i] = INFINITY; mx[i] = -INFINITY; an[i] = INT_MAX; ax[i] = INT_MAX; }
+  }
+  __device__ __forceinline__ void take(const Vec<4>& h, int off, bool on) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (NEEDS & NEED_SUM) sum[i] += on ? h.v[i] : 0.f;
+      if (NEEDS & NEED_MIN) { if (on && h.v[i] < mn[i]) { mn[i] = h.v[i]; an[i] = off; } }   // strict: the first extremal edge wins
+      if (NEEDS & NEED_MAX) { if (on && h.v[i] > mx[i]) { mx[i] = h.v[i]; ax[i] = off; } }
+    }
+  }
+};
+
+// h = drop((V + U) + Z) from raw rows - the same association as gr_message
+template <bool FUSED, bool HASZ, bool DROP>
+__device__ __forceinline__ Vec<4> blk_combine(const GrParams& p, const DropParams& dp, const Vec<4>& u, Vec<4> v, const Vec<4>& z,
+                                              uint32_t e, int c) {
+  if (FUSED) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.v[i] += u.v[i];
+    if (HASZ) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v.v[i] += z.v[i];
+    }
+    if (DROP) {
+      float f[4];
+      blk_drop(dp, e, c, f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v.v[i] *= f[i];
+    }
+  }
+  return v;
+}
+
+template <bool FUSED, bool HASZ, bool DROP, int NEEDS, bool STAGED>
+__device__ __forceinline__ void blk_fwd_items(const GrParams& p, const DropParams& dp, const BlkLds& L, int n0, int n_here, int p0) {
+  const int items = n_here * (int)p.qd;
+  for (int it = threadIdx.x; it < items; it += kBlock) {
+    const int dn = (int)udiv((uint32_t)it, p.qd_magic);
+    const int c = (it - dn * (int)p.qd) * 4;
+    const int node = n0 + dn;
+    const int b = L.rowptr[dn], deg = L.rowptr[dn + 1] - b;
+    if (deg > kGroupMaxDeg) continue;                         // a long segment: left to the wave-per-node pass
+    // ---- the item's loads, all issued before the first use: U row + three edge slots (slot i = edge min(i, deg-1); an
+    // empty segment re-reads the block's first edge and drops it)
+    int j[3], e[3], pos[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      pos[i] = deg > 0 ? b + min(i, deg - 1) : p0;
+      if (STAGED) { j[i] = L.src[pos[i] - p0]; e[i] = L.perm[pos[i] - p0]; }
+      else { j[i] = p.src[pos[i]]; e[i] = p.perm[pos[i]]; }
+    }
+    const Vec<4> u = FUSED ? ldv<4>(p.U + (size_t)node * p.lduv + c) : vzero<4>();
+    Vec<4> v[3], z[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      v[i] = FUSED ? ldv<4>(p.V + (size_t)j[i] * p.lduv + c) : ldv<4>(p.inputs + (size_t)e[i] * p.ldi + c);
+      z[i] = (FUSED && HASZ) ? ldv<4>(p.Z + (size_t)(p.by_pos ? pos[i] : e[i]) * p.ldz + c) : vzero<4>();
+    }
+    BlkAcc<NEEDS> a;
+    a.init();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.take(blk_combine<FUSED, HASZ, DROP>(p, dp, u, v[i], z[i], (uint32_t)e[i], c), i, i < deg);
+    for (int t = 3; t < deg; ++t) {                           // rare on molecule batches (degree-4 atoms)
+      const int pt = b + t;
+      const int jj = STAGED ? L.src[pt - p0] : p.src[pt], ee = STAGED ? L.perm[pt - p0] : p.perm[pt];
+      const Vec<4> vv = FUSED ? ldv<4>(p.V + (size_t)jj * p.lduv + c) : ldv<4>(p.inputs + (size_t)ee * p.ldi + c);
+      const Vec<4> zz = (FUSED && HASZ) ? ldv<4>(p.Z + (size_t)(p.by_pos ? pt : ee) * p.ldz + c) : vzero<4>();
+      a.take(blk_combine<FUSED, HASZ, DROP>(p, dp, u, vv, zz, (uint32_t)ee, c), t, true);
+    }
+    const float fdeg = (float)max(deg, 1);                    // degree(...).clamp_(1), mma_conv.py:178-179
+    for (int k = 0; k < p.K; ++k) {
+      const int code = (int)((p.aggr_pack >> (4 * k)) & 15u);
+      Vec<4> r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float val = 0.f;
+        if (NEEDS & NEED_SUM) val = code == GR_SUM ? a.sum[i] : (code == GR_MEAN ? a.sum[i] / fdeg : val);   // scatter mean: sum / clamp(count, 1)
+        if (NEEDS & NEED_MIN) val = code == GR_MIN ? (deg ? a.mn[i] : 0.f) : val;                            // empty target -> 0 (torch_scatter)
+        if (NEEDS & NEED_MAX) val = code == GR_MAX ? (deg ? a.mx[i] : 0.f) : val;
+        r.v[i] = val;
+      }
+      stv<4>(L.agg + ((size_t)dn * p.K + k) * p.D + c, r);
+    }
+    if ((NEEDS & NEED_MIN) && p.amin8) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w |= ((uint32_t)a.an[i] & 0xFFu) << (8 * i);
+      *reinterpret_cast<uint32_t*>(L.arg + (size_t)dn * p.D + c) = w;
+    }
+    if ((NEEDS & NEED_MAX) && p.amax8) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w |= ((uint32_t)a.ax[i] & 0xFFu) << (8 * i);
+      *reinterpret_cast<uint32_t*>(L.arg + (size_t)(p.nb + dn) * p.D + c) = w;
+    }
+  }
+}
+
+template <bool FUSED, bool HASZ, bool DROP, int NEEDS>
+__global__ __launch_bounds__(kBlock) void gr_fwd_block_kernel(const GrParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const BlkLds L = blk_lds(p, smem);
+  int n0, n_here, p0, p1; bool staged;
+  if (!blk_stage(p, L, n0, n_here, p0, p1, staged)) return;
+  const DropParams dp = DROP ? drop_resolve(p.drop) : p.drop;
+  const int tid = threadIdx.x;
+
+  // ---- phase A: (node, 4 columns) items -> K aggregates + args in LDS
+  if (p1 == p0) {                                             // no edge in the whole block: every aggregate is 0
+    for (int w = tid; w < n_here * p.K * (int)p.qd; w += kBlock) stv<4>(L.agg + (size_t)w * 4, vzero<4>());
+    for (int w = tid; w < (2 * p.nb * p.D) >> 2; w += kBlock) reinterpret_cast<uint32_t*>(L.arg)[w] = 0xFFFFFFFFu;
+  } else if (staged) {
+    blk_fwd_items<FUSED, HASZ, DROP, NEEDS, true>(p, dp, L, n0, n_here, p0);
+  } else {
+    blk_fwd_items<FUSED, HASZ, DROP, NEEDS, false>(p, dp, L, n0, n_here, p0);
+  }
+  __syncthreads();
+
+  // ---- phase B: the block's run of `out`, one float4 per lane and step: out[n, t, (q*K + k)*F + f] = agg_k * prod_{q' <= q} fac_q'
+  const int total = n_here * (int)p.tskf4;
+  float* ob = p.out + (size_t)n0 * p.T * ((size_t)p.S * p.K * p.F);
+  for (int w = tid; w < total; w += kBlock) {
+    const uint32_t dn = udiv((uint32_t)w, p.m_tskf4);
+    uint32_t r = (uint32_t)w - dn * p.tskf4;
+    const uint32_t t = udiv(r, p.m_skf4);
+    r -= t * p.skf4;
+    const uint32_t qk = udiv(r, p.m_f4);
+    const uint32_t fq = r - qk * p.f4;
+    const uint32_t q = udiv(qk, p.m_k), k = qk - q * (uint32_t)p.K;
+    const int deg = L.rowptr[dn + 1] - L.rowptr[dn];
+    if (deg > kGroupMaxDeg) continue;
+    Vec<4> v = ldv<4>(L.agg + ((size_t)dn * p.K + k) * p.D + t * p.F + fq * 4);
+    for (uint32_t qq = 0; qq <= q; ++qq) {                    // compounding (G7), in the reference's order: ((v f0) f1) ...
+      const float f = L.fac[deg][qq];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v.v[i] = v.v[i] * f;
+    }
+    stv<4>(ob + (size_t)w * 4, v);
+  }
+  // saved args: byte rows of the block, skipping the long segments' rows (written by the wave pass)
+  const int dq = p.D >> 2;
+  for (int w = tid; w < n_here * dq; w += kBlock) {
+    const int dn = (int)udiv((uint32_t)w, p.qd_magic), cq = w - dn * dq;    // qd == D/4 on this path
+    if (L.rowptr[dn + 1] - L.rowptr[dn] > kGroupMaxDeg) continue;
+    if ((NEEDS & NEED_MIN) && p.amin8)
+      *reinterpret_cast<uint32_t*>(p.amin8 + (size_t)(n0 + dn) * p.ldsave + cq * 4) = *reinterpret_cast<const uint32_t*>(L.arg + (size_t)dn * p.D + cq * 4);
+    if ((NEEDS & NEED_MAX) && p.amax8)
+      *reinterpret_cast<uint32_t*>(p.amax8 + (size_t)(n0 + dn) * p.ldsave + cq * 4) =
+          *reinterpret_cast<const uint32_t*>(L.arg + (size_t)(p.nb + dn) * p.D + cq * 4);
+  }
+}
+
+// backward: phase A reduces the K*S gradient blocks of a (node, 4 columns) item to the coefficients
+//   dL/dh_e = c_all + [off == amin] c_min + [off == amax] c_max        (LDS: coef[node][0..n_coef)[D], args as bytes)
+// phase B walks the item's edges and stores the message gradients (+ their sum, dL/dU) - stores only.
+template <bool FUSED, bool DROP, int NEEDS>
+__global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const BlkLds L = blk_lds(p, smem);
+  int n0, n_here, p0, p1; bool staged;
+  if (!blk_stage(p, L, n0, n_here, p0, p1, staged)) return;
+  const DropParams dp = DROP ? drop_resolve(p.drop) : p.drop;
+  const int tid = threadIdx.x;
+  constexpr int NC = ((NEEDS & NEED_SUM) ? 1 : 0) + ((NEEDS & NEED_MIN) ? 1 : 0) + ((NEEDS & NEED_MAX) ? 1 : 0);
+  constexpr int I_ALL = 0, I_MIN = (NEEDS & NEED_SUM) ? 1 : 0, I_MAX = I_MIN + ((NEEDS & NEED_MIN) ? 1 : 0);
+  const int items = n_here * (int)p.qd;
+  const int KS = p.K * p.S;                                   // <= kBlkMaxKS on this path
+
+  for (int it = tid; it < items; it += kBlock) {
+    const int dn = (int)udiv((uint32_t)it, p.qd_magic);
+    const int c = (it - dn * (int)p.qd) * 4;
+    const int node = n0 + dn;
+    const int deg = L.rowptr[dn + 1] - L.rowptr[dn];
+    if (deg > kGroupMaxDeg || deg == 0) continue;
+    const uint32_t t = udiv((uint32_t)c, p.f_magic);
+    const int f = c - (int)t * p.F;
+    const float* go = p.gout + ((size_t)node * p.T + t) * ((size_t)p.S * p.K * p.F) + f;
+    // one batch of loads: the K*S gradient blocks (slots past K*S re-read the last one and are dropped) + the arg bytes
+    Vec<4> gv[kBlkMaxKS];
+#pragma unroll
+    for (int i = 0; i < kBlkMaxKS; ++i) gv[i] = ldv<4>(go + (size_t)min(i, KS - 1) * p.F);
+    uint32_t wn = 0xFFFFFFFFu, wx = 0xFFFFFFFFu;
+    if ((NEEDS & NEED_MIN) && p.amin8) wn = ldb<4>(p.amin8 + (size_t)node * p.ldsave + c);     // NULL: no min in the aggregator list
+    if ((NEEDS & NEED_MAX) && p.amax8) wx = ldb<4>(p.amax8 + (size_t)node * p.ldsave + c);
+    float c_all[4] = {0.f, 0.f, 0.f, 0.f}, c_min[4] = {0.f, 0.f, 0.f, 0.f}, c_max[4] = {0.f, 0.f, 0.f, 0.f};
+    const float inv_cnt_scale = (float)deg;
+#pragma unroll
+    for (int i = 0; i < kBlkMaxKS; ++i) {                      // block i = (q, k) = (i / K, i % K), weight = prod_{q' <= q} fac_q'
+      if (i < KS) {
+        const uint32_t q = udiv((uint32_t)i, p.m_k), k = (uint32_t)i - q * (uint32_t)p.K;
+        const float run = L.pre[deg][q];
+        const int code = (int)((p.aggr_pack >> (4 * k)) & 15u);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          if (NEEDS & NEED_SUM) {
+            if (code == GR_SUM) c_all[x] = fmaf(gv[i].v[x], run, c_all[x]);
+            if (code == GR_MEAN) c_all[x] = fmaf(gv[i].v[x], run / inv_cnt_scale, c_all[x]);
+          }
+          if (NEEDS & NEED_MIN) { if (code == GR_MIN) c_min[x] = fmaf(gv[i].v[x], run, c_min[x]); }
+          if (NEEDS & NEED_MAX) { if (code == GR_MAX) c_max[x] = fmaf(gv[i].v[x], run, c_max[x]); }
+        }
+      }
+    }
+    float* cf = L.agg + (size_t)dn * NC * p.D + c;
+    if (NEEDS & NEED_SUM) { Vec<4> v; for (int i = 0; i < 4; ++i) v.v[i] = c_all[i]; stv<4>(cf + I_ALL * p.D, v); }
+    if (NEEDS & NEED_MIN) { Vec<4> v; for (int i = 0; i < 4; ++i) v.v[i] = c_min[i]; stv<4>(cf + I_MIN * p.D, v); }
+    if (NEEDS & NEED_MAX) { Vec<4> v; for (int i = 0; i < 4; ++i) v.v[i] = c_max[i]; stv<4>(cf + I_MAX * p.D, v); }
+    if (NEEDS & NEED_MIN) *reinterpret_cast<uint32_t*>(L.arg + (size_t)dn * p.D + c) = wn;
+    if (NEEDS & NEED_MAX) *reinterpret_cast<uint32_t*>(L.arg + (size_t)(p.nb + dn) * p.D + c) = wx;
+  }
+  __syncthreads();
+
+  for (int it = tid; it < items; it += kBlock) {
+    const int dn = (int)udiv((uint32_t)it, p.qd_magic);
+    const int c = (it - dn * (int)p.qd) * 4;
+    const int node = n0 + dn;
+    const int b = L.rowptr[dn], deg = L.rowptr[dn + 1] - b;
+    if (deg > kGroupMaxDeg) continue;
+    Vec<4> su = vzero<4>();                                   // dL/dU[node]: the sum of the segment's message gradients, in position order
+    if (deg > 0) {
+      const float* cf = L.agg + (size_t)dn * NC * p.D + c;
+      Vec<4> ca = vzero<4>(), cn = vzero<4>(), cx = vzero<4>();
+      uint32_t wn = 0xFFFFFFFFu, wx = 0xFFFFFFFFu;
+      if (NEEDS & NEED_SUM) ca = ldv<4>(cf + I_ALL * p.D);
+      if (NEEDS & NEED_MIN) { cn = ldv<4>(cf + I_MIN * p.D); wn = *reinterpret_cast<const uint32_t*>(L.arg + (size_t)dn * p.D + c); }
+      if (NEEDS & NEED_MAX) { cx = ldv<4>(cf + I_MAX * p.D); wx = *reinterpret_cast<const uint32_t*>(L.arg + (size_t)(p.nb + dn) * p.D + c); }
+      for (int tt = 0; tt < deg; ++tt) {
+        const int pos = b + tt;
+        int ee = 0;
+        if (DROP || !p.by_pos) ee = staged ? L.perm[pos - p0] : p.perm[pos];
+        float fd[4] = {1.f, 1.f, 1.f, 1.f};
+        if (DROP) blk_drop(dp, (uint32_t)ee, c, fd);
+        Vec<4> g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float gi = ca.v[i] + ((uint32_t)tt == ((wn >> (8 * i)) & 0xFFu) ? cn.v[i] : 0.f) +
+                           ((uint32_t)tt == ((wx >> (8 * i)) & 0xFFu) ? cx.v[i] : 0.f);
+          g.v[i] = gi * fd[i];
+          su.v[i] += g.v[i];
+        }
+        stv<4>(p.gmsg + (size_t)(p.by_pos ? pos : ee) * p.ldg + c, g);
+      }
+    }
+    if (p.gU) stv<4>(p.gU + (size_t)node * p.ldgu + c, su);
+  }
+}
+
 // ---- K6: CSR by key (stable), device side ---------------------------------------------------------------
 __global__ void csr_prepare_kernel(const int64_t* key, int64_t E, int32_t* key32, int32_t* iota) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += (int64_t)gridDim.x * blockDim.x) {
@@ -583,6 +943,12 @@ __global__ void csr_gather_kernel(const int64_t* other, const int32_t* perm, int
     out[i] = (int32_t)other[perm[i]];
 }
 
+// nodes whose segment is longer than kGroupMaxDeg: out[0] = count (zeroed before the launch), out[1..] = node ids (any order)
+__global__ void csr_long_nodes_kernel(const int32_t* rowptr, int64_t N, int32_t* out) {
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
+    if (rowptr[n + 1] - rowptr[n] > kGroupMaxDeg) out[1 + atomicAdd(out, 1)] = (int32_t)n;
+}
+
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 static int sort_bits(int64_t N) { int b = 1; while ((1LL << b) < N) ++b; return b; }
 
@@ -597,6 +963,8 @@ static int fill_codes(const uint8_t* aggr_host, int K, const uint8_t* scaler_hos
     p->scaler[s] = scaler_host[s];
   }
   p->K = K; p->S = S;
+  for (int k = 0; k < K; ++k) p->aggr_pack |= (uint32_t)p->aggr[k] << (4 * k);
+  for (int q = 0; q < S; ++q) p->scaler_pack |= (uint32_t)p->scaler[q] << (4 * q);
   for (int k = 0; k < K; ++k) {
     const int a = p->aggr[k];
     p->need_sum |= a == GR_SUM || a == GR_MEAN || a >= GR_VAR;
@@ -647,15 +1015,69 @@ static dim3 gr_grid(int64_t N, int D, int vec, int* lpr_log) {
 
 // the flat kernels pay when segments are short on average (molecule batches); they leave segments above kGroupMaxDeg
 // edges to a wave-per-node pass.  Sets the flat geometry; false: run everything wave-per-node.
+static uint32_t div_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ULL << 32) / d) + 1u; }   // see udiv()
 constexpr int kFlatNodes = 16;       // nodes per workgroup: ZINC rows (95 quads) -> 1520 lanes of work, 5.9 sweeps of 256 threads
 static bool gr_flat_mode(GrParams* p, int64_t E, int vec) {
   const int qd = (p->D + vec - 1) / vec;
   if (!(E <= 16 * (int64_t)p->N) || qd > 4095 || p->D > 65535) return false;
   p->nb = kFlatNodes; p->qd = (uint32_t)qd;
-  p->qd_magic = (uint32_t)((1ULL << 32) / (uint32_t)qd) + 1u;      // exact floor(n / qd) for n, qd < 2^16
-  p->f_magic = (uint32_t)((1ULL << 32) / (uint32_t)p->F) + 1u;
+  p->qd_magic = div_magic((uint32_t)qd);      // exact floor(n / qd) for n, qd < 2^16
+  p->f_magic = div_magic((uint32_t)p->F);
   return true;
 }
+// block kernels (fast path): vec4 operands, aggregators out of sum|mean|min|max only, short segments on average, and an LDS
+// budget that leaves several workgroups per CU.  Fills the geometry; returns the NEEDS mask, or 0 when the path does not apply.
+static int gr_block_mode(GrParams* p, int64_t E, bool v4, bool backward) {
+  if (!v4 || E <= 0 || !(E <= 16 * (int64_t)p->N) || p->mean || p->var || p->D > 16380 || p->F < 4) return 0;
+  if (backward && p->K * p->S > kBlkMaxKS) return 0;         // the backward loads all K*S gradient blocks of an item in one batch
+  int needs = 0;
+  for (int k = 0; k < p->K; ++k) {
+    switch (p->aggr[k]) {
+      case GR_SUM: case GR_MEAN: needs |= NEED_SUM; break;
+      case GR_MIN: needs |= NEED_MIN; break;
+      case GR_MAX: needs |= NEED_MAX; break;
+      default: return 0;                                   // var / std: generic kernels
+    }
+  }
+  if ((needs & ~(NEED_MIN | NEED_MAX)) != 0) needs = NEED_SUM | NEED_MIN | NEED_MAX;   // two instantiations: {min,max} and everything
+  const int n_coef = (needs & NEED_SUM ? 1 : 0) + (needs & NEED_MIN ? 1 : 0) + (needs & NEED_MAX ? 1 : 0);
+  const uint32_t qd = (uint32_t)p->D / 4, f4 = (uint32_t)p->F / 4, skf4 = (uint32_t)(p->S * p->K) * f4, tskf4 = (uint32_t)p->T * skf4;
+  const uint32_t head = kBlkHead;
+  const int planes = backward ? n_coef : p->K;
+  for (int nb = 16; nb >= 2; nb >>= 1) {
+    const uint32_t agg = (uint32_t)nb * planes * p->D * 4, arg = 2u * nb * p->D;
+    if (head + agg + arg > 40 * 1024 || (uint32_t)nb * tskf4 > 65535u || (uint32_t)nb * qd > 65535u) continue;
+    p->nb = nb; p->qd = qd; p->qd_magic = div_magic(qd);
+    p->f_magic = div_magic((uint32_t)p->F);
+    p->tskf4 = tskf4; p->m_tskf4 = div_magic(tskf4);
+    p->skf4 = skf4; p->m_skf4 = div_magic(skf4);
+    p->f4 = f4; p->m_f4 = div_magic(f4);
+    p->m_k = div_magic((uint32_t)p->K);
+    p->lds_agg = head; p->lds_arg = head + agg; p->lds_bytes = head + agg + arg; p->n_coef = n_coef;
+    return needs;
+  }
+  return 0;
+}
+static dim3 gr_block_grid(const GrParams& p) {
+  const int64_t nblocks = ((int64_t)p.N + p.nb - 1) / p.nb;
+  return dim3((unsigned)((nblocks + 7) / 8 * 8));            // one workgroup per node block; a multiple of 8 (XCD slots)
+}
+
+template <bool FUSED, bool HASZ, bool DROP>
+static void launch_fwd_block(int needs, dim3 grid, unsigned lds, hipStream_t st, const GrParams& p) {
+  if (needs == (NEED_MIN | NEED_MAX))
+    hipLaunchKernelGGL((gr_fwd_block_kernel<FUSED, HASZ, DROP, NEED_MIN | NEED_MAX>), grid, dim3(kBlock), lds, st, p);
+  else
+    hipLaunchKernelGGL((gr_fwd_block_kernel<FUSED, HASZ, DROP, NEED_SUM | NEED_MIN | NEED_MAX>), grid, dim3(kBlock), lds, st, p);
+}
+template <bool FUSED, bool DROP>
+static void launch_bwd_block(int needs, dim3 grid, unsigned lds, hipStream_t st, const GrParams& p) {
+  if (needs == (NEED_MIN | NEED_MAX))
+    hipLaunchKernelGGL((gr_bwd_block_kernel<FUSED, DROP, NEED_MIN | NEED_MAX>), grid, dim3(kBlock), lds, st, p);
+  else
+    hipLaunchKernelGGL((gr_bwd_block_kernel<FUSED, DROP, NEED_SUM | NEED_MIN | NEED_MAX>), grid, dim3(kBlock), lds, st, p);
+}
+
 static dim3 gr_flat_grid(int64_t N) {
   int64_t slots = ((N + kFlatNodes - 1) / kFlatNodes + 7) / 8 * 8;
   if (slots > 4 * kMaxGrid) slots = 4 * kMaxGrid;                    // a multiple of 8: grid-stride keeps a slot's XCD
@@ -675,11 +1097,14 @@ extern "C" int64_t mma_csr_workspace_bytes(int64_t E, int64_t N) {
   return (int64_t)(3 * align256((size_t)E * 4) + align256(temp) + 256);
 }
 
+extern "C" int64_t mma_gr_long_nodes_len(int64_t E) { return E < 0 ? -1 : E / (kGroupMaxDeg + 1) + 2; }
+
 extern "C" int mma_build_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N, int32_t* rowptr, int32_t* perm,
-                             int32_t* other_sorted, void* workspace, int64_t workspace_bytes, void* stream) {
+                             int32_t* other_sorted, int32_t* long_nodes, void* workspace, int64_t workspace_bytes, void* stream) {
   MMA_REQUIRE(E >= 0 && N >= 0 && E < (1LL << 31) && N < (1LL << 31), "E=%lld N=%lld out of int32 range", (long long)E, (long long)N);
   MMA_REQUIRE(rowptr != nullptr, "NULL rowptr");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (long_nodes) (void)hipMemsetAsync(long_nodes, 0, 4, st);      // the count; ids follow
   if (E == 0) {
     (void)hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 4, st);
     return check_launch("csr memset");
@@ -702,6 +1127,9 @@ extern "C" int mma_build_csr(const int64_t* key, const int64_t* other, int64_t E
   if (e != hipSuccess) return fail(100 + (int)e, "radix sort failed: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(csr_rowptr_kernel, dim3(blocks), dim3(kBlock), 0, st, skey, E, N, rowptr);
   if (other && other_sorted) hipLaunchKernelGGL(csr_gather_kernel, dim3(blocks), dim3(kBlock), 0, st, other, perm, E, other_sorted);
+  if (long_nodes && N > 0)
+    hipLaunchKernelGGL(csr_long_nodes_kernel, dim3((unsigned)min((int64_t)kMaxGrid, (N + kBlock) / kBlock)), dim3(kBlock), 0, st, rowptr, N,
+                       long_nodes);
   return check_launch("csr build");
 }
 
@@ -731,12 +1159,14 @@ extern "C" int mma_gr_fused_fwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
     float* out, uint8_t* amin8, uint8_t* amax8, int32_t* amin_side, int32_t* amax_side, float* mean, float* var, int64_t ldsave,
+    const int32_t* long_nodes,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) - (1 << 20) && E < (1LL << 31) && T >= 1 && F >= 1,
               "N=%lld E=%lld T=%d F=%d unsupported", (long long)N, (long long)E, T, F);
   GrParams p{};
   if (int rc = fill_codes(aggr_host, K, scaler_host, S, &p)) return rc;
+  p.long_nodes = long_nodes;
   if (N == 0) return 0;
   const int D = T * F;
   MMA_REQUIRE(rowptr && out, "NULL argument");
@@ -750,12 +1180,28 @@ extern "C" int mma_gr_fused_fwd(
   const bool v4 = gr_vec4(p);
   const dim3 grid = gr_grid(N, D, v4 ? 4 : 1, &p.lpr_log);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (gr_flat_mode(&p, E, v4 ? 4 : 1)) {      // short segments: flat kernel, then the wave-per-node pass for the few long ones
+  const bool drop = p.drop.mode != MMA_DROP_NONE;
+  if (const int needs = gr_block_mode(&p, E, v4, false)) {       // molecule-batch shape: two-phase block kernel
+    const dim3 bg = gr_block_grid(p);
+    if (inputs) launch_fwd_block<false, false, false>(needs, bg, p.lds_bytes, st, p);
+    else if (Z) { if (drop) launch_fwd_block<true, true, true>(needs, bg, p.lds_bytes, st, p); else launch_fwd_block<true, true, false>(needs, bg, p.lds_bytes, st, p); }
+    else { if (drop) launch_fwd_block<true, false, true>(needs, bg, p.lds_bytes, st, p); else launch_fwd_block<true, false, false>(needs, bg, p.lds_bytes, st, p); }
+    if (int rc = check_launch("gr_fwd_block_kernel")) return rc;
+    p.wave_min_deg = kGroupMaxDeg + 1;
+  } else if (gr_flat_mode(&p, E, v4 ? 4 : 1)) {      // short segments, generic form: flat kernel
     const dim3 fg = gr_flat_grid(N);
     if (v4) hipLaunchKernelGGL((gr_fwd_flat_kernel<4>), fg, dim3(kBlock), 0, st, p);
     else hipLaunchKernelGGL((gr_fwd_flat_kernel<1>), fg, dim3(kBlock), 0, st, p);
     if (int rc = check_launch("gr_fwd_flat_kernel")) return rc;
     p.wave_min_deg = kGroupMaxDeg + 1;
+  }
+  // the wave-per-node pass: everything, or - behind a block / flat kernel - the segments above kGroupMaxDeg edges only, taken
+  // from the list mma_build_csr made when the caller has one (an empty list costs one trivial launch instead of a scan of N)
+  if (p.wave_min_deg > 0 && long_nodes) {
+    const dim3 lg(128, grid.y);
+    if (v4) hipLaunchKernelGGL((gr_fwd_list_kernel<4>), lg, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((gr_fwd_list_kernel<1>), lg, dim3(kBlock), 0, st, p);
+    return check_launch("gr_fwd_list_kernel");
   }
   if (v4) hipLaunchKernelGGL((gr_fwd_kernel<4>), grid, dim3(kBlock), 0, st, p);
   else hipLaunchKernelGGL((gr_fwd_kernel<1>), grid, dim3(kBlock), 0, st, p);
@@ -766,13 +1212,14 @@ extern "C" int mma_gr_fused_bwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
     const float* gout, const uint8_t* amin8, const uint8_t* amax8, const int32_t* amin_side, const int32_t* amax_side,
-    const float* mean, const float* var, int64_t ldsave, float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
+    const float* mean, const float* var, int64_t ldsave, const int32_t* long_nodes, float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) - (1 << 20) && E < (1LL << 31) && T >= 1 && F >= 1,
               "N=%lld E=%lld T=%d F=%d unsupported", (long long)N, (long long)E, T, F);
   GrParams p{};
   if (int rc = fill_codes(aggr_host, K, scaler_host, S, &p)) return rc;
+  p.long_nodes = long_nodes;
   if (N == 0 || E == 0) return 0;
   const int D = T * F;
   MMA_REQUIRE(rowptr && src && perm && gout && gmsg && ldg >= D, "NULL argument or pitch too small");
@@ -794,12 +1241,26 @@ extern "C" int mma_gr_fused_bwd(
                   (!gU || (ldgu % 4 == 0 && (reinterpret_cast<uintptr_t>(gU) & 15) == 0));
   const dim3 grid = gr_grid(N, D, v4 ? 4 : 1, &p.lpr_log);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (gr_flat_mode(&p, E, v4 ? 4 : 1)) {
+  const bool drop = p.drop.mode != MMA_DROP_NONE;
+  if (const int needs = need_stats ? 0 : gr_block_mode(&p, E, v4, true)) {
+    const dim3 bg = gr_block_grid(p);
+    if (inputs) launch_bwd_block<false, false>(needs, bg, p.lds_bytes, st, p);
+    else if (drop) launch_bwd_block<true, true>(needs, bg, p.lds_bytes, st, p);
+    else launch_bwd_block<true, false>(needs, bg, p.lds_bytes, st, p);
+    if (int rc = check_launch("gr_bwd_block_kernel")) return rc;
+    p.wave_min_deg = kGroupMaxDeg + 1;
+  } else if (gr_flat_mode(&p, E, v4 ? 4 : 1)) {
     const dim3 fg = gr_flat_grid(N);
     if (v4) hipLaunchKernelGGL((gr_bwd_flat_kernel<4>), fg, dim3(kBlock), 0, st, p);
     else hipLaunchKernelGGL((gr_bwd_flat_kernel<1>), fg, dim3(kBlock), 0, st, p);
     if (int rc = check_launch("gr_bwd_flat_kernel")) return rc;
     p.wave_min_deg = kGroupMaxDeg + 1;
+  }
+  if (p.wave_min_deg > 0 && long_nodes) {
+    const dim3 lg(128, grid.y);
+    if (v4) hipLaunchKernelGGL((gr_bwd_list_kernel<4>), lg, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((gr_bwd_list_kernel<1>), lg, dim3(kBlock), 0, st, p);
+    return check_launch("gr_bwd_list_kernel");
   }
   if (v4) hipLaunchKernelGGL((gr_bwd_kernel<4>), grid, dim3(kBlock), 0, st, p);
   else hipLaunchKernelGGL((gr_bwd_kernel<1>), grid, dim3(kBlock), 0, st, p);

@@ -269,7 +269,7 @@ GR_SCALER = {"identity": 0, "amplification": 1, "attenuation": 2, "linear": 3, "
 class DeviceCSR:
     """Edges grouped by `key` (stable): rowptr (N+1), perm (E) original positions, other (E) = other[perm]."""
 
-    def __init__(self, key, other, N):
+    def __init__(self, key, other, N, long_list=False):
         require_gpu(key)
         E = key.numel()
         dev = key.device
@@ -283,9 +283,11 @@ class DeviceCSR:
         if nbytes < 0:
             raise _lib.MMALibraryError("graph too large for int32 CSR: E=%d N=%d" % (E, N))
         ws = torch.empty(int(nbytes) + 1024, dtype=torch.uint8, device=dev)   # per call: cheap (caching allocator), capture-safe
+        # [count, ids...] of the groups above MMA_GR_LONG_SEGMENT entries: what K3/K4 leave to their wave-per-node pass
+        self.long_nodes = torch.empty(int(_lib.lib().mma_gr_long_nodes_len(E)), dtype=torch.int32, device=dev) if long_list else None
         with _span("csr_build"):
             call("mma_build_csr", ptr(key), ptr(other.contiguous()) if other is not None else None, E, N, ptr(self.rowptr),
-                 ptr(self.perm), ptr(self.other) if other is not None else None, ptr(ws), ws.numel(), stream_ptr())
+                 ptr(self.perm), ptr(self.other) if other is not None else None, ptr(self.long_nodes), ptr(ws), ws.numel(), stream_ptr())
 
 
 class GRGraph:
@@ -294,7 +296,7 @@ class GRGraph:
 
     def __init__(self, edge_index, N):
         self.edge_index, self.N, self.E = edge_index, int(N), int(edge_index.shape[1])
-        self.by_target = DeviceCSR(edge_index[1], edge_index[0], N)
+        self.by_target = DeviceCSR(edge_index[1], edge_index[0], N, long_list=True)
         self._by_source = None
         self._inv_perm = None
         self._by_source_pos = None
@@ -401,7 +403,7 @@ class _GRAggregate(torch.autograd.Function):
             return out
         with _span("gr_fused_fwd"):
             _gr_call("mma_gr_fused_fwd", csr, U, V, Z, by_pos, inputs,
-                     (ptr(out), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), ptr(mean), ptr(var), D),
+                     (ptr(out), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), ptr(mean), ptr(var), D, ptr(csr.long_nodes)),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
         ctx.save_for_backward(inputs, UV, Z, amin, amax, amin_s, amax_s, mean, var)
         return out
@@ -424,7 +426,8 @@ class _GRAggregate(torch.autograd.Function):
         gUV = torch.empty((N, 2 * D), device=gout.device, dtype=torch.float32) if fused else None
         with _span("gr_fused_bwd"):
             _gr_call("mma_gr_fused_bwd", csr, U, V, Z, by_pos, inputs,
-                     (ptr(gout), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), ptr(mean), ptr(var), D, ptr(gmsg), D, ptr(gUV),
+                     (ptr(gout), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), ptr(mean), ptr(var), D, ptr(csr.long_nodes), ptr(gmsg), D,
+                      ptr(gUV),
                       2 * D if fused else 0),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
         if not fused:
