@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 15
+#define MMA_ABI_VERSION 16
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -166,6 +166,10 @@ int mma_pack_rows(const float* src, int64_t lds, const int32_t* idx, int64_t n_i
                   float* dst, int64_t ldd, int32_t width, void* stream);
 int mma_unpack_add_rows(const float* src, int64_t lds, const int32_t* idx, int64_t n_idx,
                         float* dst, int64_t ldd, int32_t width, void* stream);
+/* the whole reverse exchange in one launch: dst[rows[t],:] += sum_{q in [segptr[t], segptr[t+1])} src[pos[q],:] (fixed order;
+ * rows unique; pos indexes the concatenated receive buffer of all peers) - a row read by several peers has one writer */
+int mma_unpack_add_rows_csr(const float* src, int64_t lds, const int32_t* rows, const int32_t* segptr, const int32_t* pos,
+                            int64_t n_rows, float* dst, int64_t ldd, int32_t width, void* stream);
 
 /* ---- K8: column sums of a tall row-major matrix (bias gradients) ----------------------------------------
  * out[c] = sum_r g[r*ldg + c], r < R, c < C, in a fixed order (two passes over ~2*sqrt(R)-row blocks, no atomics).

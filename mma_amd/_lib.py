@@ -6,7 +6,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMA_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "libmma_amd.so")   # override: A/B builds in development
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _c = ctypes
 _P, _I64, _I32, _U32, _U64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_uint64
@@ -29,6 +29,7 @@ PROTOTYPES = {
     "mma_gemm_bf16x3": [_P, _I64, _P, _P, _I64, _I64, _I32, _I32, _I32, _P],
     "mma_pack_rows": [_P, _I64, _P, _I64, _P, _I64, _I32, _P],
     "mma_unpack_add_rows": [_P, _I64, _P, _I64, _P, _I64, _I32, _P],
+    "mma_unpack_add_rows_csr": [_P, _I64, _P, _P, _P, _I64, _P, _I64, _I32, _P],
     "mma_col_sum": [_P, _I64, _I64, _I32, _P, _P, _I64, _P],
     "mma_gemm_bf16x3_tn": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P],
     "mma_tower_linear_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P],

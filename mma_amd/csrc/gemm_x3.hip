@@ -135,6 +135,16 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_kernel(const GemmParams p, 
 // for together with them, so the prefetch is issued BEFORE the stores and its wait (a tile later) leaves them in flight.
 #define MMA_X3_TILE(C_, CT_, LAST_)                                                                          \
     {                                                                                                        \
+      /* C += A B: the tile's 16 old values per lane are fetched in ONE batch before its last MFMA block (round 1 loaded,  \
+         waited, added and stored them one by one after it: 64 serialised HBM round trips per row block of dL/dx) */      \
+      float oldv[16];                                                                                        \
+      if ((LAST_) && p.accumulate) {                                                                         \
+        const float* op = p.C + (size_t)((CT_) * 32 + r31);                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                     \
+          const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;                                         \
+          oldv[r] = (FULL || row < p.M) ? op[row * p.ldc] : 0.f;                                             \
+        }                                                                                                    \
+      }                                                                                                      \
       const unsigned char* sb = lds + (it & 1) * kSlab + r31 * kRowPitch + h * 16;                           \
       _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                                \
         const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 0 * kPiece + ks * 32);                       \
@@ -154,9 +164,16 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_kernel(const GemmParams p, 
       }                                                                                                      \
       if (LAST_) { /* acc reg r holds row (r&3) + 8*(r>>2) + 4*h, column r31 of the tile */   \
         float* cp = p.C + (size_t)((CT_) * 32 + r31);                                                        \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                     \
-          const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;                                         \
-          if (FULL || row < p.M) cp[row * p.ldc] = p.accumulate ? cp[row * p.ldc] + C_[r] : C_[r];           \
+        if (p.accumulate) {   /* two store sequences: a select would make the plain path wait for loads it never issued */ \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                   \
+            const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;                                       \
+            if (FULL || row < p.M) cp[row * p.ldc] = oldv[r] + C_[r];                                        \
+          }                                                                                                  \
+        } else {                                                                                             \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                   \
+            const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;                                       \
+            if (FULL || row < p.M) cp[row * p.ldc] = C_[r];                                                  \
+          }                                                                                                  \
         }                                                                                                    \
       }                                                                                                      \
       /* raw barrier: __syncthreads() would also drain vmcnt, i.e. wait for the C stores to reach memory */         \

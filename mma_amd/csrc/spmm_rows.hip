@@ -154,6 +154,30 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(const RowsParams p) {
   }
 }
 
+// unpack-add of a whole reverse halo exchange in ONE launch: destination row rows[t] receives the sum of the received rows
+// pos[segptr[t] .. segptr[t+1]) in that (fixed) order - a row several peers read gets all its contributions from one
+// thread, so there is no write conflict between peers and no atomics; bitwise repeatable.
+struct RowsCsrParams { const float* src; int64_t lds; const int32_t* rows; const int32_t* segptr; const int32_t* pos; int64_t n;
+                       float* dst; int64_t ldd; int width; };
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void rows_csr_add_kernel(const RowsCsrParams p) {
+  const int per_row = (p.width + VEC - 1) / VEC;
+  const int64_t total = p.n * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / per_row;
+    const int c = (int)(i % per_row) * VEC;
+    const int64_t node = p.rows[t];
+    Vec<VEC> d = ldv<VEC>(p.dst + node * p.ldd + c);
+    for (int q = p.segptr[t]; q < p.segptr[t + 1]; ++q) {
+      const Vec<VEC> a = ldv<VEC>(p.src + (int64_t)p.pos[q] * p.lds + c);
+#pragma unroll
+      for (int x = 0; x < VEC; ++x) d.v[x] += a.v[x];
+    }
+    stv<VEC>(p.dst + node * p.ldd + c, d);
+  }
+}
+
 // K8: out[rb, c] = sum of g[r, c] over the rows of row block rb.  A workgroup is 64 columns x 4 row lanes (one wave reads 256
 // contiguous bytes of a row), each thread keeps four independent accumulation chains; fixed order => deterministic.
 struct ColSumParams { const float* g; int64_t ldg; int64_t R; int C; float* out; int64_t rows_per_block; };
@@ -272,6 +296,23 @@ static int rows_call(bool unpack, const float* src, int64_t lds, const int32_t* 
     else hipLaunchKernelGGL((rows_kernel<1, false>), grid, dim3(kBlock), 0, st, p);
   }
   return check_launch("rows_kernel");
+}
+
+extern "C" int mma_unpack_add_rows_csr(const float* src, int64_t lds, const int32_t* rows, const int32_t* segptr, const int32_t* pos,
+                                       int64_t n_rows, float* dst, int64_t ldd, int32_t width, void* stream) {
+  MMA_REQUIRE(n_rows >= 0 && width >= 1 && lds >= width && ldd >= width, "n_rows=%lld width=%d lds=%lld ldd=%lld unsupported",
+              (long long)n_rows, width, (long long)lds, (long long)ldd);
+  if (n_rows == 0) return 0;
+  MMA_REQUIRE(src && rows && segptr && pos && dst, "NULL argument");
+  const bool v4 = (width % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) && al16(src) && al16(dst);
+  RowsCsrParams p{src, lds, rows, segptr, pos, n_rows, dst, ldd, width};
+  const int per_row = v4 ? width / 4 : width;
+  int64_t blocks = (n_rows * per_row + kBlock - 1) / kBlock;
+  if (blocks > kMaxGrid * 4) blocks = kMaxGrid * 4;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (v4) hipLaunchKernelGGL((rows_csr_add_kernel<4>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);
+  else hipLaunchKernelGGL((rows_csr_add_kernel<1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);
+  return check_launch("rows_csr_add_kernel");
 }
 
 extern "C" int mma_pack_rows(const float* src, int64_t lds, const int32_t* idx, int64_t n_idx, float* dst, int64_t ldd,

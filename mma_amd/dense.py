@@ -10,6 +10,11 @@ import torch
 from . import _lib
 from ._lib import call, ptr, stream_ptr
 
+
+def _span(name):
+    from . import functional as Fn      # late: functional imports this module
+    return Fn._span(name)
+
 _ROWS_PER_BATCH = 8192
 USE_BF16X3 = True     # fp32-accurate GEMM on the bf16 matrix cores (csrc/gemm_x3.hip) where the shape allows
 _MIN_ROWS_X3 = 4096
@@ -38,13 +43,14 @@ def gemm_bf16x3(a, w, out=None, accumulate=False):
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
     acc = 1 if accumulate else 0
-    if K == 128 or N <= 128:
-        call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(bt3), ptr(out), out.stride(0), M, N, K, acc, stream_ptr())
-    else:                                                    # K > 128 and N > 128: one launch per 128-column block of the output
-        blocks = bt3.view(3, N // 128, 128, K).permute(1, 0, 2, 3).contiguous()    # (N/128, 3, 128, K): a block's own three pieces
-        for b in range(N // 128):
-            call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(blocks[b]), ptr(out[:, 128 * b:128 * b + 128]), out.stride(0), M, 128, K,
-                 acc, stream_ptr())
+    with _span("gemm_x3_acc" if accumulate else ("gemm_x3_k128" if K == 128 else "gemm_x3_persist")):
+        if K == 128 or N <= 128:
+            call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(bt3), ptr(out), out.stride(0), M, N, K, acc, stream_ptr())
+        else:                                                # K > 128 and N > 128: one launch per 128-column block of the output
+            blocks = bt3.view(3, N // 128, 128, K).permute(1, 0, 2, 3).contiguous()    # (N/128, 3, 128, K): a block's own three pieces
+            for b in range(N // 128):
+                call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(blocks[b]), ptr(out[:, 128 * b:128 * b + 128]), out.stride(0), M, 128,
+                     K, acc, stream_ptr())
     return out
 
 
@@ -129,9 +135,10 @@ def gemm_bf16x3_tn(x, g):
     kb = KA if KA <= 128 else 128
     n_ws = int(_lib.lib().mma_gemm_bf16x3_tn_workspace_floats(N, kb, NC))
     ws = torch.empty((n_ws,), device=x.device, dtype=torch.float32) if n_ws else None
-    for j in range(0, KA, kb):                               # one launch per 128-column block of x (= row block of the result)
-        call("mma_gemm_bf16x3_tn", ptr(x[:, j:j + kb]), x.stride(0), ptr(g), g.stride(0), ptr(out[j:j + kb]), ptr(ws), n_ws, N, kb,
-             NC, stream_ptr())
+    with _span("gemm_x3_tn"):
+        for j in range(0, KA, kb):                           # one launch per 128-column block of x (= row block of the result)
+            call("mma_gemm_bf16x3_tn", ptr(x[:, j:j + kb]), x.stride(0), ptr(g), g.stride(0), ptr(out[j:j + kb]), ptr(ws), n_ws, N, kb,
+                 NC, stream_ptr())
     return out
 
 

@@ -28,13 +28,30 @@ from .layers import _AGG
 from .scalers import scaler_row_factor, true_degree_row_factor
 
 
-def partition_bounds(rowptr, world):
-    """Contiguous target ranges with (nearly) equal edge counts: bounds[r] .. bounds[r+1]."""
+def partition_bounds(rowptr, world, row_cost=0.0):
+    """Contiguous target ranges with (nearly) equal cost: bounds[r] .. bounds[r+1].  cost(node) = in-degree + row_cost;
+    row_cost = 0 balances the edges alone (the default: under a locality-free node order every range then also holds ~N/world
+    rows); a positive row_cost (in edge units) keeps a degree-ordered or BFS-ordered graph from handing one rank most rows."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
-    N, E = len(rowptr) - 1, int(rowptr[-1])
-    cuts = np.searchsorted(rowptr, (E * np.arange(1, world, dtype=np.float64) / world).astype(np.int64), side="left")
+    N = len(rowptr) - 1
+    cost = rowptr.astype(np.float64) + row_cost * np.arange(N + 1, dtype=np.float64)
+    cuts = np.searchsorted(cost, np.floor(cost[-1] * np.arange(1, world, dtype=np.float64) / world), side="left")
     bounds = np.concatenate([[0], np.clip(cuts, 0, N), [N]]).astype(np.int64)
     return np.maximum.accumulate(bounds)
+
+
+def halo_report(rowptr, col, world, row_cost=0.0):
+    """Per rank of a `world`-way partition: (own rows, halo rows = distinct remote sources, edges, edges with an own source).
+    numpy only - what tools/halo_report.py prints and tests/test_sharded.py bounds."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    b = partition_bounds(rowptr, world, row_cost)
+    out = []
+    for r in range(world):
+        lo, hi = int(b[r]), int(b[r + 1])
+        c = np.asarray(col[int(rowptr[lo]):int(rowptr[hi])])
+        own = (c >= lo) & (c < hi)
+        out.append((hi - lo, int(len(np.unique(c[~own]))), int(len(c)), int(own.sum())))
+    return out
 
 
 def _backend(group=None):
@@ -131,40 +148,81 @@ class HaloPlan:
         self.n_total = int(bounds[-1])                                   # global node count (the scalers' quirk Q1 uses N)
         self.send_idx = (give - self.lo).astype(np.int64)               # local row ids, concatenated per peer
         self.send_offsets = np.concatenate([[0], np.cumsum(self.send_counts)]).astype(np.int64)
+        self.build_unpack()
+
+    def build_unpack(self):
+        """The reverse exchange in ONE launch: every local row that is sent to anyone, with the positions of its copies in the
+        concatenated receive buffer (ascending = by peer rank: a fixed summation order) - mma_unpack_add_rows_csr."""
+        order = np.argsort(self.send_idx, kind="stable")
+        self.unpack_rows, first = np.unique(self.send_idx[order], return_index=True)
+        self.unpack_segptr = np.concatenate([first, [len(order)]]).astype(np.int64)
+        self.unpack_pos = order.astype(np.int64)
 
 
-class _HaloExchange(torch.autograd.Function):
-    """forward: rows of `x_own` other ranks need -> their halo; returns this rank's halo rows (n_halo, W).
-    backward: reverse exchange, contributions summed into the owner's rows."""
+def unpack_add(mod, rows, dst):
+    """dst[r] += the rows received for r (all peers), one launch, fixed order."""
+    W = rows.shape[1]
+    with Fn._span("halo_unpack"):
+        call("mma_unpack_add_rows_csr", ptr(rows), rows.stride(0), ptr(mod.unpack_rows), ptr(mod.unpack_segptr), ptr(mod.unpack_pos),
+             mod.unpack_rows.shape[0], ptr(dst), dst.stride(0), W, stream_ptr())
+
+
+class _ShardedTail(torch.autograd.Function):
+    """out = A_own S + A_halo S_halo + bias: the K-stacked SpMM of layers.py:861-865 on a shard, with the exchange of the
+    (n, C) tail rows hidden behind the own-source part of the SpMM (forward) and of its transpose (backward).
+    forward : pack -> all-to-all of the S rows others read (async) || A_own S + bias ; wait ; += A_halo S_halo
+    backward: A_halo^T g -> reverse all-to-all (async) || A_own^T g, column sum for the bias ; wait ; unpack-add."""
 
     @staticmethod
-    def forward(ctx, x_own, plan, send_idx_dev):
-        require_gpu(x_own)
-        x_own = x_own.contiguous()
-        W = x_own.shape[1]
+    def forward(ctx, S, bias, mod):
+        require_gpu(S)
+        plan, sgo, sgh = mod.plan, mod.sg_own, mod.sg_halo
+        S = S.contiguous()
+        n, C = S.shape
+        dev = S.device
         n_send = int(plan.send_counts.sum())
-        send = torch.empty((n_send, W), device=x_own.device, dtype=torch.float32)
+        send = torch.empty((n_send, C), device=dev, dtype=torch.float32)
         with Fn._span("halo_pack"):
-            call("mma_pack_rows", ptr(x_own), x_own.stride(0), ptr(send_idx_dev), n_send, ptr(send), W, W, stream_ptr())
-        with Fn._span("halo_all_to_all"):
-            recv = all_to_all_rows(send, plan.send_counts, plan.recv_counts, plan.group)
-        ctx.plan, ctx.idx, ctx.shape = plan, send_idx_dev, x_own.shape
-        return recv
+            call("mma_pack_rows", ptr(S), C, ptr(mod.send_idx), n_send, ptr(send), C, C, stream_ptr())
+        h = all_to_all_rows_start(send, plan.send_counts, plan.recv_counts, plan.group)
+        out = torch.empty((n, C), device=dev, dtype=torch.float32)
+        with Fn._span("csr_spmm_fwd"):
+            Fn._spmm_call(sgo.rowptr, sgo.col, sgo.val, sgo.items, sgo.hubs, sgo.n_slots, S, sgo.n_cols, 1, bias, out, n, C)
+        with Fn._span("halo_wait"):
+            S_halo = h.wait()
+        if plan.n_halo:
+            part = torch.empty((n, C), device=dev, dtype=torch.float32)
+            with Fn._span("csr_spmm_fwd"):
+                Fn._spmm_call(sgh.rowptr, sgh.col, sgh.val, sgh.items, sgh.hubs, sgh.n_slots, S_halo.contiguous(), sgh.n_cols, 1, None,
+                              part, n, C)
+            out += part
+        ctx.mod, ctx.has_bias = mod, bias is not None
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        plan, idx = ctx.plan, ctx.idx
+        mod = ctx.mod
+        plan, sgo, sgh = mod.plan, mod.sg_own, mod.sg_halo
         g = g.contiguous()
-        W = g.shape[1]
-        with Fn._span("halo_all_to_all"):
-            back = all_to_all_rows(g, plan.recv_counts, plan.send_counts, plan.group)      # (n_send, W)
-        gx = torch.zeros(ctx.shape, device=g.device, dtype=torch.float32)
-        with Fn._span("halo_unpack"):
-            for q in range(plan.world):      # one call per peer: rows are unique within a peer's list
-                o0, o1 = int(plan.send_offsets[q]), int(plan.send_offsets[q + 1])
-                if o1 > o0:
-                    call("mma_unpack_add_rows", ptr(back[o0:o1]), W, ptr(idx[o0:o1]), o1 - o0, ptr(gx), W, W, stream_ptr())
-        return gx, None, None
+        n, C = g.shape
+        dev = g.device
+        back = None
+        if plan.world > 1:        # a collective: every rank joins, with zero rows if it has no halo
+            gh = torch.empty((plan.n_halo, C), device=dev, dtype=torch.float32)
+            if plan.n_halo:
+                with Fn._span("csr_spmm_bwd"):
+                    Fn._spmm_call(sgh.t_rowptr, sgh.t_col, sgh.t_val, sgh.t_items, sgh.t_hubs, sgh.t_n_slots, g, n, 1, None, gh, plan.n_halo, C)
+            back = all_to_all_rows_start(gh, plan.recv_counts, plan.send_counts, plan.group)
+        gS = torch.empty((n, C), device=dev, dtype=torch.float32)
+        with Fn._span("csr_spmm_bwd"):
+            Fn._spmm_call(sgo.t_rowptr, sgo.t_col, sgo.t_val, sgo.t_items, sgo.t_hubs, sgo.t_n_slots, g, n, 1, None, gS, n, C)
+        from .dense import col_sum
+        gb = col_sum(g) if (ctx.has_bias and n > 0) else (torch.zeros(C, device=dev) if ctx.has_bias else None)
+        if back is not None:
+            with Fn._span("halo_wait"):
+                rows = back.wait()
+            unpack_add(mod, rows, gS)
+        return gS, gb, None
 
 
 class _ShardedAggregate(torch.autograd.Function):
@@ -247,12 +305,7 @@ class _ShardedAggregate(torch.autograd.Function):
         if back is not None:
             with Fn._span("halo_wait"):
                 rows = back.wait()                                                       # (n_send, H)
-            with Fn._span("halo_unpack"):
-                for q in range(plan.world):      # one call per peer: rows are unique within a peer's list
-                    o0, o1 = int(plan.send_offsets[q]), int(plan.send_offsets[q + 1])
-                    if o1 > o0:
-                        call("mma_unpack_add_rows", ptr(rows[o0:o1]), H, ptr(mod.send_idx[o0:o1]), o1 - o0, ptr(gx_own), H, H,
-                             stream_ptr())
+            unpack_add(mod, rows, gx_own)
         return gx_own, gwtop, gwbot, None, None, None, None
 
 
@@ -272,8 +325,14 @@ class ShardedMMA(torch.nn.Module):
         dev = torch.device(device)
         self.graph = NCGraph(plan.rowptr, plan.col, dev, n_src=plan.n_src, chunk=chunk, edge_base=edge_base)
         dst = np.repeat(np.arange(plan.n_own, dtype=np.int64), np.diff(plan.rowptr))
-        self.sg = SpmmGraph(dst, plan.col, adj_val, plan.n_own, plan.n_src, dev)
-        self.send_idx = torch.from_numpy(plan.send_idx.astype(np.int32)).to(dev)
+        # the tail SpMM in two parts: own sources (runs while the S rows of the halo are on the wire) and halo sources
+        own = plan.col < plan.n_own
+        val = None if adj_val is None else np.asarray(adj_val, dtype=np.float32)
+        self.sg_own = SpmmGraph(dst[own], plan.col[own], None if val is None else val[own], plan.n_own, plan.n_own, dev)
+        self.sg_halo = SpmmGraph(dst[~own], plan.col[~own] - plan.n_own, None if val is None else val[~own], plan.n_own, plan.n_halo, dev)
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        self.send_idx = i32(plan.send_idx)
+        self.unpack_rows, self.unpack_segptr, self.unpack_pos = i32(plan.unpack_rows), i32(plan.unpack_segptr), i32(plan.unpack_pos)
         self.masks = masks          # dict name -> Parameter (2H,H), owned by the caller, identical on every rank
         self.weight, self.bias = weight, bias
         self.owned = [weight, bias] + [masks[n] for n in self.names]
@@ -325,8 +384,7 @@ class ShardedMMA(torch.nn.Module):
             c3 = self._row_factor
         # sum_k A (m_k W) == A ((sum_k m_k) W): only the (n,C) rows travel and enter the SpMM
         S = mm(msum, self.weight) * c3
-        S_halo = _HaloExchange.apply(S, self.plan, self.send_idx)
-        return Fn.csr_spmm(torch.cat([S, S_halo], 0), self.bias, self.sg, 1)
+        return _ShardedTail.apply(S, self.bias, self)
 
     def allreduce_grads(self):
         """Sum the parameter gradients over the ranks: ONE collective on a flat bucket (six tiny all-reduces cost six

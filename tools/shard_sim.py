@@ -51,6 +51,7 @@ def make_plan(rank, world):
     p.send_idx = (np.concatenate(give) - p.lo).astype(np.int64) if give else np.zeros(0, np.int64)
     p.send_offsets = np.concatenate([[0], np.cumsum(p.send_counts)]).astype(np.int64)
     p.n_total = N
+    p.build_unpack()
     return p, e0
 
 def run(rank, world, steps=5):
