@@ -1,45 +1,45 @@
-"""ctypes binding of libmma_amd.so (include/mma_amd.h).  Loud failure, no fallback."""
+"""Bindings of libmma_amd.so (include/mma_amd.h).  Loud failure, no fallback.
+
+Two bindings of the SAME extern "C" entry points, both generated from the header by tools/gen_bindings.py:
+  * torch ops (default when built): `torch.ops.mma_amd.<entry point>` registered by csrc/libmma_amd_torch.so
+    (`TORCH_LIBRARY(mma_amd, ...)`, csrc/torch_ops.cpp) - tensors in, the current HIP stream taken in C++;
+  * ctypes (MMA_BINDING=ctypes, or when the op library is not built): what a non-torch host binds.
+Either way the work happens in the HIP kernels of libmma_amd.so; a missing or stale library raises MMALibraryError."""
 import ctypes
 import os
 
 import torch
 
+from . import _abi
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMA_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "libmma_amd.so")   # override: A/B builds in development
-ABI_VERSION = 16
+OPS_PATH = os.path.join(_HERE, "csrc", "libmma_amd_torch.so")
+ABI_VERSION = _abi.ABI_VERSION
 
 _c = ctypes
 _P, _I64, _I32, _U32, _U64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_uint64
+_CT = {"T": _P, "H": _P, "S": _P, "i64": _I64, "i32": _I32, "u32": _U32, "u64": _U64, "f32": _c.c_float}
+_RET = {"int": _I32, "int64_t": _I64, "const char*": _c.c_char_p}
 
-# name -> argtypes, exactly the prototypes of include/mma_amd.h
-PROTOTYPES = {
-    "mma_nc_fused_fwd": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64,
-                         _I64, _I64, _I32, _I32, _P, _P, _I32, _U32, _U64, _P, _I64, _P, _P],
-    "mma_nc_bwd_node": [_P, _I64, _I64, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P],
-    "mma_nc_fused_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64,
-                         _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I32, _I32, _P, _I32, _U32, _U64, _P, _I64, _P, _P],
-    "mma_csr_spmm": [_P, _P, _P, _P, _I64, _I64, _I32, _P, _P, _I64, _I64, _I32, _P],
-    "mma_build_csr": [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _I64, _P],
-    "mma_gr_fused_fwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P,
-                         _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P, _P],
-    "mma_gr_fused_bwd": [_P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _I64,
-                         _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _c.c_float, _c.c_float, _I32, _U32, _U64, _P, _P],
-    "mma_csr_spmm_items": [_P, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _P],
-    "mma_split_bf16x3": [_P, _I64, _P, _P],
-    "mma_gemm_bf16x3": [_P, _I64, _P, _P, _I64, _I64, _I32, _I32, _I32, _P],
-    "mma_pack_rows": [_P, _I64, _P, _I64, _P, _I64, _I32, _P],
-    "mma_unpack_add_rows": [_P, _I64, _P, _I64, _P, _I64, _I32, _P],
-    "mma_unpack_add_rows_csr": [_P, _I64, _P, _P, _P, _I64, _P, _I64, _I32, _P],
-    "mma_col_sum": [_P, _I64, _I64, _I32, _P, _P, _I64, _P],
-    "mma_gemm_bf16x3_tn": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P],
-    "mma_tower_linear_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P],
-}
+# name -> ctypes argtypes of the entry points that take a stream (the launchers), exactly the prototypes of include/mma_amd.h
+PROTOTYPES = {name: [_CT[c] for _, c, _ in params] for name, (ret, params) in _abi.FUNCTIONS.items()
+              if ret == "int" and params and params[-1][0] == "S"}
+_KINDS = {name: [k if k in "THS" else c for k, c, _ in params] for name, (ret, params) in _abi.FUNCTIONS.items()}
 
 _lib = None
+_ops = None        # torch.ops.mma_amd once the op library is loaded; False: ctypes binding
 
 
 class MMALibraryError(RuntimeError):
     pass
+
+
+class _Stream:      # placeholder the call sites pass for `void* stream`
+    pass
+
+
+STREAM = _Stream()
 
 
 def lib():
@@ -50,37 +50,97 @@ def lib():
             raise MMALibraryError(
                 "mma_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C mma_amd/csrc`). There is no CPU fallback." % LIB_PATH)
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
         L.mma_abi_version.restype = _I32
         L.mma_last_error.restype = _c.c_char_p
         if L.mma_abi_version() != ABI_VERSION:
             raise MMALibraryError("mma_amd: %s has ABI %d, expected %d: rebuild" % (LIB_PATH, L.mma_abi_version(), ABI_VERSION))
-        L.mma_nc_aux_row_floats.argtypes, L.mma_nc_aux_row_floats.restype = [_I32, _I32, _P], _I64
-        L.mma_csr_workspace_bytes.argtypes, L.mma_csr_workspace_bytes.restype = [_I64, _I64], _I64
-        L.mma_gr_arg_side_rows.argtypes, L.mma_gr_arg_side_rows.restype = [_I64], _I64
-        L.mma_gr_long_nodes_len.argtypes, L.mma_gr_long_nodes_len.restype = [_I64], _I64
-        L.mma_col_sum_workspace_floats.argtypes, L.mma_col_sum_workspace_floats.restype = [_I64, _I32], _I64
-        L.mma_gemm_bf16x3_tn_workspace_floats.argtypes, L.mma_gemm_bf16x3_tn_workspace_floats.restype = [_I64, _I32, _I32], _I64
-        L.mma_tower_linear_bwd_blocks.argtypes, L.mma_tower_linear_bwd_blocks.restype = [_I64], _I64
-        for name, args in PROTOTYPES.items():
+        for name, (ret, params) in _abi.FUNCTIONS.items():
             fn = getattr(L, name)  # AttributeError if a declared symbol is missing
-            fn.argtypes, fn.restype = args, _I32
+            fn.argtypes, fn.restype = [_CT[c] for _, c, _ in params], _RET[ret]
         _lib = L
     return _lib
 
 
+def ops():
+    """torch.ops.mma_amd (the TORCH_LIBRARY binding) or False when the ctypes binding is in use."""
+    global _ops
+    if _ops is None:
+        _ops = False
+        want = os.environ.get("MMA_BINDING", "")
+        if want not in ("", "torch", "ctypes"):
+            raise MMALibraryError("MMA_BINDING=%r: expected torch or ctypes" % want)
+        if want != "ctypes" and not os.environ.get("MMA_LIB_OVERRIDE"):
+            lib()                                   # version check first; also makes the symbols global for the op library
+            if os.path.exists(OPS_PATH):
+                torch.ops.load_library(OPS_PATH)
+                _ops = torch.ops.mma_amd
+            elif want == "torch":
+                raise MMALibraryError("mma_amd: MMA_BINDING=torch but %s is not built (python -c 'import __graft_entry__ as g; g.build()')"
+                                      % OPS_PATH)
+    return _ops
+
+
+def binding():
+    return "torch" if ops() else "ctypes"
+
+
+def _signed64(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
 def call(name, *args):
+    """Invoke a launcher.  Pointer parameters take a tensor (or None), `*_host` parameters a sequence of small ints, the
+    stream parameter is _lib.STREAM (or anything: torch's current stream is used)."""
+    kinds = _KINDS[name]
+    if len(args) != len(kinds):
+        raise TypeError("%s takes %d arguments, got %d" % (name, len(kinds), len(args)))
+    o = ops()
+    if o:
+        conv = []
+        for k, a in zip(kinds, args):
+            if k == "S":
+                continue
+            if k == "H":
+                conv.append(None if a is None else [int(x) for x in a])
+            elif k == "u64":
+                conv.append(_signed64(int(a)))
+            elif k == "f32":
+                conv.append(float(a))
+            elif k == "T":
+                conv.append(a)
+            else:
+                conv.append(int(a))
+        try:
+            getattr(o, name)(*conv)
+        except RuntimeError as e:
+            raise MMALibraryError(str(e).split("\n")[0]) from None
+        return
     L = lib()
-    rc = getattr(L, name)(*args)
+    conv = []
+    for k, a in zip(kinds, args):
+        if k == "T":
+            conv.append(None if a is None else (a.data_ptr() if torch.is_tensor(a) else a))
+        elif k == "H":
+            conv.append(None if a is None else (ctypes.c_uint8 * len(a))(*a))
+        elif k == "S":
+            conv.append(torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None)
+        else:
+            conv.append(a)
+    rc = getattr(L, name)(*conv)
     if rc != 0:
         raise MMALibraryError("%s failed (code %d): %s" % (name, rc, L.mma_last_error().decode()))
 
 
+def query(name, *args):
+    """The host-only size helpers (mma_*_workspace_*, mma_nc_aux_row_floats, ...): plain ctypes, no stream."""
+    conv = [(ctypes.c_uint8 * len(a))(*a) if isinstance(a, (list, tuple)) else a for a in args]
+    return int(getattr(lib(), name)(*conv))
+
+
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL)."""
-    if t is None:
-        return None
-    return t.data_ptr()
+    """A pointer argument: the tensor itself (None -> NULL); the binding takes its device pointer."""
+    return t
 
 
 def require_gpu(*tensors):
@@ -90,8 +150,8 @@ def require_gpu(*tensors):
 
 
 def stream_ptr():
-    return torch.cuda.current_stream().cuda_stream
+    return STREAM
 
 
 def host_codes(codes):
-    return (ctypes.c_uint8 * len(codes))(*codes)
+    return tuple(int(c) for c in codes)

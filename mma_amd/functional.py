@@ -95,7 +95,7 @@ def nc_bwd_node_launch(g, reduce_k, sel, T, graph, kinds, H, shared, gP=None):
     gs = None if shared else torch.empty((N, K * H), device=dev, dtype=torch.float32)
     aux, ldaux = None, 0
     if shared:
-        ldaux = int(_lib.lib().mma_nc_aux_row_floats(H, K, host_codes(kinds)))
+        ldaux = _lib.query("mma_nc_aux_row_floats", H, K, host_codes(kinds))
         aux = torch.empty((N, ldaux), device=dev, dtype=torch.float32)
     if gP is None:
         gP = torch.empty((N, K * H), device=dev, dtype=torch.float32)

@@ -31,6 +31,31 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().mma_abi_version() == _lib.ABI_VERSION
 
 
+def test_bindings_are_generated_from_the_header_and_the_op_library_registers_every_launcher():
+    """mma_amd/_abi.py and csrc/torch_ops.cpp are generated from include/mma_amd.h (tools/gen_bindings.py --check), and the
+    built op library registers one `torch.ops.mma_amd.<entry point>` per launcher of the header."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_bindings.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert _lib.binding() == "torch", "libmma_amd_torch.so not built/loaded"
+    for name in _lib.PROTOTYPES:
+        op = getattr(torch.ops.mma_amd, name)
+        n_args = len(op.default._schema.arguments)
+        assert n_args == len(_lib.PROTOTYPES[name]) - 1, name           # every parameter but the stream
+
+
+@pytest.mark.parametrize("binding", ["torch", "ctypes"])
+def test_argument_checks_run_on_host_in_both_bindings(binding, monkeypatch):
+    monkeypatch.setattr(_lib, "_ops", None if binding == "torch" else False)
+    if binding == "torch":
+        monkeypatch.delenv("MMA_BINDING", raising=False)
+    with pytest.raises(_lib.MMALibraryError, match="pitch"):
+        _lib.call("mma_csr_spmm", None, None, None, None, 2, 5, 1, None, None, 2, 5, 4, None)
+    with pytest.raises(TypeError):
+        _lib.call("mma_csr_spmm", None)
+
+
 def test_argument_checks_run_on_host_without_gpu():
     # a bad shape must be refused before any launch (works with no GPU present)
     with pytest.raises(_lib.MMALibraryError, match="K="):
