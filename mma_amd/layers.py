@@ -38,11 +38,14 @@ _MASK_NAMES = ["moment_3", "sum", "sum2", "sum3", "sum4", "mean", "mean2", "mean
 class GraphConvolution(Module):
     """spmm(adj, x @ W) + b  (layers.py:12-51, pygcn).  The SpMM is libmma_amd's CSR kernel."""
 
+    SPARSE_BELOW = 0.10      # feature matrices with fewer non-zeros than this fraction go through the CSR kernel
+
     def __init__(self, in_features, out_features, weight, bias, device):
         super().__init__()
         self.in_features, self.out_features, self.device = in_features, out_features, device
         self.weight, self.bias = weight, bias
         self._sg = None
+        self._xg = None          # (input tensor, version, SpmmGraph of it or None): sparse-feature first layer
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -52,11 +55,34 @@ class GraphConvolution(Module):
             self.bias.data.uniform_(-stdv, stdv)
 
     def forward(self, input, adj):
-        require_gpu(input)
+        require_gpu(input if input.layout == torch.strided else self.weight)
         if self._sg is None or self._sg[0] is not adj:
-            self._sg = (adj, adj if isinstance(adj, SpmmGraph) else SpmmGraph.from_torch_sparse(adj, input.device))
-        support = mm(input, self.weight)
+            self._sg = (adj, adj if isinstance(adj, SpmmGraph) else SpmmGraph.from_torch_sparse(adj, self.weight.device))
+        xg = self._feature_graph(input)
+        # x @ W: a Planetoid feature matrix is ~1 % dense (Cora: 49 k non-zeros of 3.9 M, models.py:54 feeds it to gc1 as a
+        # dense FloatTensor) - as a CSR operand of K5 the product reads the non-zeros only, and its weight gradient x^T g is
+        # the same kernel over the transposed CSR; dense / differentiable inputs take the GEMM
+        support = Fn.csr_spmm(self.weight, None, xg, 1) if xg is not None else mm(input, self.weight)
         return Fn.csr_spmm(support, self.bias, self._sg[1], 1)
+
+    def _feature_graph(self, input):
+        """SpmmGraph of a static, sparse enough feature matrix (decided once per tensor: one host sync), else None."""
+        if input.layout != torch.strided:
+            if self._xg is None or self._xg[0] is not input:
+                self._xg = (input, 0, SpmmGraph.from_torch_sparse(input.to_sparse_coo() if input.layout != torch.sparse_coo else input,
+                                                                  self.weight.device))
+            return self._xg[2]
+        if input.requires_grad or input.dim() != 2:
+            return None
+        if self._xg is None or self._xg[0] is not input or self._xg[1] != input._version:
+            nnz = int(torch.count_nonzero(input))
+            sg = None
+            if nnz < self.SPARSE_BELOW * input.numel():
+                idx = input.nonzero(as_tuple=True)
+                sg = SpmmGraph(idx[0].cpu().numpy(), idx[1].cpu().numpy(), input[idx].cpu().numpy(), input.shape[0], input.shape[1],
+                               input.device)
+            self._xg = (input, input._version, sg)
+        return self._xg[2]
 
     def __repr__(self):
         return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'

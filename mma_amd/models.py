@@ -23,9 +23,13 @@ class MMAConv(nn.Module):
         self.gc2 = MMA(self.add_all, activation, k, nhid, nclass, self.weight1, self.bias1,
                        *[getattr(self, "weight_" + name) for name in _MASK_NAMES], dropout, aggregator_list, device)
         self.dropout = dropout
+        self.hidden_keep = None      # tests: an explicit (N, nhid) keep mask replayed instead of F.dropout's RNG (models.py:66)
 
     def forward(self, x, adj):
         x = F.relu(self.gc1(x, adj))
-        x = F.dropout(x, self.dropout, training=self.training)
+        if self.hidden_keep is not None and self.training:
+            x = x * self.hidden_keep / (1.0 - self.dropout)
+        else:
+            x = F.dropout(x, self.dropout, training=self.training)
         x = self.gc2(x, adj)
         return F.log_softmax(x, dim=1)

@@ -184,3 +184,24 @@ def init_like_reference(H, C, names, seed):
     weight = (torch.rand(H, C, generator=g) * 2 - 1) * b
     bias = (torch.rand(C, generator=g) * 2 - 1) * b
     return Ws, weight, bias
+
+
+def gcn_forward(x, weight, bias, adj_row, adj_col, adj_val):
+    """GraphConvolution.forward (layers.py:38-45): spmm(adj, x @ W) + b."""
+    support = x @ weight
+    r = torch.as_tensor(np.asarray(adj_row), dtype=torch.int64)
+    c = torch.as_tensor(np.asarray(adj_col), dtype=torch.int64)
+    v = torch.as_tensor(np.asarray(adj_val), dtype=x.dtype)
+    out = torch.zeros(x.shape[0], weight.shape[1], dtype=x.dtype).index_add(0, r, v.unsqueeze(1) * support.index_select(0, c))
+    return out + bias if bias is not None else out
+
+
+def model_forward(features, prm, names, rowptr, col, adj_row, adj_col, adj_val, activation, p, hidden_keep, keeps):
+    """models.MMAConv.forward (models.py:64-68) in training mode: gc1 -> relu -> dropout(explicit keep mask, models.py:66)
+    -> gc2 = MMA.forward (explicit per-aggregator masks) -> log_softmax.  prm: weight0, bias0, weight1, bias1, weight_<agg>."""
+    h = torch.relu(gcn_forward(features, prm["weight0"], prm["bias0"], adj_row, adj_col, adj_val))
+    if hidden_keep is not None:
+        h = h * torch.as_tensor(hidden_keep, dtype=h.dtype) / (1.0 - p)
+    out = mma_forward(names, h, {a: prm["weight_" + a] for a in names}, prm["weight1"], prm["bias1"], rowptr, col,
+                      adj_row, adj_col, adj_val, activation, p, keeps)
+    return torch.log_softmax(out, dim=1)

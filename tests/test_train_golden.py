@@ -1,0 +1,135 @@
+"""The CALLERS of the hot path against the reference (fixture tests/golden/train3_cora.npz made by
+tests/golden/gen_train_golden.py from the reference's layers.GraphConvolution, models.MMAConv and the step of train.py:72-80
+on the real Cora data, every dropout replayed from seeded keep masks):
+  * CPU: the oracle's restatement of the model (oracle/nc_oracle.model_forward) + torch Adam walks the reference's loss
+    trajectory - pins the oracle for the whole training step;
+  * GPU: the drop-in mma_amd.models.MMAConv (HIP kernels, sparse-feature first layer) does the same."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import check_close
+from golden.inputs import ALL_MASK_NAMES, keep_mask, rng_uniform, sha
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEV = "cuda:0"
+
+
+class Fix:
+    def __init__(self):
+        z = self.z = np.load(os.path.join(HERE, "golden", "train3_cora.npz"), allow_pickle=False)
+        self.seed, self.N, self.nfeat, self.nclass, self.H = int(z["seed"]), int(z["N"]), int(z["nfeat"]), int(z["nclass"]), int(z["hidden"])
+        self.p, self.aggs, self.epochs, self.lr, self.wd = float(z["p"]), [str(a) for a in z["aggs"]], int(z["epochs"]), float(z["lr"]), float(z["wd"])
+        self.rowptr, self.col = z["rowptr"].astype(np.int64), z["col"].astype(np.int64)
+        self.E = len(self.col)
+        f = np.zeros((self.N, self.nfeat), dtype=np.float32)
+        f[z["feat_row"].astype(np.int64), z["feat_col"].astype(np.int64)] = z["feat_val"]
+        self.features = f
+        self.labels, self.idx_train = z["labels"].astype(np.int64), z["idx_train"].astype(np.int64)
+        s, nh = self.seed, self.H
+        prm = {"weight0": rng_uniform(s + 1, (self.nfeat, nh), 1.0 / np.sqrt(nh)), "bias0": rng_uniform(s + 2, (nh,), 1.0 / np.sqrt(nh)),
+               "weight1": rng_uniform(s + 3, (nh, self.nclass), 1.0 / np.sqrt(nh)), "bias1": rng_uniform(s + 4, (self.nclass,), 1.0 / np.sqrt(nh))}
+        for i, n in enumerate(ALL_MASK_NAMES):
+            prm["weight_" + n] = rng_uniform(s + 100 + i, (2 * nh, nh), 1.0 / np.sqrt(nh))
+        assert sha(prm["weight0"]) == str(z["sha_weight0"]) and sha(prm["weight_mean"]) == str(z["sha_mask_mean"])
+        self.prm = prm
+        self.add_all = [self.col[self.rowptr[i]:self.rowptr[i + 1]] for i in range(self.N)]
+
+    def hidden_keep(self, ep):
+        return (np.random.default_rng(self.seed + 7000 + ep).random((self.N, self.H), dtype=np.float32) >= self.p).astype(np.float32)
+
+    def mask_keep(self, ep, agg):
+        return keep_mask(self.seed + 10000 * (ep + 1), agg, self.E, self.H, self.p)
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return Fix()
+
+
+def _check_final(fx, named):
+    z = fx.z
+    for n, t in named.items():
+        want = z["final_" + n]
+        rows = z["wrows"].astype(np.int64) if n == "weight0" else None
+        # three Adam steps of lr 0.01: a parameter moved by at most ~0.03; fp32 noise in the gradients moves it by ~1e-7
+        check_close(t, want, rows, z["final_" + n + "_stats"], what="final " + n)
+
+
+def test_oracle_walks_the_reference_training_trajectory(fx):
+    from oracle import nc_oracle as O
+    z = fx.z
+    x = torch.from_numpy(fx.features)
+    used = ["weight0", "bias0", "weight1", "bias1"] + ["weight_" + a for a in fx.aggs]
+    prm = {n: torch.from_numpy(v.copy()).requires_grad_(n in used) for n, v in fx.prm.items()}
+    # f-1: GraphConvolution.forward + its weight / bias gradients
+    g = O.gcn_forward(x, prm["weight0"], prm["bias0"], z["adj_row"], z["adj_col"], z["adj_val"])
+    cot = torch.from_numpy(np.random.default_rng(fx.seed + 9).standard_normal((fx.N, fx.H), dtype=np.float32))
+    gw, gb = torch.autograd.grad((g * cot).sum(), [prm["weight0"], prm["bias0"]])
+    check_close(g, z["gcn_out"], z["rows"].astype(np.int64), z["gcn_out_stats"], what="GraphConvolution out", signed_sum=True)
+    check_close(gw, z["gcn_gweight"], z["wrows"].astype(np.int64), z["gcn_gweight_stats"], what="GraphConvolution gweight", signed_sum=True)
+    check_close(gb, z["gcn_gbias"], None, None, what="GraphConvolution gbias", signed_sum=True)
+    # f-3: three steps of train.py:72-80
+    opt = torch.optim.Adam([prm[n] for n in fx.prm], lr=fx.lr, weight_decay=fx.wd)       # all 25, like models.py:45-50
+    labels, idx = torch.from_numpy(fx.labels), torch.from_numpy(fx.idx_train)
+    losses = []
+    for ep in range(fx.epochs):
+        opt.zero_grad()
+        out = O.model_forward(x, prm, fx.aggs, fx.rowptr, fx.col, z["adj_row"], z["adj_col"], z["adj_val"], "new_sigmoid", fx.p,
+                              fx.hidden_keep(ep), {a: fx.mask_keep(ep, a) for a in fx.aggs})
+        loss = torch.nn.functional.nll_loss(out[idx], labels[idx])
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert np.allclose(losses, z["losses"], rtol=1e-5, atol=1e-5), (losses, z["losses"])
+    check_close(out[idx], z["final_logp_train"], None, None, what="final log-probabilities (train rows)", signed_sum=True)
+    _check_final(fx, {n: prm[n].detach() for n in ("weight0", "bias0", "weight1", "bias1", "weight_mean", "weight_mean2")})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sparse_first_layer", [True, False])
+def test_hip_model_walks_the_reference_training_trajectory(fx, sparse_first_layer):
+    import mma_amd
+    from mma_amd import functional as Fn
+    from mma_amd.layers import GraphConvolution
+    from mma_amd.models import MMAConv
+    z = fx.z
+    x = torch.from_numpy(fx.features).to(DEV)
+    idxa = torch.from_numpy(np.stack([z["adj_row"], z["adj_col"]]).astype(np.int64))
+    adj = torch.sparse_coo_tensor(idxa, torch.from_numpy(z["adj_val"]), (fx.N, fx.N)).to(DEV)
+    model = MMAConv(fx.add_all, "new_sigmoid", 2, fx.nfeat, fx.H, fx.nclass, fx.p, fx.aggs, DEV)
+    if not sparse_first_layer:
+        model.gc1.SPARSE_BELOW = 0.0                                   # dense GEMM first layer
+    with torch.no_grad():
+        for n, v in fx.prm.items():
+            getattr(model, n).copy_(torch.from_numpy(v))
+    # f-1: the first layer alone, against the reference's GraphConvolution.forward and its gradients
+    g = model.gc1(x, adj)
+    assert (model.gc1._xg[2] is not None) == sparse_first_layer       # Cora's features are 1.3 % dense -> CSR kernel
+    cot = torch.from_numpy(np.random.default_rng(fx.seed + 9).standard_normal((fx.N, fx.H), dtype=np.float32)).to(DEV)
+    gw, gb = torch.autograd.grad((g * cot).sum(), [model.weight0, model.bias0])
+    check_close(g, z["gcn_out"], z["rows"].astype(np.int64), z["gcn_out_stats"], what="GraphConvolution out", signed_sum=True)
+    check_close(gw, z["gcn_gweight"], z["wrows"].astype(np.int64), z["gcn_gweight_stats"], what="GraphConvolution gweight", signed_sum=True)
+    check_close(gb, z["gcn_gbias"], None, None, what="GraphConvolution gbias", signed_sum=True)
+    # f-3: three steps
+    params = [getattr(model, n) for n in fx.prm]
+    opt = torch.optim.Adam(params, lr=fx.lr, weight_decay=fx.wd)
+    labels, idx = torch.from_numpy(fx.labels).to(DEV), torch.from_numpy(fx.idx_train).to(DEV)
+    losses = []
+    model.train()
+    for ep in range(fx.epochs):
+        model.hidden_keep = torch.from_numpy(fx.hidden_keep(ep)).to(DEV)
+        keep = torch.from_numpy(np.stack([fx.mask_keep(ep, a) for a in fx.aggs]).astype(np.uint8)).to(DEV)
+        model.gc2.drop_override = Fn.DropoutSpec(fx.p, keep=keep)
+        opt.zero_grad()
+        out = model(x, adj)
+        loss = torch.nn.functional.nll_loss(out[idx], labels[idx])
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert np.allclose(losses, z["losses"], rtol=1e-5, atol=1e-5), (losses, z["losses"])
+    check_close(out[idx], z["final_logp_train"], None, None, what="final log-probabilities (train rows)", signed_sum=True)
+    _check_final(fx, {n: getattr(model, n).detach() for n in ("weight0", "bias0", "weight1", "bias1", "weight_mean", "weight_mean2")})
