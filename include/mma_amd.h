@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 16
+#define MMA_ABI_VERSION 17
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -188,6 +188,27 @@ int mma_col_sum(const float* g, int64_t ldg, int64_t R, int32_t C, float* out, f
 int64_t mma_tower_linear_bwd_blocks(int64_t N);
 int mma_tower_linear_bwd(const float* gy, const float* a, const float* W, float* ga, float* part, int64_t n_blocks,
                          int64_t N, int32_t T, int32_t O, int32_t C, void* stream);
+
+/* ---- K10: fused log_softmax + nll_loss of the training step (models.py:68 F.log_softmax(x, dim=1) + train.py:77
+ * F.nll_loss(output[idx_train], labels[idx_train])) ------------------------------------------------------------------------
+ * fwd: logp (N,C) = log_softmax(x) for every row (the model's return value); loss (may be NULL) = -mean_i logp[idx[i], labels[idx[i]]]
+ *      (labels is indexed by NODE, like the reference's labels[idx_train]; int64 like torch's LongTensors).
+ * bwd: gx (N,C) = gloss * (exp(logp) - onehot(labels)) / n_idx on the rows idx (unique), 0 elsewhere; gloss: DEVICE scalar. */
+int mma_logsoftmax_nll_fwd(const float* x, int64_t ldx, const int64_t* idx, const int64_t* labels, int64_t n_idx,
+                           float* logp, int64_t ldo, float* loss, int64_t N, int32_t C, void* stream);
+int mma_logsoftmax_nll_bwd(const float* logp, int64_t ldo, const int64_t* idx, const int64_t* labels, int64_t n_idx,
+                           const float* gloss, float* gx, int64_t ldg, int64_t N, int32_t C, void* stream);
+
+/* ---- K11: Adam over ALL parameter tensors in one launch (train.py:69 optim.Adam(model.parameters(), lr, weight_decay)) ---------
+ * torch.optim.Adam semantics (no amsgrad; weight decay added to the gradient; bias-corrected).  table (DEVICE memory,
+ * mma_adam_table_bytes(n_tensors, total_chunks) bytes): n_tensors records {float* p; const float* g; float* m; float* v;
+ * int64 n; int64 chunk0} followed by total_chunks int32 tensor ids, one per workgroup chunk of mma_adam_chunks(1) = 4096
+ * elements (tensor t owns chunks [chunk0, chunk0 + mma_adam_chunks(n))).  step: DEVICE float, the number of steps taken so
+ * far; incremented by the call (so a captured hipGraph replays correctly). */
+int64_t mma_adam_table_bytes(int64_t n_tensors, int64_t total_chunks);
+int64_t mma_adam_chunks(int64_t n_elements);
+int mma_adam_step(const void* table, int64_t n_tensors, int64_t total_chunks, float* step, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, void* stream);
 
 /* ---- K6: CSR by key, built on the device (graph-regression batches change every call) ----------------
  * Stable radix sort (rocPRIM) of edge positions by key[e] (int64 node ids as PyG's edge_index holds them):

@@ -1,0 +1,158 @@
+// K10 / K11: the two non-layer pieces of the reference's training step (node_classification/train.py:72-80), fused.
+//   K10  log_softmax over the classes + nll_loss over the training rows  (models.py:68 `F.log_softmax(x, dim=1)` +
+//        train.py:77 `F.nll_loss(output[idx_train], labels[idx_train])`): forward writes the (N,C) log-probabilities the
+//        model returns and the scalar mean loss; backward writes dL/dlogits = (softmax - onehot) / n on the training rows, 0
+//        elsewhere - one launch each instead of ~10 element-wise / index / reduction launches.
+//   K11  Adam (train.py:69 `optim.Adam(model.parameters(), lr, weight_decay)`), all parameter tensors in ONE launch: the
+//        reference's 25 Parameters are 25 x ~8 tiny launches per step with the stock per-tensor loop.
+// Both are deterministic (fixed reduction order, no atomics) and capture-safe (the step counter lives in device memory).
+#include "common.h"
+
+namespace mma {
+
+// one wavefront per row: C <= 64 * kMaxPerLane classes
+constexpr int kMaxPerLane = 16;
+
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = kWave / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void logsoftmax_kernel(const float* x, int64_t ldx, float* logp, int64_t ldo, int64_t N, int C) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave);
+  for (int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); r < N; r += stride) {
+    float v[kMaxPerLane];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i) {
+      const int c = lane + i * kWave;
+      v[i] = c < C ? x[r * ldx + c] : -INFINITY;
+      m = fmaxf(m, v[i]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i) if (lane + i * kWave < C) s += expf(v[i] - m);
+    const float lse = m + logf(wave_sum(s));
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i) {
+      const int c = lane + i * kWave;
+      if (c < C) logp[r * ldo + c] = v[i] - lse;
+    }
+  }
+}
+
+// loss = -(1/n) sum_i logp[idx[i], labels[idx[i]]]: ONE workgroup, fixed order (strided partial sums, then a tree)
+__global__ __launch_bounds__(kBlock) void nll_mean_kernel(const float* logp, int64_t ldo, const int64_t* idx, const int64_t* labels,
+                                                          int64_t n, float* loss) {
+  __shared__ float part[kBlock];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+    const int64_t r = idx[i];
+    s -= logp[r * ldo + labels[r]];
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = part[0] / (float)n;
+}
+
+// gx[idx[i], c] = gloss * (exp(logp) - [c == label]) / n   (the caller zeroed gx; idx rows are unique)
+__global__ __launch_bounds__(kBlock) void nll_logsoftmax_bwd_kernel(const float* logp, int64_t ldo, const int64_t* idx, const int64_t* labels,
+                                                                    int64_t n, int C, const float* gloss, float* gx, int64_t ldg) {
+  const float scale = *gloss / (float)n;
+  const int64_t total = n * C;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / C; const int c = (int)(t % C);
+    const int64_t r = idx[i];
+    gx[r * ldg + c] = scale * (expf(logp[r * ldo + c]) - (labels[r] == c ? 1.f : 0.f));
+  }
+}
+
+// ---- K11 ------------------------------------------------------------------------------------------------------------
+struct AdamTensor { float* p; const float* g; float* m; float* v; int64_t n; int64_t chunk0; };   // chunk0: first chunk id of the tensor
+constexpr int64_t kAdamChunk = 4096;     // elements per workgroup
+
+__global__ __launch_bounds__(kBlock) void adam_kernel(const AdamTensor* tab, int n_tensors, const int32_t* chunk_tensor, float* step,
+                                                      float lr, float b1, float b2, float eps, float wd) {
+  // torch.optim.Adam (no amsgrad, L2 weight decay folded into the gradient), step t = *step + 1 for every workgroup
+  const float t = *step + 1.f;
+  const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+  const float step_size = lr / bc1;
+  const AdamTensor T = tab[chunk_tensor[blockIdx.x]];
+  const int64_t base = ((int64_t)blockIdx.x - T.chunk0) * kAdamChunk;
+  const int64_t end = min(T.n, base + kAdamChunk);
+  for (int64_t i = base + threadIdx.x; i < end; i += kBlock) {
+    const float pv = T.p[i];
+    const float g = T.g[i] + wd * pv;                       // grad.add(param, alpha=weight_decay)
+    const float m = T.m[i] + (1.f - b1) * (g - T.m[i]);     // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = b2 * T.v[i] + (1.f - b2) * g * g;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    T.m[i] = m; T.v[i] = v;
+    T.p[i] = pv - step_size * (m / (sqrtf(v) / bc2s + eps));   // param.addcdiv_(exp_avg, denom, value=-step_size)
+  }
+}
+__global__ void adam_tick_kernel(float* step) { *step += 1.f; }
+
+}  // namespace mma
+
+using namespace mma;
+
+extern "C" int mma_logsoftmax_nll_fwd(const float* x, int64_t ldx, const int64_t* idx, const int64_t* labels, int64_t n_idx,
+                                      float* logp, int64_t ldo, float* loss, int64_t N, int32_t C, void* stream) {
+  MMA_REQUIRE(N >= 0 && n_idx >= 0 && C >= 1 && C <= kWave * kMaxPerLane && ldx >= C && ldo >= C, "N=%lld n_idx=%lld C=%d unsupported",
+              (long long)N, (long long)n_idx, C);
+  if (N == 0) return 0;
+  MMA_REQUIRE(x && logp, "NULL argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t blocks = (N + 3) / 4;
+  if (blocks > kMaxGrid) blocks = kMaxGrid;
+  hipLaunchKernelGGL(logsoftmax_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, ldx, logp, ldo, N, C);
+  if (loss) {
+    MMA_REQUIRE(n_idx > 0 && idx && labels, "the loss needs a non-empty idx and the labels");
+    hipLaunchKernelGGL(nll_mean_kernel, dim3(1), dim3(kBlock), 0, st, logp, ldo, idx, labels, n_idx, loss);
+  }
+  return check_launch("logsoftmax_nll_fwd");
+}
+
+extern "C" int mma_logsoftmax_nll_bwd(const float* logp, int64_t ldo, const int64_t* idx, const int64_t* labels, int64_t n_idx,
+                                      const float* gloss, float* gx, int64_t ldg, int64_t N, int32_t C, void* stream) {
+  MMA_REQUIRE(N >= 0 && n_idx >= 0 && C >= 1 && ldo >= C && ldg >= C, "N=%lld n_idx=%lld C=%d unsupported", (long long)N, (long long)n_idx, C);
+  if (N == 0) return 0;
+  MMA_REQUIRE(logp && gx && gloss && (n_idx == 0 || (idx && labels)), "NULL argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemset2DAsync(gx, (size_t)ldg * 4, 0, (size_t)C * 4, (size_t)N, st) != hipSuccess) return fail(2, "memset of the gradient failed");
+  if (n_idx == 0) return 0;
+  int64_t blocks = (n_idx * C + kBlock - 1) / kBlock;
+  if (blocks > kMaxGrid) blocks = kMaxGrid;
+  hipLaunchKernelGGL(nll_logsoftmax_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, logp, ldo, idx, labels, n_idx, C, gloss, gx, ldg);
+  return check_launch("logsoftmax_nll_bwd");
+}
+
+extern "C" int64_t mma_adam_table_bytes(int64_t n_tensors, int64_t total_chunks) {
+  if (n_tensors < 0 || total_chunks < 0) return -1;
+  return n_tensors * (int64_t)sizeof(AdamTensor) + total_chunks * 4;
+}
+extern "C" int64_t mma_adam_chunks(int64_t n_elements) { return n_elements <= 0 ? 0 : (n_elements + kAdamChunk - 1) / kAdamChunk; }
+
+extern "C" int mma_adam_step(const void* table, int64_t n_tensors, int64_t total_chunks, float* step, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, void* stream) {
+  MMA_REQUIRE(n_tensors >= 0 && total_chunks >= 0 && total_chunks < (1LL << 31), "bad table size");
+  if (n_tensors == 0 || total_chunks == 0) return 0;
+  MMA_REQUIRE(table && step, "NULL argument");
+  MMA_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "invalid Adam hyper-parameters");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const AdamTensor* tab = static_cast<const AdamTensor*>(table);
+  const int32_t* chunk_tensor = reinterpret_cast<const int32_t*>(tab + n_tensors);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)total_chunks), dim3(kBlock), 0, st, tab, (int)n_tensors, chunk_tensor, step, lr, beta1,
+                     beta2, eps, weight_decay);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step);
+  return check_launch("adam_step");
+}

@@ -25,11 +25,19 @@ class MMAConv(nn.Module):
         self.dropout = dropout
         self.hidden_keep = None      # tests: an explicit (N, nhid) keep mask replayed instead of F.dropout's RNG (models.py:66)
 
-    def forward(self, x, adj):
+    def logits(self, x, adj):
         x = F.relu(self.gc1(x, adj))
         if self.hidden_keep is not None and self.training:
             x = x * self.hidden_keep / (1.0 - self.dropout)
         else:
             x = F.dropout(x, self.dropout, training=self.training)
-        x = self.gc2(x, adj)
-        return F.log_softmax(x, dim=1)
+        return self.gc2(x, adj)
+
+    def forward(self, x, adj):
+        return F.log_softmax(self.logits(x, adj), dim=1)
+
+    def nll_loss(self, x, adj, idx, labels):
+        """(loss, output): `F.nll_loss(model(x, adj)[idx], labels[idx])` and the model output of train.py:76-77, with
+        log_softmax + nll_loss (and their backward) as the fused K10 kernels."""
+        from .train_step import fused_nll_loss
+        return fused_nll_loss(self.logits(x, adj), idx, labels)

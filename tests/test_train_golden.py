@@ -90,10 +90,13 @@ def test_oracle_walks_the_reference_training_trajectory(fx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sparse_first_layer", [True, False])
-def test_hip_model_walks_the_reference_training_trajectory(fx, sparse_first_layer):
+@pytest.mark.parametrize("sparse_first_layer,fused_step", [(True, False), (False, False), (True, True)])
+def test_hip_model_walks_the_reference_training_trajectory(fx, sparse_first_layer, fused_step):
+    """fused_step: the loss through K10 (fused log_softmax + nll_loss) and the update through K11 (multi-tensor Adam) instead
+    of torch's element-wise ops and per-tensor optimizer - SURVEY 8 f-4, checked against the REFERENCE's trajectory."""
     import mma_amd
     from mma_amd import functional as Fn
+    from mma_amd.train_step import FusedAdam
     from mma_amd.layers import GraphConvolution
     from mma_amd.models import MMAConv
     z = fx.z
@@ -116,7 +119,7 @@ def test_hip_model_walks_the_reference_training_trajectory(fx, sparse_first_laye
     check_close(gb, z["gcn_gbias"], None, None, what="GraphConvolution gbias", signed_sum=True)
     # f-3: three steps
     params = [getattr(model, n) for n in fx.prm]
-    opt = torch.optim.Adam(params, lr=fx.lr, weight_decay=fx.wd)
+    opt = (FusedAdam if fused_step else torch.optim.Adam)(params, lr=fx.lr, weight_decay=fx.wd)
     labels, idx = torch.from_numpy(fx.labels).to(DEV), torch.from_numpy(fx.idx_train).to(DEV)
     losses = []
     model.train()
@@ -125,8 +128,11 @@ def test_hip_model_walks_the_reference_training_trajectory(fx, sparse_first_laye
         keep = torch.from_numpy(np.stack([fx.mask_keep(ep, a) for a in fx.aggs]).astype(np.uint8)).to(DEV)
         model.gc2.drop_override = Fn.DropoutSpec(fx.p, keep=keep)
         opt.zero_grad()
-        out = model(x, adj)
-        loss = torch.nn.functional.nll_loss(out[idx], labels[idx])
+        if fused_step:
+            loss, out = model.nll_loss(x, adj, idx, labels)
+        else:
+            out = model(x, adj)
+            loss = torch.nn.functional.nll_loss(out[idx], labels[idx])
         loss.backward()
         opt.step()
         losses.append(loss.item())

@@ -92,3 +92,44 @@ def test_graphed_step_trains_and_beats_eager_launch_overhead():
     assert np.isfinite(last).all() and np.mean(last) < 0.8 * np.mean(first), (first, last)
     assert len({round(v, 6) for v in last}) > 1                        # fresh dropout bits per replay
     assert t_graph < 0.7 * t_eager, (t_eager, t_graph)
+
+
+@pytest.mark.parametrize("N,C,n_idx", [(300, 7, 140), (50, 100, 50), (5, 3, 1)])
+def test_fused_nll_loss_matches_torch(N, C, n_idx):
+    """K10 against plain torch fp32: log_softmax(dim=1) -> nll_loss(output[idx], labels[idx]) (models.py:68, train.py:77)."""
+    from mma_amd.train_step import fused_nll_loss
+    g = torch.Generator().manual_seed(N + C)
+    logits = (torch.randn(N, C, generator=g) * 5).to(DEV).requires_grad_(True)
+    labels = torch.randint(0, C, (N,), generator=g).to(DEV)
+    idx = torch.randperm(N, generator=g)[:n_idx].to(DEV)
+    loss, logp = fused_nll_loss(logits, idx, labels)
+    gx, = torch.autograd.grad(loss * 3.0, [logits])
+    ref_in = logits.detach().clone().requires_grad_(True)
+    ref_logp = F.log_softmax(ref_in, dim=1)
+    ref_loss = F.nll_loss(ref_logp[idx], labels[idx])
+    ref_g, = torch.autograd.grad(ref_loss * 3.0, [ref_in])
+    assert torch.allclose(logp, ref_logp, rtol=1e-6, atol=1e-6) and torch.allclose(loss, ref_loss, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(gx, ref_g, rtol=1e-5, atol=1e-7)
+    assert torch.equal(gx[~torch.isin(torch.arange(N, device=DEV), idx)], torch.zeros(N - n_idx, C, device=DEV))
+
+
+def test_fused_adam_matches_torch_adam():
+    """K11 against torch.optim.Adam (train.py:69: lr 0.01, weight_decay 5e-4) over several steps on tensors of awkward sizes."""
+    from mma_amd.train_step import FusedAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1433, 64), (64,), (64, 7), (7,), (128, 64), (5000,), (1,), (4097,)]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    grads = [[torch.randn(*s, generator=g) for s in shapes] for _ in range(6)]
+    res = []
+    for fused in (False, True):
+        ps = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+        opt = (FusedAdam if fused else torch.optim.Adam)(ps, lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+        for p in ps:
+            p.grad = torch.zeros_like(p)
+        for step_g in grads:
+            for p, gg in zip(ps, step_g):
+                p.grad.copy_(gg)
+            opt.step()
+        res.append([p.detach().clone() for p in ps])
+    for a, b in zip(*res):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (a - b).abs().max()
