@@ -207,8 +207,8 @@ int mma_logsoftmax_nll_bwd(const float* logp, int64_t ldo, const int64_t* idx, c
  * far; incremented by the call (so a captured hipGraph replays correctly). */
 int64_t mma_adam_table_bytes(int64_t n_tensors, int64_t total_chunks);
 int64_t mma_adam_chunks(int64_t n_elements);
-int mma_adam_step(const void* table, int64_t n_tensors, int64_t total_chunks, float* step, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, void* stream);
+int mma_adam_step(const void* table, int64_t n_tensors, int64_t total_chunks, float* step, double lr, double beta1, double beta2,
+                  float eps, float weight_decay, void* stream);   /* lr, betas: double, like torch's Python floats (1 - 0.999f != 1e-3) */
 
 /* ---- K6: CSR by key, built on the device (graph-regression batches change every call) ----------------
  * Stable radix sort (rocPRIM) of edge positions by key[e] (int64 node ids as PyG's edge_index holds them):

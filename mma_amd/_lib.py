@@ -19,7 +19,7 @@ ABI_VERSION = _abi.ABI_VERSION
 
 _c = ctypes
 _P, _I64, _I32, _U32, _U64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_uint64
-_CT = {"T": _P, "H": _P, "S": _P, "i64": _I64, "i32": _I32, "u32": _U32, "u64": _U64, "f32": _c.c_float}
+_CT = {"T": _P, "H": _P, "S": _P, "i64": _I64, "i32": _I32, "u32": _U32, "u64": _U64, "f32": _c.c_float, "f64": _c.c_double}
 _RET = {"int": _I32, "int64_t": _I64, "const char*": _c.c_char_p}
 
 # name -> ctypes argtypes of the entry points that take a stream (the launchers), exactly the prototypes of include/mma_amd.h
@@ -105,7 +105,7 @@ def call(name, *args):
                 conv.append(None if a is None else [int(x) for x in a])
             elif k == "u64":
                 conv.append(_signed64(int(a)))
-            elif k == "f32":
+            elif k in ("f32", "f64"):
                 conv.append(float(a))
             elif k == "T":
                 conv.append(a)

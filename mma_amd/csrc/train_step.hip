@@ -82,19 +82,22 @@ struct AdamTensor { float* p; const float* g; float* m; float* v; int64_t n; int
 constexpr int64_t kAdamChunk = 4096;     // elements per workgroup
 
 __global__ __launch_bounds__(kBlock) void adam_kernel(const AdamTensor* tab, int n_tensors, const int32_t* chunk_tensor, float* step,
-                                                      float lr, float b1, float b2, float eps, float wd) {
-  // torch.optim.Adam (no amsgrad, L2 weight decay folded into the gradient), step t = *step + 1 for every workgroup
-  const float t = *step + 1.f;
-  const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
-  const float step_size = lr / bc1;
+                                                      double lr_d, double b1_d, double b2_d, float eps, float wd) {
+  // torch.optim.Adam (no amsgrad, L2 weight decay folded into the gradient), step t = *step + 1 for every workgroup.
+  // The scalars are formed in DOUBLE from double hyper-parameters and only then rounded to fp32, as torch does with its Python
+  // floats: 1 - 0.999f is 1.3e-5 off 1e-3, which would put every second-moment update and bias correction off by that much.
+  const double t = (double)*step + 1.0;
+  const float step_size = (float)(lr_d / (1.0 - pow(b1_d, t)));
+  const float bc2s = (float)sqrt(1.0 - pow(b2_d, t));
+  const float b2 = (float)b2_d, omb1 = (float)(1.0 - b1_d), omb2 = (float)(1.0 - b2_d);
   const AdamTensor T = tab[chunk_tensor[blockIdx.x]];
   const int64_t base = ((int64_t)blockIdx.x - T.chunk0) * kAdamChunk;
   const int64_t end = min(T.n, base + kAdamChunk);
   for (int64_t i = base + threadIdx.x; i < end; i += kBlock) {
     const float pv = T.p[i];
     const float g = T.g[i] + wd * pv;                       // grad.add(param, alpha=weight_decay)
-    const float m = T.m[i] + (1.f - b1) * (g - T.m[i]);     // exp_avg.lerp_(grad, 1 - beta1)
-    const float v = b2 * T.v[i] + (1.f - b2) * g * g;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float m = T.m[i] + omb1 * (g - T.m[i]);           // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = b2 * T.v[i] + omb2 * g * g;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     T.m[i] = m; T.v[i] = v;
     T.p[i] = pv - step_size * (m / (sqrtf(v) / bc2s + eps));   // param.addcdiv_(exp_avg, denom, value=-step_size)
   }
@@ -142,12 +145,12 @@ extern "C" int64_t mma_adam_table_bytes(int64_t n_tensors, int64_t total_chunks)
 }
 extern "C" int64_t mma_adam_chunks(int64_t n_elements) { return n_elements <= 0 ? 0 : (n_elements + kAdamChunk - 1) / kAdamChunk; }
 
-extern "C" int mma_adam_step(const void* table, int64_t n_tensors, int64_t total_chunks, float* step, float lr, float beta1, float beta2,
+extern "C" int mma_adam_step(const void* table, int64_t n_tensors, int64_t total_chunks, float* step, double lr, double beta1, double beta2,
                              float eps, float weight_decay, void* stream) {
   MMA_REQUIRE(n_tensors >= 0 && total_chunks >= 0 && total_chunks < (1LL << 31), "bad table size");
   if (n_tensors == 0 || total_chunks == 0) return 0;
   MMA_REQUIRE(table && step, "NULL argument");
-  MMA_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "invalid Adam hyper-parameters");
+  MMA_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0.f, "invalid Adam hyper-parameters");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const AdamTensor* tab = static_cast<const AdamTensor*>(table);
   const int32_t* chunk_tensor = reinterpret_cast<const int32_t*>(tab + n_tensors);
