@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 17
+#define MMA_ABI_VERSION 18
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -137,7 +137,10 @@ int mma_csr_spmm(
  * {row, ebeg, eend, slot} (longest first) with hub partials, exactly as in mma_nc_fused_fwd; partial is (n_slots, C). */
 int mma_csr_spmm_items(
     const int32_t* col, const float* val, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldo,
-    const int32_t* items, int64_t n_items, const int32_t* hubs, int64_t n_hubs, float* partial, int64_t n_slots,
+    const int32_t* items, int64_t n_items,
+    int64_t n_wave_items,                        /* as in mma_nc_fused_fwd: the head of the (longest-first) list runs one item per
+                                                    wavefront, the short tail one per C/4-lane group; speed only */
+    const int32_t* hubs, int64_t n_hubs, float* partial, int64_t n_slots,
     int32_t C, void* stream);
 
 /* ---- GEMM-pre/post: fp32-accurate tall-skinny GEMM on the bf16 matrix cores ("bf16x3") -------------------

@@ -279,53 +279,70 @@ template <int VEC>
 __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodeParams p) {
   const int per_row = (p.H + VEC - 1) / VEC;
   const int64_t total = p.N * per_row;
+  // One (node, VEC columns) item per thread and pass; ALL of an item's loads (g, T_k, sel_k for every mask) are issued before
+  // its first store: vmcnt is one in-order counter for loads and stores, so the round-1 form (load T_k, store gP_k, load
+  // T_k+1, ... in a grid-stride loop) made every load wait for the stores in front of it (5.65 TB/s on a pure stream).
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t node = idx / per_row;
     const int c = (int)(idx % per_row) * VEC;
     const float deg = (float)max(p.rowptr[node + 1] - p.rowptr[node], 1);
+    Vec<VEC> gk[MMA_MAX_K], tk[MMA_MAX_K];
+    uint32_t ck[MMA_MAX_K];
+    const bool shared_g = p.g_kstride == 0;
+#pragma unroll
+    for (int k = 0; k < MMA_MAX_K; ++k) {
+      if (k < p.K) {
+        const size_t o = (size_t)node * p.ldt + (size_t)k * p.H + c;
+        if (k == 0 || !shared_g) gk[k] = ldv<VEC>(p.g + (size_t)k * p.g_kstride + (size_t)node * p.ldgr + c);
+        tk[k] = ldv<VEC>(p.T + o);
+        ck[k] = ldb<VEC>(p.sel + o);
+      }
+    }
     Vec<VEC> gx = vzero<VEC>();
-    for (int k = 0; k < p.K; ++k) {
-      const int kind = kind_of(p.kinds, k);
-      const Vec<VEC> g = ldv<VEC>(p.g + (size_t)k * p.g_kstride + (size_t)node * p.ldgr + c);
-      const size_t o = (size_t)node * p.ldt + (size_t)k * p.H + c;
-      const Vec<VEC> t = ldv<VEC>(p.T + o);
-      const uint32_t codes = ldb<VEC>(p.sel + o);
-      Vec<VEC> gsv, gpv;
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const uint32_t code = (codes >> (8 * i)) & 0xFFu;
-        float fs, fx;  // d m / d s, d m / d x_i
-        switch (kind) {
-          case MMA_KIND_SUM: fs = 1.f; fx = 1.f; break;
-          case MMA_KIND_MEAN: fs = 1.f / deg; fx = fs; break;
-          case MMA_KIND_MAX:
-          case MMA_KIND_MIN: fs = code == 1u ? 1.f : (code == 2u ? 0.5f : 0.f); fx = 1.f - fs; break;
-          default: fs = code == 3u ? __builtin_nanf("") : 1.f; fx = 0.f; break;
-        }
-        gsv.v[i] = g.v[i] * fs;
-        gpv.v[i] = gsv.v[i] * t.v[i];
-        gx.v[i] = fmaf(g.v[i], fx, gx.v[i]);
-      }
-      if (p.gs) stv<VEC>(p.gs + (size_t)node * p.ldgs + (size_t)k * p.H + c, gsv);
-      if (p.aux) {
-        float* row = p.aux + (size_t)node * p.ldaux;
-        if (k == 0) {
-          stv<VEC>(row + c, g);                                   // the shared gradient itself
-          if (c == 0) row[p.H] = 1.f / deg;
-        }
-        if (p.sel_slot[k] != 0xFF) {
-          // one byte per element = 2 * (dm/ds): 0 x_i selected, 1 tie, 2 s selected, 255 NaN.  K2b turns it back into
-          // the factor with a single v_cvt_f32_ubyte + multiply.
-          uint32_t tf = 0;
+    for (int k = 0; k < MMA_MAX_K; ++k) {
+      if (k < p.K) {
+        const int kind = kind_of(p.kinds, k);
+        const Vec<VEC> g = shared_g ? gk[0] : gk[k];
+        const Vec<VEC> t = tk[k];
+        const uint32_t codes = ck[k];
+        Vec<VEC> gsv, gpv;
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            const uint32_t code = (codes >> (8 * i)) & 0xFFu;
-            tf |= (code == 1u ? 2u : (code == 2u ? 1u : (code == 3u ? 255u : 0u))) << (8 * i);
+        for (int i = 0; i < VEC; ++i) {
+          const uint32_t code = (codes >> (8 * i)) & 0xFFu;
+          float fs, fx;  // d m / d s, d m / d x_i
+          switch (kind) {
+            case MMA_KIND_SUM: fs = 1.f; fx = 1.f; break;
+            case MMA_KIND_MEAN: fs = 1.f / deg; fx = fs; break;
+            case MMA_KIND_MAX:
+            case MMA_KIND_MIN: fs = code == 1u ? 1.f : (code == 2u ? 0.5f : 0.f); fx = 1.f - fs; break;
+            default: fs = code == 3u ? __builtin_nanf("") : 1.f; fx = 0.f; break;
           }
-          stb<VEC>(reinterpret_cast<uint8_t*>(row + p.H + 4 + (size_t)p.sel_slot[k] * p.HQ) + c, tf);
+          gsv.v[i] = g.v[i] * fs;
+          gpv.v[i] = gsv.v[i] * t.v[i];
+          gx.v[i] = fmaf(g.v[i], fx, gx.v[i]);
         }
+        if (p.gs) stv<VEC>(p.gs + (size_t)node * p.ldgs + (size_t)k * p.H + c, gsv);
+        if (p.aux) {
+          float* row = p.aux + (size_t)node * p.ldaux;
+          if (k == 0) {
+            stv<VEC>(row + c, g);                                   // the shared gradient itself
+            if (c == 0) row[p.H] = 1.f / deg;
+          }
+          if (p.sel_slot[k] != 0xFF) {
+            // one byte per element = 2 * (dm/ds): 0 x_i selected, 1 tie, 2 s selected, 255 NaN.  K2b turns it back into
+            // the factor with a single v_cvt_f32_ubyte + multiply.
+            uint32_t tf = 0;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              const uint32_t code = (codes >> (8 * i)) & 0xFFu;
+              tf |= (code == 1u ? 2u : (code == 2u ? 1u : (code == 3u ? 255u : 0u))) << (8 * i);
+            }
+            stb<VEC>(reinterpret_cast<uint8_t*>(row + p.H + 4 + (size_t)p.sel_slot[k] * p.HQ) + c, tf);
+          }
+        }
+        stv<VEC>(p.gP + (size_t)node * p.ldgp + (size_t)k * p.H + c, gpv);
       }
-      stv<VEC>(p.gP + (size_t)node * p.ldgp + (size_t)k * p.H + c, gpv);
     }
     stv<VEC>(p.gxs + (size_t)node * p.ldgx + c, gx);
   }
@@ -780,7 +797,9 @@ extern "C" int mma_nc_bwd_node(
                   aligned16(T) && (!gs || aligned16(gs)) && aligned16(gP) && aligned16(gxs);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int per_row = v4 ? H / 4 : H;
-  const dim3 grid((unsigned)elementwise_grid(N * per_row));
+  int64_t nblk = (N * per_row + kBlock - 1) / kBlock;          // one item per thread (see the kernel): no grid-stride in practice
+  if (nblk > (1LL << 30)) nblk = 1LL << 30;
+  const dim3 grid((unsigned)nblk);
   if (v4) hipLaunchKernelGGL((nc_bwd_node_kernel<4>), grid, dim3(kBlock), 0, st, p);
   else hipLaunchKernelGGL((nc_bwd_node_kernel<1>), grid, dim3(kBlock), 0, st, p);
   return check_launch("nc_bwd_node_kernel");

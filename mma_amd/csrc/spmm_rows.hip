@@ -120,6 +120,59 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(const SpmmItemParams
   }
 }
 
+// Short items, one per group of LPR lanes (64/LPR items per wavefront), each group walking its own segment with four gathers
+// in flight and no cross-lane traffic at all (a lane owns its VEC columns of the output row).  At C = 16 an item-per-wave
+// launch issues ONE 640-byte gather per ~10-edge row and then waits out the memory latency; here a wave keeps 64 rows in
+// flight.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void spmm_items_group_kernel(const SpmmItemParams p) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int lpr = 1 << p.lpr_log;
+  const int gpw = kWave >> p.lpr_log;
+  const int grp = lane >> p.lpr_log;
+  const int c = (lane & (lpr - 1)) * VEC;               // lpr lanes cover the whole row on this path (host: chunks == 1)
+  const bool fvalid = c < p.C;
+  const int cc = fvalid ? c : 0;
+  const int64_t n_w = (p.n_items + gpw - 1) / gpw;
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave);
+  for (int64_t w = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); w < n_w; w += stride) {
+    const int64_t it = w * gpw + grp;
+    if (it >= p.n_items) continue;
+    const int4 item = p.items[it];
+    Vec<VEC> acc = vzero<VEC>();
+    int e = item.y;
+    for (; e + 4 <= item.z; e += 4) {
+      int j[4]; float v[4]; Vec<VEC> b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { j[u] = p.col[e + u]; v[u] = p.val ? p.val[e + u] : 1.f; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = ldv<VEC>(p.B + (size_t)j[u] * p.ldb + cc);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(v[u], b[u].v[i], acc.v[i]);
+    }
+    for (; e < item.z; ++e) {
+      const float v = p.val ? p.val[e] : 1.f;
+      const Vec<VEC> b = ldv<VEC>(p.B + (size_t)p.col[e] * p.ldb + cc);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(v, b.v[i], acc.v[i]);
+    }
+    if (fvalid) {
+      if (item.w < 0) {
+        if (p.bias) {
+          const Vec<VEC> bb = ldv<VEC>(p.bias + c);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc.v[i] += bb.v[i];
+        }
+        stv<VEC>(p.out + (size_t)item.x * p.ldo + c, acc);
+      } else {
+        stv<VEC>(p.partial + (size_t)item.w * p.C + c, acc);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void spmm_items_finalize_kernel(const SpmmItemParams p, const int4* hubs, int64_t n_hubs) {
   const int64_t total = n_hubs * p.C;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -244,10 +297,10 @@ extern "C" int mma_csr_spmm(const int32_t* rowptr, const int32_t* col, const flo
   return check_launch("spmm_kernel");
 }
 
-extern "C" int mma_csr_spmm_items(const int32_t* col, const float* val, const float* B, int64_t ldb, const float* bias,
-                                  float* out, int64_t ldo, const int32_t* items, int64_t n_items, const int32_t* hubs,
+extern "C" int mma_csr_spmm_items(const int32_t* col, const float* val, const float* B, int64_t ldb, const float* bias, float* out,
+                                  int64_t ldo, const int32_t* items, int64_t n_items, int64_t n_wave_items, const int32_t* hubs,
                                   int64_t n_hubs, float* partial, int64_t n_slots, int32_t C, void* stream) {
-  MMA_REQUIRE(C >= 1 && ldb >= C && ldo >= C && n_items >= 0 && n_items < (1LL << 31) && n_hubs >= 0 && n_slots >= 0,
+  MMA_REQUIRE(C >= 1 && ldb >= C && ldo >= C && n_items >= 0 && n_items < (1LL << 31) && n_hubs >= 0 && n_slots >= 0 && n_wave_items >= 0,
               "C=%d ldb=%lld ldo=%lld n_items=%lld unsupported", C, (long long)ldb, (long long)ldo, (long long)n_items);
   MMA_REQUIRE(n_slots == 0 || (partial && hubs && n_hubs > 0), "hub slots without partial/hubs buffers");
   if (n_items == 0) return 0;
@@ -259,13 +312,28 @@ extern "C" int mma_csr_spmm_items(const int32_t* col, const float* val, const fl
   SpmmItemParams p{col, val, B, ldb, bias, out, ldo, reinterpret_cast<const int4*>(items), n_items, partial, C, 0};
   p.lpr_log = min(ilog2_ceil(per_row), 6);
   const int chunks = (per_row + (1 << p.lpr_log) - 1) >> p.lpr_log;
-  int64_t blocks = (n_items + 3) / 4;
-  if (blocks > kMaxGrid) blocks = kMaxGrid;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)blocks, (unsigned)chunks);
-  if (v4) hipLaunchKernelGGL((spmm_items_kernel<4>), grid, dim3(kBlock), 0, st, p);
-  else hipLaunchKernelGGL((spmm_items_kernel<1>), grid, dim3(kBlock), 0, st, p);
-  if (int rc = check_launch("spmm_items_kernel")) return rc;
+  // items [0, n_wave_items): one per wavefront; the rest (short rows) one per lpr-lane group when a wave holds several groups
+  const int gpw = kWave >> p.lpr_log;
+  if (gpw == 1 || chunks != 1 || n_wave_items > n_items) n_wave_items = n_items;
+  if (n_wave_items > 0) {
+    p.n_items = n_wave_items;
+    int64_t blocks = (n_wave_items + 3) / 4;
+    if (blocks > kMaxGrid) blocks = kMaxGrid;
+    const dim3 grid((unsigned)blocks, (unsigned)chunks);
+    if (v4) hipLaunchKernelGGL((spmm_items_kernel<4>), grid, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((spmm_items_kernel<1>), grid, dim3(kBlock), 0, st, p);
+    if (int rc = check_launch("spmm_items_kernel")) return rc;
+  }
+  if (n_items > n_wave_items) {
+    p.items = reinterpret_cast<const int4*>(items) + n_wave_items;
+    p.n_items = n_items - n_wave_items;
+    int64_t blocks = (p.n_items + 4 * gpw - 1) / (4 * gpw);
+    if (blocks > 4 * kMaxGrid) blocks = 4 * kMaxGrid;
+    if (v4) hipLaunchKernelGGL((spmm_items_group_kernel<4>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((spmm_items_group_kernel<1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);
+    if (int rc = check_launch("spmm_items_group_kernel")) return rc;
+  }
   if (n_hubs > 0) {
     int64_t fb = (n_hubs * C + kBlock - 1) / kBlock;
     if (fb > kMaxGrid) fb = kMaxGrid;

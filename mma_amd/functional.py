@@ -218,10 +218,11 @@ def nc_fused_aggregate(x, P, Q, graph, kinds, acts, drop=None, reduce_k=False):
     return _NCFused.apply(x, P, Q, graph, tuple(kinds), tuple(acts), drop or DropoutSpec(0.0), bool(reduce_k))
 
 
-def _spmm_call(rowptr, col, val, items, hubs, n_slots, B, rows_per_block, K, bias, out, n_rows, C):
+def _spmm_call(rowptr, col, val, items, hubs, n_slots, B, rows_per_block, K, bias, out, n_rows, C, n_wave_items=None):
     if K == 1 and items is not None:
         partial = torch.empty((n_slots, C), device=B.device, dtype=torch.float32) if n_slots else None
         call("mma_csr_spmm_items", ptr(col), ptr(val), ptr(B), B.stride(0), ptr(bias), ptr(out), C, ptr(items), items.shape[0],
+             items.shape[0] if n_wave_items is None else n_wave_items,
              ptr(hubs) if n_slots else None, hubs.shape[0], ptr(partial), n_slots, C, stream_ptr())
     else:
         call("mma_csr_spmm", ptr(rowptr), ptr(col), ptr(val), ptr(B), B.stride(0), rows_per_block, K,
@@ -240,7 +241,8 @@ class _CsrSpmm(torch.autograd.Function):
         C = B.shape[1]
         out = torch.empty((sg.n_rows, C), device=B.device, dtype=torch.float32)
         with _span("csr_spmm_fwd"):
-            _spmm_call(sg.rowptr, sg.col, sg.val, sg.items, sg.hubs, sg.n_slots, B, rows_per_block, K, bias, out, sg.n_rows, C)
+            _spmm_call(sg.rowptr, sg.col, sg.val, sg.items, sg.hubs, sg.n_slots, B, rows_per_block, K, bias, out, sg.n_rows, C,
+                       sg.n_wave_items)
         ctx.sg, ctx.K, ctx.has_bias = sg, K, bias is not None
         return out
 
@@ -251,7 +253,8 @@ class _CsrSpmm(torch.autograd.Function):
         C = g.shape[1]
         gB1 = torch.empty((sg.n_cols, C), device=g.device, dtype=torch.float32)
         with _span("csr_spmm_bwd"):
-            _spmm_call(sg.t_rowptr, sg.t_col, sg.t_val, sg.t_items, sg.t_hubs, sg.t_n_slots, g, sg.n_rows, 1, None, gB1, sg.n_cols, C)
+            _spmm_call(sg.t_rowptr, sg.t_col, sg.t_val, sg.t_items, sg.t_hubs, sg.t_n_slots, g, sg.n_rows, 1, None, gB1, sg.n_cols, C,
+                       sg.t_n_wave_items)
         gB = gB1 if K == 1 else gB1.unsqueeze(0).expand(K, -1, -1).reshape(K * sg.n_cols, C)  # every k-block sees the same A^T g
         from .dense import col_sum
         return gB, (col_sum(g) if ctx.has_bias else None), None, None

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 DEFAULT_CHUNK = 512   # edges per work item; longer segments (hubs) are split and summed in a second pass
+SPMM_GROUP_BELOW = 64  # SpMM rows shorter than this run one per C/4-lane group (a group walks its row alone, four gathers in flight)
 GROUP_BELOW = 16      # items shorter than this run one per H/4-lane group (several per wavefront) instead of one per wavefront
 
 
@@ -126,8 +127,10 @@ class SpmmGraph:
         self.t_val = None if self.val is None else f32(val[t_order])
         it, hb, self.n_slots = make_items(rp, DEFAULT_CHUNK)
         self.items, self.hubs = i32(it), i32(hb)
+        self.n_wave_items = int(((it[:, 2] - it[:, 1]) >= SPMM_GROUP_BELOW).sum())     # longest first: head per wave, tail grouped
         it, hb, self.t_n_slots = make_items(trp, DEFAULT_CHUNK)
         self.t_items, self.t_hubs = i32(it), i32(hb)
+        self.t_n_wave_items = int(((it[:, 2] - it[:, 1]) >= SPMM_GROUP_BELOW).sum())
 
     @classmethod
     def from_torch_sparse(cls, adj, device=None):

@@ -187,14 +187,14 @@ class _ShardedTail(torch.autograd.Function):
         h = all_to_all_rows_start(send, plan.send_counts, plan.recv_counts, plan.group)
         out = torch.empty((n, C), device=dev, dtype=torch.float32)
         with Fn._span("csr_spmm_fwd"):
-            Fn._spmm_call(sgo.rowptr, sgo.col, sgo.val, sgo.items, sgo.hubs, sgo.n_slots, S, sgo.n_cols, 1, bias, out, n, C)
+            Fn._spmm_call(sgo.rowptr, sgo.col, sgo.val, sgo.items, sgo.hubs, sgo.n_slots, S, sgo.n_cols, 1, bias, out, n, C, sgo.n_wave_items)
         with Fn._span("halo_wait"):
             S_halo = h.wait()
         if plan.n_halo:
             part = torch.empty((n, C), device=dev, dtype=torch.float32)
             with Fn._span("csr_spmm_fwd"):
                 Fn._spmm_call(sgh.rowptr, sgh.col, sgh.val, sgh.items, sgh.hubs, sgh.n_slots, S_halo.contiguous(), sgh.n_cols, 1, None,
-                              part, n, C)
+                              part, n, C, sgh.n_wave_items)
             out += part
         ctx.mod, ctx.has_bias = mod, bias is not None
         return out
@@ -211,11 +211,11 @@ class _ShardedTail(torch.autograd.Function):
             gh = torch.empty((plan.n_halo, C), device=dev, dtype=torch.float32)
             if plan.n_halo:
                 with Fn._span("csr_spmm_bwd"):
-                    Fn._spmm_call(sgh.t_rowptr, sgh.t_col, sgh.t_val, sgh.t_items, sgh.t_hubs, sgh.t_n_slots, g, n, 1, None, gh, plan.n_halo, C)
+                    Fn._spmm_call(sgh.t_rowptr, sgh.t_col, sgh.t_val, sgh.t_items, sgh.t_hubs, sgh.t_n_slots, g, n, 1, None, gh, plan.n_halo, C, sgh.t_n_wave_items)
             back = all_to_all_rows_start(gh, plan.recv_counts, plan.send_counts, plan.group)
         gS = torch.empty((n, C), device=dev, dtype=torch.float32)
         with Fn._span("csr_spmm_bwd"):
-            Fn._spmm_call(sgo.t_rowptr, sgo.t_col, sgo.t_val, sgo.t_items, sgo.t_hubs, sgo.t_n_slots, g, n, 1, None, gS, n, C)
+            Fn._spmm_call(sgo.t_rowptr, sgo.t_col, sgo.t_val, sgo.t_items, sgo.t_hubs, sgo.t_n_slots, g, n, 1, None, gS, n, C, sgo.t_n_wave_items)
         from .dense import col_sum
         gb = col_sum(g) if (ctx.has_bias and n > 0) else (torch.zeros(C, device=dev) if ctx.has_bias else None)
         if back is not None:
