@@ -58,6 +58,11 @@ def main():
         if e.get("SQ_WAVE_CYCLES"):
             line += "  valu/wave %.0f wait %.2f act %.2f" % (e["SQ_INSTS_VALU"] / max(e["SQ_WAVES"], 1), e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"],
                                                            e["SQ_ACTIVE_INST_ANY"] / e["SQ_WAVE_CYCLES"])
+            if e.get("SQ_WAIT_INST_ANY") is not None:
+                line += " inst-stall %.2f" % (e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"])
+            if e.get("SQ_VALU_MFMA_BUSY_CYCLES") and e.get("SQ_BUSY_CYCLES"):
+                # MFMA busy counts cycles summed over SIMDs; SQ_BUSY_CYCLES sums over the XCDs' SQs (MI355X_MICROARCH.md): relative only
+                line += " mfma_busy/sq_busy %.3f" % (e["SQ_VALU_MFMA_BUSY_CYCLES"] / e["SQ_BUSY_CYCLES"])
         print(line)
 
 
