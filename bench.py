@@ -19,7 +19,8 @@ Workload `c2l` (BASELINE configs[1] at ZINC-split scale): the drop-in `mma_amd.M
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant fused kernel, HIP-event timed inside the timed region,
 algorithmic bytes from DESIGN.md) and `cpu_baseline` (the CPU oracle on a bounded sample); at N=1 `extra` holds the
-other BASELINE configs that fit one GPU (C1, C3, C2, C2L: layer fwd+bwd, eager and one-hipGraph replay).
+other BASELINE configs that fit one GPU (C1, C3, C2, C2L: layer fwd+bwd, eager and one-hipGraph replay; C5 at its
+per-GPU shard shape).
 """
 import argparse
 import json
@@ -110,7 +111,7 @@ PMC_KERNEL = {"nc_fused_fwd": "mma::nc_fwd_", "nc_fused_bwd": "mma::nc_bwd_k",  
 
 def pmc_traffic(name, workload):
     """(HBM bytes per launch of the dominant kernel, source file) from the COMMITTED rocprofv3 PMC passes of this command
-    (profiles/r*_pmc_traffic*.json, made by tools/pmc_summary.py) - a recorded profile, not measured in this run;
+    (profiles/r*_pmc_traffic*.json, made by tools/make_profiles.py) - a recorded profile, not measured in this run;
     (None, None) when no profile matches the workload."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
@@ -299,9 +300,47 @@ def gr_config(tag, n_graphs, dev, reps=20, replay=True):
     return r
 
 
+def c5_shard_config(dev, reps=3):
+    """BASELINE configs[4] ("8 M nodes / 128 M edges, feat=256, K=8 aggregators + all scalers, 8 GPUs") at its PER-GPU shard
+    shape on this one GPU: R-MAT 2^20 nodes / ~16.4 M directed edges, H=256, K=8, the S=5 true-degree compounding scalers of
+    mma_conv.py:181-196 (strict_reference=False), p=0.5; layer fwd+bwd."""
+    import mma_amd
+    from mma_amd import functional as Fn
+    names = ["sum", "mean", "max", "min", "sum2", "mean2", "max2", "min2"]
+    H, C = 256, 16
+    rowptr, col = rmat_graph(20, 8_000_000, seed=42)
+    N, E, K = len(rowptr) - 1, int(rowptr[-1]), len(names)
+    graph = mma_amd.NCGraph(rowptr, col, dev)
+    layer = make_layer(mma_amd, graph, H, C, names, 0.5, dev, strict_reference=False, compound_scalers=True,
+                       scalers=["identity", "amplification", "attenuation", "linear", "inverse_linear"])
+    dst = np.repeat(np.arange(N, dtype=np.int64), np.diff(rowptr))
+    adj = mma_amd.graph.SpmmGraph(dst, col, None, N, N, dev)
+    x = torch.from_numpy(feature_rows(0, N, H, 42)).to(dev).requires_grad_(True)
+    cot = torch.from_numpy(feature_rows(0, N, C, 43, relu=False)).to(dev)
+
+    def step():
+        x.grad = None
+        for prm in layer.owned:
+            prm.grad = None
+        layer(x, adj).backward(cot)
+    step()
+    prev = Fn.TIMER
+    Fn.TIMER = t = KernelTimer(); t.enabled = True
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / reps * 1e3
+    spans = t.summary(); Fn.TIMER = prev
+    n_sel = 4 if Fn.SHARED_GRAD_BWD else None
+    return {"config": "C5 per-GPU shard shape: R-MAT 2^20 nodes / %d directed edges, feat=256, K=8 [%s], S=5 true-degree scalers, p=0.5" % (
+                E, ",".join(names)), "nodes": N, "edges": E, "hidden": H, "K": K, "ms_per_step": ms, "edges_per_s": E / ms * 1e3,
+            "kernels": _kernel_table(spans, reps, algorithmic_bytes(N, E, H, K, n_sel)),
+            "note": "one rank's share of configs[4] without the halo; the 8-GPU run itself is the driver's"}
+
+
 def extra_configs(dev):
     out = {}
-    for key, fn in (("C1", lambda: nc_config("C1: Cora structure, H=64, mean,mean2, p=0.75", "cora_h64", 64, ["mean", "mean2"], 7, 0.75, dev)),
+    for key, fn in (("C5shard", lambda: c5_shard_config(dev)), ("C1", lambda: nc_config("C1: Cora structure, H=64, mean,mean2, p=0.75", "cora_h64", 64, ["mean", "mean2"], 7, 0.75, dev)),
                     ("C3", lambda: nc_config("C3: Pubmed structure, H=16, min,min2,min3,min4, p=0.5", "pubmed_h16", 16,
                                              ["min", "min2", "min3", "min4"], 3, 0.5, dev)),
                     ("C2", lambda: gr_config("C2: ZINC-like batch of 64 molecules, MMAConv T=5 F=75 min,max x id,amp,lin", 64, dev)),

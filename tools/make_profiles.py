@@ -1,88 +1,140 @@
 #!/usr/bin/env python3
-"""Turn the raw rocprofv3 output of tools/profile_round.sh (gpurun_out/prof_stats, prof_fetch, prof_write, prof_gr, bench_default.log)
-into the committed summaries under profiles/:
+"""Turn the raw output of tools/profile_round.sh (gpurun_out/prof_c4_round_*, prof_c2l_round_*, bench_default.log,
+bench_c2l.log, parity_strict_report_gpu.jsonl) into the committed summaries under profiles/:
 
-    python tools/make_profiles.py <tag>          # e.g. r01_v4
+    python tools/make_profiles.py <round> <version>          # e.g. r02 v3
 
-  profiles/<round>_bench_kernel_stats_<v>.{md,csv}   per-kernel time of `bench.py --steps 5 --warmup 2 --cpu-sample 0`
-  profiles/<round>_pmc_traffic.json                  HBM traffic per kernel launch (FETCH_SIZE / WRITE_SIZE passes)
-  profiles/<round>_bench_default.json                the un-profiled default `python bench.py` line, traffic patched in
-  profiles/<round>_gr_c2l_kernel_stats_<v>.md        per-kernel time of the GR layer on the 10 000-graph batch
+  profiles/<round>_bench_kernel_stats_<v>.{md,csv}   per-kernel time of `bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-extra` (C4)
+  profiles/<round>_pmc_traffic.json                  C4: HBM traffic per kernel launch (FETCH_SIZE / WRITE_SIZE passes)
+  profiles/<round>_gr_c2l_kernel_stats_<v>.{md,csv}  per-kernel time of `bench.py --workload c2l --steps 5 --warmup 2 --cpu-sample 0`
+  profiles/<round>_gr_pmc_traffic.json               C2L: HBM traffic per kernel launch
+  profiles/<round>_bench_default.json / _bench_c2l.json   the un-profiled bench lines of the same build (traffic looked up again)
+  profiles/<round>_parity_strict_report.md           strict-bar (1e-5 + 1e-5|ref|) failure counts of every -m gpu comparison
 """
+import collections
 import csv
 import glob
 import json
 import os
 import shutil
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-WORKLOAD = ("C4 R-MAT 1,048,576 nodes / 10,864,894 directed edges, H=128, K=4 [sum,mean,max,min], p=0.5")
+P = os.path.join(ROOT, "profiles")
+C4 = "C4 R-MAT 1,048,576 nodes / 10,864,894 directed edges, H=128, K=4 [sum,mean,max,min], p=0.5"
+C2L = ("MMAConv 75->75, towers=5, edge_dim=50, aggregators [min,max], scalers [identity,amplification,linear] on 10 000 ZINC-like "
+       "molecules (204,552 nodes / 427,376 edges)")
 
 
-def newest(pattern):
+def find(pattern):
     fs = sorted(glob.glob(os.path.join(ROOT, pattern), recursive=True), key=os.path.getmtime)
     if not fs:
         raise SystemExit("missing " + pattern)
     return fs[-1]
 
 
-def stats_table(path, calls_per_step, title, command, notes, out_md, out_csv=None, top=26):
+def stats_table(path, calls, title, command, notes, out_md, out_csv, top=28):
     rows = list(csv.DictReader(open(path)))
     total = sum(int(r["TotalDurationNs"]) for r in rows)
     with open(out_md, "w") as f:
         f.write("# %s\n\nCommand (MI355X box): `%s`\n\n" % (title, command))
-        f.write(notes + " All GPU kernels: %.2f ms per step.\n\n" % (total / calls_per_step / 1e6))
+        f.write(notes + " All GPU kernels: %.2f ms per step (%d steps incl. warm-up).\n\n" % (total / calls / 1e6, calls))
         f.write("| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|\n")
         for r in rows[:top]:
-            f.write("| `%s` | %s | %.3f | %.3f | %s |\n" % (r["Name"][:110], r["Calls"], int(r["TotalDurationNs"]) / 1e6,
-                                                         float(r["AverageNs"]) / 1e6, r["Percentage"]))
-    if out_csv:
-        shutil.copy(path, out_csv)
-    return total / calls_per_step / 1e6
+            f.write("| `%s` | %s | %.3f | %.4f | %s |\n" % (r["Name"][:110], r["Calls"], int(r["TotalDurationNs"]) / 1e6,
+                                                          float(r["AverageNs"]) / 1e6, r["Percentage"]))
+    shutil.copy(path, out_csv)
+    return total / calls / 1e6
+
+
+def traffic(base, out, workload, note):
+    def per_kernel(d, counter):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(find(d + "/**/*counter_collection.csv"))):
+            if r["Counter_Name"] == counter:
+                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        return {k: (len(v), sum(v) / len(v)) for k, v in agg.items()}
+    F, W = per_kernel(base + "_fetch", "FETCH_SIZE"), per_kernel(base + "_write", "WRITE_SIZE")
+    res = {"note": note, "workload": workload,
+           "correction": "traffic_bytes = 2*FETCH_SIZE_KiB*1024 + WRITE_SIZE_KiB*1024 (gfx950: FETCH_SIZE halves wide reads; MI355X_MICROARCH.md HBM)",
+           "kernels": {}}
+    for k in sorted(F):
+        if "mma::" in k:
+            n, f = F[k]
+            w = W.get(k, (0, 0.0))[1]
+            res["kernels"][k] = {"launches_sampled": n, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes": 2 * f * 1024 + w * 1024}
+    json.dump(res, open(out, "w"), indent=1)
+    return res
+
+
+def bench_line(log, out):
+    import bench
+    b = json.loads([l for l in open(os.path.join(ROOT, "gpurun_out", log)) if l.startswith("{")][-1])
+    c = b["config"]
+    for key in ("roofline", "roofline_other"):
+        r = b.get(key)
+        if r:
+            wl = {"workload": "c2l", "nodes": c["nodes"], "edges": c["edges"]} if "towers" in c else \
+                {"nodes": c["nodes"], "edges": c["edges"], "hidden": c["hidden"], "K": c["K"]}
+            t, src = bench.pmc_traffic(r["kernel"], wl)
+            r["traffic"], r["traffic_source"] = t, ("recorded rocprofv3 PMC passes of this command, " + src) if src else None
+    json.dump(b, open(out, "w"))
+    return b
+
+
+def parity_report(out):
+    src = os.path.join(ROOT, "gpurun_out", "parity_strict_report_gpu.jsonl")
+    if not os.path.exists(src):
+        return
+    rows = [json.loads(l) for l in open(src)]
+    bad = [r for r in rows if r["strict_outside"]]
+    agg = collections.OrderedDict()
+    for r in rows:
+        key = r["what"].split("/")[-1] if r["what"].startswith(("set/", "single/")) else r["what"]
+        a = agg.setdefault(key, {"cmp": 0, "n": 0, "outside": 0, "max_err": 0.0, "max_ref": 0.0, "need": 0.0, "bar": r["bar"]})
+        a["cmp"] += 1; a["n"] += r["n"]; a["outside"] += r["strict_outside"]
+        a["max_err"] = max(a["max_err"], r["max_err"]); a["max_ref"] = max(a["max_ref"], r["max_ref"])
+        a["need"] = max(a["need"], r.get("noise_multiple_needed") or 0.0)
+    with open(out, "w") as f:
+        f.write("# Strict-bar report of the `-m gpu` parity comparisons\n\nEvery comparison of the HIP path with a golden vector or the CPU oracle "
+                "counts the elements outside the STRICT bar `|got - want| <= 1e-5 + 1e-5 |want|` (tests/golden_util.py), whatever bar it "
+                "asserts. %d comparisons, %d elements; %d comparisons have elements outside the strict bar, %d elements in all (%.4f %%). "
+                "`need` = the largest multiple of the reference's own fp32 noise (rowmax |reference - float64 oracle|) any element "
+                "needs on top of the strict bar (asserted: 8).\n\n" % (len(rows), sum(r["n"] for r in rows), len(bad),
+                                                                     sum(r["strict_outside"] for r in bad),
+                                                                     100.0 * sum(r["strict_outside"] for r in bad) / max(1, sum(r["n"] for r in rows))))
+        f.write("| quantity | comparisons | elements | outside strict | max err | max ref | need | asserted bar |\n|---|---|---|---|---|---|---|---|\n")
+        for k, a in agg.items():
+            f.write("| %s | %d | %d | %d | %.3g | %.3g | %.2f | %s |\n" % (k, a["cmp"], a["n"], a["outside"], a["max_err"], a["max_ref"], a["need"], a["bar"]))
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01_v4"
-    rnd, ver = tag.split("_")
-    P = os.path.join(ROOT, "profiles")
-    ms = stats_table(newest("gpurun_out/prof_stats/**/*kernel_stats.csv"), 7,
+    rnd, ver = sys.argv[1], sys.argv[2]
+    cmd4 = "python bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-extra"
+    ms = stats_table(find("gpurun_out/prof_c4_round_stats/**/*kernel_stats.csv"), 7,
                      "rocprofv3 --kernel-trace --stats, round %s, build %s" % (rnd[1:], ver),
-                     "rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python bench.py --steps 5 --warmup 2 --cpu-sample 0",
-                     "Workload: " + WORKLOAD + "; 7 layer calls (2 warmup + 5 timed). One `mma_nc_fused_fwd` / `mma_nc_fused_bwd` call = two "
-                     "launches of the kernel (last template flag false: one work item per wavefront, long segments; true: one item per "
-                     "32-lane group, short segments) + the hub finalize; bench.py's HIP-event time of a call is their sum. Un-profiled "
-                     "default run of the same build: profiles/%s_bench_default.json." % rnd,
+                     "rocprofv3 --kernel-trace --stats --output-format csv -- " + cmd4,
+                     "Workload: " + C4 + ". One `mma_nc_fused_fwd` / `mma_nc_fused_bwd` call = two launches of the kernel (last template "
+                     "flag false: one work item per wavefront, long segments; true: one item per 32-lane group, short segments) + the hub "
+                     "finalize; bench.py's HIP-event time of a call is their sum. Un-profiled default run of the same build: profiles/%s_bench_default.json." % rnd,
                      os.path.join(P, "%s_bench_kernel_stats_%s.md" % (rnd, ver)), os.path.join(P, "%s_bench_kernel_stats_%s.csv" % (rnd, ver)))
     print("C4 profiled step: %.2f ms" % ms)
-    fd = os.path.dirname(newest("gpurun_out/prof_fetch/**/*counter_collection.csv"))
-    wd = os.path.dirname(newest("gpurun_out/prof_write/**/*counter_collection.csv"))
-    out = os.path.join(P, "%s_pmc_traffic.json" % rnd)
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), fd, wd, out,
-                           "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 5 --warmup 2 "
-                           "--cpu-sample 0; MI355X, round %s, build %s" % (rnd[1:], ver)])
-    d = json.load(open(out))
-    d["workload"] = {"nodes": 1048576, "edges": 10864894, "hidden": 128, "K": 4}      # what bench.pmc_traffic matches on
-    json.dump(d, open(out, "w"), indent=1)
-    import bench
-    line = [l for l in open(os.path.join(ROOT, "gpurun_out", "bench_default.log")) if l.startswith("{")][-1]
-    b = json.loads(line)
-    c = b["config"]
-    b["roofline"]["traffic"] = bench.pmc_traffic(b["roofline"]["kernel"], c["nodes"], c["edges"], c["hidden"], c["K"])
-    json.dump(b, open(os.path.join(P, "%s_bench_default.json" % rnd), "w"))
-    print("default bench: %.2f ms/step, roofline frac %.3f, traffic %s" % (b["ms_per_step"], b["roofline"]["frac"], b["roofline"]["traffic"]))
-    try:
-        g = newest("gpurun_out/prof_gr/**/*kernel_stats.csv")
-    except SystemExit:
-        return
-    ms = stats_table(g, 35, "rocprofv3 --kernel-trace --stats, GR layer on the 10 000-graph batch (C2L), round %s, build %s" % (rnd[1:], ver),
-                     "rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_gr -- python tools/gr_c2l_step.py",
-                     "Workload: MMAConv 75->75, towers=5, edge_dim=50, aggregators [min,max], scalers [identity,amplification,linear] on 10 000 "
-                     "ZINC-like molecules (204,552 nodes / 427,376 edges); 35 layer forward+backward calls.",
-                     os.path.join(P, "%s_gr_c2l_kernel_stats_%s.md" % (rnd, ver)))
+    traffic("gpurun_out/prof_c4_round", os.path.join(P, "%s_pmc_traffic.json" % rnd), {"nodes": 1048576, "edges": 10864894, "hidden": 128, "K": 4},
+            "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- %s; MI355X, round %s, build %s" % (cmd4, rnd[1:], ver))
+    cmd2 = "python bench.py --workload c2l --steps 5 --warmup 2 --cpu-sample 0"
+    ms = stats_table(find("gpurun_out/prof_c2l_round_stats/**/*kernel_stats.csv"), 7,
+                     "rocprofv3 --kernel-trace --stats, GR layer on the 10 000-molecule batch (C2L), round %s, build %s" % (rnd[1:], ver),
+                     "rocprofv3 --kernel-trace --stats --output-format csv -- " + cmd2, "Workload: " + C2L + ".",
+                     os.path.join(P, "%s_gr_c2l_kernel_stats_%s.md" % (rnd, ver)), os.path.join(P, "%s_gr_c2l_kernel_stats_%s.csv" % (rnd, ver)))
     print("C2L profiled step: %.2f ms" % ms)
+    traffic("gpurun_out/prof_c2l_round", os.path.join(P, "%s_gr_pmc_traffic.json" % rnd), {"workload": "c2l", "nodes": 204552, "edges": 427376},
+            "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- %s; MI355X, round %s, build %s" % (cmd2, rnd[1:], ver))
+    b = bench_line("bench_default.log", os.path.join(P, "%s_bench_default.json" % rnd))
+    print("default bench: %.2f ms/step, roofline %s frac %.3f, traffic %s" % (b["ms_per_step"], b["roofline"]["kernel"], b["roofline"]["frac"], b["roofline"]["traffic"]))
+    b = bench_line("bench_c2l.log", os.path.join(P, "%s_bench_c2l.json" % rnd))
+    print("c2l bench: %.2f ms/step, roofline %s frac %.3f / %.3f" % (b["ms_per_step"], b["roofline"]["kernel"], b["roofline"]["frac"], b["roofline_other"]["frac"]))
+    parity_report(os.path.join(P, "%s_parity_strict_report.md" % rnd))
 
 
 if __name__ == "__main__":
