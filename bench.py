@@ -358,7 +358,8 @@ def shared_graph(args, rank, world, barrier):
     generating a scale-23 graph each would need 8x the host memory and time)."""
     if world == 1:
         return rmat_graph(args.scale, args.edges, seed=42)
-    tag = "/dev/shm/mma_bench_%d_%s_s%d_e%d" % (os.getuid(), os.environ.get("MASTER_PORT", "0"), args.scale, args.edges)
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else __import__("tempfile").gettempdir()
+    tag = "%s/mma_bench_%d_%s_s%d_e%d" % (base, os.getuid(), os.environ.get("MASTER_PORT", "0"), args.scale, args.edges)
     if rank == 0:
         rowptr, col = rmat_graph(args.scale, args.edges, seed=42)
         np.save(tag + "_rowptr.npy", rowptr)

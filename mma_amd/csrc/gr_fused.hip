@@ -1039,7 +1039,8 @@ static int gr_block_mode(GrParams* p, int64_t E, bool v4, bool backward) {
       default: return 0;                                   // var / std: generic kernels
     }
   }
-  if ((needs & ~(NEED_MIN | NEED_MAX)) != 0) needs = NEED_SUM | NEED_MIN | NEED_MAX;   // two instantiations: {min,max} and everything
+  // two instantiations: {min,max} and everything.  The LDS planes below are sized for the INSTANTIATION, not for the list
+  needs = (needs & ~(NEED_MIN | NEED_MAX)) != 0 ? (NEED_SUM | NEED_MIN | NEED_MAX) : (NEED_MIN | NEED_MAX);
   const int n_coef = (needs & NEED_SUM ? 1 : 0) + (needs & NEED_MIN ? 1 : 0) + (needs & NEED_MAX ? 1 : 0);
   const uint32_t qd = (uint32_t)p->D / 4, f4 = (uint32_t)p->F / 4, skf4 = (uint32_t)(p->S * p->K) * f4, tskf4 = (uint32_t)p->T * skf4;
   const uint32_t head = kBlkHead;
