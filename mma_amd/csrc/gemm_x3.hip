@@ -97,7 +97,8 @@ __device__ __forceinline__ void slab_store(unsigned char* dst, int tid, const Sl
 // NCT == 0: K == 128, any number of column tiles, one accumulator tile at a time.
 // FULL: every row of the block exists (no guards: the C stores are unconditional, so the compiler can count them in
 // vmcnt and never waits for a store); the last partial block is a separate guarded launch.
-template <int NCT, bool FULL>
+// ACC: C += A B (a template parameter: as a run-time flag the 16 old values cost the plain K == 128 form 12 spilled VGPRs).
+template <int NCT, bool FULL, bool ACC>
 __global__ __launch_bounds__(kBlock, 2) void gemm_x3_kernel(const GemmParams p, int64_t blk0, int64_t n_blocks) {
   constexpr bool PERSIST = NCT > 0;
   constexpr int KC = PERSIST ? kKCPersist : kKC;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_kernel(const GemmParams p, 
       /* C += A B: the tile's 16 old values per lane are fetched in ONE batch before its last MFMA block (round 1 loaded,  \
          waited, added and stored them one by one after it: 64 serialised HBM round trips per row block of dL/dx) */      \
       float oldv[16];                                                                                        \
-      if ((LAST_) && p.accumulate) {                                                                         \
+      if ((LAST_) && ACC) {                                                                         \
         const float* op = p.C + (size_t)((CT_) * 32 + r31);                                                  \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                     \
           const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;                                         \
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_kernel(const GemmParams p, 
       }                                                                                                      \
       if (LAST_) { /* acc reg r holds row (r&3) + 8*(r>>2) + 4*h, column r31 of the tile */   \
         float* cp = p.C + (size_t)((CT_) * 32 + r31);                                                        \
-        if (p.accumulate) {   /* two store sequences: a select would make the plain path wait for loads it never issued */ \
+        if (ACC) {                                                                                           \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                   \
             const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;                                       \
             if (FULL || row < p.M) cp[row * p.ldc] = oldv[r] + C_[r];                                        \
@@ -461,8 +462,10 @@ extern "C" int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, flo
     if (nb == 0) continue;
     const dim3 grid((unsigned)(nb < 512 ? nb : 512));      // 2 workgroups per CU (52 KB LDS, ~250 VGPRs each)
 #define MMA_X3_LAUNCH(NCT_)                                                                                       \
-    if (full) hipLaunchKernelGGL((gemm_x3_kernel<NCT_, true>), grid, dim3(kBlock), 0, st, p, blk0, nb);           \
-    else hipLaunchKernelGGL((gemm_x3_kernel<NCT_, false>), grid, dim3(kBlock), 0, st, p, blk0, nb);
+    if (full && accumulate) hipLaunchKernelGGL((gemm_x3_kernel<NCT_, true, true>), grid, dim3(kBlock), 0, st, p, blk0, nb);   \
+    else if (full) hipLaunchKernelGGL((gemm_x3_kernel<NCT_, true, false>), grid, dim3(kBlock), 0, st, p, blk0, nb);           \
+    else if (accumulate) hipLaunchKernelGGL((gemm_x3_kernel<NCT_, false, true>), grid, dim3(kBlock), 0, st, p, blk0, nb);     \
+    else hipLaunchKernelGGL((gemm_x3_kernel<NCT_, false, false>), grid, dim3(kBlock), 0, st, p, blk0, nb);
     switch (nct) {
       case 0: MMA_X3_LAUNCH(0) break;
       case 1: MMA_X3_LAUNCH(1) break;

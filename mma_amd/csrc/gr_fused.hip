@@ -1172,6 +1172,9 @@ extern "C" int mma_gr_fused_fwd(
   const int D = T * F;
   MMA_REQUIRE(rowptr && out, "NULL argument");
   MMA_REQUIRE(E == 0 || (src && perm), "NULL CSR arrays");
+  if (E == 0 && !inputs && !(U && V)) {      // given-messages form with no message: an (0, D) tensor has no address.  No row is ever
+    inputs = out; ldi = D;                   // read; the pointer only selects the form (every target is empty: 0, or sqrt(eps) for std)
+  }
   MMA_REQUIRE((inputs != nullptr) != (U != nullptr && V != nullptr), "give either `inputs` or U and V");
   MMA_REQUIRE(inputs ? ldi >= D : (lduv >= D && (!Z || ldz >= D)), "row pitch too small");
   MMA_REQUIRE(!(amin8 || amax8 || mean || var) || ldsave >= D, "ldsave=%lld < T*F", (long long)ldsave);
@@ -1182,7 +1185,8 @@ extern "C" int mma_gr_fused_fwd(
   const dim3 grid = gr_grid(N, D, v4 ? 4 : 1, &p.lpr_log);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool drop = p.drop.mode != MMA_DROP_NONE;
-  if (const int needs = gr_block_mode(&p, E, v4, false)) {       // molecule-batch shape: two-phase block kernel
+  if (E == 0) {                                                   // no edge: the plain wave-per-node kernel writes the empty results
+  } else if (const int needs = gr_block_mode(&p, E, v4, false)) { // molecule-batch shape: two-phase block kernel
     const dim3 bg = gr_block_grid(p);
     if (inputs) launch_fwd_block<false, false, false>(needs, bg, p.lds_bytes, st, p);
     else if (Z) { if (drop) launch_fwd_block<true, true, true>(needs, bg, p.lds_bytes, st, p); else launch_fwd_block<true, true, false>(needs, bg, p.lds_bytes, st, p); }

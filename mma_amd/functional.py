@@ -400,10 +400,6 @@ class _GRAggregate(torch.autograd.Function):
         mean = torch.empty((N, D), device=dev) if stats else None
         var = torch.empty((N, D), device=dev) if stats else None
         ctx.cfg = (graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, Z is not None, by_pos)
-        if E == 0:          # nothing to aggregate: every target is empty -> 0 (and a zero gradient)
-            out.zero_()
-            ctx.save_for_backward(inputs, UV, Z, None, None, None, None, None, None)
-            return out
         with _span("gr_fused_fwd"):
             _gr_call("mma_gr_fused_fwd", csr, U, V, Z, by_pos, inputs,
                      (ptr(out), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), ptr(mean), ptr(var), D, ptr(csr.long_nodes)),

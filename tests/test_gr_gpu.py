@@ -255,3 +255,27 @@ def test_gr_degenerate_inputs():
     assert torch.isfinite(x.grad).all()
     agg = conv.aggregate(torch.zeros(0, 2, 4, device=DEV), torch.zeros(0, dtype=torch.int64, device=DEV), 5)
     assert agg.shape == (5, 2, 32) and (agg == 0).all()
+
+
+@pytest.mark.parametrize("scalers", [["identity"], ["identity", "amplification", "attenuation"]])
+def test_no_edges_every_target_is_empty_like_the_reference(scalers):
+    """E == 0 (found by the generated cases): an empty target is 0 for sum / mean / min / max / var but sqrt(relu(0) + 1e-5)
+    for std (mma_conv.py:167-172), then scaled with the clamped degree 1 - in both forms (given messages, fused from x)."""
+    import mma_amd
+    from oracle import gr_oracle as G
+    aggs, T, F, N = ["sum", "mean", "min", "max", "var", "std"], 2, 4, 7
+    conv = mma_amd.MMAConv(F * T, F * T, aggs, scalers, torch.tensor([0, 4, 9, 3, 1]), towers=T, divide_input=True).to(DEV)
+    index = torch.zeros(0, dtype=torch.int64)
+    want = G.aggregate(torch.zeros(0, T, F), index, N, aggs, scalers, conv.avg_deg).numpy()
+    assert (want != 0).any()                                         # the std columns
+    xg = torch.zeros(0, T, F, device=DEV, requires_grad=True)
+    got = conv.aggregate(xg, index.to(DEV), N)
+    check_close(got, want, None, None, what="no-edge aggregate")
+    g, = torch.autograd.grad(got.sum(), [xg])
+    assert g.shape == (0, T, F)
+    conv4 = make_conv(aggs[:4], scalers, towers=T, F=F, divide_input=True)      # forward() takes the four scatter names only (G5)
+    x = torch.randn(N, F * T, device=DEV, requires_grad=True)
+    out = conv4(x, torch.zeros((2, 0), dtype=torch.int64, device=DEV))
+    assert torch.isfinite(out).all()
+    out.sum().backward()
+    assert torch.isfinite(x.grad).all()
