@@ -215,6 +215,113 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_kernel(const GemmParams p, 
 
 #undef MMA_X3_TILE
 
+// ---- K == 128, N % 128 == 0: "column group" form (round 2) ------------------------------------------------------------
+// A workgroup owns 128 columns of C for the whole launch: their three-piece B slab (4 tiles x 3 x 32 x 128 bf16 = 102 KB
+// with the row padding) is staged into LDS ONCE, so the steady state has no slab loads, no LDS writes and no barrier - a
+// wave only streams its A rows in, runs 4 x 48 MFMAs against the resident slab (fragments of the next k-step requested
+// before the current step's MFMAs) and stores its 4 tiles with buffer stores (SGPR row offsets: no per-store address VALU).
+// 8 waves = 256 rows per workgroup step; one workgroup per CU (LDS), 2 waves per SIMD.  The N/128 workgroups that take
+// the SAME rows sit on one XCD (block ids congruent mod 8 share an XCD and its L2) and share A through that L2.
+// Measured (C4 forward, M = 2^20, N = 1024; same box, back to back): gemm_x3_kernel<0> 1.65-1.67 ms, this kernel 1.51-1.53 ms.
+// With ZERO-filled operands the same two binaries take 1.31 and 1.09 ms: on real data the kernel is held by the chip's
+// power management (PMC: 1.84 GHz effective clock instead of 2.4), not by its schedule - a 12-wave variant (3 per SIMD)
+// and a variant that prefetches the next A block into registers both land on the same 1.51-1.53 ms.
+constexpr int kCgWaves = 8, kCgThreads = 64 * kCgWaves, kCgRows = 32 * kCgWaves;
+// nt on the C stores: C streams out once; with the default policy the 4 MB of C per step flush the A rows the other column
+// groups still need out of the XCD's L2 (PMC: 2.5 GB of A re-reads per launch, 1.6 GB with nt; A itself is 0.54 GB)
+constexpr int kCgStoreAux = 2;
+constexpr int kCgPitch = 128 * 2 + 16, kCgPiece = 32 * kCgPitch, kCgTile = 3 * kCgPiece, kCgLds = 4 * kCgTile;
+constexpr int kCgSlotsPerXcd = 32;                  // 256 CUs / 8 XCDs
+
+struct BFrag { bf16x8 b1, b2, b3; };
+__device__ __forceinline__ BFrag cg_frag(const unsigned char* sb, int ks) {
+  BFrag f;
+  f.b1 = *reinterpret_cast<const bf16x8*>(sb + 0 * kCgPiece + ks * 32);
+  f.b2 = *reinterpret_cast<const bf16x8*>(sb + 1 * kCgPiece + ks * 32);
+  f.b3 = *reinterpret_cast<const bf16x8*>(sb + 2 * kCgPiece + ks * 32);
+  return f;
+}
+
+__global__ __launch_bounds__(kCgThreads, 1) void gemm_x3_colgroup_kernel(const GemmParams p, int64_t n_units, int n_groups) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kCgLds];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, h = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int streams_per_xcd = kCgSlotsPerXcd / n_groups;
+  const int g = slot % n_groups;
+  const int64_t stream = xcd * streams_per_xcd + slot / n_groups, n_streams = 8 * streams_per_xcd;
+
+  for (int q = tid; q < 4 * 3 * 32 * 16; q += kCgThreads) {          // 6144 16-byte chunks, 12 per thread
+    const int kq = q & 15, col = (q >> 4) & 31, tp = q >> 9, piece = tp % 3, tile = tp / 3;
+    *reinterpret_cast<uint4*>(lds + tile * kCgTile + piece * kCgPiece + col * kCgPitch + kq * 16) =
+        *reinterpret_cast<const uint4*>(p.Bt + ((size_t)piece * p.N + (size_t)(g * 128 + tile * 32 + col)) * 128 + kq * 8);
+  }
+  __syncthreads();
+
+  // addresses = wave-uniform base (SGPRs) + one 32-bit lane offset: 16 precomputed 64-bit row pointers would cost 32 VGPRs
+  const uint32_t a_off = (uint32_t)r31 * (uint32_t)p.lda + 8u * h;
+  const uint32_t c_off = 4u * h * (uint32_t)p.ldc + (uint32_t)r31;
+  const unsigned char* sb0 = lds + r31 * kCgPitch + h * 16;
+
+  BFrag cur = cg_frag(sb0, 0);
+  for (int64_t u = stream; u < n_units; u += n_streams) {
+    float4 raw[16];                                          // this lane's 64 A values (prefetching the next block's changed nothing)
+    {
+      const float* ap = p.A + (u * kCgRows + wave * 32) * p.lda;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        raw[2 * ks] = *reinterpret_cast<const float4*>(ap + a_off + ks * 16);
+        raw[2 * ks + 1] = *reinterpret_cast<const float4*>(ap + a_off + ks * 16 + 4);
+      }
+    }
+    bf16x8 af[8][3];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const float4 lo = raw[2 * ks], hi = raw[2 * ks + 1];
+      { const Bf3 t = split3(lo.x); af[ks][0][0] = t.a; af[ks][1][0] = t.b; af[ks][2][0] = t.c; }
+      { const Bf3 t = split3(lo.y); af[ks][0][1] = t.a; af[ks][1][1] = t.b; af[ks][2][1] = t.c; }
+      { const Bf3 t = split3(lo.z); af[ks][0][2] = t.a; af[ks][1][2] = t.b; af[ks][2][2] = t.c; }
+      { const Bf3 t = split3(lo.w); af[ks][0][3] = t.a; af[ks][1][3] = t.b; af[ks][2][3] = t.c; }
+      { const Bf3 t = split3(hi.x); af[ks][0][4] = t.a; af[ks][1][4] = t.b; af[ks][2][4] = t.c; }
+      { const Bf3 t = split3(hi.y); af[ks][0][5] = t.a; af[ks][1][5] = t.b; af[ks][2][5] = t.c; }
+      { const Bf3 t = split3(hi.z); af[ks][0][6] = t.a; af[ks][1][6] = t.b; af[ks][2][6] = t.c; }
+      { const Bf3 t = split3(hi.w); af[ks][0][7] = t.a; af[ks][1][7] = t.b; af[ks][2][7] = t.c; }
+    }
+    // C goes out through buffer stores: wave-uniform descriptor + SGPR row offset + one VGPR lane offset (global stores made
+    // the compiler keep 16 64-bit row pointers in VGPRs and add to each per tile)
+    const __amdgpu_buffer_rsrc_t crow =
+        __builtin_amdgcn_make_buffer_rsrc(p.C + (u * kCgRows + wave * 32) * p.ldc + g * 128, 0, 0x7fffffff, 0x00020000);
+#pragma unroll 1
+    for (int ct = 0; ct < 4; ++ct) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const unsigned char* sb = sb0 + ct * kCgTile;
+      const unsigned char* sbn = sb0 + ((ct + 1) & 3) * kCgTile;       // B is static: the first fragments of the next tile too
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        // the fragments of the NEXT k-step are requested before this step's MFMAs (left alone the compiler reads, waits,
+        // multiplies: ~100 cycles of LDS latency exposed per 192 cycles of MFMA)
+        const BFrag nxt = ks < 7 ? cg_frag(sb, ks + 1) : cg_frag(sbn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], cur.b3, acc, 0, 0, 0);     // same product order as gemm_x3_kernel:
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1], cur.b2, acc, 0, 0, 0);     // bitwise the same C
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][2], cur.b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], cur.b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1], cur.b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], cur.b1, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), crow, c_off * 4u,
+                                              (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + ct * 32) * 4u, kCgStoreAux);
+    }
+  }
+}
+
 // split a row-major fp32 matrix (rows, cols) into its three bf16 pieces: out (3, rows, cols)
 __global__ void split3_kernel(const float* in, int64_t n, __bf16* out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -448,17 +555,26 @@ extern "C" int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, flo
   MMA_REQUIRE(M >= 0 && N >= 32 && K >= kKC && N % 32 == 0 && K % kKC == 0, "M=%lld N=%d K=%d: need N %% 32 == 0, K %% 128 == 0",
               (long long)M, N, K);
   MMA_REQUIRE(K == kKC || N <= 128, "either K == 128 or N <= 128 (accumulator tiles live in registers)");
-  MMA_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0, "row pitch too small or unaligned");
+  MMA_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && lda < (1 << 24) && ldc < (1 << 24), "row pitch too small, unaligned or >= 2^24");
   if (M == 0) return 0;
   MMA_REQUIRE(A && Bt3 && C && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt3) & 15) == 0,
               "NULL or misaligned argument");
   GemmParams p{A, lda, static_cast<const __bf16*>(Bt3), C, ldc, M, N, K, accumulate ? 1 : 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nct = K == kKC ? 0 : N / 32;
+  // tall plain K == 128 products with whole 128-column groups: the column-group kernel takes every full 256-row unit
+  int64_t first_blk = 0;
+  const int n_groups = N / 128;
+  if (K == kKC && !accumulate && N % 128 == 0 && kCgSlotsPerXcd % n_groups == 0 && M / kCgRows >= 4 * (256 / n_groups)) {
+    const int64_t n_units = M / kCgRows;
+    hipLaunchKernelGGL(gemm_x3_colgroup_kernel, dim3(256), dim3(kCgThreads), 0, st, p, n_units, n_groups);
+    if (int rc = check_launch("gemm_x3_colgroup_kernel")) return rc;
+    first_blk = n_units * (kCgRows / 128);
+  }
   const int64_t n_full = M / 128;
   for (int part = 0; part < 2; ++part) {
     const bool full = part == 0;
-    const int64_t blk0 = full ? 0 : n_full, nb = full ? n_full : ((M % 128) ? 1 : 0);
+    const int64_t blk0 = full ? first_blk : n_full, nb = full ? n_full - first_blk : ((M % 128) ? 1 : 0);
     if (nb == 0) continue;
     const dim3 grid((unsigned)(nb < 512 ? nb : 512));      // 2 workgroups per CU (52 KB LDS, ~250 VGPRs each)
 #define MMA_X3_LAUNCH(NCT_)                                                                                       \

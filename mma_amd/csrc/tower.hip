@@ -85,7 +85,9 @@ __global__ __launch_bounds__(kBlock) void tower_bwd_kernel(const TowerParams p) 
   }
   if (valid) {       // one partial tile per (node block, piece); K8 sums the node blocks in a fixed order
     float* q = p.part + ((size_t)blockIdx.x * p.T + t) * p.O * p.C + c;
-    for (int o = 0; o < p.O; ++o) *reinterpret_cast<float4*>(q + (size_t)o * p.C) = acc[o];
+#pragma unroll                 // compile-time indices: a run-time `o` keeps the whole acc array in scratch memory (it did: 272 B/lane)
+    for (int o = 0; o < kTowerMaxO; ++o)
+      if (o < p.O) *reinterpret_cast<float4*>(q + (size_t)o * p.C) = acc[o];
   }
 }
 

@@ -9,7 +9,8 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("M,K,N", [(5000, 128, 512), (4099, 512, 128), (9001, 256, 64), (4096, 128, 32), (70000, 384, 96),
-                                   (5003, 256, 384), (4100, 1024, 256)])      # the last two: column-blocked (K > 128 and N > 128)
+                                   (5003, 256, 384), (4100, 1024, 256),       # these two: column-blocked (K > 128 and N > 128)
+                                   (40037, 128, 1024), (70001, 128, 512), (140001, 128, 256), (263000, 128, 128)])   # column-group kernel + tail
 def test_gemm_bf16x3_accuracy(M, K, N):
     from mma_amd import dense
     rng = np.random.default_rng(M + K + N)

@@ -36,6 +36,7 @@ def main():
     base = sys.argv[1]
     t = trace(base + "_stats")
     cf, cw, cs = counters(base + "_fetch"), counters(base + "_write"), counters(base + "_sq")
+    ck, tk = counters(base + "_clk"), trace(base + "_clk")
     res = {}
     for k, v in sorted(t.items(), key=lambda kv: -sum(kv[1])):
         if "mma::" not in k:
@@ -48,6 +49,9 @@ def main():
             e.update(FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w, traffic_bytes=2 * f * 1024 + w * 1024)
         for c, xs in cs[k].items():
             e[c] = avg(xs)
+        gui = avg(ck[k].get("GRBM_GUI_ACTIVE", []))
+        if gui and tk.get(k):          # cycles summed over the 8 XCDs / the duration seen in the SAME pass
+            e["clock_GHz"] = gui / 8 / (avg(tk[k]) * 1e3)
         res[short] = e
     out = sys.argv[2] if len(sys.argv) > 2 else base + "_summary.json"
     json.dump(res, open(out, "w"), indent=1)
@@ -55,6 +59,8 @@ def main():
         line = "%-62s n=%3d avg %9.1f us" % (k[:62], e["launches"], e["avg_us"])
         if "traffic_bytes" in e:
             line += "  traffic %.3f GB (rd %.3f wr %.3f)" % (e["traffic_bytes"] / 1e9, 2 * e["FETCH_SIZE_KiB"] * 1024 / 1e9, e["WRITE_SIZE_KiB"] * 1024 / 1e9)
+        if e.get("clock_GHz"):
+            line += "  clk %.2f GHz" % e["clock_GHz"]
         if e.get("SQ_WAVE_CYCLES"):
             line += "  valu/wave %.0f wait %.2f act %.2f" % (e["SQ_INSTS_VALU"] / max(e["SQ_WAVES"], 1), e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"],
                                                            e["SQ_ACTIVE_INST_ANY"] / e["SQ_WAVE_CYCLES"])
