@@ -267,7 +267,9 @@ def gr_setup(n_graphs, dev, seed=0):
     rng = np.random.default_rng(seed)
     ei, N = molecule_batch(rng, n_graphs)
     E = ei.shape[1]
-    hist = np.bincount(np.bincount(ei[1], minlength=N), minlength=5)
+    # the degree histogram is a property of the training SET (mma.py:57-60), the same on every replica: batch 0's
+    hi, hN = (ei, N) if seed == 0 else molecule_batch(np.random.default_rng(0), n_graphs)
+    hist = np.bincount(np.bincount(hi[1], minlength=hN), minlength=5)
     conv = mma_amd.MMAConv(75, 75, ["min", "max"], ["identity", "amplification", "linear"], torch.tensor(hist), edge_dim=50,
                            towers=5).to(dev)
     x = torch.randn(N, 75, device=dev, requires_grad=True)
@@ -275,8 +277,12 @@ def gr_setup(n_graphs, dev, seed=0):
     eig = torch.from_numpy(ei).to(dev)
     cot = torch.randn(N, 75, device=dev)
 
+    params = [q for q in conv.parameters() if q.requires_grad]
+
     def step():
         x.grad = None
+        for q in params:                   # optimizer.zero_grad(): the backward then assigns instead of launching an add per tensor
+            q.grad = None
         conv(x, eig, ea).backward(cot)
     return conv, step, N, E
 
@@ -432,9 +438,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.workload == "c2l":
-        assert not sharded, "c2l: molecule batches are independent - run replicas, there is no halo (DESIGN.md 5)"
-        return run_c2l(args, dev)
+    if args.workload == "c2l":       # molecule batches are independent: N > 1 = data-parallel replicas, no halo
+        run_c2l(args, dev, rank, world, barrier)
+        if sharded:
+            dist.destroy_process_group()
+        return
 
     import mma_amd
     from mma_amd import functional as Fn
@@ -544,44 +552,82 @@ def main():
         dist.destroy_process_group()
 
 
-def run_c2l(args, dev):
-    """`--workload c2l`: MMAConv fwd+bwd on a molecule batch; roofline = the fused GR kernels (K3/K4)."""
+def run_c2l(args, dev, rank=0, world=1, barrier=None):
+    """`--workload c2l`: MMAConv fwd+bwd on a molecule batch; roofline = the fused GR kernels (K3/K4).  With N > 1 ranks every
+    rank takes its own batch of `--molecules` molecules (weak scaling) and the parameter gradients are averaged in one
+    bucketed all-reduce per step (mma.py:150-160 trains on independent mini-batches: replicas, no halo)."""
+    import torch.distributed as dist
     from mma_amd import functional as Fn
-    conv, step, N, E = gr_setup(args.molecules, dev)
+    from mma_amd.sharded import allreduce_grads
+    conv, fwd_bwd, N, E = gr_setup(args.molecules, dev, seed=rank)
+    params = [q for q in conv.parameters() if q.requires_grad]
+    if world > 1:
+        with torch.no_grad():                                   # replicas start from rank 0's parameters
+            for q in params:
+                if args.backend == "nccl":
+                    dist.broadcast(q.data, 0)
+                else:
+                    q.data.copy_(_bcast_cpu(q, dist))
+
+    def step():
+        fwd_bwd()
+        if world > 1:
+            allreduce_grads(params, average=True)
+    barrier = barrier or torch.cuda.synchronize
     timer = KernelTimer()
     Fn.TIMER = timer
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    barrier()
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    tot = torch.tensor([float(E), float(N)], dtype=torch.float64)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+        tot = tot.to(t.device)
+        dist.all_reduce(tot)
+    if rank != 0:
+        return
+    E_all, N_all = int(tot[0].item()), int(tot[1].item())
     T, F, K, S = 5, 75, 2, 3
     ab = gr_algorithmic_bytes(N, E, T, F, K, S)
     kernels = _kernel_table(timer.summary(), args.steps, ab)
     roofs = {}
     for n in ("gr_fused_fwd", "gr_fused_bwd"):
-        traffic, src = pmc_traffic(n, {"workload": "c2l", "nodes": N, "edges": E})
+        traffic, src = pmc_traffic(n, {"workload": "c2l", "nodes": N, "edges": E}) if world == 1 else (None, None)
         roofs[n] = {"bound": "hbm", "kernel": n, "achieved": kernels[n]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kernels[n]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": ("recorded rocprofv3 PMC passes of this command, " + src) if src else None}
     dom = max(roofs, key=lambda n: kernels[n]["avg_ms"])
     cpu = None
-    if args.cpu_sample:
+    if args.cpu_sample and world == 1:
         cpu = gr_cpu_baseline(200)
-    line = {"metric": "aggregated edges/sec (fwd+bwd) MultiMaskConv", "value": E * args.steps / dt, "unit": "edges/s", "n_gpus": 1,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+    line = {"metric": "aggregated edges/sec (fwd+bwd) MultiMaskConv", "value": E_all * args.steps / dt, "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2L: ZINC-like batch of %d molecules (%d nodes / %d directed edges), MMAConv 75->75, towers=5, "
-                                   "edge_dim=50, aggregators min,max, scalers identity,amplification,linear, dropout 0.5, layer fwd+bwd" % (
-                                       args.molecules, N, E), "nodes": N, "edges": E, "towers": T, "F": F, "K": K, "S": S,
-                       "parallelism": "single GPU"},
+            "config": {"workload": "C2L: ZINC-like batch of %d molecules per GPU (%d nodes / %d directed edges over all ranks), MMAConv "
+                                   "75->75, towers=5, edge_dim=50, aggregators min,max, scalers identity,amplification,linear, "
+                                   "dropout 0.5, layer fwd+bwd%s" % (args.molecules, N_all, E_all,
+                                                                     ", gradients averaged over the replicas" if world > 1 else ""),
+                       "nodes": N_all, "edges": E_all, "towers": T, "F": F, "K": K, "S": S,
+                       "parallelism": "data-parallel replicas x%d, one bucketed all-reduce of the gradients per step" % world
+                       if world > 1 else "single GPU"},
             "roofline": roofs[dom], "roofline_other": roofs[[n for n in roofs if n != dom][0]], "kernels": kernels, "cpu_baseline": cpu}
     print(json.dumps(line), flush=True)
+
+
+def _bcast_cpu(q, dist):
+    """gloo rehearsal (all ranks on one GPU): broadcast through a host copy."""
+    h = q.detach().cpu()
+    dist.broadcast(h, 0)
+    return h.to(q.device)
 
 
 def gr_cpu_baseline(n_graphs):

@@ -163,6 +163,28 @@ def run_gpu(rank, world, variant="hub"):
         close(sh.masks[n_].grad, masks[n_].grad, "gmask " + n_)
 
 
+def run_grads(rank, world):
+    """allreduce_grads: every bucket size from 'all in one' to 'one tensor per bucket', sum and average, tensors without grad."""
+    from mma_amd.sharded import allreduce_grads
+    shapes = [(7, 5), (1,), (33,), (4, 4, 4), (129,)]
+    for bucket_bytes in (1 << 20, 4 * 64, 4):
+        for average in (False, True):
+            ps = [torch.nn.Parameter(torch.zeros(*s_)) for s_ in shapes] + [torch.nn.Parameter(torch.zeros(3))]     # last: no grad
+            for i, p_ in enumerate(ps[:-1]):
+                p_.grad = torch.full(p_.shape, float(rank + 1) * (i + 1))
+            n = allreduce_grads(ps, average=average, bucket_bytes=bucket_bytes)
+            tot = sum(range(1, world + 1)) / (world if average else 1)
+            for i, p_ in enumerate(ps[:-1]):
+                assert torch.equal(p_.grad, torch.full(p_.shape, tot * (i + 1))), (bucket_bytes, average, i, p_.grad.flatten()[:3])
+            assert ps[-1].grad is None
+            if bucket_bytes == 1 << 20:
+                assert n == 1
+            if bucket_bytes == 4:
+                assert n == len(shapes)                                        # an oversize tensor still travels (alone)
+            assert 1 <= n <= len(shapes)
+    assert allreduce_grads([torch.nn.Parameter(torch.zeros(2))]) == 0          # nothing to send: no collective is entered
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     dist.init_process_group("gloo")
@@ -171,6 +193,8 @@ if __name__ == "__main__":
         try:
             if mode == "cpu":
                 run_cpu(rank, world)
+            elif mode == "grads":
+                run_grads(rank, world)
             else:
                 run_gpu(rank, world, sys.argv[2] if len(sys.argv) > 2 else "hub")
         except BaseException:

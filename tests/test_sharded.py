@@ -27,6 +27,29 @@ def test_sharded_cpu_gloo(world):
     _launch("cpu", world)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_bucketed_gradient_allreduce_gloo(world):
+    """the one exchange of the data-parallel graph-regression replicas (and of the sharded NC layer's parameters)."""
+    _launch("grads", world)
+
+
+@pytest.mark.gpu
+def test_gr_replicas_bench_rehearsal_two_ranks_one_device():
+    """`bench.py --workload c2l --gpus 2` (self-launched, gloo, both ranks on cuda:0): replicas with their own molecule batches,
+    gradients averaged per step; ONE JSON line, weak scaling, edges of both ranks counted."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "c2l", "--gpus", "2", "--backend", "gloo", "--molecules", "300",
+                        "--steps", "3", "--warmup", "1", "--cpu-sample", "0"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "replicas x2" in d["config"]["parallelism"]
+    assert 2 * 300 * 30 < d["config"]["edges"] < 2 * 300 * 60          # both ranks' molecules (about 43 directed edges each)
+
+
 @pytest.mark.gpu
 def test_sharded_gpu_two_ranks_one_device():
     _launch("gpu", 2)
