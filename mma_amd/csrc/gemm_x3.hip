@@ -322,6 +322,133 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_x3_colgroup_kernel(const G
   }
 }
 
+// ---- N == 128, long K: the dL/dx products g [Wtop|Wbot]^T (round 2) ---------------------------------------------------
+// The accumulator tiles of all 128 columns persist in registers over the K chunks (as in gemm_x3_kernel<4>), but a workgroup
+// is 8 waves = 256 rows and the slab of one K chunk holds ALL four column tiles (4 x 3 x 32 x 64 bf16, 54 KB, double
+// buffered): one barrier per 96 MFMAs instead of one per 24, and B crosses L2 -> LDS once per 256 rows instead of once per
+// 128.  Fragments of the next k-step are requested before the current step's MFMAs, C moves through buffer loads / stores
+// with SGPR row offsets.  A of the next chunk is prefetched raw (32 VGPRs) during the MFMAs and split after them.
+constexpr int kNlKC = 64, kNlRows = 256, kNlThreads = 512;
+constexpr int kNlPitch = kNlKC * 2 + 16;                 // 144 B per (piece, column) row: conflict-free ds_read_b128
+constexpr int kNlPiece = 128 * kNlPitch, kNlSlab = 3 * kNlPiece;       // 55 296 B per K chunk
+
+__device__ __forceinline__ SlabRegs nl_slab_load(const __bf16* src, int K) {
+  SlabRegs r;
+  r.r0 = *reinterpret_cast<const uint4*>(src);                      r.r1 = *reinterpret_cast<const uint4*>(src + (size_t)64 * K);
+  r.r2 = *reinterpret_cast<const uint4*>(src + (size_t)128 * K);    r.r3 = *reinterpret_cast<const uint4*>(src + (size_t)192 * K);
+  r.r4 = *reinterpret_cast<const uint4*>(src + (size_t)256 * K);    r.r5 = *reinterpret_cast<const uint4*>(src + (size_t)320 * K);
+  return r;
+}
+__device__ __forceinline__ void nl_slab_store(unsigned char* dst, const SlabRegs& r) {
+  *reinterpret_cast<uint4*>(dst) = r.r0;                            *reinterpret_cast<uint4*>(dst + 64 * kNlPitch) = r.r1;
+  *reinterpret_cast<uint4*>(dst + 128 * kNlPitch) = r.r2;           *reinterpret_cast<uint4*>(dst + 192 * kNlPitch) = r.r3;
+  *reinterpret_cast<uint4*>(dst + 256 * kNlPitch) = r.r4;           *reinterpret_cast<uint4*>(dst + 320 * kNlPitch) = r.r5;
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(kNlThreads, 1) void gemm_x3_n128_kernel(const GemmParams p, int64_t n_units) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kNlSlab];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, h = lane >> 5;
+  const int n_kc = p.K / kNlKC;
+  const uint32_t a_off = (uint32_t)r31 * (uint32_t)p.lda + 8u * h;
+  const uint32_t c_off = (4u * h * (uint32_t)p.ldc + (uint32_t)r31) * 4u;
+  const unsigned char* fb = lds + r31 * kNlPitch + h * 16;             // + slab + piece * kNlPiece + ct * 32 * kNlPitch + ks * 32
+  // slab staging: 384 rows (piece, column) x 8 chunks of 16 B = 3072 chunks, 6 per thread; row = q >> 3 is also the row of Bt3
+  const int s_row = tid >> 3, s_kq = tid & 7;
+  const __bf16* s_src = p.Bt + (size_t)s_row * p.K + s_kq * 8;          // + i * 64 rows * K + kc * 64
+  unsigned char* s_dst = lds + s_row * kNlPitch + s_kq * 16;            // + i * 64 rows * pitch + slab
+
+  for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+    const float* arow = p.A + (u * kNlRows + wave * 32) * p.lda;
+    const __amdgpu_buffer_rsrc_t crow = __builtin_amdgcn_make_buffer_rsrc(p.C + (u * kNlRows + wave * 32) * p.ldc, 0, 0x7fffffff, 0x00020000);
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    SlabRegs sreg = nl_slab_load(s_src, p.K);               // scalars, not an array (see SlabRegs)
+    float4 raw[8];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      raw[2 * ks] = *reinterpret_cast<const float4*>(arow + a_off + ks * 16);
+      raw[2 * ks + 1] = *reinterpret_cast<const float4*>(arow + a_off + ks * 16 + 4);
+    }
+    __syncthreads();                                     // the previous unit's last chunk has been read by every wave
+    nl_slab_store(s_dst, sreg);
+    __syncthreads();
+
+    for (int kc = 0; kc < n_kc; ++kc) {
+      bf16x8 af[4][3];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const float4 lo = raw[2 * ks], hi = raw[2 * ks + 1];
+        { const Bf3 t = split3(lo.x); af[ks][0][0] = t.a; af[ks][1][0] = t.b; af[ks][2][0] = t.c; }
+        { const Bf3 t = split3(lo.y); af[ks][0][1] = t.a; af[ks][1][1] = t.b; af[ks][2][1] = t.c; }
+        { const Bf3 t = split3(lo.z); af[ks][0][2] = t.a; af[ks][1][2] = t.b; af[ks][2][2] = t.c; }
+        { const Bf3 t = split3(lo.w); af[ks][0][3] = t.a; af[ks][1][3] = t.b; af[ks][2][3] = t.c; }
+        { const Bf3 t = split3(hi.x); af[ks][0][4] = t.a; af[ks][1][4] = t.b; af[ks][2][4] = t.c; }
+        { const Bf3 t = split3(hi.y); af[ks][0][5] = t.a; af[ks][1][5] = t.b; af[ks][2][5] = t.c; }
+        { const Bf3 t = split3(hi.z); af[ks][0][6] = t.a; af[ks][1][6] = t.b; af[ks][2][6] = t.c; }
+        { const Bf3 t = split3(hi.w); af[ks][0][7] = t.a; af[ks][1][7] = t.b; af[ks][2][7] = t.c; }
+      }
+      const bool more = kc + 1 < n_kc;
+      if (more) {                                         // next chunk: slab and A, in flight during this chunk's MFMAs
+        sreg = nl_slab_load(s_src + (kc + 1) * kNlKC, p.K);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          raw[2 * ks] = *reinterpret_cast<const float4*>(arow + a_off + (kc + 1) * kNlKC + ks * 16);
+          raw[2 * ks + 1] = *reinterpret_cast<const float4*>(arow + a_off + (kc + 1) * kNlKC + ks * 16 + 4);
+        }
+      }
+      const unsigned char* sb = fb + (kc & 1) * kNlSlab;
+      BFrag cur;
+      cur.b1 = *reinterpret_cast<const bf16x8*>(sb);
+      cur.b2 = *reinterpret_cast<const bf16x8*>(sb + kNlPiece);
+      cur.b3 = *reinterpret_cast<const bf16x8*>(sb + 2 * kNlPiece);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          BFrag nxt = cur;
+          if (ks < 3 || ct < 3) {
+            const unsigned char* q = sb + (ks < 3 ? ct : ct + 1) * 32 * kNlPitch + (ks < 3 ? ks + 1 : 0) * 32;
+            nxt.b1 = *reinterpret_cast<const bf16x8*>(q);
+            nxt.b2 = *reinterpret_cast<const bf16x8*>(q + kNlPiece);
+            nxt.b3 = *reinterpret_cast<const bf16x8*>(q + 2 * kNlPiece);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], cur.b3, acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1], cur.b2, acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][2], cur.b1, acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], cur.b2, acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1], cur.b1, acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0], cur.b1, acc[ct], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          cur = nxt;
+        }
+      }
+      if (more) {
+        nl_slab_store(s_dst + ((kc + 1) & 1) * kNlSlab, sreg);
+        __syncthreads();                                  // slab kc+1 visible; slab kc (read above) may be overwritten at kc+2
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (ACC)   // C += : ONE fp32 addition per element, done by the L2 atomic unit (every element has exactly one writer, so the
+                   // result is the deterministic old + product).  Old values in registers cost 64 VGPRs (spills); starting the
+                   // accumulators from them would round the old value once per MFMA instead of once.
+          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[t][r], crow, c_off,
+                                                          (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + t * 32) * 4u, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][r]), crow, c_off,
+                                                (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + t * 32) * 4u, 0);
+  }
+}
+
 // split a row-major fp32 matrix (rows, cols) into its three bf16 pieces: out (3, rows, cols)
 __global__ void split3_kernel(const float* in, int64_t n, __bf16* out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -570,6 +697,15 @@ extern "C" int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, flo
     hipLaunchKernelGGL(gemm_x3_colgroup_kernel, dim3(256), dim3(kCgThreads), 0, st, p, n_units, n_groups);
     if (int rc = check_launch("gemm_x3_colgroup_kernel")) return rc;
     first_blk = n_units * (kCgRows / 128);
+  }
+  // N == 128 with a long K (the dL/dx products): the 8-wave kernel takes every full 256-row unit
+  if (N == 128 && K > kKC && M / kNlRows >= 256) {
+    const int64_t n_units = M / kNlRows;
+    const dim3 g((unsigned)(n_units < 256 ? n_units : 256));
+    if (accumulate) hipLaunchKernelGGL(gemm_x3_n128_kernel<true>, g, dim3(kNlThreads), 0, st, p, n_units);
+    else hipLaunchKernelGGL(gemm_x3_n128_kernel<false>, g, dim3(kNlThreads), 0, st, p, n_units);
+    if (int rc = check_launch("gemm_x3_n128_kernel")) return rc;
+    first_blk = n_units * (kNlRows / 128);
   }
   const int64_t n_full = M / 128;
   for (int part = 0; part < 2; ++part) {

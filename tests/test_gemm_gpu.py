@@ -10,7 +10,8 @@ DEV = "cuda:0"
 
 @pytest.mark.parametrize("M,K,N", [(5000, 128, 512), (4099, 512, 128), (9001, 256, 64), (4096, 128, 32), (70000, 384, 96),
                                    (5003, 256, 384), (4100, 1024, 256),       # these two: column-blocked (K > 128 and N > 128)
-                                   (40037, 128, 1024), (70001, 128, 512), (140001, 128, 256), (263000, 128, 128)])   # column-group kernel + tail
+                                   (40037, 128, 1024), (70001, 128, 512), (140001, 128, 256), (263000, 128, 128),    # column-group kernel + tail
+                                   (66001, 256, 128), (131075, 1024, 128)])                                         # N == 128 long-K kernel + tail
 def test_gemm_bf16x3_accuracy(M, K, N):
     from mma_amd import dense
     rng = np.random.default_rng(M + K + N)
@@ -120,7 +121,7 @@ def test_tower_linear_backward(N, T, O, C):
     assert torch.equal(ga, ga2) and torch.equal(gW, gW2)
 
 
-@pytest.mark.parametrize("M,K,N", [(5000, 128, 512), (4099, 512, 128), (9001, 1024, 128)])
+@pytest.mark.parametrize("M,K,N", [(5000, 128, 512), (4099, 512, 128), (9001, 1024, 128), (70001, 512, 128)])
 def test_gemm_bf16x3_accumulate(M, K, N):
     """accumulate=True: C += A B in the kernel epilogue (used for dL/dx = direct part + g [Wtop|Wbot]^T)."""
     from mma_amd import dense
@@ -132,6 +133,8 @@ def test_gemm_bf16x3_accumulate(M, K, N):
     acc = c0.clone()
     got = dense.rows_mm_add_(acc, a, w)
     assert got.data_ptr() == acc.data_ptr()
-    assert torch.equal(acc, c0 + plain)                       # one fp32 addition on top of the same product
     ref = c0.double() + a.double() @ w.double()
+    assert torch.equal(acc, c0 + plain)                       # one fp32 addition on top of the same product (M >= 65536: by an L2 atomic)
+    again = c0.clone(); dense.rows_mm_add_(again, a, w)
+    assert torch.equal(again, acc)
     assert (acc.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
