@@ -654,9 +654,9 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_tn_kernel(const TnParams p)
 }
 
 static int tn_splits(int64_t M, int NC) {
-  const int64_t n_cb = (NC + 127) / 128;
+  const int64_t n_cb = ((int64_t)NC + 127) / 128;
   int64_t s = 512 / n_cb;                               // ~2 workgroups per CU in total
-  const int64_t max_s = (M + 8 * kTnKC - 1) / (8 * kTnKC);   // at least 8 chunks per split
+  const int64_t max_s = M / (8 * kTnKC) + 1;            // at least 8 chunks per split (no M + const: M comes from the caller)
   if (s > max_s) s = max_s;
   if (s >= 8) s = s / 8 * 8;                            // multiples of 8: the XCD-local id mapping of the kernel
   return (int)(s < 1 ? 1 : s);

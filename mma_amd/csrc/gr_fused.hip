@@ -954,6 +954,7 @@ static int sort_bits(int64_t N) { int b = 1; while ((1LL << b) < N) ++b; return 
 
 static int fill_codes(const uint8_t* aggr_host, int K, const uint8_t* scaler_host, int S, GrParams* p) {
   MMA_REQUIRE(K >= 1 && K <= MMA_MAX_K && S >= 1 && S <= 8, "K=%d (1..%d) / S=%d (1..8) unsupported", K, MMA_MAX_K, S);
+  MMA_REQUIRE(aggr_host && scaler_host, "NULL aggregator / scaler code list (host memory)");
   for (int k = 0; k < K; ++k) {
     MMA_REQUIRE(aggr_host[k] <= GR_STD, "aggregator code %d unknown", (int)aggr_host[k]);
     p->aggr[k] = aggr_host[k];
@@ -1093,7 +1094,8 @@ using namespace mma;
 extern "C" int64_t mma_csr_workspace_bytes(int64_t E, int64_t N) {
   if (E < 0 || N < 0 || E >= (1LL << 31) || N >= (1LL << 31)) return -1;
   size_t temp = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr,
+  // keys are node ids: sorted as UNSIGNED (rocPRIM's signed-key mask is (1 << 31) - 1 in int arithmetic when 31 bits are significant)
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr,
                                      (int32_t*)nullptr, (int)E, 0, sort_bits(N));
   return (int64_t)(3 * align256((size_t)E * 4) + align256(temp) + 256);
 }
@@ -1121,10 +1123,12 @@ extern "C" int mma_build_csr(const int64_t* key, const int64_t* other, int64_t E
   int32_t* iota = reinterpret_cast<int32_t*>(w + 2 * a);
   void* temp = w + 3 * a;
   size_t temp_bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, key32, skey, iota, perm, (int)E, 0, sort_bits(N));
+  const uint32_t* ukey = reinterpret_cast<const uint32_t*>(key32);
+  uint32_t* uskey = reinterpret_cast<uint32_t*>(skey);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, ukey, uskey, iota, perm, (int)E, 0, sort_bits(N));
   const int blocks = (int)min((int64_t)kMaxGrid, (E + kBlock) / kBlock);
   hipLaunchKernelGGL(csr_prepare_kernel, dim3(blocks), dim3(kBlock), 0, st, key, E, key32, iota);
-  const hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, key32, skey, iota, perm, (int)E, 0, sort_bits(N), st);
+  const hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, ukey, uskey, iota, perm, (int)E, 0, sort_bits(N), st);
   if (e != hipSuccess) return fail(100 + (int)e, "radix sort failed: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(csr_rowptr_kernel, dim3(blocks), dim3(kBlock), 0, st, skey, E, N, rowptr);
   if (other && other_sorted) hipLaunchKernelGGL(csr_gather_kernel, dim3(blocks), dim3(kBlock), 0, st, other, perm, E, other_sorted);
@@ -1163,7 +1167,7 @@ extern "C" int mma_gr_fused_fwd(
     const int32_t* long_nodes,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
-  MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) - (1 << 20) && E < (1LL << 31) && T >= 1 && F >= 1,
+  MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) - (1 << 20) && E < (1LL << 31) && T >= 1 && F >= 1 && (int64_t)T * F < (1 << 24),
               "N=%lld E=%lld T=%d F=%d unsupported", (long long)N, (long long)E, T, F);
   GrParams p{};
   if (int rc = fill_codes(aggr_host, K, scaler_host, S, &p)) return rc;
@@ -1220,7 +1224,7 @@ extern "C" int mma_gr_fused_bwd(
     const float* mean, const float* var, int64_t ldsave, const int32_t* long_nodes, float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
-  MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) - (1 << 20) && E < (1LL << 31) && T >= 1 && F >= 1,
+  MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) - (1 << 20) && E < (1LL << 31) && T >= 1 && F >= 1 && (int64_t)T * F < (1 << 24),
               "N=%lld E=%lld T=%d F=%d unsupported", (long long)N, (long long)E, T, F);
   GrParams p{};
   if (int rc = fill_codes(aggr_host, K, scaler_host, S, &p)) return rc;

@@ -603,12 +603,12 @@ static int pack_codes(const uint8_t* kind_host, const uint8_t* act_host, int K, 
 }
 
 // sel-kinds (max/min/softmax/softmin) get consecutive code slots in the packed aux row; returns the row length in floats
-static int fill_sel_slots(const uint8_t* kind_host, int K, int H, uint8_t* slots) {
+static int64_t fill_sel_slots(const uint8_t* kind_host, int K, int H, uint8_t* slots) {
   int n = 0;
   for (int k = 0; k < MMA_MAX_K; ++k) slots[k] = 0xFF;
   for (int k = 0; k < K; ++k)
     if (kind_host[k] >= MMA_KIND_MAX) slots[k] = (uint8_t)n++;
-  return ((H + 4 + n * ((H + 3) / 4)) + 3) & ~3;
+  return (((int64_t)H + 4 + (int64_t)n * (((int64_t)H + 3) / 4)) + 3) & ~(int64_t)3;      // 64-bit: H comes straight from the caller
 }
 
 static int make_drop(int32_t mode, uint32_t thr, uint64_t seed, const uint64_t* seed_dev, int64_t edge_base, const uint8_t* keep,
@@ -789,9 +789,9 @@ extern "C" int mma_nc_bwd_node(
   if (int rc = pack_codes(kind_host, nullptr, K, &kinds, &acts)) return rc;
   NcBwdNodeParams p{g, g_kstride, ldgr, sel, T, ldt, rowptr, gs, ldgs, gP, ldgp, gxs, ldgx, N, H, K, kinds};
   p.aux = aux; p.ldaux = ldaux; p.HQ = (H + 3) / 4;
-  const int aux_len = fill_sel_slots(kind_host, K, H, p.sel_slot);
+  const int64_t aux_len = fill_sel_slots(kind_host, K, H, p.sel_slot);
   MMA_REQUIRE(!aux || (g_kstride == 0 && ldaux >= aux_len && ldaux % 4 == 0 && aligned16(aux)),
-              "aux needs the shared-gradient form (g_kstride 0) and a 16-byte aligned pitch >= %d floats", aux_len);
+              "aux needs the shared-gradient form (g_kstride 0) and a 16-byte aligned pitch >= %lld floats", (long long)aux_len);
   const bool v4 = (H % 4 == 0) && (ldt % 4 == 0) && (!gs || ldgs % 4 == 0) && (ldgp % 4 == 0) && (ldgx % 4 == 0) &&
                   (ldgr % 4 == 0) && (g_kstride % 4 == 0) && aligned16(g) && aligned16(sel) &&
                   aligned16(T) && (!gs || aligned16(gs)) && aligned16(gP) && aligned16(gxs);
@@ -838,8 +838,8 @@ extern "C" int mma_nc_fused_bwd(
   p.x = x; p.ldx = ldx; p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.gs = gs; p.ldg = ldg; p.gxs = gxs; p.ldgx = ldgx;
   p.aux = aux; p.ldaux = ldaux; p.kinds = kinds;
   if (!gs) {
-    const int aux_len = fill_sel_slots(kind_host, K, H, p.sel_slot);
-    MMA_REQUIRE(ldaux >= aux_len, "ldaux=%lld < %d", (long long)ldaux, aux_len);
+    const int64_t aux_len = fill_sel_slots(kind_host, K, H, p.sel_slot);
+    MMA_REQUIRE(ldaux >= aux_len, "ldaux=%lld < %lld", (long long)ldaux, (long long)aux_len);
   }
   p.t_col = t_col; p.t_eid = t_eid; p.items = reinterpret_cast<const int4*>(items); p.n_items = n_items;
   p.partial = partial; p.pstride = (int64_t)(K + 1) * H; p.gQ = gQ; p.ldgq = ldgq; p.gx = gx; p.ldgxo = ldgxo;
