@@ -60,11 +60,37 @@ def close(a, b, what, signed_sum=True):
     assert not bad.any(), "%s: max err %.3g (atol %.3g), %d/%d outside" % (what, err.max().item(), atol, int(bad.sum()), err.numel())
 
 
+def messy_graph(seed, N):
+    """Duplicate edges, self-loops, isolated nodes at both ends, one node read by everybody."""
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(0, 7, N)
+    deg[:2] = 0
+    deg[-3:] = 0
+    rows = []
+    for i in range(N):
+        c = rng.integers(0, N, deg[i])
+        if deg[i] >= 2:
+            c[0] = i                        # self-loop
+            c[1] = c[-1]                    # duplicate
+        if deg[i] >= 3:
+            c[2] = N - 1                    # an isolated node that every rank reads
+        rows.append(np.sort(c))
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    return rowptr, (np.concatenate(rows) if rows else np.zeros(0)).astype(np.int64)
+
+
 def run_cpu(rank, world):
+    cases = [("hub", 157, graph(3, 157, 4)), ("directed", 96, directed_graph(96, world)), ("hub-first", 64, hub_first_graph(64)),
+             ("messy", 131, messy_graph(5, 131)), ("fewer nodes than ranks", 3, (np.array([0, 2, 2, 3]), np.array([1, 2, 0]))),
+             ("no edges", 9, (np.zeros(10, np.int64), np.zeros(0, np.int64)))]
+    for tag, N, (rowptr, col) in cases:
+        check_cpu(rank, world, tag, N, rowptr.astype(np.int64), col.astype(np.int64))
+
+
+def check_cpu(rank, world, tag, N, rowptr, col):
     from mma_amd.sharded import HaloPlan, all_to_all_rows, partition_bounds
     from oracle import nc_oracle as O
-    N, H, C, names, act = 157, 12, 5, ["sum", "mean", "max", "min"], "new_sigmoid"
-    rowptr, col = graph(3, N, 4)
+    H, C, names, act = 12, 5, ["sum", "mean", "max", "min"], "new_sigmoid"
     g = torch.Generator().manual_seed(0)
     x = torch.relu(torch.randn(N, H, generator=g))
     Ws, weight, bias = O.init_like_reference(H, C, names, 1)
@@ -107,9 +133,9 @@ def run_cpu(rank, world):
     S_src = torch.cat([S, Exchange.apply(S)], 0)
     dl = np.repeat(np.arange(n), np.diff(plan.rowptr))
     out = torch.zeros(n, C).index_add(0, torch.from_numpy(dl), S_src.index_select(0, torch.from_numpy(plan.col))) + bias
-    close(out, out_f[lo:hi], "sharded out (rank %d)" % rank)
+    close(out, out_f[lo:hi], "%s: sharded out (rank %d)" % (tag, rank))
     gx, = torch.autograd.grad((out * cot[lo:hi]).sum(), [x_own])
-    close(gx, gx_f[lo:hi], "sharded gx (rank %d)" % rank)
+    close(gx, gx_f[lo:hi], "%s: sharded gx (rank %d)" % (tag, rank))
 
 
 def run_gpu(rank, world, variant="hub"):
