@@ -147,9 +147,11 @@ int mma_csr_spmm_items(
  * C (M,N) = A (M,K) @ B (K,N) for M >> N,K: the x @ W_k products of layers.py:215-216 hoisted out of the node loop
  * (P = x Wtop, Q = x Wbot) and their dL/dx.  gfx950 has no TF32/xf32 and its fp32-input MFMA runs at the vector
  * rate, so A and B are split exactly into three bf16 pieces each and the six significant piece products are
- * accumulated in fp32 by v_mfma_f32_32x32x16_bf16: accuracy of an fp32 GEMM, HBM-bound instead of MFMA-bound.
+ * accumulated in fp32 by v_mfma_f32_32x32x16_bf16: accuracy of an fp32 GEMM at 6/16 of the fp32 matrix-core time.
  * Bt3: (3,N,K) bf16 = the three pieces of B^T (k contiguous), made by mma_split_bf16x3 from a row-major (N,K) fp32
- * matrix.  Requires N % 32 == 0, K % 128 == 0 and (K == 128 or N <= 128). */
+ * matrix.  Requires N % 32 == 0, K % 128 == 0, (K == 128 or N <= 128) and row pitches < 2^24 floats.  accumulate = 1
+ * adds the product to C with ONE fp32 addition per element (bit-identical to C + (A B); on the N == 128 long-K path the
+ * addition is done by the L2 atomic unit - every element has exactly one writer, so the result is deterministic). */
 int mma_split_bf16x3(const float* in, int64_t n, void* out_3n_bf16, void* stream);
 int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, float* C, int64_t ldc,
                     int64_t M, int32_t N, int32_t K, int32_t accumulate /* 0: C = A B, 1: C += A B */, void* stream);

@@ -7,9 +7,12 @@
 // piece products that matter,   a b ~= a1b3 + a2b2 + a3b1 + a1b2 + a2b1 + a1b1   (dropped terms < 2^-24 |ab|),
 // every piece product being exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  The result is as accurate as
 // an fp32 GEMM (measured max error 2.4e-7 vs 3.0e-7 for the fp32 library GEMM, both relative to sum|a||b| against
-// fp64) at 6/16 of its matrix-core time.  Measured in situ (C4, M = 2^20): 1.60 ms for (M,128)x(128,1024), 1.55 ms for
-// (M,1024)x(1024,128), vs 2.1-2.6 ms for rocBLAS fp32; matrix pipe ~50 % busy.
-// What was measured about the remaining half (round 1, so that the next attempt does not repeat it): s_memtime stamps put
+// fp64) at 6/16 of its matrix-core time.  Four kernels: gemm_x3_colgroup_kernel (K == 128, whole 128-column groups: the
+// forward [P|Q] = x W, 1.43-1.48 ms at C4), gemm_x3_n128_kernel (N == 128, long K: dL/dx, 1.53 ms), gemm_x3_tn_kernel
+// (x^T g, 1.39-1.45 ms) and the plain gemm_x3_kernel<NCT> below for every other shape and the ragged tails; rocBLAS fp32
+// takes 2.1-2.6 ms for each.  On real data all of them are held by the chip's power management (1.83-1.96 GHz effective
+// clock, 1.0-1.1 PFLOP/s of bf16 MFMA; the same binaries on zero operands: 1.12-1.35 ms) - DESIGN.md 3.
+// What was measured about gemm_x3_kernel in round 1 (so that the next attempt does not repeat it): s_memtime stamps put
 // 26 % of a tile in the issue of the 16 C stores and 23 % in the issue of the 6 slab loads queued behind them (K == 128
 // form); turning the tile through LDS into 4 dwordx4 stores changes nothing (the wait is the 4.3 GB themselves - 0.63 ms
 // at the 6.8 TB/s a plain fill reaches - not the instruction count; without any store the kernel still takes 1.43 ms); prefetching the next K chunk of A in the

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""The three bf16x3 GEMMs of the C4 step (M = 2^20 rows, H = 128, K = 4 masks) on random and on ZERO-filled operands, same
+binary, same launches: the difference is what the chip's power management takes (MI355X_MICROARCH.md "DVFS give-back": the clock
+a kernel holds depends on how much its operands toggle), i.e. how far each kernel is from its own schedule bound on real data.
+    python tools/gemm_power.py        (on the GPU box; prints a markdown table)"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mma_amd import dense  # noqa: E402
+
+DEV = "cuda:0"
+N, H, K = 1 << 20, 128, 4
+
+
+def timed(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    rows = []
+    for name, mk in (("random (N(0,1))", lambda *s: torch.randn(*s, device=DEV)), ("zeros", lambda *s: torch.zeros(*s, device=DEV))):
+        x, W, g, Wt = mk(N, H), mk(H, 2 * K * H), mk(N, 2 * K * H), mk(2 * K * H, H)
+        out = torch.zeros(N, H, device=DEV)
+        for _ in range(2):                      # second pass: clocks settled
+            r = (timed(lambda: dense.gemm_bf16x3(x, W)), timed(lambda: dense.gemm_bf16x3(g, Wt, out=out, accumulate=True)),
+                 timed(lambda: dense.gemm_bf16x3_tn(x, g)))
+        rows.append((name, r))
+    print("| operands | forward x [Wtop|Wbot] (M,128)x(128,1024) | dL/dx += g [Wtop|Wbot]^T (M,1024)x(1024,128) | weight gradient x^T g (128,M)x(M,1024) |")
+    print("|---|---|---|---|")
+    for name, r in rows:
+        print("| %s | %.3f ms | %.3f ms | %.3f ms |" % ((name,) + r))
+    flops = 2.0 * N * H * 2 * K * H * 6           # six bf16 piece products per fp32 product
+    print("\nEach is 275 GFLOP of fp32 work = %.2f TFLOP of bf16 MFMA; on random data that is %s PFLOP/s, on zeros %s PFLOP/s "
+          "(dense bf16 peak 2.5 PFLOP/s at 2.4 GHz)." % (flops / 1e12, " / ".join("%.2f" % (flops / 1e15 / (t * 1e-3)) for t in rows[0][1]),
+                                                       " / ".join("%.2f" % (flops / 1e15 / (t * 1e-3)) for t in rows[1][1])))
+
+
+if __name__ == "__main__":
+    main()

@@ -135,6 +135,33 @@ def main():
     b = bench_line("bench_c2l.log", os.path.join(P, "%s_bench_c2l.json" % rnd))
     print("c2l bench: %.2f ms/step, roofline %s frac %.3f / %.3f" % (b["ms_per_step"], b["roofline"]["kernel"], b["roofline"]["frac"], b["roofline_other"]["frac"]))
     parity_report(os.path.join(P, "%s_parity_strict_report.md" % rnd))
+    sq_clock(os.path.join(P, "%s_sq_clock.json" % rnd), rnd, ver, cmd4)
+    gp = os.path.join(ROOT, "gpurun_out", "gemm_power.log")
+    if os.path.exists(gp):
+        with open(os.path.join(P, "%s_gemm_power.md" % rnd), "w") as f:
+            f.write("# bf16x3 GEMMs on random vs zero operands, round %s, build %s\n\nCommand (MI355X box): `python tools/gemm_power.py`\n\n" % (rnd[1:], ver))
+            f.write("".join(l for l in open(gp) if not l.startswith("/opt/amdgpu")))
+
+
+def sq_clock(out, rnd, ver, cmd):
+    """SQ counters and the effective clock per mma:: kernel of the C4 bench (tools/prof_c4.sh <tag> sq -> prof_summary.py)."""
+    src = os.path.join(ROOT, "gpurun_out", "prof_c4_round_summary.json")
+    if not os.path.exists(src):
+        return
+    d = json.load(open(src))
+    res = {"note": "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES "
+                   "SQ_BUSY_CYCLES and, in its own pass, --pmc GRBM_GUI_ACTIVE -- %s; MI355X, round %s, build %s.  clock_GHz = GRBM_GUI_ACTIVE / 8 XCDs / "
+                   "kernel time of that pass (MI355X_MICROARCH.md, DVFS give-back); wait / issue_stall / active = fractions of SQ_WAVE_CYCLES" % (cmd, rnd[1:], ver),
+           "kernels": {}}
+    for k, e in d.items():
+        if not e.get("SQ_WAVE_CYCLES"):
+            continue
+        wc = e["SQ_WAVE_CYCLES"]
+        res["kernels"][k] = {"avg_us": e["avg_us"], "clock_GHz": e.get("clock_GHz"), "wait": e["SQ_WAIT_ANY"] / wc,
+                             "issue_stall": e["SQ_WAIT_INST_ANY"] / wc, "active": e["SQ_ACTIVE_INST_ANY"] / wc,
+                             "valu_per_wave": e["SQ_INSTS_VALU"] / max(e["SQ_WAVES"], 1),
+                             "mfma_busy_over_sq_busy": (e["SQ_VALU_MFMA_BUSY_CYCLES"] / e["SQ_BUSY_CYCLES"]) if e.get("SQ_VALU_MFMA_BUSY_CYCLES") else None}
+    json.dump(res, open(out, "w"), indent=1)
 
 
 if __name__ == "__main__":
