@@ -197,8 +197,14 @@ class _Linear(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.mm(g2, weight).view(x.shape)
+        x2 = x.reshape(-1, x.shape[-1])
+        if ctx.has_bias and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and x2.shape[0] >= 4 * _ROWS_PER_BATCH:
+            # tall input: the bias gradient rides on the weight-gradient GEMM as the row of a ones column appended to x, so the
+            # (rows, out) gradient is read once instead of twice (C2L: 2 x 0.13 ms of column sums over 0.62 / 0.65 GB)
+            gw1 = xt_g(g2, torch.cat([x2, x2.new_ones((x2.shape[0], 1))], 1))               # (out, in + 1)
+            return gx, gw1[:, :-1].contiguous(), gw1[:, -1].contiguous()
         if ctx.needs_input_grad[1]:
-            gw = xt_g(g2, x.reshape(-1, x.shape[-1]))                   # (out, in)
+            gw = xt_g(g2, x2)                                           # (out, in)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = col_sum(g2)
         return gx, gw, gb

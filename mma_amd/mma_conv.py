@@ -123,7 +123,8 @@ class MMAConv(torch.nn.Module):
         require_gpu(x)
         T, Fi = self.towers, self.F_in
         # G11: without divide_input every tower sees the same x; a stride-0 view stands in for the reference's repeat()
-        x = x.view(-1, T, Fi) if self.divide_input else x.view(-1, 1, Fi).expand(-1, T, -1)
+        x2 = None if self.divide_input else x.view(-1, Fi)       # the shared rows themselves: `x[:, 0]` of the expanded view would
+        x = x.view(-1, T, Fi) if self.divide_input else x2.view(-1, 1, Fi).expand(-1, T, -1)   # cost a zero-filled (N,T,F) in backward
         N = x.shape[0]
         graph = self._graph(edge_index, N)
         Fw = Fi                     # width of one aggregate block inside `out`
@@ -134,8 +135,10 @@ class MMAConv(torch.nn.Module):
             lins = [seq[0].active_linear() for seq in self.pre_nns[last]]       # T Linears (F_in, 3F|2F)
             TF = T * Fw
 
+            Wall = torch.stack([l.weight for l in lins])                        # (T, F, 3F|2F): ONE stack, then three slices
+
             def rows(lo, hi):       # the T per-tower (F, hi-lo) weight blocks as rows of one (T*Fw, hi-lo) matrix
-                return self._pad_dim(torch.stack([l.weight[:, lo:hi] for l in lins]), 1, Fw).reshape(TF, hi - lo)
+                return self._pad_dim(Wall[:, :, lo:hi], 1, Fw).reshape(TF, hi - lo)
             Wi, Wj = rows(0, Fi), rows(Fi, 2 * Fi)
             has_b = lins[0].bias is not None
             b = self._pad_dim(torch.stack([l.bias for l in lins]), 1, Fw).reshape(TF) if has_b else None   # lands in U only
@@ -144,7 +147,7 @@ class MMAConv(torch.nn.Module):
                 V = torch.einsum('ntf,tgf->ntg', x, Wj.view(T, Fw, Fi)).reshape(N, TF)
                 UV = torch.cat([dense.bias_add(U, b) if has_b else U, V], 1)
             else:                                                               # towers share x -> ONE GEMM for U | V
-                UV = dense.linear(x[:, 0], torch.cat([Wi, Wj]), torch.cat([b, torch.zeros_like(b)]) if has_b else None)
+                UV = dense.linear(x2, torch.cat([Wi, Wj]), torch.cat([b, torch.zeros_like(b)]) if has_b else None)
             Z = None
             if edge_attr is not None:
                 # enc(e) W_e^T = e (W_e W_enc)^T + W_e b_enc: the (E,F) encoding never materialises (mma_conv.py:141-146)
@@ -173,7 +176,7 @@ class MMAConv(torch.nn.Module):
                 y = y + torch.bmm(x.transpose(0, 1), Wx.transpose(1, 2)).transpose(0, 1)
                 out = dense.bias_add(y.reshape(N, T * self.F_out), bp)
             else:                                                                        # bias rides on the shared-x GEMM
-                out = y.reshape(N, T * self.F_out) + dense.linear(x[:, 0], Wx.reshape(T * self.F_out, Fi), bp)
+                out = y.reshape(N, T * self.F_out) + dense.linear(x2, Wx.reshape(T * self.F_out, Fi), bp)
         else:
             if Fw != Fi:
                 out = out.view(N, T, KS, Fw)[..., :Fi].reshape(N, T, KS * Fi)
