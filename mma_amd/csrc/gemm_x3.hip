@@ -252,6 +252,7 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_x3_colgroup_kernel(const G
   const int r31 = lane & 31, h = lane >> 5;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int streams_per_xcd = kCgSlotsPerXcd / n_groups;
+  if (slot >= streams_per_xcd * n_groups) return;       // N/128 does not divide 32: the last slots of every XCD stay idle (6 groups: 2 of 32)
   const int g = slot % n_groups;
   const int64_t stream = xcd * streams_per_xcd + slot / n_groups, n_streams = 8 * streams_per_xcd;
 
@@ -695,7 +696,7 @@ extern "C" int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, flo
   // tall plain K == 128 products with whole 128-column groups: the column-group kernel takes every full 256-row unit
   int64_t first_blk = 0;
   const int n_groups = N / 128;
-  if (K == kKC && !accumulate && N % 128 == 0 && kCgSlotsPerXcd % n_groups == 0 && M / kCgRows >= 4 * (256 / n_groups)) {
+  if (K == kKC && !accumulate && N % 128 == 0 && n_groups <= kCgSlotsPerXcd && M / kCgRows >= 4 * 8 * (kCgSlotsPerXcd / n_groups)) {
     const int64_t n_units = M / kCgRows;
     hipLaunchKernelGGL(gemm_x3_colgroup_kernel, dim3(256), dim3(kCgThreads), 0, st, p, n_units, n_groups);
     if (int rc = check_launch("gemm_x3_colgroup_kernel")) return rc;

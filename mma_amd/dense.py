@@ -215,6 +215,93 @@ def linear(x, weight, bias=None):
     return _Linear.apply(x, weight, bias)
 
 
+# ---- tall Linear layers with odd widths on the bf16x3 kernels (graph regression: 75 -> 760 on 2e5 rows, 50 -> 380 on 4e5) ------
+# rocBLAS runs these at 30-60 TFLOP/s (K or N in {50, 75, 76, 380, 760}: nothing is a multiple of anything); zero-padded to
+# K = 128 and N % 128 == 0 they are ordinary inputs of the bf16x3 kernels.  The ones column that carries the bias sits in the
+# K padding, so forward folds the bias in and the TN weight-gradient GEMM returns the bias gradient as one more row.
+X3_LINEAR = True
+X3_LINEAR_MIN_ROWS = 32768
+_PADDED = {}          # data_ptr -> weakref to a (rows, pitch) fp32 buffer whose columns beyond the payload are ZERO
+
+
+def _round_up(v, m):
+    return -(-v // m) * m
+
+
+def padded_empty(rows, cols, device, multiple=128):
+    """The (rows, cols) leading-columns view of a new (rows, round_up(cols, multiple)) fp32 buffer whose pad columns are zero
+    and which is REGISTERED: a consumer (linear_x3's backward) can take the whole buffer as a GEMM operand without a copy.
+    Producers that fill such a view must leave the pad columns alone."""
+    import weakref
+    pitch = _round_up(cols, multiple)
+    buf = torch.empty((rows, pitch), device=device, dtype=torch.float32)
+    if pitch > cols:
+        buf[:, cols:].zero_()
+    for k in [k for k, r in _PADDED.items() if r() is None]:
+        del _PADDED[k]
+    _PADDED[buf.data_ptr()] = weakref.ref(buf)
+    return buf[:, :cols]
+
+
+def _padded_parent(v, pitch):
+    ref = _PADDED.get(v.data_ptr())
+    buf = ref() if ref is not None else None
+    if (buf is not None and v.dim() == 2 and tuple(buf.shape) == (v.shape[0], pitch) and v.stride(1) == 1 and v.stride(0) == pitch
+            and v.storage_offset() == buf.storage_offset() and v.untyped_storage().data_ptr() == buf.untyped_storage().data_ptr()):
+        return buf
+    return None
+
+
+class _LinearX3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, fin = x.shape
+        fout = weight.shape[0]
+        OP = _round_up(fout, 128)
+        xp = torch.nn.functional.pad(x, (0, 128 - fin))             # (N, 128): [x | 1 | 0 ...]
+        xp[:, fin] = 1.0
+        wt = weight.new_zeros((128, OP))                             # [W^T ; b ; 0 ...], pad columns zero
+        wt[:fin, :fout] = weight.t()
+        if bias is not None:
+            wt[fin, :fout] = bias
+        y = gemm_bf16x3(xp, wt)                                      # (N, OP); columns beyond fout are exact zeros
+        ctx.save_for_backward(xp, weight)
+        ctx.dims = (fin, fout, OP, bias is not None)
+        return y[:, :fout]
+
+    @staticmethod
+    def backward(ctx, g):
+        xp, weight = ctx.saved_tensors
+        fin, fout, OP, has_bias = ctx.dims
+        gp = _padded_parent(g, OP)                                   # the producer's own zero-padded buffer: no copy
+        if gp is None:
+            gp = torch.nn.functional.pad(g, (0, OP - fout))
+        gx = gw = gb = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            KA = _round_up(fin + 1, 32)
+            gwb = gemm_bf16x3_tn(xp[:, :KA], gp)                     # (KA, OP) = [x | 1]^T g
+            gw = gwb[:fin, :fout].t().contiguous()
+            gb = gwb[fin, :fout].contiguous() if has_bias else None
+        if ctx.needs_input_grad[0]:
+            NP = _round_up(fin, 32)
+            wp = weight.new_zeros((OP, NP))
+            wp[:fout, :fin] = weight
+            gx = gemm_bf16x3(gp, wp)[:, :fin]
+        return gx, gw, gb
+
+
+def linear_x3_ok(x, weight):
+    return (X3_LINEAR and USE_BF16X3 and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= X3_LINEAR_MIN_ROWS
+            and x.shape[1] + 1 <= 128 and weight.shape[0] > 128)      # narrower outputs: measured no better than the library (A is split per 4 tiles only)
+
+
+def linear_tall(x, weight, bias=None):
+    """F.linear for a tall 2-D x: zero-padded onto the bf16x3 kernels where that pays (see above), else `linear`."""
+    if linear_x3_ok(x, weight):
+        return _LinearX3.apply(x, weight, bias)
+    return _Linear.apply(x, weight, bias)
+
+
 class _BiasAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, b):

@@ -379,8 +379,9 @@ class _GRAggregate(torch.autograd.Function):
         dev = ref.device
         U = V = None
         if fused:
-            UV = UV.contiguous()
-            Z = Z.contiguous() if Z is not None else None
+            # row-pitched inputs are fine (the kernels take lduv / ldz): only the columns of a row must be contiguous
+            UV = UV if UV.stride(1) == 1 and UV.stride(0) % 4 == 0 else UV.contiguous()
+            Z = Z if Z is None or (Z.stride(1) == 1 and Z.stride(0) % 4 == 0) else Z.contiguous()
             assert UV.shape == (N, 2 * D) and (Z is None or Z.shape == (E, D))
             U, V = UV[:, :D], UV[:, D:]
         else:
@@ -414,7 +415,11 @@ class _GRAggregate(torch.autograd.Function):
         csr = graph.by_target
         N, E, D = graph.N, graph.E, T * F
         gout = gout.contiguous()
-        gmsg = torch.empty((E, D), device=gout.device, dtype=torch.float32)
+        from . import dense
+        tall = dense.X3_LINEAR and fused
+        # the gradients of [U|V] and Z feed tall GEMMs: as views of zero-padded, registered buffers dense.linear_tall takes them as they are
+        gmsg = (dense.padded_empty(E, D, gout.device) if tall and has_z and E >= dense.X3_LINEAR_MIN_ROWS
+                else torch.empty((E, D), device=gout.device, dtype=torch.float32))
         if E == 0:
             if not fused:
                 return (gmsg.view(E, T, F),) + (None,) * 11
@@ -422,19 +427,21 @@ class _GRAggregate(torch.autograd.Function):
         U, V = (UV[:, :D], UV[:, D:]) if fused else (None, None)
         # dU[i] = sum of its target segment: produced by K4 itself (it walks exactly those segments); dV[j] = sum over the
         # edges leaving j: one segment sum (K5 kernel) over the by-source grouping.  Both land in the halves of one (N, 2D) buffer.
-        gUV = torch.empty((N, 2 * D), device=gout.device, dtype=torch.float32) if fused else None
+        gUV = None
+        if fused:
+            gUV = (dense.padded_empty(N, 2 * D, gout.device) if tall and N >= dense.X3_LINEAR_MIN_ROWS
+                   else torch.empty((N, 2 * D), device=gout.device, dtype=torch.float32))
         with _span("gr_fused_bwd"):
             _gr_call("mma_gr_fused_bwd", csr, U, V, Z, by_pos, inputs,
-                     (ptr(gout), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), ptr(mean), ptr(var), D, ptr(csr.long_nodes), ptr(gmsg), D,
-                      ptr(gUV),
-                      2 * D if fused else 0),
+                     (ptr(gout), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), ptr(mean), ptr(var), D, ptr(csr.long_nodes), ptr(gmsg),
+                      gmsg.stride(0), ptr(gUV), gUV.stride(0) if fused else 0),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
         if not fused:
             return (gmsg.view(E, T, F),) + (None,) * 11
         cs = graph.by_source
         rows = graph.by_source_pos if by_pos else cs.perm      # gmsg rows: positions (by_pos) or original edge ids
         with _span("gr_segsum"):
-            call("mma_csr_spmm", ptr(cs.rowptr), ptr(rows), None, ptr(gmsg), D, E, 1, None, ptr(gUV[:, D:]), 2 * D, N, D,
+            call("mma_csr_spmm", ptr(cs.rowptr), ptr(rows), None, ptr(gmsg), gmsg.stride(0), E, 1, None, ptr(gUV[:, D:]), gUV.stride(0), N, D,
                  stream_ptr())
         return (None, gUV, gmsg if has_z else None) + (None,) * 9
 

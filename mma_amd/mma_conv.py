@@ -147,15 +147,15 @@ class MMAConv(torch.nn.Module):
                 V = torch.einsum('ntf,tgf->ntg', x, Wj.view(T, Fw, Fi)).reshape(N, TF)
                 UV = torch.cat([dense.bias_add(U, b) if has_b else U, V], 1)
             else:                                                               # towers share x -> ONE GEMM for U | V
-                UV = dense.linear(x2, torch.cat([Wi, Wj]), torch.cat([b, torch.zeros_like(b)]) if has_b else None)
+                UV = dense.linear_tall(x2, torch.cat([Wi, Wj]), torch.cat([b, torch.zeros_like(b)]) if has_b else None)
             Z = None
             if edge_attr is not None:
                 # enc(e) W_e^T = e (W_e W_enc)^T + W_e b_enc: the (E,F) encoding never materialises (mma_conv.py:141-146)
                 # The (E, edge_dim) rows are put in target-sorted position order BEFORE the GEMM (50 floats per edge), so that Z
                 # - and in backward the (E, T*Fw) message gradients - stream contiguously through K3/K4.
                 We, enc = rows(2 * Fi, 3 * Fi), self.edge_encoder
-                Z = dense.linear(Fn.rows_by_position(edge_attr, graph), We @ enc.weight,
-                                 We @ enc.bias if enc.bias is not None else None)                               # (E, T*Fw) by position
+                Z = dense.linear_tall(Fn.rows_by_position(edge_attr, graph), We @ enc.weight,
+                                      We @ enc.bias if enc.bias is not None else None)                          # (E, T*Fw) by position
             out = Fn.gr_fused_conv(UV, Z, graph, T, Fw, self.aggregators, self.scalers,
                                    self.avg_deg['log'], self.avg_deg['lin'], self._drop(x.device), z_by_pos=True)
         else:

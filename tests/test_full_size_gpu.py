@@ -162,6 +162,34 @@ def test_c2l_full_batch_properties_and_sample_parity():
     g64, = torch.autograd.grad((w64 * torch.from_numpy(cot[:n_s]).double()).sum(), [x64])
     check_close(out[:n_s], want.detach().numpy(), None, None, what="C2L sample out", signed_sum=True, truth=w64.detach().numpy())
     check_close(gx[:n_s], gw.numpy(), None, None, what="C2L sample gx", signed_sum=True, truth=g64.numpy())
+    # the tall Linear layers ([U|V], Z) run zero-padded on the bf16x3 kernels at this size: the library-GEMM path must give the
+    # same layer - output, dL/dx and EVERY parameter gradient (whole-batch sums, which the 40-molecule oracle cannot provide)
+    from mma_amd import dense
+    prm = [q for q in conv.parameters() if q.requires_grad]
+    assert dense.X3_LINEAR and dense.linear_x3_ok(xg, torch.empty(760, 75))
+    g_x3 = torch.autograd.grad((conv(xg, eig, eag) * cg).sum(), prm, allow_unused=True)
+    dense.X3_LINEAR = False
+    try:
+        out_lib = conv(xg, eig, eag)
+        g_lib = torch.autograd.grad((out_lib * cg).sum(), [xg] + prm, allow_unused=True)
+    finally:
+        dense.X3_LINEAR = True
+    check_close(out, out_lib.detach().cpu().numpy(), None, None, what="C2L x3 vs library out", signed_sum=True)
+    # backward: the two paths differ in the last bits of U, V, Z, so among the 4.7e8 (node, column, min|max) selections a few
+    # dozen near-ties pick another edge and re-route that column's gradient (bit-exact arg parity is asserted where the inputs
+    # are identical: test_gr_gpu.py).  Rows touched by such a flip are counted, everything else meets the usual bar.
+    gl = g_lib[0]
+    flipped = ((gx - gl).abs() > 1e-5 + 1e-5 * gl.abs()).any(1)
+    assert int(flipped.sum()) <= 200, int(flipped.sum())
+    keep_rows = (~flipped).nonzero().flatten()
+    check_close(gx[keep_rows], gl[keep_rows].cpu().numpy(), None, None, what="C2L x3 vs library gx (rows without an arg flip)", signed_sum=True)
+    n_cmp = 0
+    for a, b in zip(g_x3, g_lib[1:]):
+        assert (a is None) == (b is None)
+        if a is not None:       # whole-batch sums over 2e5 nodes: every flip moves one term of size |x|*|g| (up to a few 1e-2) between two edges
+            assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-3, ((a - b).abs().max().item(), b.abs().max().item())
+            n_cmp += 1
+    assert n_cmp >= 8
 
 
 def test_c5_layer_with_all_true_degree_scalers_sample_parity():

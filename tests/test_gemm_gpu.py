@@ -138,3 +138,42 @@ def test_gemm_bf16x3_accumulate(M, K, N):
     again = c0.clone(); dense.rows_mm_add_(again, a, w)
     assert torch.equal(again, acc)
     assert (acc.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("N,fin,fout,bias,padded_grad", [(70001, 75, 760, True, True), (66000, 50, 380, True, False), (40000, 75, 380, False, True),
+                                                         (33000, 127, 129, True, False)])
+def test_linear_tall_on_the_bf16x3_kernels(N, fin, fout, bias, padded_grad):
+    """dense.linear_tall: odd-width tall Linear layers zero-padded onto the bf16x3 kernels (bias in the ones column of the K padding,
+    bias gradient = one more row of the TN product), against fp64; the upstream gradient arrives either as a view of a registered
+    zero-padded buffer (what K4 hands over: no copy) or as a plain tensor (padded by a copy)."""
+    from mma_amd import dense
+    rng = np.random.default_rng(N + fin + fout)
+    x = torch.from_numpy(rng.standard_normal((N, fin)).astype(np.float32)).to(DEV).requires_grad_(True)
+    w = torch.from_numpy((rng.standard_normal((fout, fin)) * 0.1).astype(np.float32)).to(DEV).requires_grad_(True)
+    b = torch.from_numpy(rng.standard_normal(fout).astype(np.float32)).to(DEV).requires_grad_(True) if bias else None
+    assert dense.linear_x3_ok(x, w)
+    y = dense.linear_tall(x, w, b)
+    assert y.shape == (N, fout) and y.stride(0) == -(-fout // 128) * 128
+    cot_np = rng.standard_normal((N, fout)).astype(np.float32)
+    if padded_grad:
+        cot = dense.padded_empty(N, fout, DEV)
+        cot.copy_(torch.from_numpy(cot_np))
+        assert dense._padded_parent(cot, y.stride(0)) is not None
+    else:
+        cot = torch.from_numpy(cot_np).to(DEV)
+    ins = [x, w] + ([b] if bias else [])
+    got = torch.autograd.grad(y, ins, grad_outputs=cot)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    bd = b.detach().double().requires_grad_(True) if bias else None
+    yd = torch.nn.functional.linear(xd, wd, bd)
+    ref = torch.autograd.grad(yd, [xd, wd] + ([bd] if bias else []), grad_outputs=torch.from_numpy(cot_np).double().to(DEV))
+    scale = xd.detach().abs() @ wd.detach().abs().t() + (bd.detach().abs() if bias else 0)
+    assert ((y.double() - yd).abs() / scale).max().item() < 5e-7
+    for g_, r_ in zip(got, ref):
+        assert g_.shape == r_.shape
+        assert (g_.double() - r_).abs().max().item() <= 2e-6 * r_.abs().max().item() + 1e-6 * N ** 0.5
+    dense.X3_LINEAR = False
+    try:
+        assert not dense.linear_x3_ok(x, w)
+    finally:
+        dense.X3_LINEAR = True
