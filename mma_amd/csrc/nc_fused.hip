@@ -49,7 +49,10 @@ __device__ __forceinline__ float nc_combine(int kind, float xi, float s, float d
     default: {  // softmax over a singleton dimension: (e / e) * s, NaN once exp over/underflows
       const float e = expf(kind == MMA_KIND_SOFTMAX ? s : -s);
       const float r = (e / e) * s;
-      code = (r != r) ? 3u : 1u;
+      // code 3 = the reference's GRADIENT is NaN.  That is the case when the value is, and also in the band below it where e is
+      // so small that 1/e overflows while e/e is still 1 (|s| in ~87.3..104): autograd's division backward forms
+      // g s / e - g s ((e / e) / e) = inf - inf there (found by the generated cases; fp64 and exact arithmetic give g).
+      code = (r != r || (1.0f / e) > 3.402823466e38f) ? 3u : 1u;
       return r;
     }
   }

@@ -2,6 +2,8 @@
 work-item chunk, duplicate edges, widths that are not multiples of 4 or of the wave, every K from 1 to 6 - NC forward and
 backward against the CPU oracle; and GR aggregate() on random target lists (empty targets, long segments, exact ties)
 against the oracle's scatter, with the second (sequential-loop) restatement deciding the arg of min/max."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -9,6 +11,8 @@ from hypothesis import HealthCheck, given, settings, strategies as st
 
 from golden_util import check_close
 
+N_EXAMPLES = int(os.environ.get("MMA_HYP_EXAMPLES", "60"))         # a longer one-off search: MMA_HYP_EXAMPLES=1000 MMA_HYP_RANDOM=1
+DERANDOMIZE = not os.environ.get("MMA_HYP_RANDOM")
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 NC_NAMES = ["sum", "mean", "max", "min", "sum2", "mean3", "max2", "min3", "softmax", "softmin"]
@@ -27,7 +31,7 @@ def nc_case(draw):
     return N, H, names, degs, chunk, p, act, seed
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@settings(max_examples=N_EXAMPLES, deadline=None, suppress_health_check=list(HealthCheck), derandomize=DERANDOMIZE)
 @given(nc_case())
 def test_nc_kernels_on_generated_graphs(case):
     import mma_amd
@@ -52,8 +56,8 @@ def test_nc_kernels_on_generated_graphs(case):
         return mo.detach(), torch.autograd.grad((mo * cot.to(dtype)).sum(), [xo])[0]
     mo, go = oracle(torch.float32)
     m64, g64 = oracle(torch.float64)
-    if not torch.isfinite(mo).all():
-        return                                                        # softmax-quirk overflow: NaN patterns are covered elsewhere
+    if not torch.isfinite(mo).all() or not torch.isfinite(go).all():
+        return        # the degenerate softmax's over/underflow bands: NaN values and NaN gradients are pinned in test_nc_gpu.py
     graph = mma_amd.NCGraph(rowptr, col, DEV, chunk=chunk)
     xg = x.to(DEV).requires_grad_(True)
     kinds = [Fn.KIND[O.AGGREGATORS[n][0]] for n in names]
@@ -82,7 +86,7 @@ def gr_case(draw):
     return N, E, T, F, aggs, scalers, hub, seed
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@settings(max_examples=N_EXAMPLES, deadline=None, suppress_health_check=list(HealthCheck), derandomize=DERANDOMIZE)
 @given(gr_case())
 def test_gr_aggregate_on_generated_targets(case):
     import mma_amd

@@ -272,6 +272,44 @@ def test_degenerate_graphs(N, H, names, edges):
     check_close(ms, mo.detach().sum(0).numpy(), None, None, what="degenerate msum", signed_sum=True, truth=m64.detach().sum(0).numpy())
 
 
+@pytest.mark.parametrize("name,n_edges", [("softmax", 19), ("softmin", 19), ("softmax", 22), ("softmax", 16), ("softmax", 17)])
+def test_degenerate_softmax_gradient_is_nan_where_the_reference_gradient_is(name, n_edges):
+    """learnable_softmax / softmin return (e / e) * s with e = exp(+-s) (layers.py:676-682, 716-720).  Beyond the overflow of the
+    value (|s| > ~104 on the small side, 88.7 on the large side) there is a band in which the value is still s but autograd's
+    division backward forms g s / e - g s ((e / e) / e) = inf - inf: the reference's fp32 gradient is NaN (found by the
+    generated cases; fp64 / exact arithmetic give g).  Node 2 gets s = -+5 per edge and column:
+      16 edges -> |s| = 80: finite everywhere;  19 -> 95: 1/e overflows, NaN gradient whatever g (reproduced: selection code 3);
+      22 -> 110: NaN value;  17 -> 85: e is a normal number and only g s / e overflows - that depends on the size of the
+      incoming gradient, which the forward kernel cannot know: KNOWN DEVIATION, the HIP path returns the
+      exact-arithmetic gradient g where the reference returns NaN."""
+    import mma_amd
+    from mma_amd import functional as Fn
+    from oracle import nc_oracle as O
+    N, H = 3, 4
+    sign = 1.0 if name == "softmax" else -1.0
+    rowptr = np.array([0, 0, 1, 1 + n_edges])
+    col = np.array([0] + [k % 2 for k in range(n_edges)], dtype=np.int64)
+    x = torch.full((N, H), 5.0)
+    W = torch.full((2 * H, H), -sign / 40.0)                 # z = -+1 on every edge and column; raw logits (new_sigmoid quirk, Q5)
+    def oracle(dtype):
+        xo = x.to(dtype).requires_grad_(True)
+        m = O.aggregate(name, xo, W.to(dtype), rowptr, col, "new_sigmoid")
+        return m.detach(), torch.autograd.grad(m.sum(), [xo])[0]
+    mo, go = oracle(torch.float32)
+    _, g64 = oracle(torch.float64)
+    assert torch.isnan(mo).any() == (n_edges >= 22) and torch.isnan(go).any() == (n_edges >= 17) and torch.isfinite(g64).all()
+    graph = mma_amd.NCGraph(rowptr, col, DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    kinds, acts = [Fn.KIND[O.AGGREGATORS[name][0]]], [Fn.ACT_RAW]
+    mg = Fn.nc_fused_aggregate(xg, xg @ W[:H].to(DEV), xg @ W[H:].to(DEV), graph, kinds, acts)
+    gg, = torch.autograd.grad(mg.sum(), [xg])
+    check_close(mg.reshape(-1, H), mo.reshape(-1, H).numpy(), None, None, what="softmax band m")
+    if n_edges == 17:
+        check_close(gg, g64.float().numpy(), None, None, what="softmax band gx (deviation: exact-arithmetic gradient)", signed_sum=True)
+    else:
+        check_close(gg, go.numpy(), None, None, what="softmax band gx", signed_sum=True)
+
+
 @pytest.mark.parametrize("compound,scalers", [(False, None), (True, ["identity", "amplification", "attenuation", "linear", "inverse_linear"]),
                                               (True, ["amplification", "identity", "inverse_linear"])])
 def test_true_degree_scalers_vs_oracle(compound, scalers):
