@@ -144,6 +144,13 @@ def run_gpu(rank, world, variant="hub"):
     from mma_amd.layers import _MASK_NAMES
     from mma_amd.sharded import ShardedMMA, partition_bounds
     dev = "cuda:0"
+    if variant == "sweep":        # the remaining graph shapes of the CPU test + the true-degree scalers, one launch
+        for tag, n_, gr, kw in (("messy", 131, messy_graph(5, 131), {}), ("fewer nodes than ranks", 2, (np.array([0, 1, 2]), np.array([1, 0])), {}),
+                                ("no edges", 9, (np.zeros(10, np.int64), np.zeros(0, np.int64)), {}),
+                                ("true-degree scalers", 157, graph(3, 157, 4),
+                                 dict(strict_reference=False, scalers=["identity", "amplification", "linear"], compound_scalers=True))):
+            check_gpu(rank, world, tag, n_, gr[0].astype(np.int64), gr[1].astype(np.int64), kw)
+        return
     N, H, C, names, p = 400, 32, 6, ["sum", "mean", "max", "min"], 0.5
     if variant == "directed":
         rowptr, col = directed_graph(N, world)
@@ -187,6 +194,46 @@ def run_gpu(rank, world, variant="hub"):
     close(sh.bias.grad, b.grad, "gbias")
     for n_ in names:
         close(sh.masks[n_].grad, masks[n_].grad, "gmask " + n_)
+
+
+def check_gpu(rank, world, tag, N, rowptr, col, kw):
+    """ShardedMMA (HIP kernels, halo through gloo) against the single-GPU layer with the same parameters on one graph."""
+    import mma_amd
+    from mma_amd import functional as Fn
+    from mma_amd.layers import _MASK_NAMES
+    from mma_amd.sharded import ShardedMMA
+    dev = "cuda:0"
+    H, C, names, p, seed = 16, 4, ["sum", "mean3", "max", "min2"], 0.5, 0x1234ABCD77
+    g = torch.Generator().manual_seed(1)
+    x = torch.relu(torch.randn(N, H, generator=g))
+    cot = torch.randn(N, C, generator=g)
+    sh = ShardedMMA.build(rowptr, col, rank, world, dev, H, C, names, p, seed=7, chunk=16, **kw)
+    sh.drop_override = Fn.DropoutSpec(p, seed=seed)
+    xo = x[sh.lo:sh.hi].to(dev).requires_grad_(True)
+    out = sh(xo)
+    out.backward(cot[sh.lo:sh.hi].to(dev))
+    sh.allreduce_grads()
+    PP = lambda t: torch.nn.Parameter(t.detach().clone())
+    masks = {n_: PP(sh.masks[n_]) if n_ in names else torch.nn.Parameter(torch.zeros(2, 1, device=dev)) for n_ in _MASK_NAMES}
+    w, b = PP(sh.weight), PP(sh.bias)
+    add_all = [col[rowptr[i]:rowptr[i + 1]] for i in range(N)]
+    ref = mma_amd.MMA(add_all, "new_sigmoid", 2, H, C, w, b, *[masks[n_] for n_ in _MASK_NAMES], p, names, dev, chunk=16, **kw)
+    with torch.no_grad():
+        for n_ in names:
+            masks[n_].copy_(sh.masks[n_])
+        w.copy_(sh.weight); b.copy_(sh.bias)
+    ref.drop_override = Fn.DropoutSpec(p, seed=seed)
+    dst = np.repeat(np.arange(N), np.diff(rowptr))
+    adj = mma_amd.graph.SpmmGraph(dst, col, None, N, N, dev)
+    xf = x.to(dev).requires_grad_(True)
+    of = ref(xf, adj)
+    of.backward(cot.to(dev))
+    close(out, of[sh.lo:sh.hi], "%s: out rank %d" % (tag, rank))
+    close(xo.grad if xo.grad is not None else torch.zeros_like(xo), xf.grad[sh.lo:sh.hi], "%s: gx rank %d" % (tag, rank))
+    close(sh.weight.grad, w.grad, tag + ": gweight")
+    close(sh.bias.grad, b.grad, tag + ": gbias")
+    for n_ in names:
+        close(sh.masks[n_].grad, masks[n_].grad, tag + ": gmask " + n_)
 
 
 def run_grads(rank, world):

@@ -56,7 +56,7 @@ def test_sharded_gpu_two_ranks_one_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant,world", [("directed", 2), ("empty", 3)])
+@pytest.mark.parametrize("variant,world", [("directed", 2), ("empty", 3), ("sweep", 2), ("sweep", 3)])
 def test_sharded_gpu_rank_without_halo_still_joins_the_exchange(variant, world):
     """a rank with no halo rows of its own (directed graph) or an empty shard must still take part in the
     reverse all-to-all and receive its peers' dL/dx contributions."""
