@@ -15,7 +15,9 @@ in HBM.  N>1: the same graph is 1-D node-sharded over the ranks (edge-balanced c
 all-to-all halo exchange per direction (strong scaling: total work fixed).  Rank 0 generates the graph once and shares
 it through /dev/shm; every rank materialises only its own rows of the features.
 Workload `c2l` (BASELINE configs[1] at ZINC-split scale): the drop-in `mma_amd.MMAConv` 75->75, towers=5, edge_dim=50,
-[min,max] x [identity,amplification,linear] on a 10 000-molecule batch; `roofline` is the fused GR kernel.
+[min,max] x [identity,amplification,linear] on a 10 000-molecule batch; `roofline` is the fused GR kernel.  N>1: molecule
+batches are independent, so the ranks are data-parallel REPLICAS (own batch each, parameters broadcast from rank 0, gradients
+averaged by one bucketed all-reduce per step; weak scaling).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant fused kernel, HIP-event timed inside the timed region,
 algorithmic bytes from DESIGN.md) and `cpu_baseline` (the CPU oracle on a bounded sample); at N=1 `extra` holds the

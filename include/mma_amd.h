@@ -249,7 +249,10 @@ enum { MMA_SC_IDENTITY = 0, MMA_SC_AMPLIFICATION = 1, MMA_SC_ATTENUATION = 2, MM
  *     ceil(rowptr[n]/256) of amin_side/amax_side (mma_gr_arg_side_rows(E), ldsave) - both of a pair or neither;
  *   mean/var (N,ldsave) floats for var/std.
  * When every operand's pitch is T*F rounded up to a multiple of 4 (zero padding columns) and 16-byte aligned, a lane
- * moves one dwordx4 per row; otherwise one dword. */
+ * moves one dwordx4 per row; otherwise one dword.  Row pitches beyond that (lduv, ldz, ldg, ldgu a multiple of 128 floats:
+ * the zero-padded buffers of the tall GEMMs around the kernels) are taken as they are.
+ * E == 0 is a legal graph: every target is empty and gets 0 for sum/mean/min/max/var but sqrt(0 + 1e-5) for std, times the
+ * scalers of the clamped degree 1; in the given-messages form `inputs` may then be NULL (an (0,T*F) tensor has no address). */
 int64_t mma_gr_arg_side_rows(int64_t E);
 int mma_gr_fused_fwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
