@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 18
+#define MMA_ABI_VERSION 19
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -203,6 +203,12 @@ int mma_logsoftmax_nll_fwd(const float* x, int64_t ldx, const int64_t* idx, cons
                            float* logp, int64_t ldo, float* loss, int64_t N, int32_t C, void* stream);
 int mma_logsoftmax_nll_bwd(const float* logp, int64_t ldo, const int64_t* idx, const int64_t* labels, int64_t n_idx,
                            const float* gloss, float* gx, int64_t ldg, int64_t N, int32_t C, void* stream);
+
+/* ---- K12: the graph-regression loss of the training step (graph_regression/mma.py:156 (out.squeeze() - data.y).abs().mean()) ----
+ * fwd: loss (DEVICE scalar) = mean_i |pred[i] - target[i]| over n >= 1 contiguous values, fixed summation order.
+ * bwd: gpred[i] = gloss * sign(pred[i] - target[i]) / n with sign(0) = 0 (torch's abs backward); gloss: DEVICE scalar. */
+int mma_l1_loss_fwd(const float* pred, const float* target, int64_t n, float* loss, void* stream);
+int mma_l1_loss_bwd(const float* pred, const float* target, int64_t n, const float* gloss, float* gpred, void* stream);
 
 /* ---- K11: Adam over ALL parameter tensors in one launch (train.py:69 optim.Adam(model.parameters(), lr, weight_decay)) ---------
  * torch.optim.Adam semantics (no amsgrad; weight decay added to the gradient; bias-corrected).  table (DEVICE memory,

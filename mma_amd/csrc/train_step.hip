@@ -77,6 +77,29 @@ __global__ __launch_bounds__(kBlock) void nll_logsoftmax_bwd_kernel(const float*
   }
 }
 
+// ---- K12: the graph-regression loss, mean |pred - target| (graph_regression/mma.py:156 `(out.squeeze() - data.y).abs().mean()`) ----
+// ONE workgroup, fixed order: the batch is a few thousand graphs at most.
+__global__ __launch_bounds__(kBlock) void l1_mean_kernel(const float* pred, const float* target, int64_t n, float* loss) {
+  __shared__ float part[kBlock];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kBlock) s += fabsf(pred[i] - target[i]);
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = part[0] / (float)n;
+}
+// d|d|/dd = sign(d) with sign(0) = 0 (torch's abs backward)
+__global__ void l1_mean_bwd_kernel(const float* pred, const float* target, int64_t n, const float* gloss, float* gpred) {
+  const float scale = *gloss / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = pred[i] - target[i];
+    gpred[i] = d > 0.f ? scale : (d < 0.f ? -scale : (d == d ? 0.f : d));
+  }
+}
+
 // ---- K11 ------------------------------------------------------------------------------------------------------------
 struct AdamTensor { float* p; const float* g; float* m; float* v; int64_t n; int64_t chunk0; };   // chunk0: first chunk id of the tensor
 constexpr int64_t kAdamChunk = 4096;     // elements per workgroup
@@ -158,4 +181,20 @@ extern "C" int mma_adam_step(const void* table, int64_t n_tensors, int64_t total
                      beta2, eps, weight_decay);
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step);
   return check_launch("adam_step");
+}
+
+extern "C" int mma_l1_loss_fwd(const float* pred, const float* target, int64_t n, float* loss, void* stream) {
+  MMA_REQUIRE(n >= 1, "n=%lld: the mean of an empty batch is undefined", (long long)n);
+  MMA_REQUIRE(pred && target && loss, "NULL argument");
+  hipLaunchKernelGGL(l1_mean_kernel, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream), pred, target, n, loss);
+  return check_launch("l1_mean_kernel");
+}
+
+extern "C" int mma_l1_loss_bwd(const float* pred, const float* target, int64_t n, const float* gloss, float* gpred, void* stream) {
+  MMA_REQUIRE(n >= 1, "n=%lld: the mean of an empty batch is undefined", (long long)n);
+  MMA_REQUIRE(pred && target && gloss && gpred, "NULL argument");
+  int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > kMaxGrid) blocks = kMaxGrid;
+  hipLaunchKernelGGL(l1_mean_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), pred, target, n, gloss, gpred);
+  return check_launch("l1_mean_bwd_kernel");
 }

@@ -46,6 +46,34 @@ class _FusedNLL(torch.autograd.Function):
         return gx, None, None
 
 
+class _FusedL1(torch.autograd.Function):
+    """K12: mean |pred - target| (graph_regression/mma.py:156) in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        require_gpu(pred, target)
+        assert pred.numel() == target.numel() and pred.numel() >= 1 and pred.dtype == torch.float32
+        p, t = pred.contiguous().view(-1), target.to(torch.float32).contiguous().view(-1)
+        loss = torch.empty((), device=pred.device, dtype=torch.float32)
+        call("mma_l1_loss_fwd", ptr(p), ptr(t), p.numel(), ptr(loss), stream_ptr())
+        ctx.save_for_backward(p, t)
+        ctx.shape = pred.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        p, t = ctx.saved_tensors
+        g = torch.empty_like(p)
+        gl = gloss.contiguous().to(torch.float32)
+        call("mma_l1_loss_bwd", ptr(p), ptr(t), p.numel(), ptr(gl), ptr(g), stream_ptr())
+        return g.view(ctx.shape), None
+
+
+def fused_l1_loss(pred, target):
+    """(pred - target).abs().mean() - the loss of the graph-regression script (mma.py:156) - as one kernel forward, one backward."""
+    return _FusedL1.apply(pred, target)
+
+
 def fused_nll_loss(logits, idx, labels):
     """-> (mean nll over the rows idx, log_softmax(logits)); labels is indexed by node (the reference's labels[idx_train])."""
     return _FusedNLL.apply(logits, idx.contiguous(), labels.contiguous())

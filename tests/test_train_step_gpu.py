@@ -158,3 +158,22 @@ def test_fused_step_kernels_inside_the_graphed_step():
     (le, we), (lg, wg) = runs[False], runs[True]
     assert abs(le - lg) <= 1e-4 * abs(le), (le, lg)
     assert torch.allclose(we, wg, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [1, 64, 257, 10000])
+def test_fused_l1_loss_matches_torch(n):
+    """K12 against plain torch fp32: (out.squeeze() - y).abs().mean() (graph_regression/mma.py:156), incl. exact zeros (sign(0) = 0)."""
+    from mma_amd.train_step import fused_l1_loss
+    g = torch.Generator().manual_seed(n)
+    pred = torch.randn(n, 1, generator=g).to(DEV).requires_grad_(True)
+    y = torch.randn(n, generator=g).to(DEV)
+    with torch.no_grad():
+        y[::7] = pred[::7, 0]                                   # exact ties: gradient 0 there
+    loss = fused_l1_loss(pred.squeeze(-1), y)
+    gp, = torch.autograd.grad(loss * 2.5, [pred])
+    ref_in = pred.detach().clone().requires_grad_(True)
+    ref = (ref_in.squeeze(-1) - y).abs().mean()
+    rg, = torch.autograd.grad(ref * 2.5, [ref_in])
+    assert torch.allclose(loss, ref, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(gp, rg, rtol=1e-6, atol=0) and gp.shape == pred.shape
+    assert (gp[::7] == 0).all()
