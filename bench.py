@@ -308,6 +308,49 @@ def gr_config(tag, n_graphs, dev, reps=20, replay=True):
     return r
 
 
+def gr_model_config(tag, n_graphs, dev, reps=10, n_batches=3):
+    """BASELINE configs[1] at model level: one TRAINING step of the reference's graph-regression Net (mma.py:63-127: atom / bond
+    embeddings, 4 x (MMAConv 75->75, towers=5, edge_dim=50 + BatchNorm + ReLU), add-pooling, MLP) with its L1 loss (mma.py:156)
+    and Adam - forward, fused loss, backward, fused optimizer step - on a FRESH batch every step (rotating pre-generated
+    batches, so the device CSR build of each batch is inside the step, as in training), eager."""
+    import mma_amd
+    rng = np.random.default_rng(11)
+    batches = []
+    for _ in range(n_batches):
+        ei, N, sizes = molecule_batch(rng, n_graphs, return_sizes=True)
+        E = ei.shape[1]
+        batches.append(dict(ei=torch.from_numpy(ei).to(dev), x=torch.from_numpy(rng.integers(0, 21, (N, 1))).to(dev),
+                            ea=torch.from_numpy(rng.integers(0, 4, E)).to(dev),
+                            batch=torch.from_numpy(np.repeat(np.arange(n_graphs), sizes)).to(dev),
+                            y=torch.from_numpy(rng.standard_normal(n_graphs).astype(np.float32)).to(dev), N=N, E=E))
+    ei0 = batches[0]["ei"].cpu().numpy()
+    hist = np.bincount(np.bincount(ei0[1], minlength=batches[0]["N"]), minlength=5)
+    torch.manual_seed(0)
+    from mma_amd.net import Net
+    net = Net(["min", "max"], ["identity", "amplification", "linear"], torch.tensor(hist)).to(dev)
+    opt = mma_amd.FusedAdam([q for q in net.parameters() if q.requires_grad], lr=1e-3)
+    state = {"i": 0}
+
+    def step():
+        b = batches[state["i"] % n_batches]
+        state["i"] += 1
+        b["ei"] = b["ei"].clone()                                  # a new tensor, as a data loader hands over: no cached graph plan
+        opt.zero_grad(set_to_none=True)
+        out = net(b["x"], b["ei"], b["ea"], b["batch"])
+        loss = mma_amd.fused_l1_loss(out.squeeze(-1), b["y"])
+        loss.backward()
+        opt.step()
+        return loss
+    first = [step().item() for _ in range(3)]
+    ms = wall_ms(step, reps)
+    last = step().item()
+    E_mean = float(np.mean([b["E"] for b in batches]))
+    return {"config": tag, "graphs_per_batch": n_graphs, "nodes": int(np.mean([b["N"] for b in batches])), "edges": int(E_mean),
+            "conv_layers": 4, "ms_per_step_eager": ms, "graphs_per_s": n_graphs / ms * 1e3, "edges_per_s_eager": 4 * E_mean / ms * 1e3,
+            "loss_first_steps": first, "loss_after": last,
+            "note": "whole Net training step (4 MMAConv layer calls): edges/s counts E x 4 layer calls per step"}
+
+
 def c5_shard_config(dev, reps=3):
     """BASELINE configs[4] ("8 M nodes / 128 M edges, feat=256, K=8 aggregators + all scalers, 8 GPUs") at its PER-GPU shard
     shape on this one GPU: R-MAT 2^20 nodes / ~16.4 M directed edges, H=256, K=8, the S=5 true-degree compounding scalers of
@@ -352,6 +395,8 @@ def extra_configs(dev):
                     ("C3", lambda: nc_config("C3: Pubmed structure, H=16, min,min2,min3,min4, p=0.5", "pubmed_h16", 16,
                                              ["min", "min2", "min3", "min4"], 3, 0.5, dev)),
                     ("C2", lambda: gr_config("C2: ZINC-like batch of 64 molecules, MMAConv T=5 F=75 min,max x id,amp,lin", 64, dev)),
+                    ("C2net", lambda: gr_model_config("C2 model: Net (mma.py:63-127) training step, batch 128 (mma.py's batch size)", 128, dev, reps=20)),
+                    ("C2Lnet", lambda: gr_model_config("C2L model: the same training step on 10 000 molecules per batch", 10000, dev, reps=5)),
                     ("C2L", lambda: gr_config("C2L: the same layer on a 10 000-molecule batch", 10000, dev, reps=5))):
         try:
             out[key] = fn()

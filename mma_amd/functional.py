@@ -332,6 +332,23 @@ class GRGraph:
         return self._by_source_pos
 
 
+_GR_GRAPHS = {}          # (data_ptr, version, shape, N) -> GRGraph, most recent last; shared by every layer that sees the same edge_index
+
+
+def gr_graph(edge_index, N, keep=4):
+    """The GRGraph of an edge_index tensor, built once per tensor (and in-place version): the four MMAConv layers of the
+    reference's Net (mma.py:91-97) all receive the same edge_index, so one CSR build (K6) serves them all.  The cached graph
+    holds its edge_index, so the address in the key cannot be reused by another tensor while the entry is alive."""
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(N), str(edge_index.device))
+    g = _GR_GRAPHS.pop(key, None)
+    if g is None:
+        g = GRGraph(edge_index, N)
+    _GR_GRAPHS[key] = g
+    while len(_GR_GRAPHS) > keep:
+        _GR_GRAPHS.pop(next(iter(_GR_GRAPHS)))
+    return g
+
+
 class _PermuteRows(torch.autograd.Function):
     """rows[idx] for a PERMUTATION idx; backward gathers with the inverse permutation (deterministic, no index_add)."""
 

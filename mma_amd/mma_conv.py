@@ -61,7 +61,6 @@ class MMAConv(torch.nn.Module):
         self.lin = Linear(out_channels, out_channels)
         self.reset_parameters()
 
-        self._graph_cache = None      # (edge_index tensor, version, N) -> GRGraph
         self.drop_override = None     # tests: a functional.DropoutSpec with a fixed seed
         self.graph_capturable = False  # True: the dropout seed is re-drawn on the device each call (hipGraph replays)
         self._seed_buf = None
@@ -95,10 +94,7 @@ class MMAConv(torch.nn.Module):
 
     # ---- graph plan ---------------------------------------------------------------------------------------
     def _graph(self, edge_index, N):
-        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), N)
-        if self._graph_cache is None or self._graph_cache[0] != key:
-            self._graph_cache = (key, Fn.GRGraph(edge_index, N))
-        return self._graph_cache[1]
+        return Fn.gr_graph(edge_index, N)        # shared by all layers that see this edge_index (mma.py:91-97: four of them)
 
     def _check_aggregators(self):
         for aggregator in self.aggregators:     # mma_conv.py:153-154 accepts a prefix match, torch_scatter then rejects
