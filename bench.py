@@ -264,6 +264,54 @@ def nc_config(tag, fixture, H, names, C, p, dev, reps=50, replay=True):
     return r
 
 
+def nc_model_config(tag, fixture, nfeat, density, hidden, names, nclass, p, n_train, dev, reps=30):
+    """BASELINE configs[0] / configs[2] at model level: one epoch of train.py:72-80 on the reference's models.MMAConv
+    (GraphConvolution -> ReLU -> dropout -> MMA layer -> log_softmax; nll_loss on idx_train; backward; Adam, lr 0.01, weight
+    decay 5e-4) on the committed graph structure with synthetic bag-of-words-like features of the dataset's width and
+    density: eager with torch's loss / Adam, eager with the fused K10 / K11, and the fused step replayed as ONE hipGraph."""
+    import scipy.sparse as sp
+    import mma_amd
+    from mma_amd.models import MMAConv
+    from mma_amd.utils import sparse_mx_to_torch_sparse_tensor
+    rowptr, col = golden_csr(fixture)
+    N, E = len(rowptr) - 1, len(col)
+    rng = np.random.default_rng(3)
+    add_all = [col[rowptr[i]:rowptr[i + 1]] for i in range(N)]
+    adj = sparse_mx_to_torch_sparse_tensor(sp.csr_matrix((np.ones(E, np.float32), col, rowptr), shape=(N, N))).to(dev)
+    feats = sp.random(N, nfeat, density=density, format="csr", dtype=np.float32, random_state=3)
+    x = torch.from_numpy(feats.toarray()).to(dev)
+    y = torch.from_numpy(rng.integers(0, nclass, N)).to(dev)
+    idx = torch.arange(0, n_train, device=dev)
+    res = {"config": tag, "nodes": N, "edges": E, "nfeat": nfeat, "hidden": hidden, "K": len(names), "dropout": p}
+    for key, fused, graphed in (("ms_per_epoch_eager_torch_loss_adam", False, False), ("ms_per_epoch_eager_fused", True, False),
+                                ("ms_per_epoch_hipgraph_fused", True, True)):
+        torch.manual_seed(42)
+        model = MMAConv(add_all, "new_sigmoid", 2, nfeat, hidden, nclass, p, list(names), dev).to(dev)
+        for q in model.parameters():
+            if q.dim() == 2 and not torch.isfinite(q).all():
+                torch.nn.init.uniform_(q, -0.1, 0.1)
+        model.train()
+        params = [q for q in model.parameters() if q.requires_grad]
+        if fused:
+            opt = mma_amd.FusedAdam(params, lr=0.01, weight_decay=5e-4)
+            loss_fn = lambda: model.nll_loss(x, adj, idx, y)[0]
+        else:
+            opt = torch.optim.Adam(params, lr=0.01, weight_decay=5e-4)
+            loss_fn = lambda: torch.nn.functional.nll_loss(model(x, adj)[idx], y[idx])
+        if graphed:
+            step = mma_amd.GraphedTrainStep(model, opt, loss_fn)
+        else:
+            def step():
+                opt.zero_grad(set_to_none=False)
+                loss = loss_fn(); loss.backward(); opt.step()
+                return loss
+        first = step().item()
+        res[key] = wall_ms(step, reps)
+        res.setdefault("loss_first", first)
+    res["epochs_per_s_hipgraph"] = 1e3 / res["ms_per_epoch_hipgraph_fused"]
+    return res
+
+
 def gr_setup(n_graphs, dev, seed=0):
     import mma_amd
     rng = np.random.default_rng(seed)
@@ -394,6 +442,11 @@ def extra_configs(dev):
     for key, fn in (("C5shard", lambda: c5_shard_config(dev)), ("C1", lambda: nc_config("C1: Cora structure, H=64, mean,mean2, p=0.75", "cora_h64", 64, ["mean", "mean2"], 7, 0.75, dev)),
                     ("C3", lambda: nc_config("C3: Pubmed structure, H=16, min,min2,min3,min4, p=0.5", "pubmed_h16", 16,
                                              ["min", "min2", "min3", "min4"], 3, 0.5, dev)),
+                    ("C1model", lambda: nc_model_config("C1 model: train.py epoch on Cora structure (1433 features, 1.3 % dense), hidden 64, mean,mean2, "
+                                                        "dropout 0.75", "cora_h64", 1433, 0.0127, 64, ["mean", "mean2"], 7, 0.75, 140, dev)),
+                    ("C3model", lambda: nc_model_config("C3 model: train.py epoch on Pubmed structure (500 features, 10 % dense), hidden 16, "
+                                                        "min,min2,min3,min4, dropout 0.5", "pubmed_h16", 500, 0.10, 16, ["min", "min2", "min3", "min4"], 3,
+                                                        0.5, 60, dev)),
                     ("C2", lambda: gr_config("C2: ZINC-like batch of 64 molecules, MMAConv T=5 F=75 min,max x id,amp,lin", 64, dev)),
                     ("C2net", lambda: gr_model_config("C2 model: Net (mma.py:63-127) training step, batch 128 (mma.py's batch size)", 128, dev, reps=20)),
                     ("C2Lnet", lambda: gr_model_config("C2L model: the same training step on 10 000 molecules per batch", 10000, dev, reps=5)),
