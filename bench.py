@@ -102,7 +102,10 @@ def gr_algorithmic_bytes(N, E, T, F, K, S, has_z=True):
     """SURVEY 8d, GR fused kernels: fwd 4[E(2 + TF + TF_Z) + N(1 + TF + TKSF)]; bwd reads the (N,T,K*S*F) gradient and
     the saved state and writes one message gradient per edge + dU per node."""
     D = T * F
-    fwd = 4 * (E * (2 + D + (D if has_z else 0)) + N * (1 + D + T * K * S * F))
+    if has_z == "categorical":        # SURVEY 8d: "0 + 1 byte/edge type if categorical table"
+        fwd = 4 * (E * (2 + D) + N * (1 + D + T * K * S * F)) + E
+    else:
+        fwd = 4 * (E * (2 + D + (D if has_z else 0)) + N * (1 + D + T * K * S * F))
     bwd = 4 * (E * (2 + D) + N * (1 + T * K * S * F + 2 * D))
     return {"gr_fused_fwd": fwd, "gr_fused_bwd": bwd}
 
@@ -312,7 +315,7 @@ def nc_model_config(tag, fixture, nfeat, density, hidden, names, nclass, p, n_tr
     return res
 
 
-def gr_setup(n_graphs, dev, seed=0):
+def gr_setup(n_graphs, dev, seed=0, categorical=False):
     import mma_amd
     rng = np.random.default_rng(seed)
     ei, N = molecule_batch(rng, n_graphs)
@@ -324,6 +327,8 @@ def gr_setup(n_graphs, dev, seed=0):
                            towers=5).to(dev)
     x = torch.randn(N, 75, device=dev, requires_grad=True)
     ea = torch.randn(E, 50, device=dev)
+    if categorical:     # ZINC's real edge features: 4 bond types through an Embedding(4, 50) (mma.py:88,103)
+        ea = mma_amd.CategoricalEdges(torch.from_numpy(rng.integers(0, 4, E)).to(dev), torch.randn(4, 50, device=dev))
     eig = torch.from_numpy(ei).to(dev)
     cot = torch.randn(N, 75, device=dev)
 
@@ -337,10 +342,10 @@ def gr_setup(n_graphs, dev, seed=0):
     return conv, step, N, E
 
 
-def gr_config(tag, n_graphs, dev, reps=20, replay=True):
+def gr_config(tag, n_graphs, dev, reps=20, replay=True, categorical=False):
     """MMAConv (mma.py:92-95 shape) layer fwd+bwd on a ZINC-like batch of n_graphs molecules."""
     from mma_amd import functional as Fn
-    conv, step, N, E = gr_setup(n_graphs, dev)
+    conv, step, N, E = gr_setup(n_graphs, dev, categorical=categorical)
     ms = wall_ms(step, reps)
     prev = Fn.TIMER
     Fn.TIMER = t = KernelTimer(); t.enabled = True
@@ -348,7 +353,8 @@ def gr_config(tag, n_graphs, dev, reps=20, replay=True):
         step()
     spans = t.summary(); Fn.TIMER = prev
     r = {"config": tag, "graphs": n_graphs, "nodes": N, "edges": E, "towers": 5, "F": 75, "ms_per_step_eager": ms,
-         "edges_per_s_eager": E / ms * 1e3, "kernels": _kernel_table(spans, reps, gr_algorithmic_bytes(N, E, 5, 75, 2, 3))}
+         "edges_per_s_eager": E / ms * 1e3,
+         "kernels": _kernel_table(spans, reps, gr_algorithmic_bytes(N, E, 5, 75, 2, 3, "categorical" if categorical else True))}
     if replay:
         conv.graph_capturable = True
         gms = graph_replay_ms(step, 20)
@@ -450,7 +456,10 @@ def extra_configs(dev):
                     ("C2", lambda: gr_config("C2: ZINC-like batch of 64 molecules, MMAConv T=5 F=75 min,max x id,amp,lin", 64, dev)),
                     ("C2net", lambda: gr_model_config("C2 model: Net (mma.py:63-127) training step, batch 128 (mma.py's batch size)", 128, dev, reps=20)),
                     ("C2Lnet", lambda: gr_model_config("C2L model: the same training step on 10 000 molecules per batch", 10000, dev, reps=5)),
-                    ("C2L", lambda: gr_config("C2L: the same layer on a 10 000-molecule batch", 10000, dev, reps=5))):
+                    ("C2L", lambda: gr_config("C2L: the same layer on a 10 000-molecule batch", 10000, dev, reps=5)),
+                    ("C2Lcat", lambda: gr_config("C2L with ZINC's real edge features: 4 bond types through an embedding table "
+                                                 "(mma_amd.CategoricalEdges: the kernels read a 4-row table + 1 byte per edge)", 10000, dev, reps=5,
+                                                 categorical=True))):
         try:
             out[key] = fn()
         except Exception as e:      # a secondary entry must never take the headline line down with it

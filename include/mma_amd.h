@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 19
+#define MMA_ABI_VERSION 20
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -257,12 +257,18 @@ enum { MMA_SC_IDENTITY = 0, MMA_SC_AMPLIFICATION = 1, MMA_SC_ATTENUATION = 2, MM
  * When every operand's pitch is T*F rounded up to a multiple of 4 (zero padding columns) and 16-byte aligned, a lane
  * moves one dwordx4 per row; otherwise one dword.  Row pitches beyond that (lduv, ldz, ldg, ldgu a multiple of 128 floats:
  * the zero-padded buffers of the tall GEMMs around the kernels) are taken as they are.
+ * z_index (categorical edge features, e.g. ZINC's 4 bond types: mma.py:88,103 embeds them, so Z has only 4 distinct rows):
+ * Z is then the (n_types, ldz) table enc(emb) @ W_e^T and the edge at row index r = position p (by_pos != 0) or edge id e
+ * (otherwise) reads Z[z_index[r]] - 1 byte per edge instead of T*F floats; dL/dZ_table = onehot(z_index)^T gmsg is the
+ * caller's (K4 still returns gmsg per edge).
  * E == 0 is a legal graph: every target is empty and gets 0 for sum/mean/min/max/var but sqrt(0 + 1e-5) for std, times the
  * scalers of the clamped degree 1; in the given-messages form `inputs` may then be NULL (an (0,T*F) tensor has no address). */
 int64_t mma_gr_arg_side_rows(int64_t E);
 int mma_gr_fused_fwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
-    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
+    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos,
+    const uint8_t* z_index,                      /* NULL, or categorical edge features: Z is a TABLE (<= 256 rows) and edge r takes row z_index[r] */
+    const float* inputs, int64_t ldi,
     float* out, uint8_t* amin8, uint8_t* amax8, int32_t* amin_side, int32_t* amax_side, float* mean, float* var, int64_t ldsave,
     const int32_t* long_nodes,                   /* from mma_build_csr, or NULL (the second pass then scans all N row pointers) */
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
@@ -275,7 +281,8 @@ int mma_gr_fused_fwd(
  * target) from the same pass - the kernel walks exactly those segments, so the separate segment sum is not needed. */
 int mma_gr_fused_bwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
-    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
+    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const uint8_t* z_index,
+    const float* inputs, int64_t ldi,
     const float* gout, const uint8_t* amin8, const uint8_t* amax8, const int32_t* amin_side, const int32_t* amax_side,
     const float* mean, const float* var, int64_t ldsave, const int32_t* long_nodes, float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,

@@ -37,6 +37,7 @@ struct GrParams {
   // block kernels: float4s per node / per tower / per aggregate block of `out`, with their magics; LDS byte offsets
   uint32_t tskf4, m_tskf4, skf4, m_skf4, f4, m_f4, m_k;
   uint32_t lds_agg, lds_arg, lds_bytes; int n_coef;
+  const uint8_t* zidx;          // categorical edge features: Z is a small table and its row for an edge is zidx[position or edge id]
   const int32_t* long_nodes;                         // optional [count, node ids...] of the segments above kGroupMaxDeg (mma_build_csr)
   bool need_sum, need_sq, need_min, need_max, need_mean;   // which running reductions the aggregator list uses
   uint8_t aggr[MMA_MAX_K]; uint8_t scaler[8];
@@ -58,6 +59,13 @@ __device__ __forceinline__ float scaler_factor(int code, float deg, float avg_lo
   }
 }
 
+// row of Z that belongs to the edge at target-sorted position pos / original id e: the edge's own row, or - categorical edge
+// features (ZINC bond types: mma.py:88,103 embed 4 types) - the row of its TYPE in a table that stays in L1/L2
+__device__ __forceinline__ size_t gr_zrow(const GrParams& p, int pos, int e) {
+  const int r = p.by_pos ? pos : e;
+  return p.zidx ? (size_t)p.zidx[r] : (size_t)r;
+}
+
 // the VEC messages h_e[c..c+VEC) of the edge at target-sorted position pos with original id e and source j
 // (fused: drop(U[i] + V[j] + Z[e or pos]); given: inputs[e])
 template <int VEC>
@@ -68,7 +76,7 @@ __device__ __forceinline__ Vec<VEC> gr_message(const GrParams& p, const DropPara
 #pragma unroll
   for (int i = 0; i < VEC; ++i) h.v[i] += u.v[i];
   if (p.Z) {
-    const Vec<VEC> z = ldv<VEC>(p.Z + (size_t)(p.by_pos ? pos : e) * p.ldz + cc);
+    const Vec<VEC> z = ldv<VEC>(p.Z + gr_zrow(p, pos, e) * p.ldz + cc);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) h.v[i] += z.v[i];
   }
@@ -622,9 +630,9 @@ enum { NEED_SUM = 1, NEED_MIN = 2, NEED_MAX = 4 };
 
 
 struct BlkLds {
-  float (*fac)[8]; float (*pre)[8]; int* rowptr; int* src; int* perm; float* agg; uint8_t* arg;
+  float (*fac)[8]; float (*pre)[8]; int* rowptr; int* src; int* perm; uint8_t* zt; float* agg; uint8_t* arg;
 };
-constexpr uint32_t kBlkHead = 2 * (kGroupMaxDeg + 1) * 32 + 32 * 4 + 2 * kBlkCap * 4;   // two scaler tables, row pointers, src, perm
+constexpr uint32_t kBlkHead = 2 * (kGroupMaxDeg + 1) * 32 + 32 * 4 + 2 * kBlkCap * 4 + kBlkCap;   // two scaler tables, row pointers, src, perm, edge types
 __device__ __forceinline__ BlkLds blk_lds(const GrParams& p, unsigned char* smem) {
   BlkLds L;
   L.fac = reinterpret_cast<float(*)[8]>(smem);
@@ -632,6 +640,7 @@ __device__ __forceinline__ BlkLds blk_lds(const GrParams& p, unsigned char* smem
   L.rowptr = reinterpret_cast<int*>(smem + 2 * (kGroupMaxDeg + 1) * 32);
   L.src = L.rowptr + 32;
   L.perm = L.src + kBlkCap;
+  L.zt = reinterpret_cast<uint8_t*>(L.perm + kBlkCap);
   L.agg = reinterpret_cast<float*>(smem + p.lds_agg);
   L.arg = smem + p.lds_arg;
   return L;
@@ -639,7 +648,8 @@ __device__ __forceinline__ BlkLds blk_lds(const GrParams& p, unsigned char* smem
 
 // stage the block's row pointers, edge indices and the scaler tables (fac[d][q] and its running product pre[d][q], in the
 // reference's multiplication order); returns false when the workgroup has no block
-__device__ __forceinline__ bool blk_stage(const GrParams& p, const BlkLds& L, int& n0, int& n_here, int& p0, int& p1, bool& staged) {
+__device__ __forceinline__ bool blk_stage(const GrParams& p, const BlkLds& L, int& n0, int& n_here, int& p0, int& p1, bool& staged,
+                                          bool want_types = false) {
   const int nblocks = (p.N + p.nb - 1) / p.nb;
   const int lb = flat_node_block((int)blockIdx.x, nblocks);
   if (lb < 0) return false;
@@ -650,7 +660,10 @@ __device__ __forceinline__ bool blk_stage(const GrParams& p, const BlkLds& L, in
   const int tid = threadIdx.x;
   if (tid <= n_here) L.rowptr[tid] = p.rowptr[n0 + tid];
   if (staged) {
-    for (int i = tid; i < p1 - p0; i += kBlock) { L.src[i] = p.src[p0 + i]; L.perm[i] = p.perm[p0 + i]; }
+    for (int i = tid; i < p1 - p0; i += kBlock) {
+      L.src[i] = p.src[p0 + i]; L.perm[i] = p.perm[p0 + i];
+      if (want_types && p.zidx) L.zt[i] = p.zidx[p.by_pos ? p0 + i : L.perm[i]];   // the edge's type next to its indices: no dependent load later
+    }
   }
   for (int d = tid; d <= kGroupMaxDeg; d += kBlock) {
     float run = 1.f;
@@ -732,7 +745,8 @@ __device__ __forceinline__ void blk_fwd_items(const GrParams& p, const DropParam
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       v[i] = FUSED ? ldv<4>(p.V + (size_t)j[i] * p.lduv + c) : ldv<4>(p.inputs + (size_t)e[i] * p.ldi + c);
-      z[i] = (FUSED && HASZ) ? ldv<4>(p.Z + (size_t)(p.by_pos ? pos[i] : e[i]) * p.ldz + c) : vzero<4>();
+      const size_t zr = (STAGED && p.zidx) ? (size_t)L.zt[pos[i] - p0] : gr_zrow(p, pos[i], e[i]);
+      z[i] = (FUSED && HASZ) ? ldv<4>(p.Z + zr * p.ldz + c) : vzero<4>();
     }
     BlkAcc<NEEDS> a;
     a.init();
@@ -742,7 +756,8 @@ __device__ __forceinline__ void blk_fwd_items(const GrParams& p, const DropParam
       const int pt = b + t;
       const int jj = STAGED ? L.src[pt - p0] : p.src[pt], ee = STAGED ? L.perm[pt - p0] : p.perm[pt];
       const Vec<4> vv = FUSED ? ldv<4>(p.V + (size_t)jj * p.lduv + c) : ldv<4>(p.inputs + (size_t)ee * p.ldi + c);
-      const Vec<4> zz = (FUSED && HASZ) ? ldv<4>(p.Z + (size_t)(p.by_pos ? pt : ee) * p.ldz + c) : vzero<4>();
+      const size_t zrr = (STAGED && p.zidx) ? (size_t)L.zt[pt - p0] : gr_zrow(p, pt, ee);
+      const Vec<4> zz = (FUSED && HASZ) ? ldv<4>(p.Z + zrr * p.ldz + c) : vzero<4>();
       a.take(blk_combine<FUSED, HASZ, DROP>(p, dp, u, vv, zz, (uint32_t)ee, c), t, true);
     }
     const float fdeg = (float)max(deg, 1);                    // degree(...).clamp_(1), mma_conv.py:178-179
@@ -779,7 +794,7 @@ __global__ __launch_bounds__(kBlock) void gr_fwd_block_kernel(const GrParams p) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const BlkLds L = blk_lds(p, smem);
   int n0, n_here, p0, p1; bool staged;
-  if (!blk_stage(p, L, n0, n_here, p0, p1, staged)) return;
+  if (!blk_stage(p, L, n0, n_here, p0, p1, staged, HASZ)) return;
   const DropParams dp = DROP ? drop_resolve(p.drop) : p.drop;
   const int tid = threadIdx.x;
 
@@ -1162,7 +1177,8 @@ static int gr_fill_common(GrParams& p, const int32_t* rowptr, const int32_t* src
 
 extern "C" int mma_gr_fused_fwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
-    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
+    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const uint8_t* z_index,
+    const float* inputs, int64_t ldi,
     float* out, uint8_t* amin8, uint8_t* amax8, int32_t* amin_side, int32_t* amax_side, float* mean, float* var, int64_t ldsave,
     const int32_t* long_nodes,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
@@ -1184,6 +1200,8 @@ extern "C" int mma_gr_fused_fwd(
   MMA_REQUIRE(!(amin8 || amax8 || mean || var) || ldsave >= D, "ldsave=%lld < T*F", (long long)ldsave);
   if (int rc = gr_fill_common(p, rowptr, src, perm, U, V, lduv, Z, ldz, by_pos, inputs, ldi, amin8, amax8, amin_side, amax_side, mean,
                               var, ldsave, N, E, T, F, avg_log, avg_lin, drop_mode, drop_thr, seed, seed_dev)) return rc;
+  MMA_REQUIRE(!z_index || Z, "z_index without a Z table");
+  p.zidx = z_index;
   p.out = out;
   const bool v4 = gr_vec4(p);
   const dim3 grid = gr_grid(N, D, v4 ? 4 : 1, &p.lpr_log);
@@ -1219,7 +1237,8 @@ extern "C" int mma_gr_fused_fwd(
 
 extern "C" int mma_gr_fused_bwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
-    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const float* inputs, int64_t ldi,
+    const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const uint8_t* z_index,
+    const float* inputs, int64_t ldi,
     const float* gout, const uint8_t* amin8, const uint8_t* amax8, const int32_t* amin_side, const int32_t* amax_side,
     const float* mean, const float* var, int64_t ldsave, const int32_t* long_nodes, float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
@@ -1245,6 +1264,8 @@ extern "C" int mma_gr_fused_bwd(
                               const_cast<int32_t*>(need_min ? amin_side : nullptr), const_cast<int32_t*>(need_max ? amax_side : nullptr),
                               const_cast<float*>(mean), const_cast<float*>(var), ldsave, N, E, T, F, avg_log, avg_lin, drop_mode,
                               drop_thr, seed, seed_dev)) return rc;
+  MMA_REQUIRE(!z_index || Z, "z_index without a Z table");
+  p.zidx = z_index;
   p.gout = gout; p.gmsg = gmsg; p.ldg = ldg; p.gU = gU; p.ldgu = ldgu;
   const bool v4 = gr_vec4(p) && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(gmsg) & 15) == 0 &&
                   (!gU || (ldgu % 4 == 0 && (reinterpret_cast<uintptr_t>(gU) & 15) == 0));

@@ -324,6 +324,19 @@ class GRGraph:
             self._inv_perm = inv
         return self._inv_perm
 
+    def type_onehot(self, z_index, n_types):
+        """(E, 32 | 64 | ...) fp32 one-hot rows of a uint8 type index (cached for the last index tensor): the operand that turns
+        the per-edge message gradient into the gradient of the (n_types, D) table with one fixed-order TN product."""
+        key = (z_index.data_ptr(), z_index._version, int(n_types))
+        hit = self.__dict__.get("_type_onehot")
+        if hit is None or hit[0] != key:
+            width = -(-int(n_types) // 32) * 32
+            oh = torch.zeros((self.E, width), device=z_index.device, dtype=torch.float32)
+            oh.scatter_(1, z_index.long().unsqueeze(1), 1.0)
+            hit = (key, oh, z_index)              # the index tensor is kept alive with its one-hot
+            self.__dict__["_type_onehot"] = hit
+        return hit[1]
+
     @property
     def by_source_pos(self):
         """(E,) int32: the by-source grouping expressed in target-sorted POSITIONS (rows of a by_pos message-gradient buffer)."""
@@ -369,11 +382,11 @@ def rows_by_position(x, graph):
     return _PermuteRows.apply(x, graph.perm.long(), graph.inv_perm)
 
 
-def _gr_call(fn, csr, U, V, Z, by_pos, inputs, extra, N, E, T, F, aggr, scalers, avg_log, avg_lin, drop):
+def _gr_call(fn, csr, U, V, Z, by_pos, inputs, extra, N, E, T, F, aggr, scalers, avg_log, avg_lin, drop, z_index=None):
     D = T * F
     lduv = U.stride(0) if U is not None else 0
     call(fn, ptr(csr.rowptr), ptr(csr.other), ptr(csr.perm), ptr(U), ptr(V), lduv, ptr(Z), Z.stride(0) if Z is not None else 0,
-         1 if by_pos else 0, ptr(inputs), D if inputs is not None else 0, *extra, N, E, T, F, host_codes(aggr), len(aggr),
+         1 if by_pos else 0, ptr(z_index), ptr(inputs), D if inputs is not None else 0, *extra, N, E, T, F, host_codes(aggr), len(aggr),
          host_codes(scalers), len(scalers), float(avg_log), float(avg_lin), drop.mode, drop.thr, drop.seed, ptr(drop.seed_tensor),
          stream_ptr())
 
@@ -386,7 +399,7 @@ class _GRAggregate(torch.autograd.Function):
     the gradient of UV comes back as one buffer whose halves the kernel and the by-source segment sum fill."""
 
     @staticmethod
-    def forward(ctx, inputs, UV, Z, graph, T, F, aggr, scalers, avg_log, avg_lin, drop, by_pos):
+    def forward(ctx, inputs, UV, Z, graph, T, F, aggr, scalers, avg_log, avg_lin, drop, by_pos, z_index=None):
         fused = inputs is None
         csr = graph.by_target
         N, E, D = graph.N, graph.E, T * F
@@ -399,7 +412,10 @@ class _GRAggregate(torch.autograd.Function):
             # row-pitched inputs are fine (the kernels take lduv / ldz): only the columns of a row must be contiguous
             UV = UV if UV.stride(1) == 1 and UV.stride(0) % 4 == 0 else UV.contiguous()
             Z = Z if Z is None or (Z.stride(1) == 1 and Z.stride(0) % 4 == 0) else Z.contiguous()
-            assert UV.shape == (N, 2 * D) and (Z is None or Z.shape == (E, D))
+            if z_index is not None:      # categorical edge features: Z is the (n_types, D) table, z_index (E,) uint8 its row per edge
+                assert Z is not None and Z.shape[1] == D and Z.shape[0] <= 256 and z_index.dtype == torch.uint8 and z_index.shape == (E,)
+                z_index = z_index.contiguous()
+            assert UV.shape == (N, 2 * D) and (Z is None or z_index is not None or Z.shape == (E, D))
             U, V = UV[:, :D], UV[:, D:]
         else:
             inputs = inputs.contiguous()
@@ -421,14 +437,14 @@ class _GRAggregate(torch.autograd.Function):
         with _span("gr_fused_fwd"):
             _gr_call("mma_gr_fused_fwd", csr, U, V, Z, by_pos, inputs,
                      (ptr(out), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), ptr(mean), ptr(var), D, ptr(csr.long_nodes)),
-                     N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
-        ctx.save_for_backward(inputs, UV, Z, amin, amax, amin_s, amax_s, mean, var)
+                     N, E, T, F, aggr, scalers, avg_log, avg_lin, drop, z_index)
+        ctx.save_for_backward(inputs, UV, Z, amin, amax, amin_s, amax_s, mean, var, z_index)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         graph, T, F, aggr, scalers, avg_log, avg_lin, drop, fused, has_z, by_pos = ctx.cfg
-        inputs, UV, Z, amin, amax, amin_s, amax_s, mean, var = ctx.saved_tensors
+        inputs, UV, Z, amin, amax, amin_s, amax_s, mean, var, z_index = ctx.saved_tensors
         csr = graph.by_target
         N, E, D = graph.N, graph.E, T * F
         gout = gout.contiguous()
@@ -439,8 +455,9 @@ class _GRAggregate(torch.autograd.Function):
                 else torch.empty((E, D), device=gout.device, dtype=torch.float32))
         if E == 0:
             if not fused:
-                return (gmsg.view(E, T, F),) + (None,) * 11
-            return (None, torch.zeros((N, 2 * D), device=gout.device, dtype=torch.float32), gmsg if has_z else None) + (None,) * 9
+                return (gmsg.view(E, T, F),) + (None,) * 12
+            gz = (torch.zeros_like(Z) if z_index is not None else gmsg) if has_z else None
+            return (None, torch.zeros((N, 2 * D), device=gout.device, dtype=torch.float32), gz) + (None,) * 10
         U, V = (UV[:, :D], UV[:, D:]) if fused else (None, None)
         # dU[i] = sum of its target segment: produced by K4 itself (it walks exactly those segments); dV[j] = sum over the
         # edges leaving j: one segment sum (K5 kernel) over the by-source grouping.  Both land in the halves of one (N, 2D) buffer.
@@ -452,15 +469,20 @@ class _GRAggregate(torch.autograd.Function):
             _gr_call("mma_gr_fused_bwd", csr, U, V, Z, by_pos, inputs,
                      (ptr(gout), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), ptr(mean), ptr(var), D, ptr(csr.long_nodes), ptr(gmsg),
                       gmsg.stride(0), ptr(gUV), gUV.stride(0) if fused else 0),
-                     N, E, T, F, aggr, scalers, avg_log, avg_lin, drop)
+                     N, E, T, F, aggr, scalers, avg_log, avg_lin, drop, z_index)
         if not fused:
-            return (gmsg.view(E, T, F),) + (None,) * 11
+            return (gmsg.view(E, T, F),) + (None,) * 12
         cs = graph.by_source
         rows = graph.by_source_pos if by_pos else cs.perm      # gmsg rows: positions (by_pos) or original edge ids
         with _span("gr_segsum"):
             call("mma_csr_spmm", ptr(cs.rowptr), ptr(rows), None, ptr(gmsg), gmsg.stride(0), E, 1, None, ptr(gUV[:, D:]), gUV.stride(0), N, D,
                  stream_ptr())
-        return (None, gUV, gmsg if has_z else None) + (None,) * 9
+        gz = gmsg if has_z else None
+        if has_z and z_index is not None:
+            # dL/dZ_table = onehot(z_index)^T gmsg: a fixed-order reduction (index_add_ would use atomics), one row per edge type
+            gp = dense._padded_parent(gmsg, dense._round_up(D, 128))          # the zero-padded buffer itself: bf16x3 TN kernel, no copy
+            gz = dense.xt_g(graph.type_onehot(z_index, Z.shape[0]), gp if gp is not None else gmsg)[:Z.shape[0], :D]
+        return (None, gUV, gz) + (None,) * 10
 
 
 def gr_aggregate(inputs, graph, aggregators, scalers, avg_log, avg_lin):
@@ -470,9 +492,9 @@ def gr_aggregate(inputs, graph, aggregators, scalers, avg_log, avg_lin):
                               tuple(GR_SCALER[s] for s in scalers), avg_log, avg_lin, DropoutSpec(0.0), False)
 
 
-def gr_fused_conv(UV, Z, graph, T, F, aggregators, scalers, avg_log, avg_lin, drop, z_by_pos=False):
+def gr_fused_conv(UV, Z, graph, T, F, aggregators, scalers, avg_log, avg_lin, drop, z_by_pos=False, z_index=None):
     """message + aggregate fused: messages drop(U[i] + V[j] + Z[r]) never materialise.  UV = [U | V] (N, 2*T*F).
     z_by_pos: Z's rows are in target-sorted position order (made from rows_by_position(edge_attr, graph)): the kernels then
     stream Z and the message gradients contiguously instead of gathering / scattering them by original edge id."""
     return _GRAggregate.apply(None, UV, Z, graph, T, F, tuple(GR_AGGR[a] for a in aggregators),
-                              tuple(GR_SCALER[s] for s in scalers), avg_log, avg_lin, drop, bool(z_by_pos))
+                              tuple(GR_SCALER[s] for s in scalers), avg_log, avg_lin, drop, bool(z_by_pos), z_index)

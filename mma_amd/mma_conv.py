@@ -29,6 +29,30 @@ from .pyg_compat import Linear, reset
 _SCATTER_REDUCE = ("sum", "mean", "min", "max")
 
 
+class CategoricalEdges:
+    """Edge features that are rows of a small table: `edge_attr = table[types]`, as the reference's Net makes them from bond types
+    (mma.py:88 `Embedding(4, 50)`, :103 `edge_attr = self.edge_emb(edge_attr)`).  Passing this object as MMAConv's `edge_attr`
+    is the same computation as passing `table[types]` - an opt-in extension of the drop-in surface: the fused kernels then read
+    an (n_types, T*F) table and one byte per edge instead of an (E, T*F) stream, the edge GEMM shrinks from E rows to n_types,
+    and the table's gradient is a fixed-order one-hot reduction instead of an index_add."""
+
+    def __init__(self, types, table):
+        assert types.dim() == 1 and table.dim() == 2 and table.shape[0] <= 256
+        self.types, self.table = types, table
+        self._by_pos = None
+
+    def dense(self):
+        return self.table.index_select(0, self.types.long())
+
+    def types_by_position(self, graph):
+        """(E,) uint8 in target-sorted position order (the order K3/K4 walk the edges in)."""
+        key = (id(graph), self.types.data_ptr(), self.types._version)
+        if self._by_pos is None or self._by_pos[0] != key:
+            t = self.types.to(torch.uint8)
+            self._by_pos = (key, t if graph.E == 0 else t.index_select(0, graph.perm.long()).contiguous())
+        return self._by_pos[1]
+
+
 class MMAConv(torch.nn.Module):
     def __init__(self, in_channels: int, out_channels: int, aggregators: List[str], scalers: List[str], deg: Tensor,
                  edge_dim: Optional[int] = None, towers: int = 1, pre_layers: int = 1, post_layers: int = 1,
@@ -144,18 +168,26 @@ class MMAConv(torch.nn.Module):
                 UV = torch.cat([dense.bias_add(U, b) if has_b else U, V], 1)
             else:                                                               # towers share x -> ONE GEMM for U | V
                 UV = dense.linear_tall(x2, torch.cat([Wi, Wj]), torch.cat([b, torch.zeros_like(b)]) if has_b else None)
-            Z = None
+            Z = z_index = None
             if edge_attr is not None:
                 # enc(e) W_e^T = e (W_e W_enc)^T + W_e b_enc: the (E,F) encoding never materialises (mma_conv.py:141-146)
                 # The (E, edge_dim) rows are put in target-sorted position order BEFORE the GEMM (50 floats per edge), so that Z
                 # - and in backward the (E, T*Fw) message gradients - stream contiguously through K3/K4.
                 We, enc = rows(2 * Fi, 3 * Fi), self.edge_encoder
-                Z = dense.linear_tall(Fn.rows_by_position(edge_attr, graph), We @ enc.weight,
-                                      We @ enc.bias if enc.bias is not None else None)                          # (E, T*Fw) by position
+                wz, bz = We @ enc.weight, (We @ enc.bias if enc.bias is not None else None)
+                if isinstance(edge_attr, CategoricalEdges):
+                    # edge_attr = table[types] (an Embedding: mma.py:88,103): Z has only n_types distinct rows, so the kernels get
+                    # the (n_types, T*Fw) table and one byte per edge instead of a (E, T*Fw) stream
+                    Z = dense.linear(edge_attr.table, wz, bz)
+                    z_index = edge_attr.types_by_position(graph)
+                else:
+                    Z = dense.linear_tall(Fn.rows_by_position(edge_attr, graph), wz, bz)                         # (E, T*Fw) by position
             out = Fn.gr_fused_conv(UV, Z, graph, T, Fw, self.aggregators, self.scalers,
-                                   self.avg_deg['log'], self.avg_deg['lin'], self._drop(x.device), z_by_pos=True)
+                                   self.avg_deg['log'], self.avg_deg['lin'], self._drop(x.device), z_by_pos=True, z_index=z_index)
         else:
             src, dst = edge_index[0], edge_index[1]
+            if isinstance(edge_attr, CategoricalEdges):
+                edge_attr = edge_attr.dense()
             hs = self.message(x.index_select(0, dst), x.index_select(0, src), edge_attr)
             out = self.aggregate(hs, dst, N, _graph=graph)
 

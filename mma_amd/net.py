@@ -5,7 +5,7 @@ import torch
 import torch.nn.functional as F
 from torch.nn import BatchNorm1d, Embedding, Linear, ModuleList, ReLU, Sequential
 
-from .mma_conv import MMAConv
+from .mma_conv import CategoricalEdges, MMAConv
 
 
 def global_add_pool(x, batch, size=None):
@@ -14,6 +14,8 @@ def global_add_pool(x, batch, size=None):
 
 
 class Net(torch.nn.Module):
+    categorical_edges = True      # hand the bond types and the embedding table to the layers (same math as the embedded rows)
+
     def __init__(self, aggregator_list, scaler_list, deg, mask=True, layers=4):
         super().__init__()
         self.node_emb = Embedding(21, 75)
@@ -29,7 +31,10 @@ class Net(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr, batch):
         x = self.node_emb(x.squeeze())
-        edge_attr = self.edge_emb(edge_attr)
+        if self.categorical_edges and x.is_cuda and edge_attr.dim() == 1:
+            edge_attr = CategoricalEdges(edge_attr, self.edge_emb.weight)     # = self.edge_emb(edge_attr), never materialised
+        else:
+            edge_attr = self.edge_emb(edge_attr)
         for conv, batch_norm in zip(self.convs, self.batch_norms):
             x = F.relu(batch_norm(conv(x, edge_index, edge_attr)))
         x = global_add_pool(x, batch)

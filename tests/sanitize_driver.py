@@ -91,6 +91,8 @@ def recipe(lib, name, rng, keep):
             d.update(mean=None, var=None)
         if rng.random() < 0.3:
             d.update(long_nodes=None)
+        if rng.random() < 0.7 or d.get("Z", 1) is None:
+            d.update(z_index=None)
         return d
     if name == "mma_gemm_bf16x3":
         M, Nc, Kc = rng.choice([(1 << 20, 1024, 128), (70001, 512, 128), (9001, 128, 1024), (1 << 20, 128, 512), (5, 32, 128), (0, 64, 256),
