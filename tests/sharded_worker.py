@@ -260,7 +260,11 @@ def run_grads(rank, world):
 
 if __name__ == "__main__":
     mode = sys.argv[1]
-    dist.init_process_group("gloo")
+    if mode == "nccl":          # the real RCCL code path (device-side index exchange, all_to_all_single on GPU tensors) at world size 1
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     try:
         try:
@@ -268,6 +272,9 @@ if __name__ == "__main__":
                 run_cpu(rank, world)
             elif mode == "grads":
                 run_grads(rank, world)
+            elif mode == "nccl":
+                run_gpu(rank, world, "hub")
+                run_gpu(rank, world, "sweep")
             else:
                 run_gpu(rank, world, sys.argv[2] if len(sys.argv) > 2 else "hub")
         except BaseException:

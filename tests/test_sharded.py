@@ -51,6 +51,14 @@ def test_gr_replicas_bench_rehearsal_two_ranks_one_device():
 
 
 @pytest.mark.gpu
+def test_sharded_on_the_rccl_backend_single_rank():
+    """RCCL refuses two ranks on one device, so the multi-rank tests above run over gloo; this one takes the REAL backend
+    (`nccl` = RCCL: plan exchange and all_to_all_single on device tensors, async work handles) at world size 1 and checks the
+    sharded layer against the plain one on the same graphs."""
+    _launch("nccl", 1)
+
+
+@pytest.mark.gpu
 def test_sharded_gpu_two_ranks_one_device():
     _launch("gpu", 2)
 
