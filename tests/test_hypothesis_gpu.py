@@ -135,7 +135,8 @@ def conv_case(draw):
     p = draw(st.sampled_from([0.0, 0.5]))
     hub = draw(st.booleans())
     seed = draw(st.integers(0, 2 ** 31 - 1))
-    return N, E, T, F, aggs, scalers, edge_dim, divide_input, p, hub, seed
+    n_types = draw(st.sampled_from([0, 0, 1, 4, 33]))            # > 0: the edge features are rows of an n_types-row table
+    return N, E, T, F, aggs, scalers, edge_dim, divide_input, p, hub, seed, n_types
 
 
 @settings(max_examples=max(N_EXAMPLES // 2, 10), deadline=None, suppress_health_check=list(HealthCheck), derandomize=DERANDOMIZE)
@@ -148,7 +149,7 @@ def test_mmaconv_layer_on_generated_cases(case):
     from oracle import gr_oracle as G
     from oracle.dropout_rng import keep_mask
     from test_gr_gpu import conv_params, make_conv, to64
-    N, E, T, F, aggs, scalers, edge_dim, divide_input, p, hub, seed = case
+    N, E, T, F, aggs, scalers, edge_dim, divide_input, p, hub, seed, n_types = case
     rng = np.random.default_rng(seed)
     src, dst = rng.integers(0, N, E), rng.integers(0, N, E)
     if hub and E:
@@ -157,6 +158,11 @@ def test_mmaconv_layer_on_generated_cases(case):
     conv = make_conv(aggs, scalers, towers=T, F=F, edge_dim=edge_dim, divide_input=divide_input)
     x = rng.standard_normal((N, conv.in_channels)).astype(np.float32)
     ea = rng.standard_normal((E, edge_dim)).astype(np.float32) if edge_dim else None
+    types = table = None
+    if edge_dim and n_types:                                      # mma_amd.CategoricalEdges on the HIP side, table[types] for the oracle
+        table = rng.standard_normal((n_types, edge_dim)).astype(np.float32)
+        types = rng.integers(0, n_types, E)
+        ea = table[types]
     cot = rng.standard_normal((N, conv.out_channels)).astype(np.float32)
     dseed = 0x5EED0000 + seed
     conv.drop_override = Fn.DropoutSpec(p, seed=dseed)
@@ -176,12 +182,22 @@ def test_mmaconv_layer_on_generated_cases(case):
     w64, g64 = oracle(torch.float64)
     xg = torch.from_numpy(x).to(DEV).requires_grad_(True)
     eg = torch.from_numpy(ea).to(DEV).requires_grad_(True) if ea is not None else None
-    got = conv(xg, torch.from_numpy(ei).to(DEV), eg)
-    gg = torch.autograd.grad((got * torch.from_numpy(cot).to(DEV)).sum(), [xg] + ([eg] if eg is not None and E else []), allow_unused=True)
+    if table is not None:
+        import mma_amd
+        tg = torch.from_numpy(table).to(DEV).requires_grad_(True)
+        got = conv(xg, torch.from_numpy(ei).to(DEV), mma_amd.CategoricalEdges(torch.from_numpy(types).to(DEV), tg))
+        gg = torch.autograd.grad((got * torch.from_numpy(cot).to(DEV)).sum(), [xg] + ([tg] if E else []), allow_unused=True)
+    else:
+        got = conv(xg, torch.from_numpy(ei).to(DEV), eg)
+        gg = torch.autograd.grad((got * torch.from_numpy(cot).to(DEV)).sum(), [xg] + ([eg] if eg is not None and E else []), allow_unused=True)
     check_close(got, want.numpy(), None, None, what="hyp conv out", signed_sum=True, truth=w64.numpy())
     check_close(gg[0], gw[0].numpy(), None, None, what="hyp conv gx", signed_sum=True, truth=g64[0].numpy())
-    if len(gg) > 1 and gw[1] is not None:
+    if len(gg) > 1 and gw[1] is not None and table is None:
         check_close(gg[1], gw[1].numpy(), None, None, what="hyp conv g(edge_attr)", signed_sum=True, truth=g64[1].numpy())
+    if len(gg) > 1 and gw[1] is not None and table is not None:      # the table's gradient = the per-edge gradients summed by type
+        gt = np.zeros_like(table); np.add.at(gt, types, gw[1].numpy())
+        g64t = np.zeros(table.shape); np.add.at(g64t, types, g64[1].numpy())
+        check_close(gg[1], gt, None, None, what="hyp conv g(edge table)", signed_sum=True, truth=g64t)
 
 
 ALL_NC = ["sum", "sum2", "sum3", "sum4", "mean", "mean2", "mean3", "mean4", "max", "max2", "max3", "max4", "min", "min2", "min3", "min4"]
