@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 20
+#define MMA_ABI_VERSION 21
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -155,6 +155,14 @@ int mma_csr_spmm_items(
 int mma_split_bf16x3(const float* in, int64_t n, void* out_3n_bf16, void* stream);
 int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, float* C, int64_t ldc,
                     int64_t M, int32_t N, int32_t K, int32_t accumulate /* 0: C = A B, 1: C += A B */, void* stream);
+/* Three-product form for K = 128 (the forward [P|Q] = x [Wtop|Wbot] and every other tall product whose reduction fits one
+ * 128-wide chunk): fp16 x 2 pieces, a = s_row (a_hi + 2^-11 a_lo), b = s_col (b_hi + 2^-11 b_lo), a b ~= hi hi + 2^-11 (hi lo +
+ * lo hi) - half the MFMAs of the six-product bf16 form at the accuracy of an fp32 GEMM (measured 1.1e-7 sum|a||b|).  The
+ * power-of-two row scales of A are formed in the kernel; the CALLER prepares B: Bt2 = (2, N, 128) fp16, piece 0 = hi and
+ * piece 1 = lo * 2^11 of B^T scaled per column by a power of two that puts the column maximum into [2^14, 2^15), and
+ * col_unscale (N,) fp32 = the reciprocal of that scale.  N % 128 == 0, N <= 4096; any M (ragged tails handled inside). */
+int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,
+                   int64_t M, int32_t N, void* stream);
 /* TN form for the weight gradients (autograd's x^T g of layers.py:215-216's torch.mm): C (KA,NC) = X^T G with X (M,KA),
  * G (M,NC) fp32 row-major, C contiguous.  KA in {32,64,96,128}, NC % 32 == 0.  Both operands are split to bf16x3 on the
  * fly; the reduction over M runs in fixed row ranges whose partial tiles (ws) are summed in a fixed order.

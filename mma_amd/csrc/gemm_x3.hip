@@ -326,6 +326,118 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_x3_colgroup_kernel(const G
   }
 }
 
+// ---- K == 128, three products: fp16 x 2 pieces with row / column scales (round 2) -------------------------------------------
+// a = s_row (a_hi + 2^-11 a_lo), b = s_col (b_hi + 2^-11 b_lo) with fp16 pieces (11 + 11 mantissa bits) and POWER-OF-TWO scales that
+// put every row maximum of A and column maximum of B into [2^14, 2^15): fp16's exponent range then never limits a value
+// that matters (29 binades below the maximum keep full precision), the scaling is exact, and
+//     a b ~= hi hi + 2^-11 (hi lo + lo hi)        (dropped: lo lo, 2^-22 relative)
+// needs THREE MFMAs per k-step instead of six (two accumulators).  Measured max error 1.1e-7 sum|a||b| (fp32 library GEMM:
+// 4.1e-7).  The row scale is free here: in the column-group form a wave holds whole rows of A (K = 128) in registers.  Same
+// structure as gemm_x3_colgroup_kernel (resident B slab: 70 KB, pipelined fragments, nt buffer stores); handles a ragged M itself.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+struct HFrag { f16x8 b1, b2; };
+constexpr int kHgTile = 2 * kCgPiece, kHgLds = 4 * kHgTile;
+__device__ __forceinline__ HFrag hg_frag(const unsigned char* sb, int ks) {
+  HFrag f;
+  f.b1 = *reinterpret_cast<const f16x8*>(sb + 0 * kCgPiece + ks * 32);
+  f.b2 = *reinterpret_cast<const f16x8*>(sb + 1 * kCgPiece + ks * 32);
+  return f;
+}
+__global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(const GemmParams p, const float* col_unscale, int64_t n_units,
+                                                                           int n_groups) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kHgLds];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, h = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int streams_per_xcd = kCgSlotsPerXcd / n_groups;
+  if (slot >= streams_per_xcd * n_groups) return;
+  const int g = slot % n_groups;
+  const int64_t stream = xcd * streams_per_xcd + slot / n_groups, n_streams = 8 * streams_per_xcd;
+  const _Float16* Bh = reinterpret_cast<const _Float16*>(p.Bt);            // (2, N, 128) fp16: hi, lo * 2^11
+  for (int q = tid; q < 4 * 2 * 32 * 16; q += kCgThreads) {
+    const int kq = q & 15, col = (q >> 4) & 31, tp = q >> 9, piece = tp % 2, tile = tp / 2;
+    *reinterpret_cast<uint4*>(lds + tile * kHgTile + piece * kCgPiece + col * kCgPitch + kq * 16) =
+        *reinterpret_cast<const uint4*>(Bh + ((size_t)piece * p.N + (size_t)(g * 128 + tile * 32 + col)) * 128 + kq * 8);
+  }
+  __syncthreads();
+  const uint32_t a_off = (uint32_t)r31 * (uint32_t)p.lda + 8u * h;
+  const uint32_t c_off = 4u * h * (uint32_t)p.ldc + (uint32_t)r31;
+  const unsigned char* sb0 = lds + r31 * kCgPitch + h * 16;
+  HFrag cur = hg_frag(sb0, 0);
+  // this lane's column in each of the 4 tiles: log2 of its un-scale (an exact power of two), applied together with the row's by ONE
+  // ldexp (two multiplications overflow / underflow in between for rows or columns near the ends of the fp32 range).  Loaded
+  // ONCE: a load inside the tile loop would sit behind the previous tile's 16 stores in the in-order vmcnt queue.
+  const int cue0 = (int)((__float_as_uint(col_unscale[g * 128 + 0 + r31]) >> 23) & 0xFF) - 127;
+  const int cue1 = (int)((__float_as_uint(col_unscale[g * 128 + 32 + r31]) >> 23) & 0xFF) - 127;
+  const int cue2 = (int)((__float_as_uint(col_unscale[g * 128 + 64 + r31]) >> 23) & 0xFF) - 127;
+  const int cue3 = (int)((__float_as_uint(col_unscale[g * 128 + 96 + r31]) >> 23) & 0xFF) - 127;
+  for (int64_t u = stream; u < n_units; u += n_streams) {
+    const int64_t row0 = u * kCgRows + wave * 32;
+    if (row0 >= p.M) continue;                                      // the last unit may be ragged: rows past M are re-read (the last
+    const int64_t rows_here = min((int64_t)32, p.M - row0);          // row) and their stores dropped by the buffer range check
+    float4 raw[16];
+    {
+      const float* ap = p.A + row0 * p.lda - (r31 >= rows_here ? (int64_t)(r31 - (rows_here - 1)) * p.lda : 0);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        raw[2 * ks] = *reinterpret_cast<const float4*>(ap + a_off + ks * 16);
+        raw[2 * ks + 1] = *reinterpret_cast<const float4*>(ap + a_off + ks * 16 + 4);
+      }
+    }
+    // row scale: a power of two that puts the row maximum into [2^14, 2^15)
+    float rmax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(raw[i].x), fabsf(raw[i].y)), fmaxf(fabsf(raw[i].z), fabsf(raw[i].w))));
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+    const int ex = (int)((__float_as_uint(rmax) >> 23) & 0xFF);
+    const int sce = min(max(14 - (ex - 127), -126), 127);            // log2 of the row scale
+    const float sc = __uint_as_float((uint32_t)(sce + 127) << 23);
+    int rse[16];                                                   // accumulator register r holds row (r&3) + 8 (r>>2) + 4h: that row's
+#pragma unroll                                                     // scale exponent, fetched ONCE per block (not per tile and store)
+    for (int r = 0; r < 16; ++r) rse[r] = __shfl(sce, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+    f16x8 af[8][2];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const float v[8] = {raw[2*ks].x, raw[2*ks].y, raw[2*ks].z, raw[2*ks].w, raw[2*ks+1].x, raw[2*ks+1].y, raw[2*ks+1].z, raw[2*ks+1].w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float x = v[i] * sc;
+        const _Float16 hi = (_Float16)x;
+        af[ks][0][i] = hi;
+        af[ks][1][i] = (_Float16)((x - (float)hi) * 2048.f);
+      }
+    }
+    const __amdgpu_buffer_rsrc_t crow =
+        __builtin_amdgcn_make_buffer_rsrc(p.C + row0 * p.ldc, 0, (int)min((int64_t)0x7fffffff, rows_here * p.ldc * 4), 0x00020000);
+#pragma unroll 1
+    for (int ct = 0; ct < 4; ++ct) {
+      const int cue = ct == 0 ? cue0 : (ct == 1 ? cue1 : (ct == 2 ? cue2 : cue3));
+      f32x16 acc, acl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acl[r] = 0.f; }
+      const unsigned char* sb = sb0 + ct * kHgTile;
+      const unsigned char* sbn = sb0 + ((ct + 1) & 3) * kHgTile;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const HFrag nxt = ks < 7 ? hg_frag(sb, ks + 1) : hg_frag(sbn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b2, acl, 0, 0, 0);
+        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], cur.b1, acl, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b1, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      }
+      // row r of the tile belongs to lane-row (r&3)+8*(r>>2)+4h: its scale lives in the lane with that r31
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ldexpf(acc[r] + acl[r] * (1.f / 2048.f), cue - rse[r])), crow, c_off * 4u,
+                                              (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + g * 128 + ct * 32) * 4u, kCgStoreAux);
+      }
+    }
+  }
+}
+
 // ---- N == 128, long K: the dL/dx products g [Wtop|Wbot]^T (round 2) ---------------------------------------------------
 // The accumulator tiles of all 128 columns persist in registers over the K chunks (as in gemm_x3_kernel<4>), but a workgroup
 // is 8 waves = 256 rows and the slab of one K chunk holds ALL four column tiles (4 x 3 x 32 x 64 bf16, 54 KB, double
@@ -732,6 +844,20 @@ extern "C" int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, flo
 #undef MMA_X3_LAUNCH
   }
   return check_launch("gemm_x3_kernel");
+}
+
+extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc, int64_t M,
+                              int32_t N, void* stream) {
+  MMA_REQUIRE(M >= 0 && N >= 128 && N % 128 == 0 && N / 128 <= kCgSlotsPerXcd, "M=%lld N=%d: need N %% 128 == 0, N <= 4096", (long long)M, N);
+  MMA_REQUIRE(lda >= 128 && ldc >= N && lda % 4 == 0 && lda < (1 << 24) && ldc < (1 << 24), "row pitch too small, unaligned or >= 2^24");
+  if (M == 0) return 0;
+  MMA_REQUIRE(A && Bt2 && col_unscale && C && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt2) & 15) == 0,
+              "NULL or misaligned argument");
+  GemmParams p{A, lda, static_cast<const __bf16*>(Bt2), C, ldc, M, N, 128, 0};
+  const int64_t n_units = (M + kCgRows - 1) / kCgRows;
+  hipLaunchKernelGGL(gemm_f16x2_colgroup_kernel, dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p, col_unscale, n_units,
+                     N / 128);
+  return check_launch("gemm_f16x2_colgroup_kernel");
 }
 
 extern "C" int64_t mma_gemm_bf16x3_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC) {

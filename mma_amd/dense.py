@@ -28,6 +28,25 @@ def _x3_ok(a, w):
             and N % 32 == 0 and K % 128 == 0 and (K == 128 or N <= 128 or N % 128 == 0))
 
 
+USE_F16X2 = True      # K == 128 products on the three-product fp16 x 2 kernel (csrc/gemm_x3.hip) instead of the six-product bf16 x 3 one
+
+
+def gemm_f16x2(a, w, out=None):
+    """a (M,128) @ w (128,N), N % 128 == 0: the three-product form (fp16 hi/lo pieces, power-of-two row and column scales)."""
+    M, K = a.shape
+    N = w.shape[1]
+    amax = w.abs().amax(0).clamp_min(1e-30)
+    s = torch.exp2(14.0 - torch.floor(torch.log2(amax)))                 # column maxima into [2^14, 2^15): exact scaling
+    x = (w * s).t().contiguous()                                         # (N,K): B^T, k contiguous
+    hi = x.half()
+    bt2 = torch.stack([hi, ((x - hi.float()) * 2048.0).half()]).contiguous()
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    with _span("gemm_x3_k128"):
+        call("mma_gemm_f16x2", ptr(a), a.stride(0), ptr(bt2), ptr((1.0 / s).contiguous()), ptr(out), out.stride(0), M, N, stream_ptr())
+    return out
+
+
 def gemm_bf16x3(a, w, out=None, accumulate=False):
     """a (M,K) @ w (K,N) with fp32 accuracy on the bf16 MFMA path (three-piece split of both operands).  `a` may be a
     row-strided view (a column block of a wider buffer); accumulate=True adds the product to `out`."""
@@ -35,6 +54,9 @@ def gemm_bf16x3(a, w, out=None, accumulate=False):
         a = a.contiguous()
     M, K = a.shape
     N = w.shape[1]
+    if (USE_F16X2 and K == 128 and not accumulate and N % 128 == 0 and N <= 4096 and M >= _MIN_ROWS_X3
+            and (out is None or (out.stride(1) == 1 and out.dtype == torch.float32))):
+        return gemm_f16x2(a, w, out)
     wt = w.t().contiguous()                                  # (N,K): B^T, k contiguous
     bt3 = torch.empty((3, N, K), device=a.device, dtype=torch.bfloat16)
     call("mma_split_bf16x3", ptr(wt), N * K, ptr(bt3), stream_ptr())

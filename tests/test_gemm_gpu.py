@@ -12,8 +12,14 @@ DEV = "cuda:0"
                                    (5003, 256, 384), (4100, 1024, 256),       # these two: column-blocked (K > 128 and N > 128)
                                    (40037, 128, 1024), (70001, 128, 512), (140001, 128, 256), (263000, 128, 128),    # column-group kernel + tail
                                    (66001, 256, 128), (131075, 1024, 128)])                                         # N == 128 long-K kernel + tail
-def test_gemm_bf16x3_accuracy(M, K, N):
+@pytest.mark.parametrize("f16x2", [True, False], ids=["f16x2", "bf16x3"])
+def test_gemm_bf16x3_accuracy(M, K, N, f16x2, monkeypatch):
+    """f16x2: the K == 128, N % 128 == 0 products take the three-product fp16 kernel (mma_gemm_f16x2); bf16x3: everything on the
+    six-product kernels."""
     from mma_amd import dense
+    monkeypatch.setattr(dense, "USE_F16X2", f16x2)
+    if f16x2 and not (K == 128 and N % 128 == 0):
+        pytest.skip("not a shape of the three-product kernel")
     rng = np.random.default_rng(M + K + N)
     a = torch.from_numpy((rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, 1)))).astype(np.float32)).to(DEV)
     w = torch.from_numpy(((rng.random((K, N)) * 2 - 1) / np.sqrt(K)).astype(np.float32)).to(DEV)
@@ -122,9 +128,10 @@ def test_tower_linear_backward(N, T, O, C):
 
 
 @pytest.mark.parametrize("M,K,N", [(5000, 128, 512), (4099, 512, 128), (9001, 1024, 128), (70001, 512, 128)])
-def test_gemm_bf16x3_accumulate(M, K, N):
+def test_gemm_bf16x3_accumulate(M, K, N, monkeypatch):
     """accumulate=True: C += A B in the kernel epilogue (used for dL/dx = direct part + g [Wtop|Wbot]^T)."""
     from mma_amd import dense
+    monkeypatch.setattr(dense, "USE_F16X2", False)          # `plain` below must be the six-product kernel's product as well
     rng = np.random.default_rng(M + K + N + 1)
     a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(DEV)
     w = torch.from_numpy(((rng.random((K, N)) * 2 - 1) / np.sqrt(K)).astype(np.float32)).to(DEV)
@@ -177,3 +184,28 @@ def test_linear_tall_on_the_bf16x3_kernels(N, fin, fout, bias, padded_grad):
         assert not dense.linear_x3_ok(x, w)
     finally:
         dense.X3_LINEAR = True
+
+
+def test_gemm_f16x2_edge_rows():
+    """Three-product kernel: all-zero rows, rows of one huge / one tiny value (the power-of-two row scale must keep both exact),
+    a ragged last block, a row-strided A, and a wide dynamic range INSIDE rows."""
+    from mma_amd import dense
+    rng = np.random.default_rng(5)
+    M, K, N = 9000 + 77, 128, 256
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    a[3] = 0.0
+    a[4] = 0.0; a[4, 17] = 1.0e36              # x w up to 2e37: finite only if the two un-scalings are applied as one
+    a[5] = 0.0; a[5, 99] = 1.0e-30
+    a[6] *= np.exp(rng.uniform(-20, 20, K)).astype(np.float32)
+    buf = torch.zeros((M, K + 64), device=DEV)
+    buf[:, :K] = torch.from_numpy(a).to(DEV)
+    av = buf[:, :K]                                              # row-strided view
+    w = torch.from_numpy(((rng.random((K, N)) * 2 - 1) * np.exp(rng.uniform(-3, 3, (1, N)))).astype(np.float32)).to(DEV)
+    got = dense.gemm_f16x2(av, w)
+    ref = av.double() @ w.double()
+    scale = av.double().abs() @ w.double().abs()
+    err = (got.double() - ref).abs() / scale.clamp_min(1e-300)
+    assert torch.isfinite(got).all()
+    assert (got[3] == 0).all()
+    assert err[scale > 0].max().item() < 5e-7, err[scale > 0].max().item()
+    assert torch.equal(got, dense.gemm_f16x2(av, w))
