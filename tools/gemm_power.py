@@ -41,10 +41,12 @@ def main():
     print("|---|---|---|---|")
     for name, r in rows:
         print("| %s | %.3f ms | %.3f ms | %.3f ms |" % ((name,) + r))
-    flops = 2.0 * N * H * 2 * K * H * 6           # six bf16 piece products per fp32 product
-    print("\nEach is 275 GFLOP of fp32 work = %.2f TFLOP of bf16 MFMA; on random data that is %s PFLOP/s, on zeros %s PFLOP/s "
-          "(dense bf16 peak 2.5 PFLOP/s at 2.4 GHz)." % (flops / 1e12, " / ".join("%.2f" % (flops / 1e15 / (t * 1e-3)) for t in rows[0][1]),
-                                                       " / ".join("%.2f" % (flops / 1e15 / (t * 1e-3)) for t in rows[1][1])))
+    base = 2.0 * N * H * 2 * K * H                # fp32 flops of each product
+    mf = (3, 6, 6) if dense.USE_F16X2 else (6, 6, 6)     # piece products per fp32 product: forward on the three-product fp16 kernel
+    rate = lambda ts: " / ".join("%.2f" % (base * m / 1e15 / (t * 1e-3)) for t, m in zip(ts, mf))
+    print("\nEach is 275 GFLOP of fp32 work = %s TFLOP of 16-bit MFMA (%s piece products per fp32 product); on random data that is %s "
+          "PFLOP/s, on zeros %s PFLOP/s (dense bf16/fp16 peak 2.5 PFLOP/s at 2.4 GHz)." % (
+              " / ".join("%.2f" % (base * m / 1e12) for m in mf), " / ".join(str(m) for m in mf), rate(rows[0][1]), rate(rows[1][1])))
 
 
 if __name__ == "__main__":
