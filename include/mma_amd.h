@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 21
+#define MMA_ABI_VERSION 22
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -98,6 +98,9 @@ int mma_nc_bwd_node(
                                                     [ g (H floats) | 1/d_i,0,0,0 | 1-byte codes of each max/min/softmax/softmin mask,
                                                     ceil(H/4) words each ]; pitch >= mma_nc_aux_row_floats() */
     float* gP, int64_t ldgp, float* gxs, int64_t ldgx,
+    float* row_max,                              /* optional (N,) in/out, zeroed by the caller: row_max[i] = max(row_max[i], max |gP[i,:]|)
+                                                    by atomicMax on the bit pattern - with K2b's contribution the row scale of the
+                                                    three-product dL/dx GEMM (mma_gemm_f16x2_n128) */
     int64_t N, int32_t H, int32_t K, const uint8_t* kind_host, void* stream);
 int64_t mma_nc_aux_row_floats(int32_t H, int32_t K, const uint8_t* kind_host);
 
@@ -118,6 +121,7 @@ int mma_nc_fused_bwd(
     const int32_t* items, int64_t n_items, int64_t n_wave_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots,
     float* gQ, int64_t ldgq, float* gx, int64_t ldgxo,
+    float* row_max,                              /* optional (n_src,), as in mma_nc_bwd_node: row_max[j] = max(row_max[j], max |gQ[j,:]|) */
     int64_t N, int64_t E, int32_t H, int32_t K,
     const uint8_t* act_host,
     int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, int64_t drop_edge_base, const uint8_t* keep,
@@ -163,6 +167,12 @@ int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, float* C, int6
  * col_unscale (N,) fp32 = the reciprocal of that scale.  N % 128 == 0, N <= 4096; any M (ragged tails handled inside). */
 int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,
                    int64_t M, int32_t N, void* stream);
+/* The same three-product form for N = 128 and a long reduction (dL/dx += [gP|gQ] [Wtop|Wbot]^T, K % 64 == 0): the row scales
+ * cannot be formed in the kernel (a row is consumed in 64-wide chunks), so the caller passes row_max (M,) >= the maximum
+ * |a| of every row (the backward kernels produce it: mma_nc_bwd_node / mma_nc_fused_bwd); 0 marks an all-zero row.
+ * Bt2 = (2, 128, K) fp16 and col_unscale (128,) as for mma_gemm_f16x2.  accumulate != 0: C += A B (one L2 atomic per element). */
+int mma_gemm_f16x2_n128(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale,
+                        float* C, int64_t ldc, int64_t M, int32_t K, int32_t accumulate, void* stream);
 /* TN form for the weight gradients (autograd's x^T g of layers.py:215-216's torch.mm): C (KA,NC) = X^T G with X (M,KA),
  * G (M,NC) fp32 row-major, C contiguous.  KA in {32,64,96,128}, NC % 32 == 0.  Both operands are split to bf16x3 on the
  * fly; the reduction over M runs in fixed row ranges whose partial tiles (ws) are summed in a fixed order.

@@ -565,6 +565,127 @@ __global__ __launch_bounds__(kNlThreads, 1) void gemm_x3_n128_kernel(const GemmP
   }
 }
 
+// ---- N == 128, long K, three products (round 2): gemm_x3_n128_kernel with fp16 x 2 pieces -------------------------------------
+// Same structure (8 waves = 256 rows, whole-chunk slab, one barrier per K chunk, pipelined fragments, atomic C +=), half the
+// MFMAs.  The row scale comes from row_max (>= the row's maximum |a|, produced by the kernels that wrote A); both un-scalings
+// are one ldexp in the epilogue.  Handles a ragged M itself (rows past M re-read the last row, their stores / atomics are
+// dropped by the buffer range check).
+constexpr int kHnSlab = 2 * kNlPiece;                    // 36 864 B per K chunk (two fp16 pieces of all 128 columns)
+
+template <bool ACC>
+__global__ __launch_bounds__(kNlThreads, 1) void gemm_f16x2_n128_kernel(const GemmParams p, const float* row_max, const float* col_unscale,
+                                                                        int64_t n_units) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kHnSlab];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, h = lane >> 5;
+  const int n_kc = p.K / kNlKC;
+  const uint32_t c_off = (4u * h * (uint32_t)p.ldc + (uint32_t)r31) * 4u;
+  const unsigned char* fb = lds + r31 * kNlPitch + h * 16;
+  // slab staging: 256 rows (piece, column) x 8 chunks of 16 B = 2048 chunks, 4 per thread
+  const int s_row = tid >> 3, s_kq = tid & 7;
+  const _Float16* s_src = reinterpret_cast<const _Float16*>(p.Bt) + (size_t)s_row * p.K + s_kq * 8;
+  unsigned char* s_dst = lds + s_row * kNlPitch + s_kq * 16;
+
+  for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+    const int64_t row0 = u * kNlRows + wave * 32;
+    const int64_t rows_here = min((int64_t)32, p.M - row0);          // <= 0: this wave has no row, but it still stages and syncs
+    const int64_t arow_i = row0 + min((int64_t)r31, max(rows_here, (int64_t)1) - 1);
+    const float* ap = p.A + min(arow_i, p.M - 1) * p.lda + 8 * h;
+    // power-of-two row scale from the caller's bound on the row maximum
+    const float rmax = row_max[min(arow_i, p.M - 1)];
+    const int ex = (int)((__float_as_uint(rmax) >> 23) & 0xFF);
+    const int sce = min(max(14 - (ex - 127), -126), 127);
+    const float sc = __uint_as_float((uint32_t)(sce + 127) << 23);
+    f32x16 acc[4], acl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; acl[t][r] = 0.f; }
+    uint4 s0 = *reinterpret_cast<const uint4*>(s_src), s1 = *reinterpret_cast<const uint4*>(s_src + (size_t)64 * p.K);
+    uint4 s2 = *reinterpret_cast<const uint4*>(s_src + (size_t)128 * p.K), s3 = *reinterpret_cast<const uint4*>(s_src + (size_t)192 * p.K);
+    float4 raw[8];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      raw[2 * ks] = *reinterpret_cast<const float4*>(ap + ks * 16);
+      raw[2 * ks + 1] = *reinterpret_cast<const float4*>(ap + ks * 16 + 4);
+    }
+    __syncthreads();                                     // the previous unit's last chunk has been read by every wave
+    *reinterpret_cast<uint4*>(s_dst) = s0;                          *reinterpret_cast<uint4*>(s_dst + 64 * kNlPitch) = s1;
+    *reinterpret_cast<uint4*>(s_dst + 128 * kNlPitch) = s2;         *reinterpret_cast<uint4*>(s_dst + 192 * kNlPitch) = s3;
+    __syncthreads();
+
+    for (int kc = 0; kc < n_kc; ++kc) {
+      f16x8 af[4][2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const float v[8] = {raw[2*ks].x, raw[2*ks].y, raw[2*ks].z, raw[2*ks].w, raw[2*ks+1].x, raw[2*ks+1].y, raw[2*ks+1].z, raw[2*ks+1].w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float x = v[i] * sc;
+          const _Float16 hi = (_Float16)x;
+          af[ks][0][i] = hi;
+          af[ks][1][i] = (_Float16)((x - (float)hi) * 2048.f);
+        }
+      }
+      const bool more = kc + 1 < n_kc;
+      if (more) {                                         // next chunk: slab and A, in flight during this chunk's MFMAs
+        const _Float16* q = s_src + (kc + 1) * kNlKC;
+        s0 = *reinterpret_cast<const uint4*>(q);                           s1 = *reinterpret_cast<const uint4*>(q + (size_t)64 * p.K);
+        s2 = *reinterpret_cast<const uint4*>(q + (size_t)128 * p.K);       s3 = *reinterpret_cast<const uint4*>(q + (size_t)192 * p.K);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          raw[2 * ks] = *reinterpret_cast<const float4*>(ap + (kc + 1) * kNlKC + ks * 16);
+          raw[2 * ks + 1] = *reinterpret_cast<const float4*>(ap + (kc + 1) * kNlKC + ks * 16 + 4);
+        }
+      }
+      const unsigned char* sb = fb + (kc & 1) * kHnSlab;
+      HFrag cur;
+      cur.b1 = *reinterpret_cast<const f16x8*>(sb);
+      cur.b2 = *reinterpret_cast<const f16x8*>(sb + kNlPiece);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          HFrag nxt = cur;
+          if (ks < 3 || ct < 3) {
+            const unsigned char* q = sb + (ks < 3 ? ct : ct + 1) * 32 * kNlPitch + (ks < 3 ? ks + 1 : 0) * 32;
+            nxt.b1 = *reinterpret_cast<const f16x8*>(q);
+            nxt.b2 = *reinterpret_cast<const f16x8*>(q + kNlPiece);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acl[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b2, acl[ct], 0, 0, 0);
+          acl[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], cur.b1, acl[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b1, acc[ct], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          cur = nxt;
+        }
+      }
+      if (more) {
+        unsigned char* d = s_dst + ((kc + 1) & 1) * kHnSlab;
+        *reinterpret_cast<uint4*>(d) = s0;                          *reinterpret_cast<uint4*>(d + 64 * kNlPitch) = s1;
+        *reinterpret_cast<uint4*>(d + 128 * kNlPitch) = s2;         *reinterpret_cast<uint4*>(d + 192 * kNlPitch) = s3;
+        __syncthreads();
+      }
+    }
+    if (rows_here <= 0) continue;                         // (after the barriers)
+    const __amdgpu_buffer_rsrc_t crow =
+        __builtin_amdgcn_make_buffer_rsrc(p.C + row0 * p.ldc, 0, (int)min((int64_t)0x7fffffff, rows_here * p.ldc * 4), 0x00020000);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int cue = (int)((__float_as_uint(col_unscale[t * 32 + r31]) >> 23) & 0xFF) - 127;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rse = __shfl(sce, (r & 3) + 8 * (r >> 2) + 4 * h, 64);          // once per 256 x 128 block: not worth 16 registers
+        const float val = ldexpf(acc[t][r] + acl[t][r] * (1.f / 2048.f), cue - rse);
+        const uint32_t so = (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + t * 32) * 4u;
+        if (ACC) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(val, crow, c_off, so, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), crow, c_off, so, 0);
+      }
+    }
+  }
+}
+
 // split a row-major fp32 matrix (rows, cols) into its three bf16 pieces: out (3, rows, cols)
 __global__ void split3_kernel(const float* in, int64_t n, __bf16* out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -858,6 +979,22 @@ extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, cons
   hipLaunchKernelGGL(gemm_f16x2_colgroup_kernel, dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p, col_unscale, n_units,
                      N / 128);
   return check_launch("gemm_f16x2_colgroup_kernel");
+}
+
+extern "C" int mma_gemm_f16x2_n128(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale, float* C,
+                                   int64_t ldc, int64_t M, int32_t K, int32_t accumulate, void* stream) {
+  MMA_REQUIRE(M >= 0 && K >= kNlKC && K % kNlKC == 0 && K <= (1 << 20), "M=%lld K=%d: need K %% 64 == 0", (long long)M, K);
+  MMA_REQUIRE(lda >= K && ldc >= 128 && lda % 4 == 0 && lda < (1 << 24) && ldc < (1 << 24), "row pitch too small, unaligned or >= 2^24");
+  if (M == 0) return 0;
+  MMA_REQUIRE(A && row_max && Bt2 && col_unscale && C && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt2) & 15) == 0,
+              "NULL or misaligned argument");
+  GemmParams p{A, lda, static_cast<const __bf16*>(Bt2), C, ldc, M, 128, K, accumulate ? 1 : 0};
+  const int64_t n_units = (M + kNlRows - 1) / kNlRows;
+  const dim3 g((unsigned)(n_units < 256 ? n_units : 256));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (accumulate) hipLaunchKernelGGL(gemm_f16x2_n128_kernel<true>, g, dim3(kNlThreads), 0, st, p, row_max, col_unscale, n_units);
+  else hipLaunchKernelGGL(gemm_f16x2_n128_kernel<false>, g, dim3(kNlThreads), 0, st, p, row_max, col_unscale, n_units);
+  return check_launch("gemm_f16x2_n128_kernel");
 }
 
 extern "C" int64_t mma_gemm_bf16x3_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC) {

@@ -276,6 +276,7 @@ struct NcBwdNodeParams {
   int64_t N; int H, K; uint32_t kinds;
   // shared-gradient form: one packed row per target for K2b, [ g (H floats) | 1/d_i, 0, 0, 0 | codes of sel-kind 0 (HQ words) | ... ]
   float* aux; int64_t ldaux; int HQ; uint8_t sel_slot[MMA_MAX_K];
+  uint32_t* rowmax;        // optional: max |gP| per node (bits of a non-negative float), merged with K2b's max |gQ| by atomicMax
 };
 
 template <int VEC>
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
       }
     }
     Vec<VEC> gx = vzero<VEC>();
+    float mxp = 0.f;
 #pragma unroll
     for (int k = 0; k < MMA_MAX_K; ++k) {
       if (k < p.K) {
@@ -324,6 +326,7 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
           gsv.v[i] = g.v[i] * fs;
           gpv.v[i] = gsv.v[i] * t.v[i];
           gx.v[i] = fmaf(g.v[i], fx, gx.v[i]);
+          mxp = fmaxf(mxp, fabsf(gpv.v[i]));
         }
         if (p.gs) stv<VEC>(p.gs + (size_t)node * p.ldgs + (size_t)k * p.H + c, gsv);
         if (p.aux) {
@@ -348,6 +351,14 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
       }
     }
     stv<VEC>(p.gxs + (size_t)node * p.ldgx + c, gx);
+    if (p.rowmax) {          // the row maximum of gP for the three-product dL/dx GEMM (its A rows are scaled by a power of two)
+      if ((per_row & (per_row - 1)) == 0 && per_row <= kWave) {     // a node's threads are an aligned lane group: one atomic per node
+        for (int off = per_row >> 1; off > 0; off >>= 1) mxp = fmaxf(mxp, __shfl_xor(mxp, off, kWave));
+        if ((idx & (per_row - 1)) == 0 && mxp > 0.f) atomicMax(p.rowmax + node, __float_as_uint(mxp));
+      } else if (mxp > 0.f) {
+        atomicMax(p.rowmax + node, __float_as_uint(mxp));
+      }
+    }
   }
 }
 
@@ -368,6 +379,7 @@ struct NcBwdParams {
   uint32_t acts;
   DropParams drop;
   int first_pass;  // k_base == 0: gx starts from gxs; later K-slices accumulate onto gx
+  uint32_t* rowmax;  // optional: max |gQ| per source row (see NcBwdNodeParams::rowmax)
 };
 
 // dm/ds of the combine from the saved selection code (same table as nc_bwd_node_kernel)
@@ -522,6 +534,17 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
       }
     }
 
+    if (p.rowmax) {           // wave-uniform
+      float mxq = 0.f;
+      if (sub == 0 && fvalid && ivalid && slot < 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) mxq = fmaxf(mxq, fabsf(xj.v[i] * aq[k].v[i]));
+      }
+      for (int off = lpr >> 1; off > 0; off >>= 1) mxq = fmaxf(mxq, __shfl_xor(mxq, off, kWave));
+      if (sub == 0 && (lane & (lpr - 1)) == 0 && ivalid && slot < 0 && mxq > 0.f) atomicMax(p.rowmax + node, __float_as_uint(mxq));
+    }
     if (sub == 0 && fvalid && ivalid) {
       if (slot < 0) {
 #pragma unroll
@@ -577,6 +600,12 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_finalize_kernel(const NcBwdPara
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o.v[i] = xj.v[i] * s.v[i];
       stv<VEC>(p.gQ + (size_t)node * p.ldgq + (size_t)k * p.H + c, o);
+      if (p.rowmax) {
+        float mxq = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) mxq = fmaxf(mxq, fabsf(o.v[i]));
+        if (mxq > 0.f) atomicMax(p.rowmax + node, __float_as_uint(mxq));
+      }
     } else {
       const Vec<VEC> g0 = ldv<VEC>(p.gxs + (size_t)node * p.ldgx + c);
 #pragma unroll
@@ -781,7 +810,7 @@ extern "C" int64_t mma_nc_aux_row_floats(int32_t H, int32_t K, const uint8_t* ki
 
 extern "C" int mma_nc_bwd_node(
     const float* g, int64_t g_kstride, int64_t ldgr, const uint8_t* sel, const float* T, int64_t ldt, const int32_t* rowptr,
-    float* gs, int64_t ldgs, float* aux, int64_t ldaux, float* gP, int64_t ldgp, float* gxs, int64_t ldgx,
+    float* gs, int64_t ldgs, float* aux, int64_t ldaux, float* gP, int64_t ldgp, float* gxs, int64_t ldgx, float* row_max,
     int64_t N, int32_t H, int32_t K, const uint8_t* kind_host, void* stream) {
   MMA_REQUIRE(N >= 0 && N < (1LL << 31) && H >= 1 && K >= 1 && K <= MMA_MAX_K, "N=%lld H=%d K=%d unsupported", (long long)N, H, K);
   MMA_REQUIRE(ldt >= (int64_t)K * H && (!gs || ldgs >= (int64_t)K * H) && ldgp >= (int64_t)K * H && ldgx >= H && ldgr >= H &&
@@ -791,6 +820,7 @@ extern "C" int mma_nc_bwd_node(
   uint32_t kinds, acts;
   if (int rc = pack_codes(kind_host, nullptr, K, &kinds, &acts)) return rc;
   NcBwdNodeParams p{g, g_kstride, ldgr, sel, T, ldt, rowptr, gs, ldgs, gP, ldgp, gxs, ldgx, N, H, K, kinds};
+  p.rowmax = reinterpret_cast<uint32_t*>(row_max);
   p.aux = aux; p.ldaux = ldaux; p.HQ = (H + 3) / 4;
   const int64_t aux_len = fill_sel_slots(kind_host, K, H, p.sel_slot);
   MMA_REQUIRE(!aux || (g_kstride == 0 && ldaux >= aux_len && ldaux % 4 == 0 && aligned16(aux)),
@@ -813,7 +843,7 @@ extern "C" int mma_nc_fused_bwd(
     const float* gs, int64_t ldg, const float* aux, int64_t ldaux, const uint8_t* kind_host, const float* gxs, int64_t ldgx,
     const int32_t* t_col, const int32_t* t_eid,
     const int32_t* items, int64_t n_items, int64_t n_wave_items, const int32_t* hubs, int64_t n_hubs,
-    float* partial, int64_t n_slots, float* gQ, int64_t ldgq, float* gx, int64_t ldgxo,
+    float* partial, int64_t n_slots, float* gQ, int64_t ldgq, float* gx, int64_t ldgxo, float* row_max,
     int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* act_host,
     int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, int64_t drop_edge_base, const uint8_t* keep,
     void* stream) {
@@ -846,6 +876,7 @@ extern "C" int mma_nc_fused_bwd(
   }
   p.t_col = t_col; p.t_eid = t_eid; p.items = reinterpret_cast<const int4*>(items); p.n_items = n_items;
   p.partial = partial; p.pstride = (int64_t)(K + 1) * H; p.gQ = gQ; p.ldgq = ldgq; p.gx = gx; p.ldgxo = ldgxo;
+  p.rowmax = reinterpret_cast<uint32_t*>(row_max);
   p.H = H; p.HQ = (H + 3) / 4; p.K_total = K; p.lpr_log = g.lpr_log; p.acts = acts;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ipw = kWave >> g.lpr_log;

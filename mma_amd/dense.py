@@ -35,15 +35,37 @@ def gemm_f16x2(a, w, out=None):
     """a (M,128) @ w (128,N), N % 128 == 0: the three-product form (fp16 hi/lo pieces, power-of-two row and column scales)."""
     M, K = a.shape
     N = w.shape[1]
+    bt2, cu = _split_f16x2(w)
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    with _span("gemm_x3_k128"):
+        call("mma_gemm_f16x2", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(out), out.stride(0), M, N, stream_ptr())
+    return out
+
+
+def _split_f16x2(w):
+    """w (K,N) fp32 -> ((2,N,K) fp16 pieces of B^T scaled per column by a power of two, (N,) fp32 reciprocal scales)."""
     amax = w.abs().amax(0).clamp_min(1e-30)
     s = torch.exp2(14.0 - torch.floor(torch.log2(amax)))                 # column maxima into [2^14, 2^15): exact scaling
     x = (w * s).t().contiguous()                                         # (N,K): B^T, k contiguous
     hi = x.half()
-    bt2 = torch.stack([hi, ((x - hi.float()) * 2048.0).half()]).contiguous()
-    if out is None:
-        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
-    with _span("gemm_x3_k128"):
-        call("mma_gemm_f16x2", ptr(a), a.stride(0), ptr(bt2), ptr((1.0 / s).contiguous()), ptr(out), out.stride(0), M, N, stream_ptr())
+    return torch.stack([hi, ((x - hi.float()) * 2048.0).half()]).contiguous(), (1.0 / s).contiguous()
+
+
+USE_F16X2_N128 = __import__("os").environ.get("MMA_F16X2_DX", "1") != "0"
+
+
+def f16x2_n128_ok(M, K, N):
+    return USE_F16X2 and USE_F16X2_N128 and USE_BF16X3 and N == 128 and K % 64 == 0 and K > 128 and M >= (1 << 16)
+
+
+def gemm_f16x2_n128(a, row_max, w, out, accumulate=False):
+    """out (M,128) (+)= a (M,K) @ w (K,128) on the three-product kernel; row_max (M,) >= max |a[i,:]| (0 for an all-zero row)."""
+    M, K = a.shape
+    bt2, cu = _split_f16x2(w)
+    with _span("gemm_x3_acc" if accumulate else "gemm_x3_persist"):
+        call("mma_gemm_f16x2_n128", ptr(a), a.stride(0), ptr(row_max), ptr(bt2), ptr(cu), ptr(out), out.stride(0), M, K, 1 if accumulate else 0,
+             stream_ptr())
     return out
 
 

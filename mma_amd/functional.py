@@ -87,7 +87,7 @@ def nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, save):
     return (msum if reduce_k else m), T, sel
 
 
-def nc_bwd_node_launch(g, reduce_k, sel, T, graph, kinds, H, shared, gP=None):
+def nc_bwd_node_launch(g, reduce_k, sel, T, graph, kinds, H, shared, gP=None, row_max=None):
     """K2a -> (gs or None, aux or None, ldaux, gP (N,K*H), gxs (n_src,H) with zero halo rows).
     gP may be a (N,K*H) column block of a wider buffer (row pitch = its stride(0))."""
     K, N, S = len(kinds), graph.N, graph.n_src
@@ -104,11 +104,11 @@ def nc_bwd_node_launch(g, reduce_k, sel, T, graph, kinds, H, shared, gP=None):
         gxs[N:].zero_()
     with _span("nc_bwd_node"):
         call("mma_nc_bwd_node", ptr(g), 0 if reduce_k else N * H, H, ptr(sel), ptr(T), K * H, ptr(graph.rowptr),
-             ptr(gs), K * H, ptr(aux), ldaux, ptr(gP), gP.stride(0), ptr(gxs), H, N, H, K, host_codes(kinds), stream_ptr())
+             ptr(gs), K * H, ptr(aux), ldaux, ptr(gP), gP.stride(0), ptr(gxs), H, ptr(row_max), N, H, K, host_codes(kinds), stream_ptr())
     return gs, aux, ldaux, gP, gxs
 
 
-def nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, part=None):
+def nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, part=None, row_max=None):
     """K2b over the transposed CSR; `part` = (items, n_wave_items, hubs) restricts it to a subset of the sources."""
     K = len(acts)
     S, H = x_src.shape
@@ -120,8 +120,8 @@ def nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, dr
              ptr(gs), K * H, ptr(aux), ldaux, host_codes(kinds) if shared else None, ptr(gxs), H,
              ptr(graph.t_col), ptr(graph.t_eid), ptr(items), items.shape[0], n_wave,
              ptr(hubs) if hubs.shape[0] else None, hubs.shape[0], ptr(partial), graph.t_n_slots if hubs.shape[0] else 0,
-             ptr(gQ), gQ.stride(0), ptr(gx), H, S, graph.E, H, K, host_codes(acts), mode, thr, seed, seed_dev, graph.edge_base, keep,
-             stream_ptr())
+             ptr(gQ), gQ.stride(0), ptr(gx), H, ptr(row_max), S, graph.E, H, K, host_codes(acts), mode, thr, seed, seed_dev, graph.edge_base,
+             keep, stream_ptr())
 
 
 class _NCFused(torch.autograd.Function):
@@ -192,13 +192,20 @@ class _NCLocalLayer(torch.autograd.Function):
         K = len(kinds)
         KH = K * H
         g = g.contiguous()
+        from . import dense
         gPQ = torch.empty((N, 2 * KH), device=g.device, dtype=torch.float32)
-        gs, aux, ldaux, gP, gxs = nc_bwd_node_launch(g, True, sel, T, graph, kinds, H, SHARED_GRAD_BWD, gP=gPQ[:, :KH])
+        # the three-product dL/dx GEMM scales every row of [gP|gQ] by a power of two: K2a and K2b leave the row maxima here
+        row_max = torch.zeros((N,), device=g.device, dtype=torch.float32) if dense.f16x2_n128_ok(N, 2 * KH, H) and K <= 8 else None
+        gs, aux, ldaux, gP, gxs = nc_bwd_node_launch(g, True, sel, T, graph, kinds, H, SHARED_GRAD_BWD, gP=gPQ[:, :KH], row_max=row_max)
         gx = torch.empty((N, H), device=g.device, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=g.device, dtype=torch.float32)
                    if graph.t_n_slots else None)
-        nc_bwd_edges_launch(x, PQ[:, :KH], PQ[:, KH:], gs, aux, ldaux, gxs, graph, kinds, acts, drop, gPQ[:, KH:], gx, partial)
-        rows_mm_add_(gx, gPQ, wcat.t())                                      # direct + through P and Q in one GEMM (C += A B)
+        nc_bwd_edges_launch(x, PQ[:, :KH], PQ[:, KH:], gs, aux, ldaux, gxs, graph, kinds, acts, drop, gPQ[:, KH:], gx, partial,
+                            row_max=row_max)
+        if row_max is not None:
+            dense.gemm_f16x2_n128(gPQ, row_max, wcat.t(), gx, accumulate=True)
+        else:
+            rows_mm_add_(gx, gPQ, wcat.t())                                  # direct + through P and Q in one GEMM (C += A B)
         gw = xt_g(x, gPQ) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
         return gx, (gw[:, :KH] if gw is not None else None), (gw[:, KH:] if gw is not None else None), None, None, None, None
 

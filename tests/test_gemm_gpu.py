@@ -209,3 +209,31 @@ def test_gemm_f16x2_edge_rows():
     assert (got[3] == 0).all()
     assert err[scale > 0].max().item() < 5e-7, err[scale > 0].max().item()
     assert torch.equal(got, dense.gemm_f16x2(av, w))
+
+
+@pytest.mark.parametrize("M,K,acc", [(70001, 1024, True), (66000, 512, False), (65536 + 255, 192, True)])
+def test_gemm_f16x2_n128(M, K, acc):
+    """Three-product N == 128 kernel (the dL/dx shape): caller-supplied row maxima (exact, or a loose bound 8x above), rows of
+    very different magnitudes, all-zero rows with row_max 0, ragged M, C += by one atomic per element (bit-repeatable)."""
+    from mma_amd import dense
+    rng = np.random.default_rng(M + K)
+    a = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-12, 12, (M, 1)))).astype(np.float32)
+    a[5] = 0.0
+    a[M - 1] = 0.0
+    at = torch.from_numpy(a).to(DEV)
+    w = torch.from_numpy(((rng.random((K, 128)) * 2 - 1) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    c0 = torch.from_numpy(rng.standard_normal((M, 128)).astype(np.float32)).to(DEV) if acc else torch.zeros((M, 128), device=DEV)
+    rm = at.abs().amax(1)
+    rm[::3] *= 8.0                                               # a bound, not the exact maximum
+    out = c0.clone()
+    dense.gemm_f16x2_n128(at, rm, w, out, accumulate=acc)
+    prod = at.double() @ w.double()
+    scale = at.double().abs() @ w.double().abs()
+    got_prod = out.double() - (c0.double() if acc else 0)
+    nz = scale > 0
+    tol = 5e-7 * scale + (1.2e-7 * c0.double().abs() if acc else 0)      # + the one fp32 addition onto c0
+    assert ((got_prod - prod).abs()[nz] <= tol[nz]).all(), ((got_prod - prod).abs() / scale.clamp_min(1e-300))[nz].max().item()
+    assert torch.equal(out[5], c0[5]) and torch.equal(out[M - 1], c0[M - 1])
+    again = c0.clone()
+    dense.gemm_f16x2_n128(at, rm, w, again, accumulate=acc)
+    assert torch.equal(again, out)
