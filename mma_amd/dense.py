@@ -69,6 +69,15 @@ def gemm_f16x2_n128(a, row_max, w, out, accumulate=False):
     return out
 
 
+def rows_mm_add_scaled_(acc, a, w, row_max):
+    """acc += a @ w like rows_mm_add_, on the three-product kernel when the rows' maxima are known (row_max (M,) >= max |a[i,:]|,
+    as K2a / K2b leave them) and the shape is the dL/dx one; else the six-product / library path."""
+    if (row_max is not None and a.shape[0] > 0 and f16x2_n128_ok(a.shape[0], a.shape[1], w.shape[1]) and acc.stride(1) == 1
+            and a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0):
+        return gemm_f16x2_n128(a, row_max, w, acc, accumulate=True)
+    return rows_mm_add_(acc, a, w)
+
+
 def gemm_bf16x3(a, w, out=None, accumulate=False):
     """a (M,K) @ w (K,N) with fp32 accuracy on the bf16 MFMA path (three-piece split of both operands).  `a` may be a
     row-strided view (a column block of a wider buffer); accumulate=True adds the product to `out`."""

@@ -202,10 +202,7 @@ class _NCLocalLayer(torch.autograd.Function):
                    if graph.t_n_slots else None)
         nc_bwd_edges_launch(x, PQ[:, :KH], PQ[:, KH:], gs, aux, ldaux, gxs, graph, kinds, acts, drop, gPQ[:, KH:], gx, partial,
                             row_max=row_max)
-        if row_max is not None:
-            dense.gemm_f16x2_n128(gPQ, row_max, wcat.t(), gx, accumulate=True)
-        else:
-            rows_mm_add_(gx, gPQ, wcat.t())                                  # direct + through P and Q in one GEMM (C += A B)
+        dense.rows_mm_add_scaled_(gx, gPQ, wcat.t(), row_max)                # direct + through P and Q in one GEMM (C += A B)
         gw = xt_g(x, gPQ) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
         return gx, (gw[:, :KH] if gw is not None else None), (gw[:, KH:] if gw is not None else None), None, None, None, None
 

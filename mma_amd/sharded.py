@@ -304,7 +304,10 @@ class _ShardedAggregate(torch.autograd.Function):
         g = g.contiguous()
         shared = Fn.SHARED_GRAD_BWD
         gPQ = torch.empty((S, 2 * KH), device=dev, dtype=torch.float32)          # [dL/dP | dL/dQ], halo rows: Q half only
-        gs, aux, ldaux, gP, gxs = Fn.nc_bwd_node_launch(g, True, sel, T, graph, kinds, H, shared, gP=gPQ[:n, :KH])
+        from .dense import f16x2_n128_ok, rows_mm_add_scaled_
+        # row maxima of [gP|gQ] for the three-product dL/dx GEMMs (own rows: both halves; halo rows: the Q half only)
+        row_max = torch.zeros((S,), device=dev, dtype=torch.float32) if f16x2_n128_ok(max(n, S - n), KH, H) and K <= 8 else None
+        gs, aux, ldaux, gP, gxs = Fn.nc_bwd_node_launch(g, True, sel, T, graph, kinds, H, shared, gP=gPQ[:n, :KH], row_max=row_max)
         gQ = gPQ[:, KH:]
         gx = torch.empty((S, H), device=dev, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32) if graph.t_n_slots else None)
@@ -314,15 +317,15 @@ class _ShardedAggregate(torch.autograd.Function):
         back = None
         if S > n:
             halo_part, own_part = graph.t_parts
-            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, halo_part)
-            gxh = rows_mm_add_(gx[n:], gQ[n:], wbot.t())      # dL/dx of the halo rows: direct + through Q = x Wbot
+            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, halo_part, row_max=row_max)
+            gxh = rows_mm_add_scaled_(gx[n:], gQ[n:], wbot.t(), row_max[n:] if row_max is not None else None)   # halo rows: direct + via Q
             back = all_to_all_rows_start(gxh, plan.recv_counts, plan.send_counts, plan.group)
-            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, own_part)
+            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, own_part, row_max=row_max)
         else:
             if plan.world > 1:
                 back = all_to_all_rows_start(gx[n:], plan.recv_counts, plan.send_counts, plan.group)    # sends (0,H), still receives
-            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial)
-        gx_own = rows_mm_add_(gx[:n], gPQ[:n], wcat.t())         # direct + through P and Q of the own rows in one GEMM
+            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, row_max=row_max)
+        gx_own = rows_mm_add_scaled_(gx[:n], gPQ[:n], wcat.t(), row_max[:n] if row_max is not None else None)   # own rows, one GEMM
         gwtop = gwbot = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             gw = xt_g(x_src[:n], gPQ[:n])                        # (H, 2KH) = [dL/dWtop | own part of dL/dWbot]

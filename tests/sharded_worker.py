@@ -148,7 +148,8 @@ def run_gpu(rank, world, variant="hub"):
         for tag, n_, gr, kw in (("messy", 131, messy_graph(5, 131), {}), ("fewer nodes than ranks", 2, (np.array([0, 1, 2]), np.array([1, 0])), {}),
                                 ("no edges", 9, (np.zeros(10, np.int64), np.zeros(0, np.int64)), {}),
                                 ("true-degree scalers", 157, graph(3, 157, 4),
-                                 dict(strict_reference=False, scalers=["identity", "amplification", "linear"], compound_scalers=True))):
+                                 dict(strict_reference=False, scalers=["identity", "amplification", "linear"], compound_scalers=True)),
+                                ("tall shards: three-product GEMMs with K2a/K2b row maxima", 150000 * world, big_graph(150000 * world), dict(H=128))):
             check_gpu(rank, world, tag, n_, gr[0].astype(np.int64), gr[1].astype(np.int64), kw)
         return
     N, H, C, names, p = 400, 32, 6, ["sum", "mean", "max", "min"], 0.5
@@ -196,6 +197,14 @@ def run_gpu(rank, world, variant="hub"):
         close(sh.masks[n_].grad, masks[n_].grad, "gmask " + n_)
 
 
+def big_graph(N):
+    """Random sources, degree 2-5, vectorised (the per-row Python loop of graph() is too slow at this size)."""
+    rng = np.random.default_rng(21)
+    deg = rng.integers(2, 6, N)
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    return rowptr, rng.integers(0, N, rowptr[-1]).astype(np.int64)
+
+
 def check_gpu(rank, world, tag, N, rowptr, col, kw):
     """ShardedMMA (HIP kernels, halo through gloo) against the single-GPU layer with the same parameters on one graph."""
     import mma_amd
@@ -203,7 +212,8 @@ def check_gpu(rank, world, tag, N, rowptr, col, kw):
     from mma_amd.layers import _MASK_NAMES
     from mma_amd.sharded import ShardedMMA
     dev = "cuda:0"
-    H, C, names, p, seed = 16, 4, ["sum", "mean3", "max", "min2"], 0.5, 0x1234ABCD77
+    kw = dict(kw)
+    H, C, names, p, seed = kw.pop("H", 16), 4, ["sum", "mean3", "max", "min2"], 0.5, 0x1234ABCD77
     g = torch.Generator().manual_seed(1)
     x = torch.relu(torch.randn(N, H, generator=g))
     cot = torch.randn(N, C, generator=g)
