@@ -33,16 +33,18 @@ def main():
     for name, mk in (("random (N(0,1))", lambda *s: torch.randn(*s, device=DEV)), ("zeros", lambda *s: torch.zeros(*s, device=DEV))):
         x, W, g, Wt = mk(N, H), mk(H, 2 * K * H), mk(N, 2 * K * H), mk(2 * K * H, H)
         out = torch.zeros(N, H, device=DEV)
+        rm = g.abs().amax(1)                    # in the step K2a / K2b produce this bound
+        dx = ((lambda: dense.gemm_f16x2_n128(g, rm, Wt, out, accumulate=True)) if dense.f16x2_n128_ok(N, 2 * K * H, H)
+              else (lambda: dense.gemm_bf16x3(g, Wt, out=out, accumulate=True)))
         for _ in range(2):                      # second pass: clocks settled
-            r = (timed(lambda: dense.gemm_bf16x3(x, W)), timed(lambda: dense.gemm_bf16x3(g, Wt, out=out, accumulate=True)),
-                 timed(lambda: dense.gemm_bf16x3_tn(x, g)))
+            r = (timed(lambda: dense.gemm_bf16x3(x, W)), timed(dx), timed(lambda: dense.gemm_bf16x3_tn(x, g)))
         rows.append((name, r))
     print("| operands | forward x [Wtop|Wbot] (M,128)x(128,1024) | dL/dx += g [Wtop|Wbot]^T (M,1024)x(1024,128) | weight gradient x^T g (128,M)x(M,1024) |")
     print("|---|---|---|---|")
     for name, r in rows:
         print("| %s | %.3f ms | %.3f ms | %.3f ms |" % ((name,) + r))
     base = 2.0 * N * H * 2 * K * H                # fp32 flops of each product
-    mf = (3, 6, 6) if dense.USE_F16X2 else (6, 6, 6)     # piece products per fp32 product: forward on the three-product fp16 kernel
+    mf = (3, 3 if dense.f16x2_n128_ok(N, 2 * K * H, H) else 6, 6) if dense.USE_F16X2 else (6, 6, 6)     # piece products per fp32 product
     rate = lambda ts: " / ".join("%.2f" % (base * m / 1e15 / (t * 1e-3)) for t, m in zip(ts, mf))
     print("\nEach is 275 GFLOP of fp32 work = %s TFLOP of 16-bit MFMA (%s piece products per fp32 product); on random data that is %s "
           "PFLOP/s, on zeros %s PFLOP/s (dense bf16/fp16 peak 2.5 PFLOP/s at 2.4 GHz)." % (
