@@ -56,16 +56,20 @@ USE_F16X2_N128 = __import__("os").environ.get("MMA_F16X2_DX", "1") != "0"
 
 
 def f16x2_n128_ok(M, K, N):
-    return USE_F16X2 and USE_F16X2_N128 and USE_BF16X3 and N == 128 and K % 64 == 0 and K > 128 and M >= (1 << 16)
+    return (USE_F16X2 and USE_F16X2_N128 and USE_BF16X3 and N % 128 == 0 and N <= 512 and K % 64 == 0 and K > 128 and M >= (1 << 16))
 
 
 def gemm_f16x2_n128(a, row_max, w, out, accumulate=False):
-    """out (M,128) (+)= a (M,K) @ w (K,128) on the three-product kernel; row_max (M,) >= max |a[i,:]| (0 for an all-zero row)."""
+    """out (M,N) (+)= a (M,K) @ w (K,N), N a multiple of 128, on the three-product kernel, one launch per 128-column block of the
+    output (hidden width 256: C5); row_max (M,) >= max |a[i,:]| (0 for an all-zero row)."""
     M, K = a.shape
-    bt2, cu = _split_f16x2(w)
+    N = w.shape[1]
+    bt2, cu = _split_f16x2(w)                                            # (2, N, K), (N,)
     with _span("gemm_x3_acc" if accumulate else "gemm_x3_persist"):
-        call("mma_gemm_f16x2_n128", ptr(a), a.stride(0), ptr(row_max), ptr(bt2), ptr(cu), ptr(out), out.stride(0), M, K, 1 if accumulate else 0,
-             stream_ptr())
+        for b in range(N // 128):
+            blk = bt2[:, 128 * b:128 * b + 128].contiguous() if N > 128 else bt2
+            call("mma_gemm_f16x2_n128", ptr(a), a.stride(0), ptr(row_max), ptr(blk), ptr(cu[128 * b:]), ptr(out[:, 128 * b:]), out.stride(0), M, K,
+                 1 if accumulate else 0, stream_ptr())
     return out
 
 
@@ -88,6 +92,13 @@ def gemm_bf16x3(a, w, out=None, accumulate=False):
     if (USE_F16X2 and K == 128 and not accumulate and N % 128 == 0 and N <= 4096 and M >= _MIN_ROWS_X3
             and (out is None or (out.stride(1) == 1 and out.dtype == torch.float32))):
         return gemm_f16x2(a, w, out)
+    if (USE_F16X2 and USE_F16X2_N128 and not accumulate and K > 128 and N > 128 and K % 64 == 0 and N % 128 == 0 and M >= (1 << 16)
+            and (out is None or (out.stride(1) == 1 and out.dtype == torch.float32))):
+        # hidden width 256 (C5): K = 256 does not fit the whole-row form of mma_gemm_f16x2; the chunked three-product kernel
+        # takes the row maxima from one cheap pass over `a` (M x K floats read against M x N written)
+        if out is None:
+            out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        return gemm_f16x2_n128(a, a.abs().amax(1), w, out)
     wt = w.t().contiguous()                                  # (N,K): B^T, k contiguous
     bt3 = torch.empty((3, N, K), device=a.device, dtype=torch.bfloat16)
     call("mma_split_bf16x3", ptr(wt), N * K, ptr(bt3), stream_ptr())
