@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 22
+#define MMA_ABI_VERSION 23
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -166,6 +166,8 @@ int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, float* C, int6
  * piece 1 = lo * 2^11 of B^T scaled per column by a power of two that puts the column maximum into [2^14, 2^15), and
  * col_unscale (N,) fp32 = the reciprocal of that scale.  N % 128 == 0, N <= 4096; any M (ragged tails handled inside). */
 int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,
+                   float* a_row_max,             /* optional (M,) out: max |a| of every row (the kernel forms it for its row scales
+                                                    anyway) - the x_row_max of the weight-gradient product mma_gemm_f16x2_tn */
                    int64_t M, int32_t N, void* stream);
 /* The same three-product form for N = 128 and a long reduction (dL/dx += [gP|gQ] [Wtop|Wbot]^T, K % 64 == 0): the row scales
  * cannot be formed in the kernel (a row is consumed in 64-wide chunks), so the caller passes row_max (M,) >= the maximum
@@ -180,6 +182,17 @@ int mma_gemm_f16x2_n128(const float* A, int64_t lda, const float* row_max, const
 int64_t mma_gemm_bf16x3_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC);
 int mma_gemm_bf16x3_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, float* C, float* ws, int64_t ws_floats,
                        int64_t M, int32_t KA, int32_t NC, void* stream);
+/* The TN product in the three-product fp16 x 2 form (half the MFMAs).  The reduction runs over the rows, so the power-of-two scales
+ * are per ROW of both operands, balanced between them (x_i 2^a and g_i 2^-a leave x_i g_i unchanged) so that ONE un-scaling serves
+ * the whole product; they are derived on the device from the row maxima: x_row_max / g_row_max (M,) >= max |.| of every row of X /
+ * G (0 marks an all-zero row), either may be NULL (then one extra pass over that operand forms them; the backward kernels
+ * produce G's: mma_nc_bwd_node / mma_nc_fused_bwd).  |error| <= 2^-22 sum|x||g| + M 2^-39 max_i(max|x_i| max|g_i|).  If some row's
+ * products lie more than 2^40 below the largest row's, or a row maximum is inf / NaN / subnormal, the six-product kernel
+ * (mma_gemm_bf16x3_tn) does the call instead - decided on the device, no synchronisation.  Shapes as mma_gemm_bf16x3_tn, M < 2^30.
+ * ws: mma_gemm_f16x2_tn_workspace_floats(M, KA, NC) floats, 16-byte aligned (never NULL). */
+int64_t mma_gemm_f16x2_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC);
+int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, const float* x_row_max, const float* g_row_max,
+                      float* C, float* ws, int64_t ws_floats, int64_t M, int32_t KA, int32_t NC, void* stream);
 
 /* ---- K7: halo pack / unpack for the 1-D node-sharded multi-GPU path --------------------------------
  * pack:   dst[r,:] = src[idx[r],:]            (send buffer for the all-to-all of halo rows)

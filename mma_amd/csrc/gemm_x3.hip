@@ -344,7 +344,7 @@ __device__ __forceinline__ HFrag hg_frag(const unsigned char* sb, int ks) {
   return f;
 }
 __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(const GemmParams p, const float* col_unscale, int64_t n_units,
-                                                                           int n_groups) {
+                                                                           int n_groups, float* a_row_max) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kHgLds];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -390,6 +390,7 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
 #pragma unroll
     for (int i = 0; i < 16; ++i) rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(raw[i].x), fabsf(raw[i].y)), fmaxf(fabsf(raw[i].z), fabsf(raw[i].w))));
     rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+    if (a_row_max && g == 0 && h == 0 && r31 < rows_here) a_row_max[row0 + r31] = rmax;     // for the weight-gradient product (TN form)
     const int ex = (int)((__float_as_uint(rmax) >> 23) & 0xFF);
     const int sce = min(max(14 - (ex - 127), -126), 127);            // log2 of the row scale
     const float sc = __uint_as_float((uint32_t)(sce + 127) << 23);
@@ -715,6 +716,11 @@ struct TnParams {
   const float* X; int64_t ldx; const float* G; int64_t ldg;
   float* part;                 // (splits, KA, NC)
   int64_t M, rows_per_split; int KA, NC, splits;
+  // three-product (fp16 x 2) form only - zero / NULL for the six-product kernel called on its own
+  const uint16_t* sxh;         // (M,) upper 16 bits of the power-of-two fp32 scale of each X row
+  const uint16_t* sgh;         // (M,) the same for the G rows
+  const int* state;            // {max t, min t, bad, unscale exponent}: see tn_scale_* below.  state != NULL: the kernel runs only
+  int want_bad;                //   if (state[2] != 0) == want_bad (the two forms are launched back to back, one of them leaves at once)
 };
 
 constexpr int kTnKC = 32;                        // rows of X / G per chunk
@@ -734,6 +740,7 @@ __device__ __forceinline__ void split3x8(const float (&v)[16], int o, bf16x8& a,
 template <bool FULLCT>
 __global__ __launch_bounds__(kBlock, 2) void gemm_x3_tn_kernel(const TnParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kTnSlab];
+  if (p.state && (p.state[2] != 0) != (p.want_bad != 0)) return;   // the three-product form does this call (uniform: before any barrier)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r31 = lane & 31, h = lane >> 5;
@@ -890,6 +897,262 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_tn_kernel(const TnParams p)
   }
 }
 
+// ---- TN form, three products (round 2): fp16 x 2 pieces, one power-of-two scale per ROW of each operand -------------------------
+// The reduction index of x^T g is the row, so a row scale does not factor out of the sum - but a power of two can be MOVED between
+// the two operands of a row for free: (x_i 2^a)(g_i 2^-a) = x_i g_i.  With ex_i / eg_i the exponents of the row maxima, t_i = ex_i +
+// eg_i the size of row i's products, T = max t_i and r_i = T - t_i, the rows are scaled to
+//     x~_i = x_i 2^(14 - ex_i - floor(r_i/2)),     g~_i = g_i 2^(14 - eg_i - ceil(r_i/2)),      x~_i g~_i = x_i g_i 2^(28 - T):
+// ONE un-scaling 2^(T-28) for the whole product (applied in the epilogue), the largest rows have their maxima in [2^14, 2^15) in
+// BOTH operands, and a row whose products are 2^-r of the largest ones gives up r/2 binades per operand, not r.  Pieces: hi =
+// fp16(x~), lo = fp16(x~ - hi) (plain, not pre-scaled: one accumulator set - the 64 registers of a second one do not exist here);
+// x~ g~ ~= hi hi + hi lo + lo hi, three MFMAs per k-step and tile instead of six.  Accuracy: 22 bits for every element within
+// 2^(17 - r_i/2) of its row maximum, an absolute 2^-25 (scaled) below that, i.e. |error| <= 2^-22 sum|x||g| + (rows) 2^-39 max_i(mx_i
+// mg_i).  Rows whose products are more than 2^40 below the largest (they would keep < 19 bits), infinite / NaN / subnormal row
+// maxima or scales outside the fp32 exponent range set `bad`, and the six-product kernel does the call instead - decided on the
+// device (tn_scale_* kernels: two launches over the (M,) row maxima), no host synchronisation.
+// Structure, chunking, XCD mapping and the fixed-order split reduction are gemm_x3_tn_kernel's; the row scales travel as the
+// upper halves of their fp32 patterns (8 rows = one 16-byte load) with the raw chunk they belong to.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr int kTn2Slab = 2 * kTnPiece;           // 20 KB
+constexpr int kTnMaxSpread = 40;
+
+__global__ void tn_scale_range_kernel(const float* xmax, const float* gmax, int64_t M, int* state) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int hi = 0, lo = 0, bad = 0;                  // t + 1024 and 1024 - t: 0 = "no row yet", so the state starts as plain zeros
+  if (i < M) {
+    const uint32_t xb = __float_as_uint(xmax[i]) & 0x7fffffffu, gb = __float_as_uint(gmax[i]) & 0x7fffffffu;
+    if (xb != 0 && gb != 0) {
+      const int ex = (int)(xb >> 23), eg = (int)(gb >> 23);
+      if (ex == 255 || eg == 255 || ex == 0 || eg == 0) bad = 1;
+      else { const int t = ex + eg - 254; hi = t + 1024; lo = 1024 - t; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    hi = max(hi, __shfl_xor(hi, o, 64)); lo = max(lo, __shfl_xor(lo, o, 64)); bad |= __shfl_xor(bad, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (hi) atomicMax(state + 0, hi);
+    if (lo) atomicMax(state + 1, lo);
+    if (bad) atomicOr(state + 2, 1);
+  }
+}
+
+// sxh / sgh have M_pad = M rounded up to 32 entries (a chunk's scale loads never straddle the end); the padding gets scale 0
+__global__ void tn_scale_rows_kernel(const float* xmax, const float* gmax, int64_t M, int64_t M_pad, int* state, uint16_t* sxh,
+                                     uint16_t* sgh) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int T = state[0] ? state[0] - 1024 : 28;
+  if (i == 0) state[3] = T - 28;
+  if (i >= M_pad) return;
+  const uint32_t xb = i < M ? __float_as_uint(xmax[i]) & 0x7fffffffu : 0u, gb = i < M ? __float_as_uint(gmax[i]) & 0x7fffffffu : 0u;
+  uint16_t hx = 0, hg = 0;
+  if (xb != 0 && gb != 0) {
+    const int ex = (int)(xb >> 23) - 127, eg = (int)(gb >> 23) - 127;
+    const int r = T - (ex + eg);
+    const int px = 14 - ex - (r >> 1), pg = 14 - eg - (r - (r >> 1));
+    if (r > kTnMaxSpread || px < -126 || px > 127 || pg < -126 || pg > 127) atomicOr(state + 2, 1);
+    else { hx = (uint16_t)((px + 127) << 7); hg = (uint16_t)((pg + 127) << 7); }
+  }
+  sxh[i] = hx; sgh[i] = hg;
+}
+
+// max |a| of every row of a (M, cols) matrix: 32 lanes per row (only for callers that do not bring the maxima along)
+template <bool VEC>
+__global__ void row_absmax_kernel(const float* A, int64_t lda, int64_t M, int cols, float* out) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int l = threadIdx.x & 31;
+  uint32_t m = 0;                                  // the bit patterns of |a| order like the values, and a NaN (or inf) stays on top
+  if (row < M) {
+    if (VEC) {
+      for (int c = 4 * l; c < cols; c += 128) {
+        const uint4 v = *reinterpret_cast<const uint4*>(A + row * lda + c);
+        m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+      }
+    } else {
+      for (int c = l; c < cols; c += 32) m = max(m, __float_as_uint(A[row * lda + c]) & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if (row < M && l == 0) out[row] = __uint_as_float(m);
+}
+static void launch_row_absmax(const float* A, int64_t lda, int64_t M, int cols, float* out, hipStream_t st) {
+  const unsigned blocks = (unsigned)((M + 7) / 8);                     // 8 rows per 256-thread block
+  if (cols % 4 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0)
+    hipLaunchKernelGGL(row_absmax_kernel<true>, dim3(blocks), dim3(256), 0, st, A, lda, M, cols, out);
+  else hipLaunchKernelGGL(row_absmax_kernel<false>, dim3(blocks), dim3(256), 0, st, A, lda, M, cols, out);
+}
+
+__device__ __forceinline__ void split2s(const float v, const float s, _Float16& hi, _Float16& lo) {
+  const float x = v * s;
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
+// element i (0..7) of a row-scale vector: the upper halves of eight fp32 powers of two
+__device__ __forceinline__ float scale_of(const u32x4& q, const int i) {
+  const uint32_t w = q[i >> 1];
+  return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+
+template <bool FULLCT>
+__global__ __launch_bounds__(kBlock, 2) void gemm_f16x2_tn_kernel(const TnParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kTn2Slab];
+  if (p.state[2] != 0) return;                    // the six-product kernel does this call
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r31 = lane & 31, h = lane >> 5;
+  const int n_cb = (p.NC + 127) / 128;
+  int cb, split;
+  if (p.splits % 8 == 0) {
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    cb = slot % n_cb;
+    split = (slot / n_cb) * 8 + xcd;
+  } else {
+    cb = (int)blockIdx.x % n_cb;
+    split = (int)blockIdx.x / n_cb;
+  }
+  const int gcol0 = cb * 128;
+  const int n_ct = FULLCT ? 4 : min(4, (p.NC - gcol0) / 32);
+  const int64_t r0 = (int64_t)split * p.rows_per_split;
+  const int64_t r1 = min(p.M, r0 + p.rows_per_split);
+  const int n_chunks = r1 > r0 ? (int)((r1 - r0 + kTnKC - 1) / kTnKC) : 0;
+  const bool wave_active = wave * 32 < p.KA;
+  const int sn = tid & 127, skg = tid >> 7;
+  const int scol = gcol0 + sn < p.NC ? sn : 0;
+  const int xcol = min(wave * 32, p.KA - 32) + r31;
+  const int ldg_b = (int)p.ldg * 4, ldx_b = (int)p.ldx * 4;
+  const int rows = (int)(r1 > r0 ? r1 - r0 : 0);
+  const int64_t rbase = r1 > r0 ? r0 : 0;
+  const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G + rbase * p.ldg + gcol0), 0,
+                                                        rows ? (rows - 1) * ldg_b + min(128, p.NC - gcol0) * 4 : 0, 0x00020000);
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + rbase * p.ldx), 0,
+                                                        rows ? (rows - 1) * ldx_b + p.KA * 4 : 0, 0x00020000);
+  // the scale vectors of this split's rows (rows past the split read as scale 0: their values read as 0 as well)
+  const int rows_pad = (rows + kTnKC - 1) / kTnKC * kTnKC;   // the arrays are padded to whole chunks (scale 0), rbase % 32 == 0
+  const auto sg_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.sgh + rbase), 0, rows_pad * 2, 0x00020000);
+  const auto sx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.sxh + rbase), 0, rows_pad * 2, 0x00020000);
+  const int g_voff = skg * 8 * ldg_b + scol * 4;
+  const int x_voff = 8 * h * ldx_b + xcol * 4;
+  const int sg_voff = skg * 16, sx_voff = h * 16;            // bytes: 8 rows x 2
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float graw0[16], xraw0[16], graw1[16], xraw1[16];
+  u32x4 gs0[2], xs0[2], gs1[2], xs1[2];                       // row scales of the raw sets
+  f16x8 af[2][2];
+
+#define MMA_TN2_LOAD(C_, GR_, XR_, GS_, XS_)                                                   \
+  {                                                                                            \
+    int gv = g_voff + (C_) * (kTnKC * ldg_b);                                                  \
+    int xv = x_voff + (C_) * (kTnKC * ldx_b);                                                  \
+    asm volatile("" : "+v"(gv), "+v"(xv));                                                     \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                            \
+      GS_[g] = __builtin_amdgcn_raw_buffer_load_b128(sg_rsrc, sg_voff + (C_) * (kTnKC * 2) + g * 32, 0, 0); \
+      XS_[g] = __builtin_amdgcn_raw_buffer_load_b128(sx_rsrc, sx_voff + (C_) * (kTnKC * 2) + g * 32, 0, 0); \
+    }                                                                                          \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g)                                              \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                            \
+        GR_[g * 8 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rsrc, gv, (g * 16 + i) * ldg_b, 0)); \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                            \
+        XR_[ks * 8 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, xv, (ks * 16 + i) * ldx_b, 0)); \
+  }
+#define MMA_TN2_SPLITX(XR_, XS_)                                                               \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                             \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                            \
+      _Float16 a, b;                                                                           \
+      split2s(XR_[ks * 8 + i], scale_of(XS_[ks], i), a, b);                                    \
+      af[ks][0][i] = a; af[ks][1][i] = b;                                                      \
+    }
+#define MMA_TN2_PUBLISH(B_, GR_, XR_, GS_, XS_)                                                \
+  {                                                                                            \
+    unsigned char* d = lds + (B_) * kTn2Slab + sn * kTnPitch;                                  \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                            \
+      f16x8 a, b;                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                          \
+        _Float16 u, v;                                                                         \
+        split2s(GR_[g * 8 + i], scale_of(GS_[g], i), u, v);                                    \
+        a[i] = u; b[i] = v;                                                                    \
+      }                                                                                        \
+      *reinterpret_cast<f16x8*>(d + 0 * kTnPiece + (skg + 2 * g) * 16) = a;                    \
+      *reinterpret_cast<f16x8*>(d + 1 * kTnPiece + (skg + 2 * g) * 16) = b;                    \
+    }                                                                                          \
+    MMA_TN2_SPLITX(XR_, XS_)                                                                   \
+  }
+// One chunk: four groups of SIX MFMAs (k-step x pair of column tiles x {hi hi, hi lo, lo hi}), each followed in program order by the
+// split of four of the next chunk's G values; fragments of group m+1 are read while group m multiplies.
+#define MMA_TN2_STEP(C_, B_, GR_, XR_, GS_, XS_)                                               \
+  {                                                                                            \
+    const unsigned char* sb = lds + (B_) * kTn2Slab + r31 * kTnPitch + h * 16;                 \
+    unsigned char* pd = lds + (1 - (B_)) * kTn2Slab + sn * kTnPitch + skg * 16;                \
+    f16x8 bq[2][2][2], ga, gb;           /* [parity][tile of the pair][piece] */               \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                              \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q)                                            \
+        bq[0][t][q] = *reinterpret_cast<const f16x8*>(sb + t * 32 * kTnPitch + q * kTnPiece);  \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                            \
+      const int ks = m >> 1, c0 = 2 * (m & 1), c1 = c0 + 1, pa = m & 1;                        \
+      if (m + 1 < 4) {                                                                         \
+        const unsigned char* qn = sb + (2 * ((m + 1) & 1)) * 32 * kTnPitch + ((m + 1) >> 1) * 32; \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                          \
+          _Pragma("unroll") for (int q = 0; q < 2; ++q)                                        \
+            bq[1 - pa][t][q] = *reinterpret_cast<const f16x8*>(qn + t * 32 * kTnPitch + q * kTnPiece); \
+      }                                                                                        \
+      const bool t0 = FULLCT || c0 < n_ct, t1 = FULLCT || c1 < n_ct;                           \
+      if (t0) acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], bq[pa][0][0], acc[c0], 0, 0, 0); \
+      if (t1) acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], bq[pa][1][0], acc[c1], 0, 0, 0); \
+      if (t0) acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], bq[pa][0][1], acc[c0], 0, 0, 0); \
+      if (t1) acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], bq[pa][1][1], acc[c1], 0, 0, 0); \
+      if (t0) acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], bq[pa][0][0], acc[c0], 0, 0, 0); \
+      if (t1) acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], bq[pa][1][0], acc[c1], 0, 0, 0); \
+      _Pragma("unroll") for (int j = 4 * m; j < 4 * m + 4; ++j) { /* values 4m..4m+3 of the next chunk's G set */ \
+        _Float16 u, v;                                                                         \
+        split2s(GR_[j], scale_of(GS_[j >> 3], j & 7), u, v);                                   \
+        ga[j & 7] = u; gb[j & 7] = v;                                                          \
+      }                                                                                        \
+      if (m & 1) {                                                                             \
+        *reinterpret_cast<f16x8*>(pd + 0 * kTnPiece + (m >> 1) * 32) = ga;                     \
+        *reinterpret_cast<f16x8*>(pd + 1 * kTnPiece + (m >> 1) * 32) = gb;                     \
+      }                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+    }                                                                                          \
+    MMA_TN2_SPLITX(XR_, XS_)                                                                   \
+    MMA_TN2_LOAD((C_) + 3, GR_, XR_, GS_, XS_)                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+    __builtin_amdgcn_s_barrier();                                                              \
+    asm volatile("" ::: "memory");                                                             \
+  }
+
+  MMA_TN2_LOAD(0, graw0, xraw0, gs0, xs0)
+  MMA_TN2_PUBLISH(0, graw0, xraw0, gs0, xs0)
+  MMA_TN2_LOAD(1, graw1, xraw1, gs1, xs1)
+  MMA_TN2_LOAD(2, graw0, xraw0, gs0, xs0)
+  __syncthreads();
+  for (int c = 0; c < n_chunks; c += 2) {
+    MMA_TN2_STEP(c, 0, graw1, xraw1, gs1, xs1)
+    MMA_TN2_STEP(c + 1, 1, graw0, xraw0, gs0, xs0)
+  }
+#undef MMA_TN2_STEP
+#undef MMA_TN2_LOAD
+#undef MMA_TN2_PUBLISH
+#undef MMA_TN2_SPLITX
+
+  if (wave_active) {
+    const int ue = p.state[3];                   // log2 of the un-scaling (T - 28)
+    float* out = p.part + ((size_t)split * p.KA + (size_t)wave * 32) * p.NC + gcol0 + r31;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      if (ct < n_ct) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * p.NC + ct * 32] = ldexpf(acc[ct][r], ue);
+      }
+    }
+  }
+}
+
 static int tn_splits(int64_t M, int NC) {
   const int64_t n_cb = ((int64_t)NC + 127) / 128;
   int64_t s = 512 / n_cb;                               // ~2 workgroups per CU in total
@@ -967,8 +1230,8 @@ extern "C" int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, flo
   return check_launch("gemm_x3_kernel");
 }
 
-extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc, int64_t M,
-                              int32_t N, void* stream) {
+extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,
+                              float* a_row_max, int64_t M, int32_t N, void* stream) {
   MMA_REQUIRE(M >= 0 && N >= 128 && N % 128 == 0 && N / 128 <= kCgSlotsPerXcd, "M=%lld N=%d: need N %% 128 == 0, N <= 4096", (long long)M, N);
   MMA_REQUIRE(lda >= 128 && ldc >= N && lda % 4 == 0 && lda < (1 << 24) && ldc < (1 << 24), "row pitch too small, unaligned or >= 2^24");
   if (M == 0) return 0;
@@ -977,7 +1240,7 @@ extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, cons
   GemmParams p{A, lda, static_cast<const __bf16*>(Bt2), C, ldc, M, N, 128, 0};
   const int64_t n_units = (M + kCgRows - 1) / kCgRows;
   hipLaunchKernelGGL(gemm_f16x2_colgroup_kernel, dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p, col_unscale, n_units,
-                     N / 128);
+                     N / 128, a_row_max);
   return check_launch("gemm_f16x2_colgroup_kernel");
 }
 
@@ -1025,4 +1288,51 @@ extern "C" int mma_gemm_bf16x3_tn(const float* X, int64_t ldx, const float* G, i
   if (int rc = check_launch("gemm_x3_tn_kernel")) return rc;
   if (s == 1) return 0;
   return mma_col_sum(ws, (int64_t)KA * NC, s, KA * NC, C, nullptr, 0, stream);      // <= 512 rows: one pass, fixed order
+}
+
+static int64_t tn_pad32(int64_t M) { return (M + 31) / 32 * 32; }
+
+extern "C" int64_t mma_gemm_f16x2_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC) {
+  if (M <= 0 || KA <= 0 || NC <= 0) return 0;
+  const int s = tn_splits(M, NC);
+  return (s > 1 ? (int64_t)s * KA * NC : 0) + 3 * tn_pad32(M) + 4;     // partial tiles | row maxima of X, of G | scale halves | state
+}
+
+extern "C" int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, const float* x_row_max, const float* g_row_max,
+                                 float* C, float* ws, int64_t ws_floats, int64_t M, int32_t KA, int32_t NC, void* stream) {
+  MMA_REQUIRE(M >= 1 && M < (1LL << 30) && KA >= 32 && KA <= 128 && KA % 32 == 0 && NC >= 32 && NC % 32 == 0 && (int64_t)KA * NC < (1LL << 31),
+              "M=%lld KA=%d NC=%d: need KA in {32,64,96,128}, NC %% 32 == 0", (long long)M, KA, NC);
+  MMA_REQUIRE(X && G && C && ws && ldx >= KA && ldg >= NC && ldx < (1 << 24) && ldg < (1 << 24), "NULL argument or row pitch out of range");
+  MMA_REQUIRE((reinterpret_cast<uintptr_t>(X) & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & 3) == 0 &&
+              (reinterpret_cast<uintptr_t>(ws) & 15) == 0, "misaligned argument");
+  const int s = tn_splits(M, NC);
+  const int64_t n_part = s > 1 ? (int64_t)s * KA * NC : 0, Mp = tn_pad32(M);
+  MMA_REQUIRE(ws_floats >= n_part + 3 * Mp + 4, "workspace too small: %lld floats, need %lld", (long long)ws_floats,
+              (long long)(n_part + 3 * Mp + 4));
+  int64_t rps = (M + s - 1) / s;
+  rps = (rps + kTnKC - 1) / kTnKC * kTnKC;
+  MMA_REQUIRE((rps + kTnKC) * (ldx > ldg ? ldx : ldg) * 4 < (1LL << 31), "row range of one split exceeds a 2 GB buffer window");
+  float* xmax = ws + n_part;
+  float* gmax = xmax + Mp;
+  uint16_t* sxh = reinterpret_cast<uint16_t*>(gmax + Mp);
+  uint16_t* sgh = sxh + Mp;
+  int* state = reinterpret_cast<int*>(gmax + 2 * Mp);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (const hipError_t e = hipMemsetAsync(state, 0, 4 * sizeof(int), st); e != hipSuccess)
+    return fail((int)e, "hipMemsetAsync of the scale state: %s", hipGetErrorString(e));
+  if (!x_row_max) { launch_row_absmax(X, ldx, M, KA, xmax, st); x_row_max = xmax; }
+  if (!g_row_max) { launch_row_absmax(G, ldg, M, NC, gmax, st); g_row_max = gmax; }
+  hipLaunchKernelGGL(tn_scale_range_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, x_row_max, g_row_max, M, state);
+  hipLaunchKernelGGL(tn_scale_rows_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, st, x_row_max, g_row_max, M, Mp, state, sxh, sgh);
+  if (int rc = check_launch("tn_scale_rows_kernel")) return rc;
+  TnParams p{X, ldx, G, ldg, s == 1 ? C : ws, M, rps, KA, NC, s, sxh, sgh, state, 0};
+  const dim3 grid((unsigned)(((NC + 127) / 128) * s));
+  if (NC % 128 == 0) hipLaunchKernelGGL(gemm_f16x2_tn_kernel<true>, grid, dim3(kBlock), 0, st, p);
+  else hipLaunchKernelGGL(gemm_f16x2_tn_kernel<false>, grid, dim3(kBlock), 0, st, p);
+  p.want_bad = 1;                                                    // the six-product form takes over when the scale kernels said so
+  if (NC % 128 == 0) hipLaunchKernelGGL(gemm_x3_tn_kernel<true>, grid, dim3(kBlock), 0, st, p);
+  else hipLaunchKernelGGL(gemm_x3_tn_kernel<false>, grid, dim3(kBlock), 0, st, p);
+  if (int rc = check_launch("gemm_f16x2_tn_kernel")) return rc;
+  if (s == 1) return 0;
+  return mma_col_sum(ws, (int64_t)KA * NC, s, KA * NC, C, nullptr, 0, stream);
 }

@@ -31,15 +31,16 @@ def _x3_ok(a, w):
 USE_F16X2 = True      # K == 128 products on the three-product fp16 x 2 kernel (csrc/gemm_x3.hip) instead of the six-product bf16 x 3 one
 
 
-def gemm_f16x2(a, w, out=None):
-    """a (M,128) @ w (128,N), N % 128 == 0: the three-product form (fp16 hi/lo pieces, power-of-two row and column scales)."""
+def gemm_f16x2(a, w, out=None, row_max_out=None):
+    """a (M,128) @ w (128,N), N % 128 == 0: the three-product form (fp16 hi/lo pieces, power-of-two row and column scales).
+    row_max_out (M,): the kernel also leaves max |a[i,:]| there (it forms them for its row scales anyway)."""
     M, K = a.shape
     N = w.shape[1]
     bt2, cu = _split_f16x2(w)
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     with _span("gemm_x3_k128"):
-        call("mma_gemm_f16x2", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(out), out.stride(0), M, N, stream_ptr())
+        call("mma_gemm_f16x2", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(out), out.stride(0), ptr(row_max_out), M, N, stream_ptr())
     return out
 
 
@@ -82,23 +83,30 @@ def rows_mm_add_scaled_(acc, a, w, row_max):
     return rows_mm_add_(acc, a, w)
 
 
-def gemm_bf16x3(a, w, out=None, accumulate=False):
+def gemm_bf16x3(a, w, out=None, accumulate=False, row_max_box=None):
     """a (M,K) @ w (K,N) with fp32 accuracy on the bf16 MFMA path (three-piece split of both operands).  `a` may be a
-    row-strided view (a column block of a wider buffer); accumulate=True adds the product to `out`."""
+    row-strided view (a column block of a wider buffer); accumulate=True adds the product to `out`.  row_max_box: a list that
+    receives the (M,) row maxima of |a| when the path taken forms them anyway (the three-product forms)."""
     if a.stride(1) != 1 or a.stride(0) % 4 or a.data_ptr() % 16:
         a = a.contiguous()
     M, K = a.shape
     N = w.shape[1]
     if (USE_F16X2 and K == 128 and not accumulate and N % 128 == 0 and N <= 4096 and M >= _MIN_ROWS_X3
             and (out is None or (out.stride(1) == 1 and out.dtype == torch.float32))):
-        return gemm_f16x2(a, w, out)
+        rm = torch.empty((M,), device=a.device, dtype=torch.float32) if row_max_box is not None else None
+        if rm is not None:
+            row_max_box.append(rm)
+        return gemm_f16x2(a, w, out, rm)
     if (USE_F16X2 and USE_F16X2_N128 and not accumulate and K > 128 and N > 128 and K % 64 == 0 and N % 128 == 0 and M >= (1 << 16)
             and (out is None or (out.stride(1) == 1 and out.dtype == torch.float32))):
         # hidden width 256 (C5): K = 256 does not fit the whole-row form of mma_gemm_f16x2; the chunked three-product kernel
         # takes the row maxima from one cheap pass over `a` (M x K floats read against M x N written)
         if out is None:
             out = torch.empty((M, N), device=a.device, dtype=torch.float32)
-        return gemm_f16x2_n128(a, a.abs().amax(1), w, out)
+        rm = a.abs().amax(1)
+        if row_max_box is not None:
+            row_max_box.append(rm)
+        return gemm_f16x2_n128(a, rm, w, out)
     wt = w.t().contiguous()                                  # (N,K): B^T, k contiguous
     bt3 = torch.empty((3, N, K), device=a.device, dtype=torch.bfloat16)
     call("mma_split_bf16x3", ptr(wt), N * K, ptr(bt3), stream_ptr())
@@ -118,12 +126,13 @@ def gemm_bf16x3(a, w, out=None, accumulate=False):
     return out
 
 
-def mm_into(a, w, out):
-    """out[...] = a @ w (no autograd): the forward GEMMs of the sharded layer write row blocks of one buffer."""
+def mm_into(a, w, out, row_max_box=None):
+    """out[...] = a @ w (no autograd): the forward GEMMs of the sharded layer write row blocks of one buffer.  row_max_box: see
+    gemm_bf16x3 (stays empty when the path taken does not form the row maxima of a)."""
     if a.shape[0] == 0:
         return out
     if _x3_ok(a, w):
-        return gemm_bf16x3(a, w, out)
+        return gemm_bf16x3(a, w, out, row_max_box=row_max_box)
     return torch.mm(a, w, out=out)
 
 
@@ -206,9 +215,34 @@ def gemm_bf16x3_tn(x, g):
     return out
 
 
-def xt_g(x, g):
-    """x^T @ g for tall x (N,in), g (N,out): the bf16x3 TN kernel where the shape allows, else split-N batched GEMM + sum."""
+USE_F16X2_TN = __import__("os").environ.get("MMA_F16X2_TN", "1") != "0"
+_MIN_ROWS_F16X2_TN = 1 << 16
+
+
+def gemm_f16x2_tn(x, g, x_row_max=None, g_row_max=None):
+    """x^T @ g like gemm_bf16x3_tn on the three-product fp16 x 2 kernel: row scales balanced between the operands, derived on
+    the device from the row maxima ((N,) upper bounds of max |x[i,:]| / max |g[i,:]|; None = one extra pass over that operand);
+    rows too far apart in size send the call to the six-product kernel (decided on the device)."""
+    N, KA = x.shape
+    NC = g.shape[1]
+    out = torch.empty((KA, NC), device=x.device, dtype=torch.float32)
+    kb = KA if KA <= 128 else 128
+    n_ws = int(_lib.lib().mma_gemm_f16x2_tn_workspace_floats(N, kb, NC))
+    ws = torch.empty((n_ws,), device=x.device, dtype=torch.float32)
+    with _span("gemm_x3_tn"):
+        for j in range(0, KA, kb):          # wider x (C5): 128-column blocks; the maxima of the whole row bound every block's
+            call("mma_gemm_f16x2_tn", ptr(x[:, j:j + kb]), x.stride(0), ptr(g), g.stride(0),
+                 ptr(x_row_max), ptr(g_row_max), ptr(out[j:j + kb]), ptr(ws), n_ws, N, kb,
+                 NC, stream_ptr())
+    return out
+
+
+def xt_g(x, g, x_row_max=None, g_row_max=None):
+    """x^T @ g for tall x (N,in), g (N,out): the TN kernels where the shape allows (three products when the caller brings g's row
+    maxima along - a pass over the wide operand would cost what the form saves -, else six), else split-N batched GEMM + sum."""
     if _x3_tn_ok(x, g):
+        if USE_F16X2 and USE_F16X2_TN and g_row_max is not None and x.shape[0] >= _MIN_ROWS_F16X2_TN:
+            return gemm_f16x2_tn(x, g, x_row_max, g_row_max)
         return gemm_bf16x3_tn(x, g)
     N = x.shape[0]
     B = N // _ROWS_PER_BATCH

@@ -176,18 +176,19 @@ class _NCLocalLayer(torch.autograd.Function):
         KH = K * H
         PQ = torch.empty((N, 2 * KH), device=x.device, dtype=torch.float32)
         wcat = torch.cat([wtop, wbot], 1)                                   # (H, 2*K*H)
-        mm_into(x, wcat, PQ)
         need = any(ctx.needs_input_grad[:3])
+        box = [] if need else None                                          # row maxima of x, when the forward GEMM forms them: the
+        mm_into(x, wcat, PQ, row_max_box=box)                               # weight-gradient product's row scales (three-product TN form)
         msum, T, sel = nc_fwd_launch(x, PQ[:, :KH], PQ[:, KH:], graph, kinds, acts, drop, True, need)
         ctx.graph, ctx.kinds, ctx.acts, ctx.drop = graph, kinds, acts, drop
-        ctx.save_for_backward(x, PQ, T, sel, wcat)
+        ctx.save_for_backward(x, PQ, T, sel, wcat, box[0] if box else None)
         return msum
 
     @staticmethod
     def backward(ctx, g):
         from .dense import rows_mm_add_, xt_g
         graph, kinds, acts, drop = ctx.graph, ctx.kinds, ctx.acts, ctx.drop
-        x, PQ, T, sel, wcat = ctx.saved_tensors
+        x, PQ, T, sel, wcat, x_row_max = ctx.saved_tensors
         N, H = x.shape
         K = len(kinds)
         KH = K * H
@@ -203,7 +204,7 @@ class _NCLocalLayer(torch.autograd.Function):
         nc_bwd_edges_launch(x, PQ[:, :KH], PQ[:, KH:], gs, aux, ldaux, gxs, graph, kinds, acts, drop, gPQ[:, KH:], gx, partial,
                             row_max=row_max)
         dense.rows_mm_add_scaled_(gx, gPQ, wcat.t(), row_max)                # direct + through P and Q in one GEMM (C += A B)
-        gw = xt_g(x, gPQ) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
+        gw = xt_g(x, gPQ, x_row_max, row_max) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
         return gx, (gw[:, :KH] if gw is not None else None), (gw[:, KH:] if gw is not None else None), None, None, None, None
 
 

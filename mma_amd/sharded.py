@@ -328,10 +328,11 @@ class _ShardedAggregate(torch.autograd.Function):
         gx_own = rows_mm_add_scaled_(gx[:n], gPQ[:n], wcat.t(), row_max[:n] if row_max is not None else None)   # own rows, one GEMM
         gwtop = gwbot = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            gw = xt_g(x_src[:n], gPQ[:n])                        # (H, 2KH) = [dL/dWtop | own part of dL/dWbot]
+            rm = row_max if row_max is not None else None        # K2a / K2b's row maxima also scale the three-product TN form
+            gw = xt_g(x_src[:n], gPQ[:n], None, rm[:n] if rm is not None else None)   # (H, 2KH) = [dL/dWtop | own part of dL/dWbot]
             gwtop, gwbot = gw[:, :KH], gw[:, KH:]
             if S > n:
-                gwbot = gwbot + xt_g(x_src[n:], gQ[n:])
+                gwbot = gwbot + xt_g(x_src[n:], gQ[n:], None, rm[n:] if rm is not None else None)
         if back is not None:
             with Fn._span("halo_wait"):
                 rows = back.wait()                                                       # (n_send, H)

@@ -103,6 +103,23 @@ def recipe(lib, name, rng, keep):
         lib.mma_gemm_bf16x3_tn_workspace_floats.restype = ctypes.c_int64
         ws = int(lib.mma_gemm_bf16x3_tn_workspace_floats(M, KA, NC))
         return dict(ldx=KA + rng.choice([0, 128]), ldg=NC + rng.choice([0, 32]), ws_floats=ws, M=M, KA=KA, NC=NC)
+    if name == "mma_gemm_f16x2_tn":
+        M, KA, NC = rng.choice([(1 << 20, 128, 1024), (5000, 64, 96), (33, 32, 32), (262161, 96, 160), (1, 128, 512), ((1 << 31) + 9, 128, 1024),
+                                ((1 << 30) - 1, 128, 1024)])
+        lib.mma_gemm_f16x2_tn_workspace_floats.restype = ctypes.c_int64
+        ws = int(lib.mma_gemm_f16x2_tn_workspace_floats(M, KA, NC))
+        d = dict(ldx=KA + rng.choice([0, 128]), ldg=NC + rng.choice([0, 32]), ws_floats=ws, M=M, KA=KA, NC=NC)
+        if rng.random() < 0.5:
+            d.update(x_row_max=None)
+        if rng.random() < 0.3:
+            d.update(g_row_max=None)
+        return d
+    if name == "mma_gemm_f16x2":
+        M, Nc = rng.choice([(1 << 20, 1024), (70001, 512), (5, 128), (0, 256), ((1 << 31) + 7, 128)])
+        d = dict(lda=128 + rng.choice([0, 4, 128]), ldc=Nc + rng.choice([0, 4]), M=M, N=Nc)
+        if rng.random() < 0.5:
+            d.update(a_row_max=None)
+        return d
     if name == "mma_col_sum":
         R, C = rng.choice([(0, 7), (1, 1), (1000, 375), (204552, 375), (427376, 75), (300001, 130), (1 << 31, 16)])
         lib.mma_col_sum_workspace_floats.restype = ctypes.c_int64

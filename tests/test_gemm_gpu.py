@@ -106,6 +106,84 @@ def test_gemm_bf16x3_tn_accuracy(M, KA, NC, padx, padg):
     assert torch.equal(dense.gemm_bf16x3_tn(x, g), got)
 
 
+@pytest.mark.parametrize("M,KA,NC,padx,padg", [(70001, 128, 1024, 0, 0), (4097, 64, 96, 0, 32), (70001, 128, 512, 128, 0),
+                                               (33, 32, 32, 0, 0), (262144 + 17, 96, 160, 0, 0), (66000, 256, 512, 0, 0)])
+@pytest.mark.parametrize("maxima", ["given", "loose", "own"])
+def test_gemm_f16x2_tn_accuracy(M, KA, NC, padx, padg, maxima):
+    """x^T g on the THREE-product TN kernel (fp16 x 2 pieces, row scales balanced between the operands): error at the level of an
+    fp32 GEMM's against fp64 with the row sizes of both operands spread over e^+-3 (a spread of ~2^17 in the row products),
+    ReLU zeros in x, all-zero rows, exact / 8x-loose / kernel-made row maxima, ragged M, row-strided operands; repeatable."""
+    from mma_amd import dense
+    rng = np.random.default_rng(M + KA + NC)
+    xf = np.maximum(rng.standard_normal((M, KA + padx)), 0) * np.exp(rng.uniform(-3, 3, (M, 1)))
+    gf = rng.standard_normal((M, NC + padg)) * 1e-3 * np.exp(rng.uniform(-3, 3, (M, 1)))
+    xf[::11] = 0
+    gf[::13] = 0
+    xf, gf = torch.from_numpy(xf.astype(np.float32)).to(DEV), torch.from_numpy(gf.astype(np.float32)).to(DEV)
+    x, g = xf[:, padx:], gf[:, :NC]
+    xm, gm = x.abs().amax(1), g.abs().amax(1)
+    if maxima == "loose":
+        xm, gm = xm * 8.0, gm * 3.0
+    elif maxima == "own":
+        xm = gm = None
+    got = dense.gemm_f16x2_tn(x, g, xm, gm)
+    six = dense.gemm_bf16x3_tn(x, g)
+    ref = x.double().t() @ g.double()
+    f32 = x.t() @ g
+    scale = x.double().abs().t() @ g.double().abs()
+    e_got = ((got.double() - ref).abs() / scale).max().item()
+    e_six = ((six.double() - ref).abs() / scale).max().item()
+    e_f32 = ((f32.double() - ref).abs() / scale).max().item()
+    assert got.shape == (KA, NC) and e_got < 5e-7 and e_got < 1.5 * e_f32 + 1e-7, (e_got, e_six, e_f32)
+    assert not torch.equal(got, six)                          # the three-product kernel did the work, not the fall-back
+    assert torch.equal(dense.gemm_f16x2_tn(x, g, xm, gm), got)
+
+
+@pytest.mark.parametrize("case", ["spread", "inf", "nan", "subnormal", "zero"])
+def test_gemm_f16x2_tn_falls_back_on_the_device(case):
+    """Rows whose products lie more than 2^40 apart, or an inf / NaN / subnormal row maximum: the scale kernels flag the call and
+    the six-product kernel does it - the result is bit-for-bit gemm_bf16x3_tn's.  All-zero operands give exact zeros."""
+    from mma_amd import dense
+    rng = np.random.default_rng(7)
+    M, KA, NC = 70001, 128, 256
+    x = rng.standard_normal((M, KA)).astype(np.float32)
+    g = rng.standard_normal((M, NC)).astype(np.float32)
+    if case == "spread":
+        x *= np.exp(rng.uniform(-25, 25, (M, 1))).astype(np.float32)
+    elif case == "inf":
+        x[1234, 5] = np.inf
+    elif case == "nan":
+        g[4321, 7] = np.nan
+    elif case == "subnormal":
+        x[77] = 1e-41
+        x[77, 3] = 3e-39
+    elif case == "zero":
+        x[:] = 0
+    x, g = torch.from_numpy(x).to(DEV), torch.from_numpy(g).to(DEV)
+    got = dense.gemm_f16x2_tn(x, g)
+    if case == "zero":
+        assert torch.equal(got, torch.zeros_like(got))
+        return
+    six = dense.gemm_bf16x3_tn(x, g)
+    assert torch.equal(got.isnan(), six.isnan()) and torch.equal(got.nan_to_num(0.0, 1.0, -1.0), six.nan_to_num(0.0, 1.0, -1.0))
+
+
+def test_forward_gemm_exports_the_row_maxima():
+    """mma_gemm_f16x2 leaves max |a[i,:]| in a_row_max (ragged M), and the layer-level autograd product through xt_g matches."""
+    from mma_amd import dense
+    rng = np.random.default_rng(3)
+    a = torch.from_numpy((rng.standard_normal((70001, 128)) * np.exp(rng.uniform(-6, 6, (70001, 1)))).astype(np.float32)).to(DEV)
+    a[17] = 0
+    w = torch.from_numpy((rng.standard_normal((128, 256)) * 0.1).astype(np.float32)).to(DEV)
+    box = []
+    out = torch.empty((70001, 256), device=DEV)
+    dense.mm_into(a, w, out, row_max_box=box)
+    assert len(box) == 1 and torch.equal(box[0], a.abs().amax(1))
+    g = torch.from_numpy(rng.standard_normal((70001, 256)).astype(np.float32)).to(DEV)
+    got = dense.xt_g(a, g, box[0], g.abs().amax(1))
+    assert torch.equal(got, dense.gemm_f16x2_tn(a, g, box[0], g.abs().amax(1)))
+
+
 @pytest.mark.parametrize("N,T,O,C", [(1, 1, 1, 4), (7, 2, 3, 12), (1000, 5, 15, 456), (70001, 3, 16, 260), (513, 1, 15, 456)])
 def test_tower_linear_backward(N, T, O, C):
     """K9: both gradients of y[n,t,:] = a[n,t,:] W[t]^T in one pass over `a`, against an fp64 einsum; repeatable."""
