@@ -176,7 +176,8 @@ int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, const float* co
 int mma_gemm_f16x2_n128(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale,
                         float* C, int64_t ldc, int64_t M, int32_t K, int32_t accumulate, void* stream);
 /* TN form for the weight gradients (autograd's x^T g of layers.py:215-216's torch.mm): C (KA,NC) = X^T G with X (M,KA),
- * G (M,NC) fp32 row-major, C contiguous.  KA in {32,64,96,128}, NC % 32 == 0.  Both operands are split to bf16x3 on the
+ * G (M,NC) fp32 row-major, C contiguous.  Any 1 <= KA <= 128 and NC >= 1 (ragged tiles are clamped on load and guarded on
+ * store; KA % 32 == 0 with NC % 128 == 0 runs without the guards).  Both operands are split to bf16x3 on the
  * fly; the reduction over M runs in fixed row ranges whose partial tiles (ws) are summed in a fixed order.
  * ws: mma_gemm_bf16x3_tn_workspace_floats(M, KA, NC) floats (0 => may be NULL). */
 int64_t mma_gemm_bf16x3_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC);

@@ -736,7 +736,9 @@ __device__ __forceinline__ void split3x8(const float (&v)[16], int o, bf16x8& a,
   }
 }
 
-// FULLCT: all four 32-column tiles of the block exist (NC % 128 == 0): the MFMA phase is then one branch-free block.
+// FULLCT: all four 32-column tiles of the block exist and are whole (NC % 128 == 0, KA % 32 == 0): the MFMA phase is then one
+// branch-free block and the stores need no guards.  Otherwise any KA <= 128 and any NC: ragged tiles load clamped columns and
+// store under a guard.
 template <bool FULLCT>
 __global__ __launch_bounds__(kBlock, 2) void gemm_x3_tn_kernel(const TnParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kTnSlab];
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_tn_kernel(const TnParams p)
     split = (int)blockIdx.x / n_cb;
   }
   const int gcol0 = cb * 128;
-  const int n_ct = FULLCT ? 4 : min(4, (p.NC - gcol0) / 32);
+  const int n_ct = FULLCT ? 4 : min(4, (p.NC - gcol0 + 31) / 32);     // the last tile may be ragged (stores are guarded)
   const int64_t r0 = (int64_t)split * p.rows_per_split;
   const int64_t r1 = min(p.M, r0 + p.rows_per_split);
   const int n_chunks = r1 > r0 ? (int)((r1 - r0 + kTnKC - 1) / kTnKC) : 0;
@@ -765,7 +767,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_tn_kernel(const TnParams p)
   // staging role: column sn of the block's 128, k-groups skg and skg + 2 (8 rows each)
   const int sn = tid & 127, skg = tid >> 7;
   const int scol = gcol0 + sn < p.NC ? sn : 0;       // columns past NC belong to tiles that are never multiplied
-  const int xcol = min(wave * 32, p.KA - 32) + r31;
+  const int xcol = min(wave * 32 + r31, p.KA - 1);   // columns past KA repeat the last one: they only reach rows that are never stored
   const int ldg_b = (int)p.ldg * 4, ldx_b = (int)p.ldx * 4;                    // row pitches in bytes
   const int rows = (int)(r1 > r0 ? r1 - r0 : 0);
   const int64_t rbase = r1 > r0 ? r0 : 0;                                      // an empty split still gets a valid base
@@ -891,7 +893,9 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_tn_kernel(const TnParams p)
     for (int ct = 0; ct < 4; ++ct) {
       if (ct < n_ct) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * p.NC + ct * 32] = acc[ct][r];
+        for (int r = 0; r < 16; ++r)
+          if (FULLCT || (wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < p.KA && gcol0 + ct * 32 + r31 < p.NC))
+            out[(size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * p.NC + ct * 32] = acc[ct][r];
       }
     }
   }
@@ -1013,14 +1017,14 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_f16x2_tn_kernel(const TnParams
     split = (int)blockIdx.x / n_cb;
   }
   const int gcol0 = cb * 128;
-  const int n_ct = FULLCT ? 4 : min(4, (p.NC - gcol0) / 32);
+  const int n_ct = FULLCT ? 4 : min(4, (p.NC - gcol0 + 31) / 32);     // the last tile may be ragged (stores are guarded)
   const int64_t r0 = (int64_t)split * p.rows_per_split;
   const int64_t r1 = min(p.M, r0 + p.rows_per_split);
   const int n_chunks = r1 > r0 ? (int)((r1 - r0 + kTnKC - 1) / kTnKC) : 0;
   const bool wave_active = wave * 32 < p.KA;
   const int sn = tid & 127, skg = tid >> 7;
   const int scol = gcol0 + sn < p.NC ? sn : 0;
-  const int xcol = min(wave * 32, p.KA - 32) + r31;
+  const int xcol = min(wave * 32 + r31, p.KA - 1);   // columns past KA repeat the last one: they only reach rows that are never stored
   const int ldg_b = (int)p.ldg * 4, ldx_b = (int)p.ldx * 4;
   const int rows = (int)(r1 > r0 ? r1 - r0 : 0);
   const int64_t rbase = r1 > r0 ? r0 : 0;
@@ -1147,7 +1151,9 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_f16x2_tn_kernel(const TnParams
     for (int ct = 0; ct < 4; ++ct) {
       if (ct < n_ct) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * p.NC + ct * 32] = ldexpf(acc[ct][r], ue);
+        for (int r = 0; r < 16; ++r)
+          if (FULLCT || (wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < p.KA && gcol0 + ct * 32 + r31 < p.NC))
+            out[(size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * p.NC + ct * 32] = ldexpf(acc[ct][r], ue);
       }
     }
   }
@@ -1270,8 +1276,8 @@ extern "C" int mma_col_sum(const float* g, int64_t ldg, int64_t R, int32_t C, fl
 
 extern "C" int mma_gemm_bf16x3_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, float* C, float* ws, int64_t ws_floats,
                                   int64_t M, int32_t KA, int32_t NC, void* stream) {
-  MMA_REQUIRE(M >= 1 && KA >= 32 && KA <= 128 && KA % 32 == 0 && NC >= 32 && NC % 32 == 0 && (int64_t)KA * NC < (1LL << 31),
-              "M=%lld KA=%d NC=%d: need KA in {32,64,96,128}, NC %% 32 == 0", (long long)M, KA, NC);
+  MMA_REQUIRE(M >= 1 && KA >= 1 && KA <= 128 && NC >= 1 && (int64_t)KA * NC < (1LL << 31), "M=%lld KA=%d NC=%d: need 1 <= KA <= 128, NC >= 1",
+              (long long)M, KA, NC);
   MMA_REQUIRE(X && G && C && ldx >= KA && ldg >= NC && ldx < (1 << 24) && ldg < (1 << 24), "NULL argument or row pitch out of range");
   MMA_REQUIRE((reinterpret_cast<uintptr_t>(X) & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & 3) == 0, "misaligned argument");
   const int s = tn_splits(M, NC);
@@ -1283,7 +1289,7 @@ extern "C" int mma_gemm_bf16x3_tn(const float* X, int64_t ldx, const float* G, i
   TnParams p{X, ldx, G, ldg, s == 1 ? C : ws, M, rps, KA, NC, s};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)(((NC + 127) / 128) * s));
-  if (NC % 128 == 0) hipLaunchKernelGGL(gemm_x3_tn_kernel<true>, grid, dim3(kBlock), 0, st, p);
+  if (NC % 128 == 0 && KA % 32 == 0) hipLaunchKernelGGL(gemm_x3_tn_kernel<true>, grid, dim3(kBlock), 0, st, p);
   else hipLaunchKernelGGL(gemm_x3_tn_kernel<false>, grid, dim3(kBlock), 0, st, p);
   if (int rc = check_launch("gemm_x3_tn_kernel")) return rc;
   if (s == 1) return 0;
@@ -1300,8 +1306,8 @@ extern "C" int64_t mma_gemm_f16x2_tn_workspace_floats(int64_t M, int32_t KA, int
 
 extern "C" int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, const float* x_row_max, const float* g_row_max,
                                  float* C, float* ws, int64_t ws_floats, int64_t M, int32_t KA, int32_t NC, void* stream) {
-  MMA_REQUIRE(M >= 1 && M < (1LL << 30) && KA >= 32 && KA <= 128 && KA % 32 == 0 && NC >= 32 && NC % 32 == 0 && (int64_t)KA * NC < (1LL << 31),
-              "M=%lld KA=%d NC=%d: need KA in {32,64,96,128}, NC %% 32 == 0", (long long)M, KA, NC);
+  MMA_REQUIRE(M >= 1 && M < (1LL << 30) && KA >= 1 && KA <= 128 && NC >= 1 && (int64_t)KA * NC < (1LL << 31),
+              "M=%lld KA=%d NC=%d: need M < 2^30, 1 <= KA <= 128, NC >= 1", (long long)M, KA, NC);
   MMA_REQUIRE(X && G && C && ws && ldx >= KA && ldg >= NC && ldx < (1 << 24) && ldg < (1 << 24), "NULL argument or row pitch out of range");
   MMA_REQUIRE((reinterpret_cast<uintptr_t>(X) & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & 3) == 0 &&
               (reinterpret_cast<uintptr_t>(ws) & 15) == 0, "misaligned argument");
@@ -1327,10 +1333,11 @@ extern "C" int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, in
   if (int rc = check_launch("tn_scale_rows_kernel")) return rc;
   TnParams p{X, ldx, G, ldg, s == 1 ? C : ws, M, rps, KA, NC, s, sxh, sgh, state, 0};
   const dim3 grid((unsigned)(((NC + 127) / 128) * s));
-  if (NC % 128 == 0) hipLaunchKernelGGL(gemm_f16x2_tn_kernel<true>, grid, dim3(kBlock), 0, st, p);
+  const bool full = NC % 128 == 0 && KA % 32 == 0;
+  if (full) hipLaunchKernelGGL(gemm_f16x2_tn_kernel<true>, grid, dim3(kBlock), 0, st, p);
   else hipLaunchKernelGGL(gemm_f16x2_tn_kernel<false>, grid, dim3(kBlock), 0, st, p);
   p.want_bad = 1;                                                    // the six-product form takes over when the scale kernels said so
-  if (NC % 128 == 0) hipLaunchKernelGGL(gemm_x3_tn_kernel<true>, grid, dim3(kBlock), 0, st, p);
+  if (full) hipLaunchKernelGGL(gemm_x3_tn_kernel<true>, grid, dim3(kBlock), 0, st, p);
   else hipLaunchKernelGGL(gemm_x3_tn_kernel<false>, grid, dim3(kBlock), 0, st, p);
   if (int rc = check_launch("gemm_f16x2_tn_kernel")) return rc;
   if (s == 1) return 0;

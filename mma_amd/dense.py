@@ -187,10 +187,11 @@ class _MM(torch.autograd.Function):
 
 
 def _x3_tn_ok(x, g):
-    """The kernel takes up to 128 x columns; wider x (hidden width 256: C5) runs as 128-column blocks of x."""
+    """The kernel takes up to 128 x columns (any count: ragged tiles are guarded); wider x (hidden width 256: C5) runs as
+    128-column blocks of x.  Any g width from 32 columns on (the odd-width Linear layers of graph regression: 75 x 76)."""
     KA = x.shape[1]
     ok = (USE_BF16X3 and x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32 and x.shape[0] >= _MIN_ROWS_X3
-          and (KA in (32, 64, 96, 128) or KA % 128 == 0) and g.shape[1] % 32 == 0 and x.stride(1) == 1 and g.stride(1) == 1)
+          and (8 <= KA <= 128 or KA % 128 == 0) and g.shape[1] >= 32 and x.stride(1) == 1 and g.stride(1) == 1)
     if not ok:
         return False
     # the kernel addresses one row range through a 32-bit buffer window: (rows per split) x (row pitch) must stay < 2 GB
