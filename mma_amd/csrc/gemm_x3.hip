@@ -24,6 +24,7 @@
 // ([piece][col][k], k contiguous, rows padded by 16 B against LDS bank conflicts) are staged through a double-buffered
 // LDS slab shared by the 4 waves, prefetched one tile ahead.  K > 128 is processed in chunks of 128 with the (at most
 // four) accumulator tiles kept in registers, so either K == 128 or N <= 128 is required.
+#include <algorithm>
 #include "common.h"
 
 namespace mma {
@@ -920,22 +921,29 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 constexpr int kTn2Slab = 2 * kTnPiece;           // 20 KB
 constexpr int kTnMaxSpread = 40;
 
-__global__ void tn_scale_range_kernel(const float* xmax, const float* gmax, int64_t M, int* state) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void tn_scale_range_kernel(const float* xmax, const float* gmax, int64_t M, int* state) {
+  // a FEW workgroups, grid-stride, one atomic each: 16 000 wavefronts updating the same three words took 0.37 ms at M = 2^20
+  __shared__ int red[3][4];
   int hi = 0, lo = 0, bad = 0;                  // t + 1024 and 1024 - t: 0 = "no row yet", so the state starts as plain zeros
-  if (i < M) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t xb = __float_as_uint(xmax[i]) & 0x7fffffffu, gb = __float_as_uint(gmax[i]) & 0x7fffffffu;
     if (xb != 0 && gb != 0) {
       const int ex = (int)(xb >> 23), eg = (int)(gb >> 23);
       if (ex == 255 || eg == 255 || ex == 0 || eg == 0) bad = 1;
-      else { const int t = ex + eg - 254; hi = t + 1024; lo = 1024 - t; }
+      else { const int t = ex + eg - 254; hi = max(hi, t + 1024); lo = max(lo, 1024 - t); }
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     hi = max(hi, __shfl_xor(hi, o, 64)); lo = max(lo, __shfl_xor(lo, o, 64)); bad |= __shfl_xor(bad, o, 64);
   }
-  if ((threadIdx.x & 63) == 0) {
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = hi; red[1][wave] = lo; red[2][wave] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    hi = max(max(red[0][0], red[0][1]), max(red[0][2], red[0][3]));
+    lo = max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3]));
+    bad = red[2][0] | red[2][1] | red[2][2] | red[2][3];
     if (hi) atomicMax(state + 0, hi);
     if (lo) atomicMax(state + 1, lo);
     if (bad) atomicOr(state + 2, 1);
@@ -948,17 +956,18 @@ __global__ void tn_scale_rows_kernel(const float* xmax, const float* gmax, int64
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int T = state[0] ? state[0] - 1024 : 28;
   if (i == 0) state[3] = T - 28;
-  if (i >= M_pad) return;
   const uint32_t xb = i < M ? __float_as_uint(xmax[i]) & 0x7fffffffu : 0u, gb = i < M ? __float_as_uint(gmax[i]) & 0x7fffffffu : 0u;
   uint16_t hx = 0, hg = 0;
+  bool bad = false;
   if (xb != 0 && gb != 0) {
     const int ex = (int)(xb >> 23) - 127, eg = (int)(gb >> 23) - 127;
     const int r = T - (ex + eg);
     const int px = 14 - ex - (r >> 1), pg = 14 - eg - (r - (r >> 1));
-    if (r > kTnMaxSpread || px < -126 || px > 127 || pg < -126 || pg > 127) atomicOr(state + 2, 1);
-    else { hx = (uint16_t)((px + 127) << 7); hg = (uint16_t)((pg + 127) << 7); }
+    bad = r > kTnMaxSpread || px < -126 || px > 127 || pg < -126 || pg > 127;
+    if (!bad) { hx = (uint16_t)((px + 127) << 7); hg = (uint16_t)((pg + 127) << 7); }
   }
-  sxh[i] = hx; sgh[i] = hg;
+  if (__any(bad) && (threadIdx.x & 63) == 0 && state[2] == 0) atomicOr(state + 2, 1);     // at most one atomic per wavefront
+  if (i < M_pad) { sxh[i] = hx; sgh[i] = hg; }
 }
 
 // max |a| of every row of a (M, cols) matrix: 32 lanes per row (only for callers that do not bring the maxima along)
@@ -1328,7 +1337,8 @@ extern "C" int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, in
     return fail((int)e, "hipMemsetAsync of the scale state: %s", hipGetErrorString(e));
   if (!x_row_max) { launch_row_absmax(X, ldx, M, KA, xmax, st); x_row_max = xmax; }
   if (!g_row_max) { launch_row_absmax(G, ldg, M, NC, gmax, st); g_row_max = gmax; }
-  hipLaunchKernelGGL(tn_scale_range_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, x_row_max, g_row_max, M, state);
+  hipLaunchKernelGGL(tn_scale_range_kernel, dim3((unsigned)std::min<int64_t>((M + 255) / 256, 256)), dim3(256), 0, st, x_row_max, g_row_max, M,
+                     state);
   hipLaunchKernelGGL(tn_scale_rows_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, st, x_row_max, g_row_max, M, Mp, state, sxh, sgh);
   if (int rc = check_launch("tn_scale_rows_kernel")) return rc;
   TnParams p{X, ldx, G, ldg, s == 1 ? C : ws, M, rps, KA, NC, s, sxh, sgh, state, 0};
