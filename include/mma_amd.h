@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 23
+#define MMA_ABI_VERSION 24
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -159,6 +159,11 @@ int mma_csr_spmm_items(
 int mma_split_bf16x3(const float* in, int64_t n, void* out_3n_bf16, void* stream);
 int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, float* C, int64_t ldc,
                     int64_t M, int32_t N, int32_t K, int32_t accumulate /* 0: C = A B, 1: C += A B */, void* stream);
+/* The B operand of the three-product kernels below from w (K,N) fp32 with element strides (stride_k, stride_n) - a transposed view
+ * is fine: Bt2 = (2, N, K) fp16, piece 0 = hi and piece 1 = lo * 2^11 of w^T scaled per column by the power of two that puts the
+ * column maximum into [2^14, 2^15); col_unscale (N,) = the reciprocal scales.  One launch. */
+int mma_split_f16x2(const float* w, int64_t stride_k, int64_t stride_n, int32_t K, int32_t N, void* bt2, float* col_unscale,
+                    void* stream);
 /* Three-product form for K = 128 (the forward [P|Q] = x [Wtop|Wbot] and every other tall product whose reduction fits one
  * 128-wide chunk): fp16 x 2 pieces, a = s_row (a_hi + 2^-11 a_lo), b = s_col (b_hi + 2^-11 b_lo), a b ~= hi hi + 2^-11 (hi lo +
  * lo hi) - half the MFMAs of the six-product bf16 form at the accuracy of an fp32 GEMM (measured 1.1e-7 sum|a||b|).  The

@@ -689,6 +689,32 @@ __global__ __launch_bounds__(kNlThreads, 1) void gemm_f16x2_n128_kernel(const Ge
 }
 
 // split a row-major fp32 matrix (rows, cols) into its three bf16 pieces: out (3, rows, cols)
+// B operand of the three-product kernels in ONE launch: column n of w (K,N) -> power-of-two scale that puts max_k |w[k,n]| into
+// [2^14, 2^15), pieces hi = fp16(w s), lo = fp16((w s - hi) 2^11) at [piece][n][k] (k contiguous), col_unscale[n] = 1/s.
+// (The torch expression of the same thing was twelve small launches per GEMM call.)  One workgroup per column, any strides.
+__global__ __launch_bounds__(256) void split_f16x2_kernel(const float* w, int64_t stride_k, int64_t stride_n, int K, int N, _Float16* bt2,
+                                                          float* col_unscale) {
+  __shared__ uint32_t red[4];
+  const int n = blockIdx.x;
+  uint32_t m = 0;
+  for (int k = threadIdx.x; k < K; k += 256) m = max(m, __float_as_uint(w[k * stride_k + n * stride_n]) & 0x7fffffffu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = max(max(red[0], red[1]), max(red[2], red[3]));
+  const float amax = fmaxf(__uint_as_float(m), 1e-30f);                     // an all-zero column: any scale will do
+  const int e = min((int)((__float_as_uint(amax) >> 23) & 0xFF) - 127, 113);  // inf / NaN columns keep a finite scale
+  const float sc = __uint_as_float((uint32_t)(14 - e + 127) << 23);
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float x = w[k * stride_k + n * stride_n] * sc;
+    const _Float16 hi = (_Float16)x;
+    bt2[(size_t)n * K + k] = hi;
+    bt2[((size_t)N + n) * K + k] = (_Float16)((x - (float)hi) * 2048.f);
+  }
+  if (threadIdx.x == 0) col_unscale[n] = __uint_as_float((uint32_t)(e - 14 + 127) << 23);
+}
+
 __global__ void split3_kernel(const float* in, int64_t n, __bf16* out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const Bf3 t = split3(in[i]);
@@ -1243,6 +1269,16 @@ extern "C" int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, flo
 #undef MMA_X3_LAUNCH
   }
   return check_launch("gemm_x3_kernel");
+}
+
+extern "C" int mma_split_f16x2(const float* w, int64_t stride_k, int64_t stride_n, int32_t K, int32_t N, void* bt2, float* col_unscale,
+                               void* stream) {
+  MMA_REQUIRE(K >= 1 && N >= 1 && K <= (1 << 20) && N <= (1 << 20) && (int64_t)K * N < (1LL << 31), "K=%d N=%d out of range", K, N);
+  MMA_REQUIRE(w && bt2 && col_unscale, "NULL argument");
+  MMA_REQUIRE(stride_k >= 0 && stride_n >= 0 && (int64_t)(K - 1) * stride_k + (int64_t)(N - 1) * stride_n < (1LL << 31), "strides out of range");
+  hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)N), dim3(256), 0, static_cast<hipStream_t>(stream), w, stride_k, stride_n, K, N,
+                     static_cast<_Float16*>(bt2), col_unscale);
+  return check_launch("split_f16x2_kernel");
 }
 
 extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,

@@ -45,12 +45,13 @@ def gemm_f16x2(a, w, out=None, row_max_out=None):
 
 
 def _split_f16x2(w):
-    """w (K,N) fp32 -> ((2,N,K) fp16 pieces of B^T scaled per column by a power of two, (N,) fp32 reciprocal scales)."""
-    amax = w.abs().amax(0).clamp_min(1e-30)
-    s = torch.exp2(14.0 - torch.floor(torch.log2(amax)))                 # column maxima into [2^14, 2^15): exact scaling
-    x = (w * s).t().contiguous()                                         # (N,K): B^T, k contiguous
-    hi = x.half()
-    return torch.stack([hi, ((x - hi.float()) * 2048.0).half()]).contiguous(), (1.0 / s).contiguous()
+    """w (K,N) fp32, any strides -> ((2,N,K) fp16 pieces of B^T scaled per column by a power of two that puts the column maximum
+    into [2^14, 2^15), (N,) fp32 reciprocal scales): one launch (mma_split_f16x2)."""
+    K, N = w.shape
+    bt2 = torch.empty((2, N, K), device=w.device, dtype=torch.float16)
+    cu = torch.empty((N,), device=w.device, dtype=torch.float32)
+    call("mma_split_f16x2", ptr(w), w.stride(0), w.stride(1), K, N, ptr(bt2), ptr(cu), stream_ptr())
+    return bt2, cu
 
 
 USE_F16X2_N128 = __import__("os").environ.get("MMA_F16X2_DX", "1") != "0"

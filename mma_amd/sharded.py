@@ -279,22 +279,23 @@ class _ShardedAggregate(torch.autograd.Function):
         KH = K * H
         PQ = torch.empty((S, 2 * KH), device=dev, dtype=torch.float32)
         wcat = torch.cat([wtop, wbot], 1)                                   # (H, 2KH)
-        mm_into(x_own, wcat, PQ[:n])
+        need = any(ctx.needs_input_grad[:3])
+        box_own, box_halo = ([], []) if need else (None, None)              # row maxima of x from the forward GEMMs (three-product TN form)
+        mm_into(x_own, wcat, PQ[:n], row_max_box=box_own)
         with Fn._span("halo_wait"):
             h.wait()
-        mm_into(x_src[n:], wbot, PQ[n:, KH:])
+        mm_into(x_src[n:], wbot, PQ[n:, KH:], row_max_box=box_halo)
         P, Q = PQ[:n, :KH], PQ[:, KH:]
-        need = any(ctx.needs_input_grad[:3])
         msum, T, sel = Fn.nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, True, need)
         ctx.mod, ctx.kinds, ctx.acts, ctx.drop = mod, kinds, acts, drop
-        ctx.save_for_backward(x_src, PQ, T, sel, wcat)
+        ctx.save_for_backward(x_src, PQ, T, sel, wcat, box_own[0] if box_own else None, box_halo[0] if box_halo else None)
         return msum
 
     @staticmethod
     def backward(ctx, g):
         mod, kinds, acts, drop = ctx.mod, ctx.kinds, ctx.acts, ctx.drop
         plan, graph = mod.plan, mod.graph
-        x_src, PQ, T, sel, wcat = ctx.saved_tensors
+        x_src, PQ, T, sel, wcat, xrm_own, xrm_halo = ctx.saved_tensors
         n, S, H = plan.n_own, plan.n_src, x_src.shape[1]
         K = len(kinds)
         KH = K * H
@@ -329,10 +330,10 @@ class _ShardedAggregate(torch.autograd.Function):
         gwtop = gwbot = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             rm = row_max if row_max is not None else None        # K2a / K2b's row maxima also scale the three-product TN form
-            gw = xt_g(x_src[:n], gPQ[:n], None, rm[:n] if rm is not None else None)   # (H, 2KH) = [dL/dWtop | own part of dL/dWbot]
+            gw = xt_g(x_src[:n], gPQ[:n], xrm_own, rm[:n] if rm is not None else None)   # (H, 2KH) = [dL/dWtop | own part of dL/dWbot]
             gwtop, gwbot = gw[:, :KH], gw[:, KH:]
             if S > n:
-                gwbot = gwbot + xt_g(x_src[n:], gQ[n:], None, rm[n:] if rm is not None else None)
+                gwbot = gwbot + xt_g(x_src[n:], gQ[n:], xrm_halo, rm[n:] if rm is not None else None)
         if back is not None:
             with Fn._span("halo_wait"):
                 rows = back.wait()                                                       # (n_send, H)

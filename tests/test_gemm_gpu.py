@@ -170,6 +170,25 @@ def test_gemm_f16x2_tn_falls_back_on_the_device(case):
     assert torch.equal(got.isnan(), six.isnan()) and torch.equal(got.nan_to_num(0.0, 1.0, -1.0), six.nan_to_num(0.0, 1.0, -1.0))
 
 
+@pytest.mark.parametrize("K,N,transposed", [(128, 1024, False), (1024, 128, True), (256, 4096, False), (64, 1, False), (1, 7, True)])
+def test_split_f16x2_one_launch_matches_the_torch_expression(K, N, transposed):
+    """mma_split_f16x2 (B operand of the three-product kernels: column scales, hi / lo pieces, k contiguous) against the torch
+    expression it replaced, bit for bit, for plain and transposed-view weights, zero columns and columns near the ends of the range."""
+    from mma_amd import dense
+    rng = np.random.default_rng(K + N)
+    w = (rng.standard_normal((K, N)) * np.exp(rng.uniform(-40, 40, (1, N)))).astype(np.float32)
+    w[:, N // 2] = 0
+    w = torch.from_numpy(w).to(DEV)
+    if transposed:
+        w = w.t().contiguous().t()                                       # same values, (K,N) view of an (N,K) buffer
+    bt2, cu = dense._split_f16x2(w)
+    amax = w.abs().amax(0).clamp_min(1e-30)
+    s = torch.exp2(14.0 - torch.floor(torch.log2(amax.double()))).float()
+    x = (w * s).t().contiguous()
+    hi = x.half()
+    assert torch.equal(cu, 1.0 / s) and torch.equal(bt2[0], hi) and torch.equal(bt2[1], ((x - hi.float()) * 2048.0).half())
+
+
 def test_forward_gemm_exports_the_row_maxima():
     """mma_gemm_f16x2 leaves max |a[i,:]| in a_row_max (ragged M), and the layer-level autograd product through xt_g matches."""
     from mma_amd import dense
