@@ -344,9 +344,13 @@ __device__ __forceinline__ HFrag hg_frag(const unsigned char* sb, int ks) {
   f.b2 = *reinterpret_cast<const f16x8*>(sb + 1 * kCgPiece + ks * 32);
   return f;
 }
+// G2 = 2: a workgroup owns TWO adjacent 128-column groups (136 KB of B in LDS): a wave's rows are loaded, scaled and split once for
+// 256 columns of C instead of once per 128 - half the A traffic through L2 and half the split work per output (N/128 even).
+template <int G2>
 __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(const GemmParams p, const float* col_unscale, int64_t n_units,
                                                                            int n_groups, float* a_row_max) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kHgLds];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G2 * kHgLds];
+  constexpr int NT = 4 * G2;                                           // 32-column tiles per workgroup
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r31 = lane & 31, h = lane >> 5;
@@ -356,10 +360,10 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
   const int g = slot % n_groups;
   const int64_t stream = xcd * streams_per_xcd + slot / n_groups, n_streams = 8 * streams_per_xcd;
   const _Float16* Bh = reinterpret_cast<const _Float16*>(p.Bt);            // (2, N, 128) fp16: hi, lo * 2^11
-  for (int q = tid; q < 4 * 2 * 32 * 16; q += kCgThreads) {
+  for (int q = tid; q < NT * 2 * 32 * 16; q += kCgThreads) {
     const int kq = q & 15, col = (q >> 4) & 31, tp = q >> 9, piece = tp % 2, tile = tp / 2;
     *reinterpret_cast<uint4*>(lds + tile * kHgTile + piece * kCgPiece + col * kCgPitch + kq * 16) =
-        *reinterpret_cast<const uint4*>(Bh + ((size_t)piece * p.N + (size_t)(g * 128 + tile * 32 + col)) * 128 + kq * 8);
+        *reinterpret_cast<const uint4*>(Bh + ((size_t)piece * p.N + (size_t)(g * 32 * NT + tile * 32 + col)) * 128 + kq * 8);
   }
   __syncthreads();
   const uint32_t a_off = (uint32_t)r31 * (uint32_t)p.lda + 8u * h;
@@ -369,10 +373,9 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
   // this lane's column in each of the 4 tiles: log2 of its un-scale (an exact power of two), applied together with the row's by ONE
   // ldexp (two multiplications overflow / underflow in between for rows or columns near the ends of the fp32 range).  Loaded
   // ONCE: a load inside the tile loop would sit behind the previous tile's 16 stores in the in-order vmcnt queue.
-  const int cue0 = (int)((__float_as_uint(col_unscale[g * 128 + 0 + r31]) >> 23) & 0xFF) - 127;
-  const int cue1 = (int)((__float_as_uint(col_unscale[g * 128 + 32 + r31]) >> 23) & 0xFF) - 127;
-  const int cue2 = (int)((__float_as_uint(col_unscale[g * 128 + 64 + r31]) >> 23) & 0xFF) - 127;
-  const int cue3 = (int)((__float_as_uint(col_unscale[g * 128 + 96 + r31]) >> 23) & 0xFF) - 127;
+  int cues[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) cues[t] = (int)((__float_as_uint(col_unscale[g * 32 * NT + 32 * t + r31]) >> 23) & 0xFF) - 127;
   for (int64_t u = stream; u < n_units; u += n_streams) {
     const int64_t row0 = u * kCgRows + wave * 32;
     if (row0 >= p.M) continue;                                      // the last unit may be ragged: rows past M are re-read (the last
@@ -413,13 +416,15 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
     const __amdgpu_buffer_rsrc_t crow =
         __builtin_amdgcn_make_buffer_rsrc(p.C + row0 * p.ldc, 0, (int)min((int64_t)0x7fffffff, rows_here * p.ldc * 4), 0x00020000);
 #pragma unroll 1
-    for (int ct = 0; ct < 4; ++ct) {
-      const int cue = ct == 0 ? cue0 : (ct == 1 ? cue1 : (ct == 2 ? cue2 : cue3));
+    for (int ct = 0; ct < NT; ++ct) {
+      int cue = cues[0];
+#pragma unroll
+      for (int t = 1; t < NT; ++t) cue = ct == t ? cues[t] : cue;       // selects: a run-time index would put the array in scratch
       f32x16 acc, acl;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acl[r] = 0.f; }
       const unsigned char* sb = sb0 + ct * kHgTile;
-      const unsigned char* sbn = sb0 + ((ct + 1) & 3) * kHgTile;
+      const unsigned char* sbn = sb0 + ((ct + 1) & (NT - 1)) * kHgTile;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const HFrag nxt = ks < 7 ? hg_frag(sb, ks + 1) : hg_frag(sbn, 0);
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ldexpf(acc[r] + acl[r] * (1.f / 2048.f), cue - rse[r])), crow, c_off * 4u,
-                                              (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + g * 128 + ct * 32) * 4u, kCgStoreAux);
+                                              (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + g * 32 * NT + ct * 32) * 4u, kCgStoreAux);
       }
     }
   }
@@ -1290,8 +1295,13 @@ extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, cons
               "NULL or misaligned argument");
   GemmParams p{A, lda, static_cast<const __bf16*>(Bt2), C, ldc, M, N, 128, 0};
   const int64_t n_units = (M + kCgRows - 1) / kCgRows;
-  hipLaunchKernelGGL(gemm_f16x2_colgroup_kernel, dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p, col_unscale, n_units,
-                     N / 128, a_row_max);
+  const int groups = N / 128;
+  if (groups % 2 == 0)        // pairs of column groups per workgroup
+    hipLaunchKernelGGL(gemm_f16x2_colgroup_kernel<2>, dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p, col_unscale,
+                       n_units, groups / 2, a_row_max);
+  else
+    hipLaunchKernelGGL(gemm_f16x2_colgroup_kernel<1>, dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p, col_unscale,
+                       n_units, groups, a_row_max);
   return check_launch("gemm_f16x2_colgroup_kernel");
 }
 
