@@ -61,29 +61,19 @@ def f16x2_n128_ok(M, K, N):
     return (USE_F16X2 and USE_F16X2_N128 and USE_BF16X3 and N % 128 == 0 and N <= 512 and K % 64 == 0 and K > 128 and M >= (1 << 16))
 
 
-SLAB_BYTES = int(__import__("os").environ.get("MMA_SLAB_MB", "128")) << 20
-SLAB_MIN_BLOCKS = 4
-
-
 def gemm_f16x2_n128(a, row_max, w, out, accumulate=False):
     """out (M,N) (+)= a (M,K) @ w (K,N), N a multiple of 128, on the three-product kernel, one launch per 128-column block of the
     output (hidden width 256: C5); row_max (M,) >= max |a[i,:]| (0 for an all-zero row)."""
     M, K = a.shape
     N = w.shape[1]
     bt2, cu = _split_f16x2(w)                                            # (2, N, K), (N,)
-    nb = N // 128
-    blks = [bt2[:, 128 * b:128 * b + 128].contiguous() if N > 128 else bt2 for b in range(nb)]
-    # Many column blocks over a narrow A (C5 forward: K = 256, N = 4096): every block launch re-reads A, 32 x 1 GB from HBM.  Walked
-    # in row slabs of ~SLAB_BYTES the slab's A rows are still in the 256 MB Infinity Cache when the next column block asks for them.
-    slab = M
-    if nb >= SLAB_MIN_BLOCKS and M * K * 4 > 2 * SLAB_BYTES:
-        slab = max(256, (SLAB_BYTES // (K * 4)) // 256 * 256)
     with _span("gemm_x3_acc" if accumulate else "gemm_x3_persist"):
-        for r0 in range(0, M, slab):
-            r1 = min(M, r0 + slab)
-            for b in range(nb):
-                call("mma_gemm_f16x2_n128", ptr(a[r0:r1]), a.stride(0), ptr(row_max[r0:r1]), ptr(blks[b]), ptr(cu[128 * b:]),
-                     ptr(out[r0:r1, 128 * b:]), out.stride(0), r1 - r0, K, 1 if accumulate else 0, stream_ptr())
+        # (walking A in row slabs that stay in the Infinity Cache between the column blocks was measured at C5's forward shape -
+        # 32 blocks over a 1 GB A: 11.3 -> 11.2 ms, i.e. the kernel, not the re-reads of A, is what the product costs)
+        for b in range(N // 128):
+            blk = bt2[:, 128 * b:128 * b + 128].contiguous() if N > 128 else bt2
+            call("mma_gemm_f16x2_n128", ptr(a), a.stride(0), ptr(row_max), ptr(blk), ptr(cu[128 * b:]), ptr(out[:, 128 * b:]), out.stride(0), M, K,
+                 1 if accumulate else 0, stream_ptr())
     return out
 
 
