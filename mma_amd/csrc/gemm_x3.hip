@@ -1356,7 +1356,7 @@ static int64_t tn_pad32(int64_t M) { return (M + 31) / 32 * 32; }
 extern "C" int64_t mma_gemm_f16x2_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC) {
   if (M <= 0 || KA <= 0 || NC <= 0) return 0;
   const int s = tn_splits(M, NC);
-  return (s > 1 ? (int64_t)s * KA * NC : 0) + 3 * tn_pad32(M) + 4;     // partial tiles | row maxima of X, of G | scale halves | state
+  return (s > 1 ? ((int64_t)s * KA * NC + 3) / 4 * 4 : 0) + 3 * tn_pad32(M) + 4;     // partial tiles | row maxima of X, of G | scale halves | state
 }
 
 extern "C" int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, const float* x_row_max, const float* g_row_max,
@@ -1367,7 +1367,7 @@ extern "C" int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, in
   MMA_REQUIRE((reinterpret_cast<uintptr_t>(X) & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & 3) == 0 &&
               (reinterpret_cast<uintptr_t>(ws) & 15) == 0, "misaligned argument");
   const int s = tn_splits(M, NC);
-  const int64_t n_part = s > 1 ? (int64_t)s * KA * NC : 0, Mp = tn_pad32(M);
+  const int64_t n_part = s > 1 ? ((int64_t)s * KA * NC + 3) / 4 * 4 : 0, Mp = tn_pad32(M);   // whole 16-byte units: the scale vectors behind it are read as such
   MMA_REQUIRE(ws_floats >= n_part + 3 * Mp + 4, "workspace too small: %lld floats, need %lld", (long long)ws_floats,
               (long long)(n_part + 3 * Mp + 4));
   int64_t rps = (M + s - 1) / s;
