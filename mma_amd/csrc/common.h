@@ -42,12 +42,34 @@ template <> __device__ __forceinline__ void stv<4>(float* p, const Vec<4>& a) {
 }
 template <> __device__ __forceinline__ void stv<1>(float* p, const Vec<1>& a) { *p = a.v[0]; }
 
+// streaming forms: data written once and not read again by this kernel / read exactly once (the `nt` policy keeps them from
+// displacing the gathered rows in L2)
+typedef float mma_f32x4 __attribute__((ext_vector_type(4)));
+template <int VEC> __device__ __forceinline__ void stv_nt(float* p, const Vec<VEC>& a);
+template <> __device__ __forceinline__ void stv_nt<4>(float* p, const Vec<4>& a) {
+  mma_f32x4 v = {a.v[0], a.v[1], a.v[2], a.v[3]};
+  __builtin_nontemporal_store(v, reinterpret_cast<mma_f32x4*>(p));
+}
+template <> __device__ __forceinline__ void stv_nt<1>(float* p, const Vec<1>& a) { __builtin_nontemporal_store(a.v[0], p); }
+template <int VEC> __device__ __forceinline__ Vec<VEC> ldv_nt(const float* p);
+template <> __device__ __forceinline__ Vec<4> ldv_nt<4>(const float* p) {
+  const mma_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const mma_f32x4*>(p));
+  Vec<4> r; r.v[0] = t[0]; r.v[1] = t[1]; r.v[2] = t[2]; r.v[3] = t[3]; return r;
+}
+template <> __device__ __forceinline__ Vec<1> ldv_nt<1>(const float* p) { Vec<1> r; r.v[0] = __builtin_nontemporal_load(p); return r; }
+
 // 1 byte per element (selection codes, explicit keep masks)
 template <int VEC> __device__ __forceinline__ uint32_t ldb(const uint8_t* p);
 template <> __device__ __forceinline__ uint32_t ldb<4>(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
 template <> __device__ __forceinline__ uint32_t ldb<1>(const uint8_t* p) { return *p; }
 template <int VEC> __device__ __forceinline__ void stb(uint8_t* p, uint32_t codes);
 template <> __device__ __forceinline__ void stb<4>(uint8_t* p, uint32_t c) { *reinterpret_cast<uint32_t*>(p) = c; }
+template <int VEC> __device__ __forceinline__ void stb_nt(uint8_t* p, uint32_t codes);
+template <> __device__ __forceinline__ void stb_nt<4>(uint8_t* p, uint32_t c) { __builtin_nontemporal_store(c, reinterpret_cast<uint32_t*>(p)); }
+template <> __device__ __forceinline__ void stb_nt<1>(uint8_t* p, uint32_t c) { __builtin_nontemporal_store((uint8_t)c, p); }
+template <int VEC> __device__ __forceinline__ uint32_t ldb_nt(const uint8_t* p);
+template <> __device__ __forceinline__ uint32_t ldb_nt<4>(const uint8_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p)); }
+template <> __device__ __forceinline__ uint32_t ldb_nt<1>(const uint8_t* p) { return __builtin_nontemporal_load(p); }
 template <> __device__ __forceinline__ void stb<1>(uint8_t* p, uint32_t c) { *p = (uint8_t)c; }
 
 // ---- mask activation ---------------------------------------------------------------------------------

@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_f16x2_tn_kernel(const TnParams
     }                                                                                          \
     _Pragma("unroll") for (int g = 0; g < 2; ++g)                                              \
       _Pragma("unroll") for (int i = 0; i < 8; ++i)                                            \
-        GR_[g * 8 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rsrc, gv, (g * 16 + i) * ldg_b, 0)); \
+        GR_[g * 8 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rsrc, gv, (g * 16 + i) * ldg_b, 2 /* nt: G streams through once, X is what the column blocks share in L2 */)); \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
       _Pragma("unroll") for (int i = 0; i < 8; ++i)                                            \
         XR_[ks * 8 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, xv, (ks * 16 + i) * ldx_b, 0)); \

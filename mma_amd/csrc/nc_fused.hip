@@ -73,8 +73,8 @@ __device__ __forceinline__ Vec<VEC> nc_fwd_write(const NcFwdParams& p, int node,
   if (p.m) stv<VEC>(p.m + (size_t)k_abs * p.m_kstride + (size_t)node * p.H + c, mo);
   if (SAVE) {
     const size_t o = (size_t)node * p.ldt + (size_t)k_abs * p.H + c;
-    stv<VEC>(p.T + o, t);
-    stb<VEC>(p.sel + o, codes);
+    stv_nt<VEC>(p.T + o, t);
+    stb_nt<VEC>(p.sel + o, codes);
   }
   return mo;
 }
@@ -88,7 +88,7 @@ __device__ __forceinline__ void nc_msum_store(const NcFwdParams& p, int node, in
 #pragma unroll
     for (int i = 0; i < VEC; ++i) ms.v[i] += prev.v[i];
   }
-  stv<VEC>(o, ms);
+  if (accumulate) stv<VEC>(o, ms); else stv_nt<VEC>(o, ms);
 }
 
 // MULTI = false: one item per wavefront (EPG = 64/LPR neighbour rows per step) - long segments.
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_k
     Vec<VEC> pk[K], acc[K], tac[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      pk[k] = ldv<VEC>(p.P + (size_t)node * p.ldp + (size_t)(p.k_base + k) * p.H + cc);
+      pk[k] = ldv_nt<VEC>(p.P + (size_t)node * p.ldp + (size_t)(p.k_base + k) * p.H + cc);
       acc[k] = vzero<VEC>();
       tac[k] = vzero<VEC>();
     }
@@ -297,9 +297,9 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
     for (int k = 0; k < MMA_MAX_K; ++k) {
       if (k < p.K) {
         const size_t o = (size_t)node * p.ldt + (size_t)k * p.H + c;
-        if (k == 0 || !shared_g) gk[k] = ldv<VEC>(p.g + (size_t)k * p.g_kstride + (size_t)node * p.ldgr + c);
-        tk[k] = ldv<VEC>(p.T + o);
-        ck[k] = ldb<VEC>(p.sel + o);
+        if (k == 0 || !shared_g) gk[k] = ldv_nt<VEC>(p.g + (size_t)k * p.g_kstride + (size_t)node * p.ldgr + c);
+        tk[k] = ldv_nt<VEC>(p.T + o);
+        ck[k] = ldb_nt<VEC>(p.sel + o);
       }
     }
     Vec<VEC> gx = vzero<VEC>();
@@ -347,10 +347,10 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
             stb<VEC>(reinterpret_cast<uint8_t*>(row + p.H + 4 + (size_t)p.sel_slot[k] * p.HQ) + c, tf);
           }
         }
-        stv<VEC>(p.gP + (size_t)node * p.ldgp + (size_t)k * p.H + c, gpv);
+        stv_nt<VEC>(p.gP + (size_t)node * p.ldgp + (size_t)k * p.H + c, gpv);
       }
     }
-    stv<VEC>(p.gxs + (size_t)node * p.ldgx + c, gx);
+    stv_nt<VEC>(p.gxs + (size_t)node * p.ldgx + c, gx);
     if (p.rowmax) {          // the row maximum of gP for the three-product dL/dx GEMM (its A rows are scaled by a power of two)
       if ((per_row & (per_row - 1)) == 0 && per_row <= kWave) {     // a node's threads are an aligned lane group: one atomic per node
         for (int off = per_row >> 1; off > 0; off >>= 1) mxp = fmaxf(mxp, __shfl_xor(mxp, off, kWave));
@@ -435,12 +435,12 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
       maxlen = __builtin_amdgcn_readfirstlane(maxlen);
     }
 
-    const Vec<VEC> xj = ldv<VEC>(p.x + (size_t)node * p.ldx + cc);
+    const Vec<VEC> xj = ldv_nt<VEC>(p.x + (size_t)node * p.ldx + cc);
     Vec<VEC> qk[K], aq[K];
     Vec<VEC> ax = vzero<VEC>();
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      qk[k] = ldv<VEC>(p.Q + (size_t)node * p.ldq + (size_t)(p.k_base + k) * p.H + cc);
+      qk[k] = ldv_nt<VEC>(p.Q + (size_t)node * p.ldq + (size_t)(p.k_base + k) * p.H + cc);
       aq[k] = vzero<VEC>();
     }
 
@@ -552,14 +552,14 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
           Vec<VEC> o;
 #pragma unroll
           for (int i = 0; i < VEC; ++i) o.v[i] = xj.v[i] * aq[k].v[i];
-          stv<VEC>(p.gQ + (size_t)node * p.ldgq + (size_t)(p.k_base + k) * p.H + c, o);
+          stv_nt<VEC>(p.gQ + (size_t)node * p.ldgq + (size_t)(p.k_base + k) * p.H + c, o);
         }
-        const Vec<VEC> g0 = p.first_pass ? ldv<VEC>(p.gxs + (size_t)node * p.ldgx + c)
+        const Vec<VEC> g0 = p.first_pass ? ldv_nt<VEC>(p.gxs + (size_t)node * p.ldgx + c)
                                          : ldv<VEC>(p.gx + (size_t)node * p.ldgxo + c);
         Vec<VEC> o;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) o.v[i] = g0.v[i] + ax.v[i];
-        stv<VEC>(p.gx + (size_t)node * p.ldgxo + c, o);
+        stv_nt<VEC>(p.gx + (size_t)node * p.ldgxo + c, o);
       } else {
         float* ps = p.partial + (size_t)slot * p.pstride;
 #pragma unroll
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_finalize_kernel(const NcBwdPara
       const Vec<VEC> xj = ldv<VEC>(p.x + (size_t)node * p.ldx + c);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o.v[i] = xj.v[i] * s.v[i];
-      stv<VEC>(p.gQ + (size_t)node * p.ldgq + (size_t)k * p.H + c, o);
+      stv_nt<VEC>(p.gQ + (size_t)node * p.ldgq + (size_t)k * p.H + c, o);
       if (p.rowmax) {
         float mxq = 0.f;
 #pragma unroll
