@@ -871,7 +871,7 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
     // one batch of loads: the K*S gradient blocks (slots past K*S re-read the last one and are dropped) + the arg bytes
     Vec<4> gv[kBlkMaxKS];
 #pragma unroll
-    for (int i = 0; i < kBlkMaxKS; ++i) gv[i] = ldv<4>(go + (size_t)min(i, KS - 1) * p.F);
+    for (int i = 0; i < kBlkMaxKS; ++i) gv[i] = ldv_nt<4>(go + (size_t)min(i, KS - 1) * p.F);
     uint32_t wn = 0xFFFFFFFFu, wx = 0xFFFFFFFFu;
     if ((NEEDS & NEED_MIN) && p.amin8) wn = ldb<4>(p.amin8 + (size_t)node * p.ldsave + c);     // NULL: no min in the aggregator list
     if ((NEEDS & NEED_MAX) && p.amax8) wx = ldb<4>(p.amax8 + (size_t)node * p.ldsave + c);
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
           g.v[i] = gi * fd[i];
           su.v[i] += g.v[i];
         }
-        stv<4>(p.gmsg + (size_t)(p.by_pos ? pos : ee) * p.ldg + c, g);
+        stv_nt<4>(p.gmsg + (size_t)(p.by_pos ? pos : ee) * p.ldg + c, g);
       }
     }
     if (p.gU) stv<4>(p.gU + (size_t)node * p.ldgu + c, su);
