@@ -248,15 +248,27 @@ __global__ __launch_bounds__(kBlock) void nc_fwd_finalize_kernel(const NcFwdPara
     Vec<VEC> ms = vzero<VEC>();
     for (int k = 0; k < p.K_total; ++k) {
       Vec<VEC> s = vzero<VEC>(), t = vzero<VEC>();
-      for (int sl = hub.y; sl < hub.z; ++sl) {
-        const float* ps = p.partial + (size_t)sl * p.pstride;
-        const Vec<VEC> a = ldv<VEC>(ps + (size_t)k * p.H + c);
+      // the partials of a hub are summed in slot order (fixed: bitwise repeatable), but FETCHED eight slots at a time: one load,
+      // one wait, one add per slot left the largest hub's 52 slots x K masks as ~200 exposed memory latencies (0.10 ms per call)
+      constexpr int kAhead = 8;
+      for (int sl0 = hub.y; sl0 < hub.z; sl0 += kAhead) {
+        Vec<VEC> a[kAhead], b[kAhead];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) s.v[i] += a.v[i];
-        if (SAVE) {
-          const Vec<VEC> b = ldv<VEC>(ps + (size_t)(p.K_total + k) * p.H + c);
+        for (int u = 0; u < kAhead; ++u) {
+          const float* ps = p.partial + (size_t)min(sl0 + u, hub.z - 1) * p.pstride;     // past the end: re-read the last one, dropped below
+          a[u] = ldv<VEC>(ps + (size_t)k * p.H + c);
+          if (SAVE) b[u] = ldv<VEC>(ps + (size_t)(p.K_total + k) * p.H + c);
+        }
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) t.v[i] += b.v[i];
+        for (int u = 0; u < kAhead; ++u) {
+          if (sl0 + u < hub.z) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s.v[i] += a[u].v[i];
+            if (SAVE) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) t.v[i] += b[u].v[i];
+            }
+          }
         }
       }
       const Vec<VEC> mo = nc_fwd_write<VEC, SAVE>(p, node, k, c, xi, s, t, deg);
@@ -588,10 +600,18 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_finalize_kernel(const NcBwdPara
     const int k = (int)((idx / per_row) % (p.K_total + 1));
     const int4 hub = hubs[idx / ((int64_t)per_row * (p.K_total + 1))];
     Vec<VEC> s = vzero<VEC>();
-    for (int sl = hub.y; sl < hub.z; ++sl) {
-      const Vec<VEC> a = ldv<VEC>(p.partial + (size_t)sl * p.pstride + (size_t)k * p.H + c);
+    constexpr int kAhead = 8;                       // slot order kept, eight fetches in flight (see nc_fwd_finalize_kernel)
+    for (int sl0 = hub.y; sl0 < hub.z; sl0 += kAhead) {
+      Vec<VEC> a[kAhead];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) s.v[i] += a.v[i];
+      for (int u = 0; u < kAhead; ++u) a[u] = ldv<VEC>(p.partial + (size_t)min(sl0 + u, hub.z - 1) * p.pstride + (size_t)k * p.H + c);
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        if (sl0 + u < hub.z) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) s.v[i] += a[u].v[i];
+        }
+      }
     }
     const int node = hub.x;
     Vec<VEC> o;
