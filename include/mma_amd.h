@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 24
+#define MMA_ABI_VERSION 25
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -159,6 +159,9 @@ int mma_csr_spmm_items(
 int mma_split_bf16x3(const float* in, int64_t n, void* out_3n_bf16, void* stream);
 int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, float* C, int64_t ldc,
                     int64_t M, int32_t N, int32_t K, int32_t accumulate /* 0: C = A B, 1: C += A B */, void* stream);
+/* out[i] = max_j |A[i,j]| of a (M, cols) fp32 matrix (a NaN or inf in the row is returned as such): the row maxima the
+ * three-product kernels below scale by, for callers whose producers do not leave them (one pass over A, 32 lanes per row). */
+int mma_row_absmax(const float* A, int64_t lda, int64_t M, int32_t cols, float* out, void* stream);
 /* The B operand of the three-product kernels below from w (K,N) fp32 with element strides (stride_k, stride_n) - a transposed view
  * is fine: Bt2 = (2, N, K) fp16, piece 0 = hi and piece 1 = lo * 2^11 of w^T scaled per column by the power of two that puts the
  * column maximum into [2^14, 2^15); col_unscale (N,) = the reciprocal scales.  One launch. */

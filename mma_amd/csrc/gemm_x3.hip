@@ -1353,6 +1353,14 @@ extern "C" int mma_gemm_bf16x3_tn(const float* X, int64_t ldx, const float* G, i
 
 static int64_t tn_pad32(int64_t M) { return (M + 31) / 32 * 32; }
 
+extern "C" int mma_row_absmax(const float* A, int64_t lda, int64_t M, int32_t cols, float* out, void* stream) {
+  MMA_REQUIRE(M >= 0 && cols >= 1 && lda >= cols && lda < (1 << 24), "M=%lld cols=%d lda=%lld out of range", (long long)M, cols, (long long)lda);
+  if (M == 0) return 0;
+  MMA_REQUIRE(A && out && (reinterpret_cast<uintptr_t>(A) & 3) == 0, "NULL or misaligned argument");
+  launch_row_absmax(A, lda, M, cols, out, static_cast<hipStream_t>(stream));
+  return check_launch("row_absmax_kernel");
+}
+
 extern "C" int64_t mma_gemm_f16x2_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC) {
   if (M <= 0 || KA <= 0 || NC <= 0) return 0;
   const int s = tn_splits(M, NC);

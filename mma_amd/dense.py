@@ -61,6 +61,16 @@ def f16x2_n128_ok(M, K, N):
     return (USE_F16X2 and USE_F16X2_N128 and USE_BF16X3 and N % 128 == 0 and N <= 512 and K % 64 == 0 and K > 128 and M >= (1 << 16))
 
 
+def row_absmax(a):
+    """max |a[i,:]| per row in one pass (mma_row_absmax); torch's a.abs().amax(1) is two kernels and a full-size temporary."""
+    M, C = a.shape
+    out = torch.empty((M,), device=a.device, dtype=torch.float32)
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    call("mma_row_absmax", ptr(a), a.stride(0) if M > 1 else C, M, C, ptr(out), stream_ptr())
+    return out
+
+
 def gemm_f16x2_n128(a, row_max, w, out, accumulate=False):
     """out (M,N) (+)= a (M,K) @ w (K,N), N a multiple of 128, on the three-product kernel, one launch per 128-column block of the
     output (hidden width 256: C5); row_max (M,) >= max |a[i,:]| (0 for an all-zero row)."""
@@ -106,7 +116,7 @@ def gemm_bf16x3(a, w, out=None, accumulate=False, row_max_box=None):
         # takes the row maxima from one cheap pass over `a` (M x K floats read against M x N written)
         if out is None:
             out = torch.empty((M, N), device=a.device, dtype=torch.float32)
-        rm = a.abs().amax(1)
+        rm = row_absmax(a)
         if row_max_box is not None:
             row_max_box.append(rm)
         return gemm_f16x2_n128(a, rm, w, out)

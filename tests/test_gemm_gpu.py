@@ -189,6 +189,18 @@ def test_split_f16x2_one_launch_matches_the_torch_expression(K, N, transposed):
     assert torch.equal(cu, 1.0 / s) and torch.equal(bt2[0], hi) and torch.equal(bt2[1], ((x - hi.float()) * 2048.0).half())
 
 
+@pytest.mark.parametrize("M,C,pad", [(1, 1, 0), (7, 33, 3), (70001, 256, 0), (5000, 75, 5), (1025, 4096, 0)])
+def test_row_absmax(M, C, pad):
+    from mma_amd import dense
+    rng = np.random.default_rng(M + C)
+    a = torch.from_numpy(rng.standard_normal((M, C + pad)).astype(np.float32)).to(DEV)[:, :C]
+    assert torch.equal(dense.row_absmax(a), a.abs().amax(1))
+    if M > 3:
+        a = a.clone(); a[2, C // 2] = float("nan"); a[3, 0] = float("inf")
+        r = dense.row_absmax(a)
+        assert bool(r[2].isnan()) and bool(r[3].isinf())
+
+
 def test_forward_gemm_exports_the_row_maxima():
     """mma_gemm_f16x2 leaves max |a[i,:]| in a_row_max (ragged M), and the layer-level autograd product through xt_g matches."""
     from mma_amd import dense
