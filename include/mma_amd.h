@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 25
+#define MMA_ABI_VERSION 26
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -177,6 +177,11 @@ int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, const float* co
                    float* a_row_max,             /* optional (M,) out: max |a| of every row (the kernel forms it for its row scales
                                                     anyway) - the x_row_max of the weight-gradient product mma_gemm_f16x2_tn */
                    int64_t M, int32_t N, void* stream);
+/* The three-product column-group form for K = 256 (the forward product of hidden width 256: C5): as mma_gemm_f16x2 with Bt2 = (2, N, 256),
+ * but the row scales come from the caller's row_max (M,) >= max |a| of every row (mma_row_absmax, or a producer's bound; 0 marks an
+ * all-zero row): 256 floats per row do not fit the registers beside their own fp16 pieces while an in-kernel maximum forms. */
+int mma_gemm_f16x2_k256(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale, float* C,
+                        int64_t ldc, int64_t M, int32_t N, void* stream);
 /* The same three-product form for N = 128 and a long reduction (dL/dx += [gP|gQ] [Wtop|Wbot]^T, K % 64 == 0): the row scales
  * cannot be formed in the kernel (a row is consumed in 64-wide chunks), so the caller passes row_max (M,) >= the maximum
  * |a| of every row (the backward kernels produce it: mma_nc_bwd_node / mma_nc_fused_bwd); 0 marks an all-zero row.

@@ -445,6 +445,109 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
   }
 }
 
+// ---- K == 256, three products (round 2, late): the forward [P|Q] = x [Wtop|Wbot] of hidden width 256 (C5) -----------------------------
+// The column-group form with a 256-deep reduction: a workgroup owns 128 columns, their B slab (2 pieces x 128 columns x 256 k fp16 = 135 KB
+// with the row padding) stays in LDS for the whole launch, a wave's 32 rows (256 floats each) are loaded once, scaled by the power of
+// two the caller's row maximum implies (mma_row_absmax / a producer's bound: 32 float4 per lane cannot all wait for an in-kernel
+// maximum beside their own fp16 pieces) and split into 16 k-steps x 2 pieces (128 registers), then 4 tiles x 48 MFMAs.  A is read
+// once per column group through the XCD's L2 (the N/128 groups of one row stream share an XCD); the chunked N = 128 kernel, one
+// launch per 128 columns, re-read A from HBM 32 times at C5 (N = 4096).
+constexpr int kH2Pitch = 256 * 2 + 16, kH2Piece = 32 * kH2Pitch, kH2Tile = 2 * kH2Piece, kH2Lds = 4 * kH2Tile;      // 135 168 B
+__global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_k256_kernel(const GemmParams p, const float* row_max, const float* col_unscale,
+                                                                                int64_t n_units, int n_groups) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kH2Lds];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, h = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int streams_per_xcd = kCgSlotsPerXcd / n_groups;
+  if (slot >= streams_per_xcd * n_groups) return;
+  const int g = slot % n_groups;
+  const int64_t stream = xcd * streams_per_xcd + slot / n_groups, n_streams = 8 * streams_per_xcd;
+  const _Float16* Bh = reinterpret_cast<const _Float16*>(p.Bt);            // (2, N, 256) fp16: hi, lo * 2^11
+  for (int q = tid; q < 4 * 2 * 32 * 32; q += kCgThreads) {                // 16-byte chunks: 32 per (piece, column) row
+    const int kq = q & 31, col = (q >> 5) & 31, tp = q >> 10, piece = tp % 2, tile = tp / 2;
+    *reinterpret_cast<uint4*>(lds + tile * kH2Tile + piece * kH2Piece + col * kH2Pitch + kq * 16) =
+        *reinterpret_cast<const uint4*>(Bh + ((size_t)piece * p.N + (size_t)(g * 128 + tile * 32 + col)) * 256 + kq * 8);
+  }
+  __syncthreads();
+  const uint32_t a_off = (uint32_t)r31 * (uint32_t)p.lda + 8u * h;
+  const uint32_t c_off = 4u * h * (uint32_t)p.ldc + (uint32_t)r31;
+  const unsigned char* sb0 = lds + r31 * kH2Pitch + h * 16;
+  int cues[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) cues[t] = (int)((__float_as_uint(col_unscale[g * 128 + 32 * t + r31]) >> 23) & 0xFF) - 127;
+  for (int64_t u = stream; u < n_units; u += n_streams) {
+    const int64_t row0 = u * kCgRows + wave * 32;
+    if (row0 >= p.M) break;                                          // units ascend: every later one starts past M as well
+    const int64_t rows_here = min((int64_t)32, p.M - row0);          // ragged last unit: rows past M re-read the last row, stores dropped
+    const int64_t myrow = row0 + min((int64_t)r31, rows_here - 1);
+    const float* ap = p.A + myrow * p.lda + 8 * h;
+    const float rmax = row_max[myrow];
+    const int ex = (int)((__float_as_uint(rmax) >> 23) & 0xFF);
+    const int sce = min(max(14 - (ex - 127), -126), 127);            // log2 of the row scale
+    const float sc = __uint_as_float((uint32_t)(sce + 127) << 23);
+    int rse[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rse[r] = __shfl(sce, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+    f16x8 af[16][2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                            // 16 float4 at a time: raw pieces turn into fp16 pieces in place
+      float4 raw[16];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        raw[2 * ks] = *reinterpret_cast<const float4*>(ap + (half * 8 + ks) * 16);
+        raw[2 * ks + 1] = *reinterpret_cast<const float4*>(ap + (half * 8 + ks) * 16 + 4);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const float v[8] = {raw[2*ks].x, raw[2*ks].y, raw[2*ks].z, raw[2*ks].w, raw[2*ks+1].x, raw[2*ks+1].y, raw[2*ks+1].z, raw[2*ks+1].w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float x = v[i] * sc;
+          const _Float16 hi = (_Float16)x;
+          af[half * 8 + ks][0][i] = hi;
+          af[half * 8 + ks][1][i] = (_Float16)((x - (float)hi) * 2048.f);
+        }
+      }
+    }
+    const __amdgpu_buffer_rsrc_t crow =
+        __builtin_amdgcn_make_buffer_rsrc(p.C + row0 * p.ldc, 0, (int)min((int64_t)0x7fffffff, rows_here * p.ldc * 4), 0x00020000);
+#pragma unroll 1
+    for (int ct = 0; ct < 4; ++ct) {
+      int cue = cues[0];
+#pragma unroll
+      for (int t = 1; t < 4; ++t) cue = ct == t ? cues[t] : cue;
+      f32x16 acc, acl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acl[r] = 0.f; }
+      const unsigned char* sb = sb0 + ct * kH2Tile;
+      HFrag cur;
+      cur.b1 = *reinterpret_cast<const f16x8*>(sb);
+      cur.b2 = *reinterpret_cast<const f16x8*>(sb + kH2Piece);
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        HFrag nxt = cur;
+        if (ks < 15) {
+          nxt.b1 = *reinterpret_cast<const f16x8*>(sb + (ks + 1) * 32);
+          nxt.b2 = *reinterpret_cast<const f16x8*>(sb + kH2Piece + (ks + 1) * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b2, acl, 0, 0, 0);
+        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], cur.b1, acl, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b1, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ldexpf(acc[r] + acl[r] * (1.f / 2048.f), cue - rse[r])), crow, c_off * 4u,
+                                              (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + g * 128 + ct * 32) * 4u, kCgStoreAux);
+      }
+    }
+  }
+}
+
 // ---- N == 128, long K: the dL/dx products g [Wtop|Wbot]^T (round 2) ---------------------------------------------------
 // The accumulator tiles of all 128 columns persist in registers over the K chunks (as in gemm_x3_kernel<4>), but a workgroup
 // is 8 waves = 256 rows and the slab of one K chunk holds ALL four column tiles (4 x 3 x 32 x 64 bf16, 54 KB, double
@@ -1303,6 +1406,20 @@ extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, cons
     hipLaunchKernelGGL(gemm_f16x2_colgroup_kernel<1>, dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p, col_unscale,
                        n_units, groups, a_row_max);
   return check_launch("gemm_f16x2_colgroup_kernel");
+}
+
+extern "C" int mma_gemm_f16x2_k256(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale, float* C,
+                                   int64_t ldc, int64_t M, int32_t N, void* stream) {
+  MMA_REQUIRE(M >= 0 && N >= 128 && N % 128 == 0 && N / 128 <= kCgSlotsPerXcd, "M=%lld N=%d: need N %% 128 == 0, N <= 4096", (long long)M, N);
+  MMA_REQUIRE(lda >= 256 && ldc >= N && lda % 4 == 0 && lda < (1 << 24) && ldc < (1 << 24), "row pitch too small, unaligned or >= 2^24");
+  if (M == 0) return 0;
+  MMA_REQUIRE(A && row_max && Bt2 && col_unscale && C && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt2) & 15) == 0,
+              "NULL or misaligned argument");
+  GemmParams p{A, lda, static_cast<const __bf16*>(Bt2), C, ldc, M, N, 256, 0};
+  const int64_t n_units = (M + kCgRows - 1) / kCgRows;
+  hipLaunchKernelGGL(gemm_f16x2_colgroup_k256_kernel, dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p, row_max, col_unscale,
+                     n_units, N / 128);
+  return check_launch("gemm_f16x2_colgroup_k256_kernel");
 }
 
 extern "C" int mma_gemm_f16x2_n128(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale, float* C,

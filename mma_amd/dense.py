@@ -55,6 +55,7 @@ def _split_f16x2(w):
 
 
 USE_F16X2_N128 = __import__("os").environ.get("MMA_F16X2_DX", "1") != "0"
+USE_F16X2_K256 = __import__("os").environ.get("MMA_F16X2_K256", "1") != "0"
 
 
 def f16x2_n128_ok(M, K, N):
@@ -119,6 +120,13 @@ def gemm_bf16x3(a, w, out=None, accumulate=False, row_max_box=None):
         rm = row_absmax(a)
         if row_max_box is not None:
             row_max_box.append(rm)
+        if K == 256 and N <= 4096 and USE_F16X2_K256:
+            # column-group form with the whole 256-deep B slab resident: A is read once per column group through L2 instead of once per
+            # 128-column launch from HBM (C5 forward, N = 4096: 32 launches of the chunked kernel)
+            bt2, cu = _split_f16x2(w)
+            with _span("gemm_x3_persist"):
+                call("mma_gemm_f16x2_k256", ptr(a), a.stride(0), ptr(rm), ptr(bt2), ptr(cu), ptr(out), out.stride(0), M, N, stream_ptr())
+            return out
         return gemm_f16x2_n128(a, rm, w, out)
     wt = w.t().contiguous()                                  # (N,K): B^T, k contiguous
     bt3 = torch.empty((3, N, K), device=a.device, dtype=torch.bfloat16)

@@ -120,6 +120,15 @@ def recipe(lib, name, rng, keep):
         if rng.random() < 0.5:
             d.update(a_row_max=None)
         return d
+    if name == "mma_gemm_f16x2_k256":
+        M, Nc = rng.choice([(1 << 20, 4096), (70001, 512), (5, 128), (0, 256), ((1 << 31) + 7, 128)])
+        return dict(lda=256 + rng.choice([0, 4, 128]), ldc=Nc + rng.choice([0, 4]), M=M, N=Nc)
+    if name == "mma_row_absmax":
+        M, C = rng.choice([(0, 7), (1, 1), (70001, 256), (1 << 20, 128), ((1 << 31) + 3, 75)])
+        return dict(lda=C + rng.choice([0, 5]), M=M, cols=C)
+    if name == "mma_split_f16x2":
+        K, Nc = rng.choice([(128, 1024), (1024, 128), (256, 4096), (1, 1), (1 << 20, 4096)])
+        return dict(stride_k=rng.choice([Nc, 1]), stride_n=rng.choice([1, K]), K=K, N=Nc)
     if name == "mma_col_sum":
         R, C = rng.choice([(0, 7), (1, 1), (1000, 375), (204552, 375), (427376, 75), (300001, 130), (1 << 31, 16)])
         lib.mma_col_sum_workspace_floats.restype = ctypes.c_int64

@@ -201,6 +201,31 @@ def test_row_absmax(M, C, pad):
         assert bool(r[2].isnan()) and bool(r[3].isinf())
 
 
+@pytest.mark.parametrize("M,N", [(66001, 4096), (70000, 384), (131075, 1024), (65536, 256)])
+def test_gemm_f16x2_k256(M, N):
+    """K = 256 column-group three-product kernel (C5 forward shape) against fp64: rows spread over e^+-6, zero rows, ragged M; the
+    chunked N = 128 kernel on the same operands gives the same error level."""
+    from mma_amd import dense
+    rng = np.random.default_rng(M + N)
+    a = (rng.standard_normal((M, 256)) * np.exp(rng.uniform(-6, 6, (M, 1)))).astype(np.float32)
+    a[::17] = 0
+    a = torch.from_numpy(a).to(DEV)
+    w = torch.from_numpy(((rng.random((256, N)) * 2 - 1) / 16).astype(np.float32)).to(DEV)
+    got = dense.gemm_bf16x3(a, w)
+    f32 = a @ w
+    idx = torch.from_numpy(rng.choice(M, 4096, replace=False)).to(DEV)          # fp64 truth on a row sample
+    ref = a[idx].double() @ w.double()
+    scale = a[idx].double().abs() @ w.double().abs() + 1e-300
+    e_got = ((got[idx].double() - ref).abs() / scale).max().item()
+    e_f32 = ((f32[idx].double() - ref).abs() / scale).max().item()
+    assert e_got < 5e-7 and e_got < 1.5 * e_f32 + 1e-7, (e_got, e_f32)
+    assert torch.equal(got[::17], torch.zeros_like(got[::17]))
+    assert torch.equal(dense.gemm_bf16x3(a, w), got)
+    box = []
+    dense.gemm_bf16x3(a, w, row_max_box=box)
+    assert len(box) == 1 and torch.equal(box[0], a.abs().amax(1))
+
+
 def test_forward_gemm_exports_the_row_maxima():
     """mma_gemm_f16x2 leaves max |a[i,:]| in a_row_max (ragged M), and the layer-level autograd product through xt_g matches."""
     from mma_amd import dense
