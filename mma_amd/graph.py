@@ -6,9 +6,12 @@ graph on the host with numpy and then lives in HBM as int32."""
 import numpy as np
 import torch
 
-DEFAULT_CHUNK = 512   # edges per work item; longer segments (hubs) are split and summed in a second pass
+DEFAULT_CHUNK = 1024  # edges per work item; longer segments (hubs) are split and summed in a second pass
 SPMM_GROUP_BELOW = 64  # SpMM rows shorter than this run one per C/4-lane group (a group walks its row alone, four gathers in flight)
-GROUP_BELOW = 16      # items shorter than this run one per H/4-lane group (several per wavefront) instead of one per wavefront
+GROUP_BELOW = 48      # items shorter than this run one per H/4-lane group (several per wavefront) instead of one per wavefront
+T_GROUP_BELOW = 64    # the same threshold for the backward (by-source) item lists
+# (chunk, thresholds) re-swept on the C4 graph after the nt policy went in (same box, 10 steps each): (512, 16, 16) 15.12 ms/step,
+# K1 4.55, K2b 5.25; (1024, 32, 64) 14.80; (1024, 48, 64) 14.72, K1 4.36, K2b 4.97; (1024, 32, 128) 14.74; (1536, 32, 64) 14.83
 
 
 def make_items(rowptr, chunk):
@@ -60,7 +63,7 @@ def transpose_csr(rowptr, col, n_src):
 class NCGraph:
     """Device-resident plan.  n_src >= N allows extra source rows (halo rows in the sharded path)."""
 
-    def __init__(self, rowptr, col, device, n_src=None, chunk=DEFAULT_CHUNK, edge_base=0, group_below=GROUP_BELOW):
+    def __init__(self, rowptr, col, device, n_src=None, chunk=DEFAULT_CHUNK, edge_base=0, group_below=GROUP_BELOW, t_group_below=None):
         rowptr = np.asarray(rowptr, dtype=np.int64)
         col = np.asarray(col, dtype=np.int64)
         self.N = len(rowptr) - 1
@@ -75,7 +78,8 @@ class NCGraph:
         t_items, t_hubs, self.t_n_slots = make_items(t_rowptr, self.chunk)
         # the lists are sorted longest first: the head runs one item per wavefront, the short tail grouped
         self.n_wave_items = int(((items[:, 2] - items[:, 1]) >= group_below).sum())
-        self.t_n_wave_items = int(((t_items[:, 2] - t_items[:, 1]) >= group_below).sum())
+        t_group_below = T_GROUP_BELOW if t_group_below is None else t_group_below   # the backward (by-source) lists have their own threshold
+        self.t_n_wave_items = int(((t_items[:, 2] - t_items[:, 1]) >= t_group_below).sum())
         dev = torch.device(device)
         i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
         self.device = dev
@@ -92,7 +96,7 @@ class NCGraph:
                 mi = (t_items[:, 0] >= self.N) == sel_halo
                 mh = (t_hubs[:, 0] >= self.N) == sel_halo
                 it = t_items[mi]
-                parts.append((i32(it), int(((it[:, 2] - it[:, 1]) >= group_below).sum()), i32(t_hubs[mh])))
+                parts.append((i32(it), int(((it[:, 2] - it[:, 1]) >= t_group_below).sum()), i32(t_hubs[mh])))
             self.t_parts = parts
         deg = np.diff(rowptr)
         self.max_degree = int(deg.max()) if self.N else 0
