@@ -6,12 +6,26 @@ graph on the host with numpy and then lives in HBM as int32."""
 import numpy as np
 import torch
 
-DEFAULT_CHUNK = 1024  # edges per work item; longer segments (hubs) are split and summed in a second pass
+DEFAULT_CHUNK = None   # edges per work item (longer segments - hubs - are split and summed in a second pass); None: by graph size
+SPMM_CHUNK = 512       # the same for the SpMM plans (64-byte rows: as tuned in round 1)
 SPMM_GROUP_BELOW = 64  # SpMM rows shorter than this run one per C/4-lane group (a group walks its row alone, four gathers in flight)
-GROUP_BELOW = 48      # items shorter than this run one per H/4-lane group (several per wavefront) instead of one per wavefront
-T_GROUP_BELOW = 64    # the same threshold for the backward (by-source) item lists
-# (chunk, thresholds) re-swept on the C4 graph after the nt policy went in (same box, 10 steps each): (512, 16, 16) 15.12 ms/step,
-# K1 4.55, K2b 5.25; (1024, 32, 64) 14.80; (1024, 48, 64) 14.72, K1 4.36, K2b 4.97; (1024, 32, 128) 14.74; (1536, 32, 64) 14.83
+
+
+def auto_plan(E):
+    """(chunk, group_below, t_group_below) for a graph (or shard) of E edges.  chunk: a hub chunk is walked by ONE wavefront, ~0.4 us
+    per edge, so it must stay a small part of the kernel's time - which scales with E; group_below / t_group_below: items shorter
+    than this run one per H/4-lane group (several per wavefront) in the forward (by-target) / backward (by-source) lists.
+    Swept on the C4 R-MAT graph and on its 2 / 4 / 8-way shards after the nt policy went in (ms per step, same box each):
+      E = 10.9 M (whole graph)  (512,16,16) 15.12   (1024,32,64) 14.80   (1024,48,64) 14.72   (1536,32,64) 14.83
+      E = 5.4 M  (1 of 2 ranks) (512,16,16) 9.55    (512,48,64) 9.45     (1024,48,64) 9.64    (256,32,32) 9.50
+      E = 2.7 M  (1 of 4)       (512,16,16) 5.80    (256,16,16) 5.71     (256,32,32) 5.60     (1024,48,64) 6.47
+      E = 1.4 M  (1 of 8)       (512,16,16) 3.82    (256,16,16) 3.76     (256,32,32) 3.63     (1024,48,64) 4.74"""
+    if E >= 8_000_000:
+        return 1024, 48, 64
+    if E >= 4_000_000:
+        return 512, 48, 64
+    return 256, 32, 32
+
 
 
 def make_items(rowptr, chunk):
@@ -63,7 +77,7 @@ def transpose_csr(rowptr, col, n_src):
 class NCGraph:
     """Device-resident plan.  n_src >= N allows extra source rows (halo rows in the sharded path)."""
 
-    def __init__(self, rowptr, col, device, n_src=None, chunk=DEFAULT_CHUNK, edge_base=0, group_below=GROUP_BELOW, t_group_below=None):
+    def __init__(self, rowptr, col, device, n_src=None, chunk=DEFAULT_CHUNK, edge_base=0, group_below=None, t_group_below=None):
         rowptr = np.asarray(rowptr, dtype=np.int64)
         col = np.asarray(col, dtype=np.int64)
         self.N = len(rowptr) - 1
@@ -71,6 +85,10 @@ class NCGraph:
         self.n_src = self.N if n_src is None else int(n_src)
         assert len(col) == self.E and (self.E == 0 or (col.min() >= 0 and col.max() < self.n_src)), "bad CSR"
         assert self.n_src < 2 ** 31 and self.E < 2 ** 31
+        auto = auto_plan(self.E)
+        chunk = auto[0] if chunk is None else chunk
+        group_below = auto[1] if group_below is None else group_below
+        t_group_below = auto[2] if t_group_below is None else t_group_below
         self.chunk = int(chunk)
         self.edge_base = int(edge_base)   # global position of this shard's first edge (keys the dropout hash)
         items, hubs, self.n_slots = make_items(rowptr, self.chunk)
@@ -78,7 +96,6 @@ class NCGraph:
         t_items, t_hubs, self.t_n_slots = make_items(t_rowptr, self.chunk)
         # the lists are sorted longest first: the head runs one item per wavefront, the short tail grouped
         self.n_wave_items = int(((items[:, 2] - items[:, 1]) >= group_below).sum())
-        t_group_below = T_GROUP_BELOW if t_group_below is None else t_group_below   # the backward (by-source) lists have their own threshold
         self.t_n_wave_items = int(((t_items[:, 2] - t_items[:, 1]) >= t_group_below).sum())
         dev = torch.device(device)
         i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
@@ -129,10 +146,10 @@ class SpmmGraph:
         trp = np.zeros(n_cols + 1, dtype=np.int64); np.cumsum(np.bincount(col, minlength=n_cols), out=trp[1:])
         self.t_rowptr, self.t_col = i32(trp), i32(row[t_order])
         self.t_val = None if self.val is None else f32(val[t_order])
-        it, hb, self.n_slots = make_items(rp, DEFAULT_CHUNK)
+        it, hb, self.n_slots = make_items(rp, SPMM_CHUNK)
         self.items, self.hubs = i32(it), i32(hb)
         self.n_wave_items = int(((it[:, 2] - it[:, 1]) >= SPMM_GROUP_BELOW).sum())     # longest first: head per wave, tail grouped
-        it, hb, self.t_n_slots = make_items(trp, DEFAULT_CHUNK)
+        it, hb, self.t_n_slots = make_items(trp, SPMM_CHUNK)
         self.t_items, self.t_hubs = i32(it), i32(hb)
         self.t_n_wave_items = int(((it[:, 2] - it[:, 1]) >= SPMM_GROUP_BELOW).sum())
 
