@@ -41,6 +41,11 @@ from tools.synth import feature_rows, golden_csr, molecule_batch, rmat_graph  # 
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured streaming copy)
 C4_DEFAULTS = dict(scale=20, edges=5_000_000, hidden=128, nclass=16, aggregators="sum,mean,max,min", dropout=0.5)
+# BASELINE configs[4] (SURVEY 8d "C5"): R-MAT scale 23, 64 M undirected -> ~128 M directed edges, feat=256, K=8, S=5 true-degree scalers.
+# P/Q/T of the whole graph are > 200 GB: it runs 1-D sharded over the 8 GPUs of a node (`--workload c5 --gpus 8`), never on one.
+C5_PRESET = dict(scale=23, edges=64_000_000, hidden=256, nclass=16, aggregators="sum,mean,max,min,sum2,mean2,max2,min2", dropout=0.5,
+                 true_degree_scalers=True)
+C5_MIN_GPUS = 4
 
 
 # ---- self-launch -----------------------------------------------------------------------------------------
@@ -115,10 +120,14 @@ PMC_KERNEL = {"nc_fused_fwd": "mma::nc_fwd_", "nc_fused_bwd": "mma::nc_bwd_k",  
 
 
 def pmc_traffic(name, workload):
-    """(HBM bytes per launch of the dominant kernel, source file) from the COMMITTED rocprofv3 PMC passes of this command
-    (profiles/r*_pmc_traffic*.json, made by tools/make_profiles.py) - a recorded profile, not measured in this run;
-    (None, None) when no profile matches the workload."""
+    """(HBM bytes per launch of the dominant kernel, source) from the COMMITTED rocprofv3 PMC passes of this command
+    (profiles/r*_pmc_traffic*.json, made by tools/make_profiles.py) - a recorded profile, not measured in this run.  A profile is
+    used only if its `build` stamp (ABI version + SHA over the kernel sources, tools/build_stamp.py, written on the GPU box next to
+    the passes) equals the running tree's: a traffic figure never outlives the kernel it was measured on.  (None, reason) when no
+    profile matches the workload or the newest matching one is stale."""
     import glob
+    from tools.build_stamp import build_stamp
+    now = build_stamp()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         try:
             d = json.load(open(f))
@@ -126,11 +135,20 @@ def pmc_traffic(name, workload):
             continue
         if d.get("workload") != workload:
             continue
+        if d.get("build") != now:
+            return None, "REFUSED %s: recorded on build %s, this tree is %s - re-run tools/profile_round.sh" % (
+                os.path.relpath(f, ROOT), json.dumps(d.get("build")), json.dumps(now))
         # one C-ABI call = up to two launches of the kernel (items run one per wavefront / grouped) + the hub finalize
         parts = [v["traffic_bytes"] for k, v in d["kernels"].items() if PMC_KERNEL.get(name, "?") in k]
         if parts:
             return sum(parts), os.path.relpath(f, ROOT)
     return None, None
+
+
+def _traffic_source(traffic, src):
+    if src is None:
+        return None
+    return ("recorded rocprofv3 PMC passes of this command, " + src) if traffic is not None else src
 
 
 # ---- CPU baselines (the oracle is the checker/baseline, never the product path) ------------------------------
@@ -454,7 +472,9 @@ def extra_configs(dev):
                                                         "min,min2,min3,min4, dropout 0.5", "pubmed_h16", 500, 0.10, 16, ["min", "min2", "min3", "min4"], 3,
                                                         0.5, 60, dev)),
                     ("C2", lambda: gr_config("C2: ZINC-like batch of 64 molecules, MMAConv T=5 F=75 min,max x id,amp,lin", 64, dev)),
-                    ("C2net", lambda: gr_model_config("C2 model: Net (mma.py:63-127) training step, batch 128 (mma.py's batch size)", 128, dev, reps=20)),
+                    ("C2net", lambda: gr_model_config("C2 model: Net (mma.py:63-127) training step, batch 64 (mma.py:52-54 hard-codes 64)", 64, dev, reps=20)),
+                    ("C2net128", lambda: gr_model_config("C2 model at batch 128 (not a reference setting; round-2 entry kept for comparison)", 128, dev,
+                                                         reps=20)),
                     ("C2Lnet", lambda: gr_model_config("C2L model: the same training step on 10 000 molecules per batch", 10000, dev, reps=5)),
                     ("C2L", lambda: gr_config("C2L: the same layer on a 10 000-molecule batch", 10000, dev, reps=5)),
                     ("C2Lcat", lambda: gr_config("C2L with ZINC's real edge features: 4 bond types through an embedding table "
@@ -490,7 +510,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c2l"], help="c4: MMA layer on the R-MAT graph (headline); "
+    ap.add_argument("--workload", default="c4", choices=["c4", "c5", "c2l"], help="c4: MMA layer on the R-MAT graph (headline); "
+                    "c5: BASELINE configs[4] (scale 23, 128 M directed edges, feat 256, K=8, S=5 true-degree scalers; needs --gpus >= 4); "
                     "c2l: MMAConv on a 10 000-molecule ZINC-like batch (roofline = the fused GR kernel)")
     ap.add_argument("--scale", type=int, default=C4_DEFAULTS["scale"], help="R-MAT scale (2^scale nodes)")
     ap.add_argument("--edges", type=int, default=C4_DEFAULTS["edges"], help="undirected R-MAT edges before symmetrisation")
@@ -509,6 +530,13 @@ def main():
     ap.add_argument("--rendezvous-only", action="store_true", help="(tests) ranks meet, all-reduce their rank and leave: "
                     "checks the launch path without a GPU")
     args = ap.parse_args()
+    if args.workload == "c5":
+        for k, v in C5_PRESET.items():
+            setattr(args, k, v)
+        if args.gpus < C5_MIN_GPUS:
+            sys.exit("--workload c5 is BASELINE configs[4]: 8 M nodes / 128 M edges, feat 256, K=8 - its P, Q, T tables alone are > 200 GB, "
+                     "so it runs sharded: `python bench.py --workload c5 --gpus 8` (at least %d GPUs).  Its per-GPU shard shape on one "
+                     "GPU is `extra.C5shard` of the default run; one rank of eight WITH its halo is tools/shard_sim.py --c5." % C5_MIN_GPUS)
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
@@ -628,9 +656,10 @@ def main():
         traffic, src = (None, None) if sharded else pmc_traffic(dom, {"nodes": N, "edges": E, "hidden": H, "K": K})
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": ("recorded rocprofv3 PMC passes of this command, " + src) if src else None}
+                "traffic_source": _traffic_source(traffic, src)}
         is_c4 = all(getattr(args, k) == v for k, v in C4_DEFAULTS.items()) and not args.true_degree_scalers
-        label = "C4" if is_c4 else "custom (not a BASELINE config)"
+        is_c5 = all(getattr(args, k) == v for k, v in C5_PRESET.items())
+        label = "C4" if is_c4 else ("C5" if is_c5 else "custom (not a BASELINE config)")
         cpu = None
         extra = None
         if not sharded:
@@ -713,7 +742,7 @@ def run_c2l(args, dev, rank=0, world=1, barrier=None):
         traffic, src = pmc_traffic(n, {"workload": "c2l", "nodes": N, "edges": E}) if world == 1 else (None, None)
         roofs[n] = {"bound": "hbm", "kernel": n, "achieved": kernels[n]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kernels[n]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": ("recorded rocprofv3 PMC passes of this command, " + src) if src else None}
+                    "traffic_source": _traffic_source(traffic, src)}
     dom = max(roofs, key=lambda n: kernels[n]["avg_ms"])
     cpu = None
     if args.cpu_sample and world == 1:

@@ -49,12 +49,16 @@ __global__ __launch_bounds__(kBlock) void logsoftmax_kernel(const float* x, int6
 
 // loss = -(1/n) sum_i logp[idx[i], labels[idx[i]]]: ONE workgroup, fixed order (strided partial sums, then a tree)
 __global__ __launch_bounds__(kBlock) void nll_mean_kernel(const float* logp, int64_t ldo, const int64_t* idx, const int64_t* labels,
-                                                          int64_t n, float* loss) {
+                                                          int64_t n, float* loss, int64_t N, int C) {
   __shared__ float part[kBlock];
   float s = 0.f;
+  // rows / labels outside [0,N) x [0,C) contribute nothing (never an out-of-bounds access); the Python side has already raised
+  // for them, as F.nll_loss does (mma_amd/train_step.py::_check_targets)
   for (int64_t i = threadIdx.x; i < n; i += kBlock) {
     const int64_t r = idx[i];
-    s -= logp[r * ldo + labels[r]];
+    if ((uint64_t)r >= (uint64_t)N) continue;
+    const int64_t lab = labels[r];
+    if ((uint64_t)lab < (uint64_t)C) s -= logp[r * ldo + lab];
   }
   part[threadIdx.x] = s;
   __syncthreads();
@@ -67,12 +71,13 @@ __global__ __launch_bounds__(kBlock) void nll_mean_kernel(const float* logp, int
 
 // gx[idx[i], c] = gloss * (exp(logp) - [c == label]) / n   (the caller zeroed gx; idx rows are unique)
 __global__ __launch_bounds__(kBlock) void nll_logsoftmax_bwd_kernel(const float* logp, int64_t ldo, const int64_t* idx, const int64_t* labels,
-                                                                    int64_t n, int C, const float* gloss, float* gx, int64_t ldg) {
+                                                                    int64_t n, int C, const float* gloss, float* gx, int64_t ldg, int64_t N) {
   const float scale = *gloss / (float)n;
   const int64_t total = n * C;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = t / C; const int c = (int)(t % C);
     const int64_t r = idx[i];
+    if ((uint64_t)r >= (uint64_t)N) continue;
     gx[r * ldg + c] = scale * (expf(logp[r * ldo + c]) - (labels[r] == c ? 1.f : 0.f));
   }
 }
@@ -143,7 +148,7 @@ extern "C" int mma_logsoftmax_nll_fwd(const float* x, int64_t ldx, const int64_t
   hipLaunchKernelGGL(logsoftmax_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, ldx, logp, ldo, N, C);
   if (loss) {
     MMA_REQUIRE(n_idx > 0 && idx && labels, "the loss needs a non-empty idx and the labels");
-    hipLaunchKernelGGL(nll_mean_kernel, dim3(1), dim3(kBlock), 0, st, logp, ldo, idx, labels, n_idx, loss);
+    hipLaunchKernelGGL(nll_mean_kernel, dim3(1), dim3(kBlock), 0, st, logp, ldo, idx, labels, n_idx, loss, N, C);
   }
   return check_launch("logsoftmax_nll_fwd");
 }
@@ -158,7 +163,7 @@ extern "C" int mma_logsoftmax_nll_bwd(const float* logp, int64_t ldo, const int6
   if (n_idx == 0) return 0;
   int64_t blocks = (n_idx * C + kBlock - 1) / kBlock;
   if (blocks > kMaxGrid) blocks = kMaxGrid;
-  hipLaunchKernelGGL(nll_logsoftmax_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, logp, ldo, idx, labels, n_idx, C, gloss, gx, ldg);
+  hipLaunchKernelGGL(nll_logsoftmax_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, logp, ldo, idx, labels, n_idx, C, gloss, gx, ldg, N);
   return check_launch("logsoftmax_nll_bwd");
 }
 

@@ -20,6 +20,35 @@ from . import _lib
 from ._lib import call, ptr, require_gpu, stream_ptr
 
 
+_CHECKED_TARGETS = {}        # (idx ptr, version, labels ptr, version, N, C) -> True: one host check per (idx, labels) pair
+
+
+def _check_targets(idx, labels, N, C):
+    """What F.nll_loss / advanced indexing would have raised for (train.py:77 `F.nll_loss(output[idx_train], labels[idx_train])`):
+    a row id outside [0,N), a class outside [0,C) - torch's ignore_index=-100 included, the reference never uses it - and, a K10
+    precondition, DUPLICATE rows (the backward assigns one gradient row per training row).  Checked once per tensor pair and
+    in-place version (one host sync, at the first eager call: the warm-up of a captured step), never inside a capture."""
+    key = (idx.data_ptr(), idx._version, labels.data_ptr(), labels._version, int(N), int(C), idx.numel())
+    if key in _CHECKED_TARGETS:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return          # first call inside a capture: nothing may sync here; the kernels skip out-of-range rows / classes
+    if idx.numel():
+        lo, hi = int(idx.min()), int(idx.max())
+        if lo < 0 or hi >= N:
+            raise IndexError("index %d is out of bounds for dimension 0 with size %d" % (lo if lo < 0 else hi, N))
+        if int(torch.unique(idx).numel()) != idx.numel():
+            raise ValueError("fused_nll_loss: duplicate rows in idx (the fused backward writes one gradient row per index; "
+                             "use F.nll_loss for a multiset of rows)")
+        lab = labels[idx]
+        lo, hi = int(lab.min()), int(lab.max())
+        if lo < 0 or hi >= C:
+            raise IndexError("Target %d is out of bounds." % (lo if lo < 0 else hi))
+    if len(_CHECKED_TARGETS) > 64:
+        _CHECKED_TARGETS.clear()
+    _CHECKED_TARGETS[key] = True
+
+
 class _FusedNLL(torch.autograd.Function):
     """K10: log_softmax over the classes + mean nll over the rows `idx` (models.py:68, train.py:77)."""
 
@@ -29,6 +58,7 @@ class _FusedNLL(torch.autograd.Function):
         logits = logits.contiguous()
         N, C = logits.shape
         assert idx.dtype == torch.int64 and labels.dtype == torch.int64 and labels.numel() == N
+        _check_targets(idx, labels, N, C)
         logp = torch.empty_like(logits)
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
         call("mma_logsoftmax_nll_fwd", ptr(logits), C, ptr(idx), ptr(labels), idx.numel(), ptr(logp), C, ptr(loss), N, C, stream_ptr())
@@ -82,49 +112,96 @@ def fused_nll_loss(logits, idx, labels):
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr, betas, eps, weight_decay) semantics (train.py:69; no amsgrad) with ONE K11 launch for all
     parameter tensors and the step counter in device memory (hipGraph-capturable).  fp32 CUDA parameters only; parameters
-    whose .grad is None at the first step are left out for good (the reference's unused masks never get a gradient)."""
+    whose .grad is None at the first step are left out for good (the reference's unused masks never get a gradient).
+
+    State lives where torch.optim.Adam keeps it - `state[p] = {"step", "exp_avg", "exp_avg_sq"}` - so `state_dict()` /
+    `load_state_dict()` checkpoint and resume like the optimizer it replaces, also from a torch.optim.Adam checkpoint; the step
+    counter is ONE 0-dim fp32 device tensor per group, shared by that group's parameters.  Loading after the first step copies
+    INTO the buffers the device table (and any captured hipGraph) already points at; they are never replaced."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=True))
         self._tables = None
 
+    @staticmethod
+    def _rec(p, st):
+        return (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr())
+
     def _build(self):
         self._tables = []
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             require_gpu(*ps)
+            dev = ps[0].device if ps else "cpu"
+            # one counter per group; a state loaded before the first step brings its own (all parameters of a group step together)
+            loaded = [self.state[p]["step"] for p in ps if "step" in self.state[p]]
+            step = torch.zeros((), device=dev, dtype=torch.float32)
+            if loaded:
+                vals = {float(t) for t in loaded}
+                if len(vals) != 1:
+                    raise RuntimeError("FusedAdam: the parameters of one group carry different step counts %s" % sorted(vals))
+                step.fill_(vals.pop())
             recs, chunk_ids, chunk0 = b"", [], 0
             for t, p in enumerate(ps):
                 assert p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
                 st = self.state[p]
-                if "exp_avg" not in st:
-                    st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+                for key in ("exp_avg", "exp_avg_sq"):
+                    if key not in st:
+                        st[key] = torch.zeros_like(p)
+                    elif st[key].device != p.device or st[key].dtype != torch.float32 or not st[key].is_contiguous():
+                        st[key] = st[key].to(device=p.device, dtype=torch.float32).contiguous()
+                st["step"] = step
                 n_chunks = _lib.query("mma_adam_chunks", p.numel())
-                recs += struct.pack("<QQQQqq", p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                    p.numel(), chunk0)
+                recs += struct.pack("<QQQQqq", *self._rec(p, st), p.numel(), chunk0)
                 chunk_ids += [t] * n_chunks
                 chunk0 += n_chunks
-            dev = ps[0].device if ps else "cpu"
             raw = recs + struct.pack("<%di" % len(chunk_ids), *chunk_ids)
             assert len(raw) == _lib.query("mma_adam_table_bytes", len(ps), chunk0)
             table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev) if ps else None
-            step = torch.zeros((), device=dev, dtype=torch.float32)
-            self._tables.append((group, ps, table, chunk0, step, [(p.data_ptr(), p.grad.data_ptr()) for p in ps]))
+            self._tables.append((gi, ps, table, chunk0, step, [self._rec(p, self.state[p]) for p in ps]))
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         if self._tables is None:
             self._build()
-        for group, ps, table, n_chunks, step, ptrs in self._tables:
+        for gi, ps, table, n_chunks, step, ptrs in self._tables:
             if not ps:
                 continue
-            if any((p.data_ptr(), p.grad.data_ptr()) != q for p, q in zip(ps, ptrs)):
-                raise RuntimeError("FusedAdam: a parameter or gradient buffer moved; keep gradients allocated (zero_grad(set_to_none=False))")
+            group = self.param_groups[gi]        # looked up per step: load_state_dict() replaces the group dicts
+            if any(self._rec(p, self.state[p]) != q for p, q in zip(ps, ptrs)):
+                raise RuntimeError("FusedAdam: a parameter, gradient or moment buffer moved; keep gradients allocated "
+                                   "(zero_grad(set_to_none=False)) and load checkpoints with load_state_dict()")
             b1, b2 = group["betas"]
             call("mma_adam_step", ptr(table), len(ps), n_chunks, ptr(step), group["lr"], b1, b2, group["eps"], group["weight_decay"],
                  stream_ptr())
         return loss
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Before the first step: plain load, `_build` adopts the loaded moments and step.  After it: the loaded values are copied
+        into the live buffers (the device table and a captured graph hold their addresses), which stay in `self.state`."""
+        live = None
+        if self._tables is not None:
+            live = {p: dict(self.state[p]) for _, ps, *_ in self._tables for p in ps}
+        super().load_state_dict(state_dict)
+        if live is None:
+            return
+        for _gi, ps, _table, _n, step, _ptrs in self._tables:
+            steps = set()
+            for p in ps:
+                new, old = self.state.get(p, {}), live[p]
+                for key in ("exp_avg", "exp_avg_sq"):
+                    if key in new:
+                        old[key].copy_(new[key])
+                    else:
+                        old[key].zero_()
+                steps.add(float(new["step"]) if "step" in new else 0.0)
+                self.state[p] = old
+            if len(steps) > 1:
+                raise RuntimeError("FusedAdam: the parameters of one group carry different step counts %s" % sorted(steps))
+            if steps:
+                step.fill_(steps.pop())
 
     def zero_grad(self, set_to_none=False):
         super().zero_grad(set_to_none=False if self._tables is not None else set_to_none)

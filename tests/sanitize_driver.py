@@ -164,7 +164,22 @@ def recipe(lib, name, rng, keep):
     return None
 
 
+def refuse_if_a_gpu_is_visible():
+    """Launchers are called with arguments that PASS validation and fake device pointers: harmless only while every launch
+    fails.  tools/sanitize_host.sh hides the devices; this is the second lock."""
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        return          # no HIP runtime at all: nothing can launch
+    n = ctypes.c_int(0)
+    rc = hip.hipGetDeviceCount(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        sys.exit("sanitize_driver: %d GPU(s) visible - refusing to call launchers with fake device pointers "
+                 "(run through tools/sanitize_host.sh, which sets HIP_VISIBLE_DEVICES=-1)" % n.value)
+
+
 def main():
+    refuse_if_a_gpu_is_visible()
     lib = ctypes.CDLL(sys.argv[1])
     n_calls = int(sys.argv[2]) if len(sys.argv) > 2 else 400
     rng = random.Random(int(sys.argv[3]) if len(sys.argv) > 3 else 0)

@@ -135,6 +135,70 @@ def test_fused_adam_matches_torch_adam():
         assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (a - b).abs().max()
 
 
+def test_fused_adam_checkpoint_round_trip_like_torch_adam():
+    """FusedAdam checkpoints and resumes like the torch.optim.Adam it replaces.  Three steps, state_dict(), then
+    (a) a FRESH FusedAdam loads it before its first step, (b) a LIVE FusedAdam (tables built, two unrelated steps taken) loads it
+    - the loaded moments and step count must land in the buffers the device table points at -, (c) a FusedAdam loads a
+    torch.optim.Adam checkpoint; all continue for three more steps exactly like an uninterrupted torch.optim.Adam."""
+    import copy
+    from mma_amd.train_step import FusedAdam
+    g = torch.Generator().manual_seed(1)
+    shapes = [(33, 7), (4097,), (64, 16), (1,)]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    grads = [[torch.randn(*s, generator=g) for s in shapes] for _ in range(6)]
+    hyper = dict(lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+
+    def make(cls, values):
+        ps = [torch.nn.Parameter(t.clone().to(DEV)) for t in values]
+        for q in ps:
+            q.grad = torch.zeros_like(q)
+        return ps, cls(ps, **hyper)
+
+    def run(ps, opt, steps):
+        for step_g in steps:
+            for q, gg in zip(ps, step_g):
+                q.grad.copy_(gg)
+            opt.step()
+
+    ref_ps, ref_opt = make(torch.optim.Adam, init)
+    run(ref_ps, ref_opt, grads[:3])
+    ref_mid = [q.detach().clone() for q in ref_ps]
+    torch_ckpt = copy.deepcopy(ref_opt.state_dict())
+    run(ref_ps, ref_opt, grads[3:])
+
+    ps, opt = make(FusedAdam, init)
+    run(ps, opt, grads[:3])
+    ckpt = copy.deepcopy(opt.state_dict())
+    mid = [q.detach().clone() for q in ps]
+    assert len(ckpt["state"]) == len(shapes) and all(float(st["step"]) == 3.0 for st in ckpt["state"].values())
+
+    def check(ps2, what):
+        for a, b in zip(ps2, ref_ps):
+            assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (what, (a - b).abs().max())
+
+    # (a) fresh optimizer, load before the first step
+    ps_a, opt_a = make(FusedAdam, mid)
+    opt_a.load_state_dict(copy.deepcopy(ckpt))
+    run(ps_a, opt_a, grads[3:])
+    check(ps_a, "fresh load")
+    # (b) live optimizer: its table exists and its state is elsewhere; load must overwrite the live buffers in place
+    ps_b, opt_b = make(FusedAdam, mid)
+    run(ps_b, opt_b, grads[4:])                   # two unrelated steps: moments and step count are now wrong on purpose
+    with torch.no_grad():
+        for q, t in zip(ps_b, mid):
+            q.copy_(t)
+    before = [opt_b.state[q]["exp_avg"].data_ptr() for q in ps_b]
+    opt_b.load_state_dict(copy.deepcopy(ckpt))
+    assert before == [opt_b.state[q]["exp_avg"].data_ptr() for q in ps_b]          # same buffers, new contents
+    run(ps_b, opt_b, grads[3:])
+    check(ps_b, "live load")
+    # (c) a torch.optim.Adam checkpoint resumes under FusedAdam
+    ps_c, opt_c = make(FusedAdam, ref_mid)
+    opt_c.load_state_dict(torch_ckpt)
+    run(ps_c, opt_c, grads[3:])
+    check(ps_c, "torch checkpoint")
+
+
 def test_fused_step_kernels_inside_the_graphed_step():
     """K10 + K11 are capture-safe: the hipGraph of (forward, fused nll, backward, FusedAdam) replays the eager fused trajectory
     (dropout off), and the fused step needs fewer kernels per replay than torch's loss + per-tensor Adam."""

@@ -7,6 +7,7 @@ TAG=${1:-run}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python bench.py --workload c2l --steps 5 --warmup 2 --cpu-sample 0"
 O=gpurun_out/prof_c2l_$TAG
+python tools/build_stamp.py > ${O}_stamp.json      # which kernel build these passes belong to (bench.py refuses a stale traffic figure)
 rm -rf ${O}_stats ${O}_fetch ${O}_write ${O}_sq
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d ${O}_stats -- $B > ${O}_stats.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d ${O}_fetch -- $B > ${O}_fetch.log 2>&1 || exit 1

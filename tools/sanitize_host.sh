@@ -15,5 +15,8 @@ printf "%s\n" abi nc_fused spmm_rows gr_fused gemm_x3 tower train_step | xargs -
   -c {}.hip -o "$OUT/{}.o"
 $HIPCC -shared -fPIC --offload-arch=gfx950 -fsanitize=address,undefined -fno-gpu-sanitize -o "$OUT/libmma_amd.so" "$OUT"/*.o
 cd "$ROOT"
+# The driver hands FAKE device pointers to launchers whose arguments pass validation: with a GPU visible those launches would
+# succeed and fault on the device.  Hide every device from this process (the driver also refuses to run if it can see one).
+export HIP_VISIBLE_DEVICES=-1 ROCR_VISIBLE_DEVICES= CUDA_VISIBLE_DEVICES=
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
   python3 tests/sanitize_driver.py "$OUT/libmma_amd.so" "$CALLS" "$SEED"
