@@ -91,15 +91,22 @@ class KernelTimer:
         return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.spans.items()}
 
 
-def algorithmic_bytes(N, E, H, K, n_sel=None):
+def algorithmic_bytes(N, E, H, K, n_sel=None, fused_node_bwd=None):
     """Zero-reuse byte counts per call (DESIGN.md 'algorithmic bytes'; fwd = SURVEY 8d B_fwd).
-    n_sel: number of max/min/softmax-type masks when K2b runs in the shared-gradient form, None for the gs form."""
+    n_sel: number of max/min/softmax-type masks when K2b runs in the shared-gradient form, None for the gs form.
+    fused_node_bwd (default: what mma_amd.functional does): the node-level backward (K2a) runs in K2b's per-source epilogue, so the
+    call also moves K2a's streams: g, T and the code row in, gP out - and no gxs."""
     fwd = 4 * (E * (1 + (K + 1) * H) + N * (1 + (2 * K + 1) * H))
     per_node = 4 * N * (1 + (2 * K + 3) * H)                      # x, Q, gxs in; gQ, gx out
     if n_sel is None:                                             # per edge: t_col, t_eid + gs and P rows
         bwd = 4 * E * (2 + 2 * K * H) + per_node
-    else:                                                         # per edge: t_col, t_eid + P row + packed [g | 1/d | codes] row
+    else:                                                         # per edge: t_col, t_eid + P row + g row + code row [1/d,0,0,0 | codes]
         bwd = E * (8 + 4 * K * H + 4 * H + 16 + n_sel * H) + per_node
+        if fused_node_bwd is None:
+            from mma_amd import functional as Fn
+            fused_node_bwd = Fn.FUSE_NODE_BWD
+        if fused_node_bwd:                                        # + g, T, code row in, gP out; - gxs in
+            bwd += N * (4 * H + 4 * K * H + 16 + n_sel * H + 4 * K * H) - 4 * N * H
     return {"nc_fused_fwd": fwd, "nc_fused_bwd": bwd}
 
 

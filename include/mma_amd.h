@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 26
+#define MMA_ABI_VERSION 27
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -60,6 +60,10 @@ const char* mma_last_error(void);
  * When T and sel are non-NULL (training) the kernel also saves, per node, what backward needs:
  *     T[i, k*H+h]   = sum_j drop * act_k'(z) * x_j[h]          (so grad_P = gs * T needs no edge pass)
  *     sel[i, k*H+h] = 0: x_i selected  1: s selected  2: tie (0.5/0.5, torch.max/min backward)  3: NaN
+ * and/or (ABI 27) the packed code row the shared-gradient backward gathers per edge:
+ *     crow[i] = [ 1/max(d_i,1), 0, 0, 0 | for every max/min/softmax/softmin mask, in mask order: ceil(H/4) words of bytes
+ *                 = 2 * dm/ds of the element (0: x_i selected, 1: tie, 2: s selected, 255: NaN gradient) ]
+ *     (round 2 had K2a write a [g | 1/d | codes] row per target: 0.8 GB per step at C4 that K1 now leaves in place of `sel`).
  */
 int mma_nc_fused_fwd(
     const float* x, int64_t ldx,                 /* (n_src,H): rows [0,N) are the targets, the rest source-only (halo) */
@@ -76,7 +80,8 @@ int mma_nc_fused_fwd(
     float* m,                                    /* (K,N,H) out: m[k] = learnable_<k>(x); may be NULL if m_sum is given */
     float* m_sum, int64_t ldms,                  /* (N,H) out: sum_k m[k] (all MMA.forward needs, since
                                                     sum_k A (m_k W) = A ((sum_k m_k) W)); may be NULL */
-    float* T, uint8_t* sel, int64_t ldt,         /* (N,K*H) out, both NULL or both non-NULL */
+    float* T, uint8_t* sel, int64_t ldt,         /* (N,K*H) out; T NULL: nothing is saved; with T give sel, crow, or both */
+    float* crow, int64_t ldc,                    /* (N,ldc) out or NULL; ldc >= mma_nc_crow_floats(H, K, kinds), a multiple of 4 */
     int64_t N, int64_t E, int32_t H, int32_t K,
     const uint8_t* kind_host, const uint8_t* act_host,   /* K codes each, HOST memory */
     int32_t drop_mode, uint32_t drop_thr, uint64_t seed,
@@ -89,20 +94,19 @@ int mma_nc_fused_fwd(
 /* ---- K2a: node-level backward of the combine (element-wise) -------------------------------------
  * From g = dL/dm (K,N,H): gs = dL/ds (N,K*H), gP = gs * T (N,K*H) = dL/dP, gxs = sum_k dL/dx_i
  * through the combine (N,H).  Mirrors autograd of layers.py:221,326-329,452,562 (ties split 0.5/0.5).
- * gs may be NULL (shared-gradient form: K2b rebuilds it on the fly). */
+ * gs may be NULL (shared-gradient form: K2b rebuilds it on the fly).  The selection state is read from `sel`, or - when crow is
+ * given - from the packed code rows K1 wrote.  (With the epilogue of mma_nc_fused_bwd fused, this call is not needed at all.) */
 int mma_nc_bwd_node(
     const float* g, int64_t g_kstride, int64_t ldgr, /* g[k*g_kstride + i*ldgr + h]; g_kstride = 0: one (N,H) gradient for all k */
     const uint8_t* sel, const float* T, int64_t ldt, const int32_t* rowptr,
     float* gs, int64_t ldgs,                     /* (N,K*H) out, or NULL */
-    float* aux, int64_t ldaux,                   /* shared-gradient form only (g_kstride 0), or NULL: one packed row per target
-                                                    [ g (H floats) | 1/d_i,0,0,0 | 1-byte codes of each max/min/softmax/softmin mask,
-                                                    ceil(H/4) words each ]; pitch >= mma_nc_aux_row_floats() */
+    const float* crow, int64_t ldc,              /* the code rows of mma_nc_fused_fwd instead of sel, or NULL */
     float* gP, int64_t ldgp, float* gxs, int64_t ldgx,
     float* row_max,                              /* optional (N,) in/out, zeroed by the caller: row_max[i] = max(row_max[i], max |gP[i,:]|)
                                                     by atomicMax on the bit pattern - with K2b's contribution the row scale of the
                                                     three-product dL/dx GEMM (mma_gemm_f16x2_n128) */
     int64_t N, int32_t H, int32_t K, const uint8_t* kind_host, void* stream);
-int64_t mma_nc_aux_row_floats(int32_t H, int32_t K, const uint8_t* kind_host);
+int64_t mma_nc_crow_floats(int32_t H, int32_t K, const uint8_t* kind_host);   /* row length of crow in floats (-1: bad arguments) */
 
 /* ---- K2b: edge-level backward, source-major (no atomics, deterministic) ---------------------------
  * Walks the TRANSPOSED CSR (edges grouped by source j): t_col[e'] = target i, t_eid[e'] = position of
@@ -110,13 +114,26 @@ int64_t mma_nc_aux_row_floats(int32_t H, int32_t K, const uint8_t* kind_host);
  *     gQ[j, k*H+h] = x_j[h] * sum_i gs[i,k,h] * drop * act_k'(z_k(i,j))
  *     gx[j, h]     = gxs[j,h] + sum_i sum_k gs[i,k,h] * drop * act_k(z_k(i,j))
  * items/hubs/partial as in mma_nc_fused_fwd but over the transposed segments; partial is
- * (n_slots, K+1, H).  N here is the number of SOURCE rows (n_src); gs and P have one row per target. */
+ * (n_slots, K+1, H).  N here is the number of SOURCE rows (n_src); gs, g, crow, T, gP and P have one row per target.
+ * Three forms:
+ *   gs given                      : gathers the materialised dL/ds rows (any upstream gradient; K2a made them);
+ *   gs NULL (shared gradient)     : all masks share ONE upstream gradient g (n_targets,H) (MMA.forward: the gradient of sum_k m_k);
+ *                                   gs_k[i] is rebuilt per edge from g[i] and crow[i]: (1 + K_sel/4) H floats + 16 B gathered per
+ *                                   edge instead of K H.  gxs comes from mma_nc_bwd_node;
+ *   gs NULL and T given (ABI 27)  : the same, and the node-level backward (K2a) runs in the per-source epilogue: source j <
+ *                                   n_targets is also target j, so gP[j] = g[j] dm/ds T[j] and the direct term sum_k g[j] dm/dx_i
+ *                                   are formed where gx[j] is stored - mma_nc_bwd_node, its launch and the gxs round trip go away;
+ *                                   row_max then receives max(|gP[j,:]|, |gQ[j,:]|).  Sources >= n_targets (halo rows) have no
+ *                                   target role. */
 int mma_nc_fused_bwd(
     const float* x, int64_t ldx, const float* P, int64_t ldp, const float* Q, int64_t ldq,
-    const float* gs, int64_t ldg,                /* (n_tgt,K*H) from K2a, or NULL for the shared-gradient form: */
-    const float* aux, int64_t ldaux,             /*   the packed rows K2a wrote; gs_k[i] is rebuilt per edge from g[i], the codes */
-    const uint8_t* kind_host,                    /*   and 1/d_i: ~(1+K_sel/4)*H floats gathered per edge instead of K*H */
-    const float* gxs, int64_t ldgx,
+    const float* gs, int64_t ldg,                /* (n_targets,K*H) from K2a, or NULL for the shared-gradient forms: */
+    const float* g, int64_t ldgg,                /*   the upstream gradient (n_targets,H), */
+    const float* crow, int64_t ldc,              /*   the code rows K1 wrote, */
+    const uint8_t* kind_host,                    /*   and the K kinds (HOST) */
+    const float* gxs, int64_t ldgx,              /* (N,H) from K2a; unused (may be NULL) when T is given */
+    const float* T, int64_t ldt,                 /* NULL, or K1's saved T (n_targets,K*H): fuse the node-level backward */
+    float* gP, int64_t ldgp, int64_t n_targets,  /*   -> gP (n_targets,K*H) out; 0 <= n_targets <= N */
     const int32_t* t_col, const int32_t* t_eid,
     const int32_t* items, int64_t n_items, int64_t n_wave_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots,

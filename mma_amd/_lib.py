@@ -133,7 +133,7 @@ def call(name, *args):
 
 
 def query(name, *args):
-    """The host-only size helpers (mma_*_workspace_*, mma_nc_aux_row_floats, ...): plain ctypes, no stream."""
+    """The host-only size helpers (mma_*_workspace_*, mma_nc_crow_floats, ...): plain ctypes, no stream."""
     conv = [(ctypes.c_uint8 * len(a))(*a) if isinstance(a, (list, tuple)) else a for a in args]
     return int(getattr(lib(), name)(*conv))
 

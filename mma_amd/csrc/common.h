@@ -77,13 +77,28 @@ template <> __device__ __forceinline__ void stb<1>(uint8_t* p, uint32_t c) { *p 
 __device__ __forceinline__ float sigmoid_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
 
 // ---- dropout keep bits: counter-based, stateless, identical in forward and backward -------------------
-// One 32-bit hash per (edge position e, mask k, feature quad q) yields 4 bytes, one per feature of the
-// quad; an element is KEPT iff its byte >= thr, so P(drop) = thr/256 and survivors scale by 256/(256-thr).
-// The numpy restatement the parity tests use is oracle/dropout_rng.py.
+// ONE full 32-bit hash per (edge position e, feature quad q) - h = mix32(edge_key(e) ^ col_key(q)) - serves all K masks of
+// a launch group (round 3; round 2 ran one full hash per mask): mask 0 uses h itself, mask k >= 1 the folded 64-bit product
+// r_k = hi32(h * M_k) ^ lo32(h * M_k) with a fixed odd multiplier per mask (one v_mad_u64_u32 + one xor instead of two
+// v_mul_lo_u32 and seven ALU operations).  A word yields 4 bytes, one per feature of the quad; an element is KEPT iff its
+// byte >= thr, so P(drop) = thr/256 and survivors scale by 256/(256-thr).  The numpy restatement the parity tests use is
+// oracle/dropout_rng.py; tests/test_dropout_rng.py checks keep rate and the independence of masks / bytes / neighbouring
+// edges and quads (a cheaper derivation, r_k = fold16(h * M_k), failed exactly that test: the XOR of two bytes of one mask
+// was 800 sigma correlated with the same XOR of another mask).
 __host__ __device__ __forceinline__ uint32_t drop_edge_key(uint32_t e, uint32_t seed_lo) { return e * 0x9E3779B1u + seed_lo; }
-__host__ __device__ __forceinline__ uint32_t drop_col_key(uint32_t kq, uint32_t seed_hi) { return kq * 0x85EBCA77u + seed_hi; }
+__host__ __device__ __forceinline__ uint32_t drop_col_key(uint32_t q, uint32_t seed_hi) { return q * 0x85EBCA77u + seed_hi; }
 __host__ __device__ __forceinline__ uint32_t drop_mix(uint32_t a) {
   a ^= a >> 16; a *= 0x7FEB352Du; a ^= a >> 15; a *= 0x846CA68Bu; a ^= a >> 16; return a;
+}
+// multiplier of mask k (k = 0: unused, the base word itself)
+__host__ __device__ __forceinline__ uint32_t drop_mask_mult(int k) {
+  constexpr uint32_t m[8] = {1u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu, 0x165667B1u, 0xCC9E2D51u, 0x1B873593u, 0xE6546B65u};
+  return m[k & 7];
+}
+__host__ __device__ __forceinline__ uint32_t drop_mask_word(uint32_t h, int k_abs, uint32_t mult) {
+  if (k_abs == 0) return h;
+  const uint64_t t = (uint64_t)h * (uint64_t)mult;
+  return (uint32_t)t ^ (uint32_t)(t >> 32);
 }
 
 struct DropParams {
@@ -106,21 +121,34 @@ __device__ __forceinline__ DropParams drop_resolve(DropParams d) {
   return d;
 }
 
-// keep multiplier (0 or scale) for the VEC features starting at column c of mask k_abs on edge e
+// the base word of (edge e, quad q): shared by every mask of the launch group
+__device__ __forceinline__ uint32_t drop_base_word(const DropParams& d, uint32_t e, int q) {
+  return drop_mix(drop_edge_key(e + d.edge_base, d.seed_lo) ^ drop_col_key((uint32_t)q, d.seed_hi));
+}
+template <int VEC>
+__device__ __forceinline__ void drop_unpack(const DropParams& d, uint32_t r, int c, float (&f)[VEC]) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const uint32_t byte = (r >> (8 * ((c + i) & 3))) & 0xFFu;
+    f[i] = byte >= d.thr ? d.scale : 0.f;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void drop_explicit(const DropParams& d, uint32_t e, int k_abs, int c, int H, float (&f)[VEC]) {
+  const uint32_t bits = ldb<VEC>(d.keep + ((size_t)k_abs * (size_t)d.E + e) * (size_t)H + c);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) f[i] = ((bits >> (8 * i)) & 0xFFu) ? d.scale : 0.f;
+}
+
+// keep multiplier (0 or scale) for the VEC features starting at column c of mask k_abs on edge e (run-time mode; the fused NC
+// kernels use the pieces above with the mode as a template parameter and ONE base word for all their masks)
 template <int VEC>
 __device__ __forceinline__ void drop_factors(const DropParams& d, uint32_t e, int k_abs, int c, int H, int HQ,
                                              float (&f)[VEC]) {
   if (d.mode == MMA_DROP_HASH) {
-    const uint32_t r = drop_mix(drop_edge_key(e + d.edge_base, d.seed_lo) ^ drop_col_key((uint32_t)(k_abs * HQ + (c >> 2)), d.seed_hi));
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const uint32_t byte = (r >> (8 * ((c + i) & 3))) & 0xFFu;
-      f[i] = byte >= d.thr ? d.scale : 0.f;
-    }
+    drop_unpack<VEC>(d, drop_mask_word(drop_base_word(d, e, c >> 2), k_abs, drop_mask_mult(k_abs)), c, f);
   } else {  // EXPLICIT
-    const uint32_t bits = ldb<VEC>(d.keep + ((size_t)k_abs * (size_t)d.E + e) * (size_t)H + c);
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) f[i] = ((bits >> (8 * i)) & 0xFFu) ? d.scale : 0.f;
+    drop_explicit<VEC>(d, e, k_abs, c, H, f);
   }
 }
 

@@ -31,12 +31,20 @@ struct NcFwdParams {
   float* m; int64_t m_kstride;       // (K,N,H) per-mask outputs, may be NULL
   float* msum; int64_t ldms;         // (N,H) sum over the K masks, may be NULL
   float* T; uint8_t* sel; int64_t ldt;
+  // shared-gradient backward (round 3): K1 itself leaves the packed code row K2b gathers per edge,
+  // crow[i] = [ 1/d_i, 0, 0, 0 | one byte per element for every max/min/softmax-type mask = 2 * dm/ds (0, 1, 2; 255: NaN) ]
+  float* crow; int64_t ldc; uint32_t sel_slots;      // 4 bits per mask: its code slot in the row, 0xF = none (sum / mean)
   int H, HQ, K_total, k_base, lpr_log;
   uint32_t kinds, acts;              // 4 bits / 1 bit per mask, indexed by absolute k
   DropParams drop;
 };
 
+// row * pitch as ONE v_mad_u64_u32: rows and pitches are < 2^31 (checked on the host), so the 64-bit product needs neither the
+// sign extension nor the two extra quarter-rate v_mul_lo_u32 the int * int64 form compiles to (3 multiplies per gathered row)
+__device__ __forceinline__ size_t row_off(int row, int64_t ld) { return (size_t)((uint64_t)(uint32_t)row * (uint64_t)(uint32_t)ld); }
+
 __device__ __forceinline__ int kind_of(uint32_t kinds, int k) { return (kinds >> (4 * k)) & 0xF; }
+__device__ __forceinline__ uint32_t sel_slot_of(uint32_t slots, int k) { return (slots >> (4 * k)) & 0xFu; }
 
 // combine + selection code for one element (layers.py:221,326-329,452,562,676-682,716-720)
 __device__ __forceinline__ float nc_combine(int kind, float xi, float s, float deg, uint32_t& code) {
@@ -74,7 +82,17 @@ __device__ __forceinline__ Vec<VEC> nc_fwd_write(const NcFwdParams& p, int node,
   if (SAVE) {
     const size_t o = (size_t)node * p.ldt + (size_t)k_abs * p.H + c;
     stv_nt<VEC>(p.T + o, t);
-    stb_nt<VEC>(p.sel + o, codes);
+    if (p.sel) stb_nt<VEC>(p.sel + o, codes);
+    if (p.crow && sel_slot_of(p.sel_slots, k_abs) != 0xFu) {
+      // code -> 2 * dm/ds: 1 (s selected) -> 2, 2 (tie) -> 1, 0 (x_i selected) -> 0, 3 (NaN gradient) -> 255
+      uint32_t tf = 0;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const uint32_t code = (codes >> (8 * i)) & 0xFFu;
+        tf |= (code == 1u ? 2u : (code == 2u ? 1u : (code == 3u ? 255u : 0u))) << (8 * i);
+      }
+      stb<VEC>(reinterpret_cast<uint8_t*>(p.crow + (size_t)node * p.ldc + 4 + (size_t)sel_slot_of(p.sel_slots, k_abs) * p.HQ) + c, tf);   // re-read per edge by K2b: plain store
+    }
   }
   return mo;
 }
@@ -94,9 +112,14 @@ __device__ __forceinline__ void nc_msum_store(const NcFwdParams& p, int node, in
 // MULTI = false: one item per wavefront (EPG = 64/LPR neighbour rows per step) - long segments.
 // MULTI = true : one item per group of G = LPR lanes, 64/G items per wavefront - short segments, where the per-item
 //                latency chain (item -> indices -> rows -> store) dominates and more items in flight is what pays.
-template <int K, int VEC, bool SAVE, bool DROP, bool MULTI>
+// DM: dropout mode as a TEMPLATE parameter (MMA_DROP_NONE / HASH / EXPLICIT) - as a run-time field every mask of every edge step
+// carried a scalar branch between the hash and the explicit-mask code, which cut the step into basic blocks
+template <int K, int VEC, bool SAVE, int DM, bool MULTI>
 __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_kernel(const NcFwdParams p) {
-  const DropParams dp = DROP ? drop_resolve(p.drop) : p.drop;
+  const DropParams dp = DM == MMA_DROP_HASH ? drop_resolve(p.drop) : p.drop;
+  uint32_t mult[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) mult[k] = drop_mask_mult(p.k_base + k);
   // edge steps in flight per lane: 2 (2*(K+1) row loads before the first use); 1 for K = 8, where two would need all
   // 256 VGPRs and leave a single wave per SIMD
   constexpr int U = NC_FWD_UNROLL(K);
@@ -138,11 +161,11 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_k
       maxlen = __builtin_amdgcn_readfirstlane(maxlen);
     }
 
-    const Vec<VEC> xi = ldv<VEC>(p.x + (size_t)node * p.ldx + cc);
+    const Vec<VEC> xi = ldv<VEC>(p.x + row_off(node, p.ldx) + cc);
     Vec<VEC> pk[K], acc[K], tac[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      pk[k] = ldv_nt<VEC>(p.P + (size_t)node * p.ldp + (size_t)(p.k_base + k) * p.H + cc);
+      pk[k] = ldv_nt<VEC>(p.P + row_off(node, p.ldp) + (size_t)(p.k_base + k) * p.H + cc);
       acc[k] = vzero<VEC>();
       tac[k] = vzero<VEC>();
     }
@@ -160,10 +183,11 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_k
           ev[u] = tt[u] < cnt;
           const int j = __shfl(myj, gbase + (tt[u] & (G - 1)), kWave);
           const int jj = ev[u] ? j : node;   // inactive sub-rows re-read the own row (cached) and are zeroed by SELECTS below
-          xj[u] = ldv<VEC>(p.x + (size_t)jj * p.ldx + cc);
+          xj[u] = ldv<VEC>(p.x + row_off(jj, p.ldx) + cc);
+          const float* qrow = p.Q + row_off(jj, p.ldq) + cc;
 #pragma unroll
           for (int k = 0; k < K; ++k)
-            qv[u][k] = ldv<VEC>(p.Q + (size_t)jj * p.ldq + (size_t)(p.k_base + k) * p.H + cc);
+            qv[u][k] = ldv<VEC>(qrow + (size_t)(p.k_base + k) * p.H);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -174,13 +198,17 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_k
           // mask and element was measured at +5.7 % of the kernel: 4.62 -> 4.89 ms at C4.)
 #pragma unroll
           for (int i = 0; i < VEC; ++i) xj[u].v[i] = ev[u] ? xj[u].v[i] : 0.f;
+          // inactive: edge 0 (any valid position; EXPLICIT mode reads keep[(k*E + e)*H + c], and ebeg may equal E)
+          const uint32_t eu = (uint32_t)(ev[u] ? ebeg + base + tt[u] : 0);
+          const uint32_t hw = DM == MMA_DROP_HASH ? drop_base_word(dp, eu, cc >> 2) : 0u;      // ONE full hash for the K masks
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const bool raw = (p.acts >> (p.k_base + k)) & 1u;
             float f[VEC];
-            if (DROP) {
-              // inactive: edge 0 (any valid position; EXPLICIT mode reads keep[(k*E + e)*H + c], and ebeg may equal E)
-              drop_factors<VEC>(dp, (uint32_t)(ev[u] ? ebeg + base + tt[u] : 0), p.k_base + k, cc, p.H, p.HQ, f);
+            if (DM == MMA_DROP_HASH) {
+              drop_unpack<VEC>(dp, drop_mask_word(hw, k == 0 ? p.k_base : 1, mult[k]), cc, f);     // k > 0: never the base word (compile time)
+            } else if (DM == MMA_DROP_EXPLICIT) {
+              drop_explicit<VEC>(dp, eu, p.k_base + k, cc, p.H, f);
             } else {
 #pragma unroll
               for (int i = 0; i < VEC; ++i) f[i] = 1.f;
@@ -222,6 +250,7 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_k
           for (int i = 0; i < VEC; ++i) ms.v[i] += mo.v[i];
         }
         if (p.msum) nc_msum_store<VEC>(p, node, c, ms, p.k_base > 0);
+        if (SAVE && p.crow && c == 0 && p.k_base == 0) p.crow[(size_t)node * p.ldc] = 1.f / deg;
       } else {
         float* ps = p.partial + (size_t)slot * p.pstride;
 #pragma unroll
@@ -276,6 +305,7 @@ __global__ __launch_bounds__(kBlock) void nc_fwd_finalize_kernel(const NcFwdPara
       for (int i = 0; i < VEC; ++i) ms.v[i] += mo.v[i];
     }
     if (p.msum) nc_msum_store<VEC>(p, node, c, ms, false);
+    if (SAVE && p.crow && c == 0) p.crow[(size_t)node * p.ldc] = 1.f / deg;
   }
 }
 
@@ -286,10 +316,23 @@ struct NcBwdNodeParams {
   const uint8_t* sel; const float* T; int64_t ldt; const int32_t* rowptr;
   float* gs; int64_t ldgs; float* gP; int64_t ldgp; float* gxs; int64_t ldgx;
   int64_t N; int H, K; uint32_t kinds;
-  // shared-gradient form: one packed row per target for K2b, [ g (H floats) | 1/d_i, 0, 0, 0 | codes of sel-kind 0 (HQ words) | ... ]
-  float* aux; int64_t ldaux; int HQ; uint8_t sel_slot[MMA_MAX_K];
+  // shared-gradient form (round 3): the selection state comes from the packed code rows K1 wrote (see NcFwdParams::crow) instead
+  // of `sel`; nothing is written for K2b any more (round 2 wrote one packed [g | 1/d | codes] row per target here: 0.8 GB at C4)
+  const float* crow; int64_t ldc; int HQ; uint32_t sel_slots;
   uint32_t* rowmax;        // optional: max |gP| per node (bits of a non-negative float), merged with K2b's max |gQ| by atomicMax
 };
+
+// dm/ds and dm/dx_i of one element from the packed byte tf = 2 * dm/ds of a max/min/softmax-type mask (255: NaN gradient), or
+// from the kind alone for sum / mean
+__device__ __forceinline__ void combine_grad_tf(int kind, uint32_t tf, float inv_deg, float& fs, float& fx) {
+  switch (kind) {
+    case MMA_KIND_SUM: fs = 1.f; fx = 1.f; break;
+    case MMA_KIND_MEAN: fs = inv_deg; fx = inv_deg; break;
+    case MMA_KIND_MAX:
+    case MMA_KIND_MIN: fs = 0.5f * (float)tf; fx = 1.f - fs; break;
+    default: fs = tf == 255u ? __builtin_nanf("") : 1.f; fx = 0.f; break;
+  }
+}
 
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodeParams p) {
@@ -302,6 +345,7 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
     const int64_t node = idx / per_row;
     const int c = (int)(idx % per_row) * VEC;
     const float deg = (float)max(p.rowptr[node + 1] - p.rowptr[node], 1);
+    const float inv_deg = 1.f / deg;
     Vec<VEC> gk[MMA_MAX_K], tk[MMA_MAX_K];
     uint32_t ck[MMA_MAX_K];
     const bool shared_g = p.g_kstride == 0;
@@ -311,7 +355,12 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
         const size_t o = (size_t)node * p.ldt + (size_t)k * p.H + c;
         if (k == 0 || !shared_g) gk[k] = ldv_nt<VEC>(p.g + (size_t)k * p.g_kstride + (size_t)node * p.ldgr + c);
         tk[k] = ldv_nt<VEC>(p.T + o);
-        ck[k] = ldb_nt<VEC>(p.sel + o);
+        if (p.crow) {
+          ck[k] = sel_slot_of(p.sel_slots, k) != 0xFu
+              ? ldb<VEC>(reinterpret_cast<const uint8_t*>(p.crow + (size_t)node * p.ldc + 4 + (size_t)sel_slot_of(p.sel_slots, k) * p.HQ) + c) : 0u;
+        } else {
+          ck[k] = ldb_nt<VEC>(p.sel + o);
+        }
       }
     }
     Vec<VEC> gx = vzero<VEC>();
@@ -326,39 +375,16 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_node_kernel(const NcBwdNodePara
         Vec<VEC> gsv, gpv;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-          const uint32_t code = (codes >> (8 * i)) & 0xFFu;
+          uint32_t tf = (codes >> (8 * i)) & 0xFFu;
+          if (!p.crow) tf = tf == 1u ? 2u : (tf == 2u ? 1u : (tf == 3u ? 255u : 0u));     // sel code -> 2 * dm/ds
           float fs, fx;  // d m / d s, d m / d x_i
-          switch (kind) {
-            case MMA_KIND_SUM: fs = 1.f; fx = 1.f; break;
-            case MMA_KIND_MEAN: fs = 1.f / deg; fx = fs; break;
-            case MMA_KIND_MAX:
-            case MMA_KIND_MIN: fs = code == 1u ? 1.f : (code == 2u ? 0.5f : 0.f); fx = 1.f - fs; break;
-            default: fs = code == 3u ? __builtin_nanf("") : 1.f; fx = 0.f; break;
-          }
+          combine_grad_tf(kind, tf, inv_deg, fs, fx);
           gsv.v[i] = g.v[i] * fs;
           gpv.v[i] = gsv.v[i] * t.v[i];
           gx.v[i] = fmaf(g.v[i], fx, gx.v[i]);
           mxp = fmaxf(mxp, fabsf(gpv.v[i]));
         }
         if (p.gs) stv<VEC>(p.gs + (size_t)node * p.ldgs + (size_t)k * p.H + c, gsv);
-        if (p.aux) {
-          float* row = p.aux + (size_t)node * p.ldaux;
-          if (k == 0) {
-            stv<VEC>(row + c, g);                                   // the shared gradient itself
-            if (c == 0) row[p.H] = 1.f / deg;
-          }
-          if (p.sel_slot[k] != 0xFF) {
-            // one byte per element = 2 * (dm/ds): 0 x_i selected, 1 tie, 2 s selected, 255 NaN.  K2b turns it back into
-            // the factor with a single v_cvt_f32_ubyte + multiply.
-            uint32_t tf = 0;
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-              const uint32_t code = (codes >> (8 * i)) & 0xFFu;
-              tf |= (code == 1u ? 2u : (code == 2u ? 1u : (code == 3u ? 255u : 0u))) << (8 * i);
-            }
-            stb<VEC>(reinterpret_cast<uint8_t*>(row + p.H + 4 + (size_t)p.sel_slot[k] * p.HQ) + c, tf);
-          }
-        }
         stv_nt<VEC>(p.gP + (size_t)node * p.ldgp + (size_t)k * p.H + c, gpv);
       }
     }
@@ -380,9 +406,12 @@ struct NcBwdParams {
   const float* x; int64_t ldx;
   const float* P; int64_t ldp; const float* Q; int64_t ldq;
   const float* gs; int64_t ldg; const float* gxs; int64_t ldgx;
-  // SHARED mode (gs == NULL): all masks share one upstream gradient; gs_k[i] = g[i] * f(kind_k, code_k[i], 1/d_i) is
-  // rebuilt per edge from ONE packed row per target written by K2a: [ g (H) | 1/d_i,0,0,0 | codes per sel-kind (HQ words) ]
-  const float* aux; int64_t ldaux; uint8_t sel_slot[MMA_MAX_K]; uint32_t kinds;
+  // SHARED mode (gs == NULL): all masks share one upstream gradient g (n_targets, ldgg); gs_k[i] = g[i] * f(kind_k, code_k[i], 1/d_i)
+  // is rebuilt per edge from g[i] and the packed code row K1 wrote, crow[i] = [ 1/d_i,0,0,0 | codes per sel-kind (HQ words) ]
+  const float* g; int64_t ldgg; const float* crow; int64_t ldc; uint32_t sel_slots; uint32_t kinds;
+  // EPI (T != NULL, SHARED only): the node-level backward of the combine (K2a) runs in the per-source epilogue - source j < n_targets
+  // is also target j: gP[j] = g[j] * dm/ds * T[j] and the direct term sum_k g[j] * dm/dx_i are formed here, gxs is not used
+  const float* T; int64_t ldt; float* gP; int64_t ldgp; int64_t n_targets;
   const int32_t* t_col; const int32_t* t_eid;
   const int4* items; int64_t n_items;
   float* partial; int64_t pstride;   // floats per slot = (K_total+1)*H
@@ -390,24 +419,53 @@ struct NcBwdParams {
   int H, HQ, K_total, k_base, lpr_log;
   uint32_t acts;
   DropParams drop;
-  int first_pass;  // k_base == 0: gx starts from gxs; later K-slices accumulate onto gx
-  uint32_t* rowmax;  // optional: max |gQ| per source row (see NcBwdNodeParams::rowmax)
+  int first_pass;  // k_base == 0: gx starts from gxs (or the epilogue's direct term); later K-slices accumulate onto gx
+  uint32_t* rowmax;  // optional: max |gQ| (EPI: and |gP|) per source row (see NcBwdNodeParams::rowmax)
 };
 
-// dm/ds of the combine from the saved selection code (same table as nc_bwd_node_kernel)
-__device__ __forceinline__ float combine_ds(int kind, uint32_t code, float inv_deg) {
-  switch (kind) {
-    case MMA_KIND_SUM: return 1.f;
-    case MMA_KIND_MEAN: return inv_deg;
-    case MMA_KIND_MAX:
-    case MMA_KIND_MIN: return code == 1u ? 1.f : (code == 2u ? 0.5f : 0.f);
-    default: return code == 3u ? __builtin_nanf("") : 1.f;
+// the K2a work of one (node, VEC columns) for the masks [k0, k0 + nk): stores gP, returns the direct term sum_k g * dm/dx_i and
+// the running max |gP|.  Shared by the K2b epilogue and the hub finalize kernel.
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> nc_bwd_epilogue(const NcBwdParams& p, int node, int c, int k0, int nk, float& mx) {
+  const Vec<VEC> g = ldv_nt<VEC>(p.g + row_off(node, p.ldgg) + c);
+  const float* crow = p.crow + row_off(node, p.ldc);
+  const float inv_deg = crow[0];
+  Vec<VEC> gxd = vzero<VEC>();
+  Vec<VEC> tk[MMA_MAX_K]; uint32_t ck[MMA_MAX_K];
+#pragma unroll
+  for (int k = 0; k < MMA_MAX_K; ++k) {
+    if (k < nk) {
+      tk[k] = ldv_nt<VEC>(p.T + row_off(node, p.ldt) + (size_t)(k0 + k) * p.H + c);
+      const uint32_t sslot = sel_slot_of(p.sel_slots, k0 + k);
+      ck[k] = sslot != 0xFu ? ldb<VEC>(reinterpret_cast<const uint8_t*>(crow + 4 + (size_t)sslot * p.HQ) + c) : 0u;
+    }
   }
+#pragma unroll
+  for (int k = 0; k < MMA_MAX_K; ++k) {
+    if (k < nk) {
+      const int kind = kind_of(p.kinds, k0 + k);
+      Vec<VEC> gpv;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float fs, fx;
+        combine_grad_tf(kind, (ck[k] >> (8 * i)) & 0xFFu, inv_deg, fs, fx);
+        gpv.v[i] = (g.v[i] * fs) * tk[k].v[i];
+        gxd.v[i] = fmaf(g.v[i], fx, gxd.v[i]);
+        mx = fmaxf(mx, fabsf(gpv.v[i]));
+      }
+      stv_nt<VEC>(p.gP + row_off(node, p.ldgp) + (size_t)(k0 + k) * p.H + c, gpv);
+    }
+  }
+  return gxd;
 }
 
-template <int K, int VEC, bool DROP, bool SHARED, bool MULTI>
+template <int K, int VEC, int DM, bool SHARED, bool MULTI, bool EPI>
 __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_kernel(const NcBwdParams p) {
-  const DropParams dp = DROP ? drop_resolve(p.drop) : p.drop;
+  constexpr bool DROP = DM != MMA_DROP_NONE;
+  const DropParams dp = DM == MMA_DROP_HASH ? drop_resolve(p.drop) : p.drop;
+  uint32_t mult[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) mult[k] = drop_mask_mult(p.k_base + k);
   constexpr int U = NC_BWD_UNROLL(K);           // edge steps in flight per lane (see nc_fwd_kernel)
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log;
@@ -447,19 +505,20 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
       maxlen = __builtin_amdgcn_readfirstlane(maxlen);
     }
 
-    const Vec<VEC> xj = ldv_nt<VEC>(p.x + (size_t)node * p.ldx + cc);
+    const Vec<VEC> xj = ldv_nt<VEC>(p.x + row_off(node, p.ldx) + cc);
     Vec<VEC> qk[K], aq[K];
     Vec<VEC> ax = vzero<VEC>();
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      qk[k] = ldv_nt<VEC>(p.Q + (size_t)node * p.ldq + (size_t)(p.k_base + k) * p.H + cc);
+      qk[k] = ldv_nt<VEC>(p.Q + row_off(node, p.ldq) + (size_t)(p.k_base + k) * p.H + cc);
       aq[k] = vzero<VEC>();
     }
 
     for (int base = 0; base < maxlen; base += G) {
       const int cnt = min(G, max(len - base, 0));
       const int ucnt = min(G, maxlen - base);
-      const int myi = (gl < cnt) ? p.t_col[ebeg + base + gl] : 0;
+      // lane 0 of a group with no edge in this chunk (but edges in an earlier one) offers the item's FIRST target: see the load phase
+      const int myi = (gl < cnt) ? p.t_col[ebeg + base + gl] : ((gl == 0 && len > 0) ? p.t_col[ebeg] : 0);
       const int mye = (DROP && gl < cnt) ? p.t_eid[ebeg + base + gl] : 0;
       for (int t0 = 0; t0 < ucnt; t0 += U * epg) {
         // load phase: raw operands only (no arithmetic on loaded values, so all edge steps stay in flight)
@@ -469,53 +528,61 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
         for (int u = 0; u < U; ++u) {
           tt[u] = t0 + u * epg + sub;
           ev[u] = tt[u] < cnt;
-          const int i_ = __shfl(myi, gbase + (tt[u] & (G - 1)), kWave);
-          eid[u] = DROP ? (uint32_t)__shfl(mye, gbase + (tt[u] & (G - 1)), kWave) : 0u;
-          const int ii = ev[u] ? i_ : 0;   // inactive sub-rows read target row 0 (valid), contribute 0
-          const float* arow = SHARED ? p.aux + (size_t)ii * p.ldaux : nullptr;
+          // A sub-row past the end of its item repeats the item's LAST valid edge of this index chunk (rows that are in flight
+          // or cached anyway) and contributes exactly 0 through ONE select per element of g below - nothing FOREIGN is read, so
+          // a non-finite value can only reach an item that holds it itself (round 2 sent such lanes to target row 0 and replaced
+          // everything they loaded: 30 selects per edge step).  A group with no edge in this chunk (cnt == 0) repeats its item's first
+          // edge; an item with no edge at all (len == 0) reads target 0 and its sums are discarded below.
+          const int tl = min(tt[u], max(cnt - 1, 0));
+          const int ii = __shfl(myi, gbase + (tl & (G - 1)), kWave);
+          eid[u] = DROP ? (uint32_t)__shfl(mye, gbase + (tl & (G - 1)), kWave) : 0u;
           if (SHARED) {
-            gv[u][0] = ldv<VEC>(arow + cc);
-            idg[u] = arow[p.H];
-          }
+            gv[u][0] = ldv<VEC>(p.g + row_off(ii, p.ldgg) + cc);
+            const float* crow = p.crow + row_off(ii, p.ldc);
+            idg[u] = crow[0];
 #pragma unroll
-          for (int k = 0; k < K; ++k) {
-            const size_t o = (size_t)(p.k_base + k) * p.H + cc;
-            if (SHARED) {
+            for (int k = 0; k < K; ++k) {
               // sum/mean never look at the code: a constant "s selected" (2 = twice the factor 1.0) keeps the arithmetic
               // below branch-free
-              const uint32_t sslot = p.sel_slot[p.k_base + k];
-              codes[u][k] = (sslot != 0xFFu) ? ldb<VEC>(reinterpret_cast<const uint8_t*>(arow + p.H + 4 + (size_t)sslot * p.HQ) + cc)
+              const uint32_t sslot = sel_slot_of(p.sel_slots, p.k_base + k);
+              codes[u][k] = (sslot != 0xFu) ? ldb<VEC>(reinterpret_cast<const uint8_t*>(crow + 4 + (size_t)sslot * p.HQ) + cc)
                                              : 0x02020202u;
-            } else {
-              gv[u][k] = ldv<VEC>(p.gs + (size_t)ii * p.ldg + o);
             }
-            pv[u][k] = ldv<VEC>(p.P + (size_t)ii * p.ldp + o);
+          }
+          const float* prow = p.P + row_off(ii, p.ldp) + cc;
+          const float* grow = SHARED ? nullptr : p.gs + row_off(ii, p.ldg) + cc;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const size_t o = (size_t)(p.k_base + k) * p.H;
+            if (!SHARED) gv[u][k] = ldv<VEC>(grow + o);
+            pv[u][k] = ldv<VEC>(prow + o);
           }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          // inactive sub-rows read target row 0: everything they loaded is replaced by 0 with selects (see nc_fwd_kernel)
-          if (SHARED) {
+          const bool live = ev[u];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) gv[u][0].v[i] = ev[u] ? gv[u][0].v[i] : 0.f;
-            idg[u] = ev[u] ? idg[u] : 0.f;
-          }
+          for (int kk = 0; kk < (SHARED ? 1 : K); ++kk)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) gv[u][kk].v[i] = live ? gv[u][kk].v[i] : 0.f;
+          const uint32_t hw = DM == MMA_DROP_HASH ? drop_base_word(dp, eid[u], cc >> 2) : 0u;      // ONE full hash for the K masks
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const bool raw = (p.acts >> (p.k_base + k)) & 1u;
             const int kind = SHARED ? kind_of(p.kinds, p.k_base + k) : 0;
-            if (SHARED) codes[u][k] = ev[u] ? codes[u][k] : 0u;
             const float kscale = 0.5f * (kind == MMA_KIND_MEAN ? idg[u] : 1.f);   // the code byte holds TWICE dm/ds
             float f[VEC];
-            if (DROP) {
-              drop_factors<VEC>(dp, eid[u], p.k_base + k, cc, p.H, p.HQ, f);
+            if (DM == MMA_DROP_HASH) {
+              drop_unpack<VEC>(dp, drop_mask_word(hw, k == 0 ? p.k_base : 1, mult[k]), cc, f);     // k > 0: never the base word (compile time)
+            } else if (DM == MMA_DROP_EXPLICIT) {
+              drop_explicit<VEC>(dp, eid[u], p.k_base + k, cc, p.H, f);
             } else {
 #pragma unroll
               for (int i = 0; i < VEC; ++i) f[i] = 1.f;
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-              const float z = ev[u] ? pv[u][k].v[i] + qk[k].v[i] : 0.f;
+              const float z = pv[u][k].v[i] + qk[k].v[i];
               float a, da;
               if (raw) { a = z; da = 1.f; }
               else { a = sigmoid_fast(z); da = a - a * a; }
@@ -526,7 +593,7 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
                 if (kind >= MMA_KIND_SOFTMAX && tf == 255u) cf = __builtin_nanf("");   // exp overflow in the forward combine
                 gsv = gv[u][0].v[i] * (cf * kscale);
               } else {
-                gsv = ev[u] ? gv[u][k].v[i] : 0.f;
+                gsv = gv[u][k].v[i];
               }
               const float w = f[i] * gsv;
               aq[k].v[i] = fmaf(da, w, aq[k].v[i]);
@@ -537,6 +604,13 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
       }
     }
 
+    // EPI: the node-level loads of the epilogue go out before the butterfly (they do not depend on the sums)
+    const bool writer = sub == 0 && fvalid && ivalid;
+    const bool tgt = EPI && writer && slot < 0 && (int64_t)node < p.n_targets;
+    Vec<VEC> gxd = vzero<VEC>();
+    float mxp = 0.f;
+    if (EPI) { if (tgt) gxd = nc_bwd_epilogue<VEC>(p, node, c, p.k_base, K, mxp); }
+
     for (int off = G / 2; off >= lpr; off >>= 1) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -545,10 +619,15 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
         for (int k = 0; k < K; ++k) aq[k].v[i] += __shfl_xor(aq[k].v[i], off, kWave);
       }
     }
+    if (len == 0) {            // nothing was accumulated for this item (a chunk trip on behalf of other groups may have run)
+      ax = vzero<VEC>();
+#pragma unroll
+      for (int k = 0; k < K; ++k) aq[k] = vzero<VEC>();
+    }
 
     if (p.rowmax) {           // wave-uniform
-      float mxq = 0.f;
-      if (sub == 0 && fvalid && ivalid && slot < 0) {
+      float mxq = mxp;
+      if (writer && slot < 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
@@ -557,21 +636,30 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
       for (int off = lpr >> 1; off > 0; off >>= 1) mxq = fmaxf(mxq, __shfl_xor(mxq, off, kWave));
       if (sub == 0 && (lane & (lpr - 1)) == 0 && ivalid && slot < 0 && mxq > 0.f) atomicMax(p.rowmax + node, __float_as_uint(mxq));
     }
-    if (sub == 0 && fvalid && ivalid) {
+    if (writer) {
       if (slot < 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           Vec<VEC> o;
 #pragma unroll
           for (int i = 0; i < VEC; ++i) o.v[i] = xj.v[i] * aq[k].v[i];
-          stv_nt<VEC>(p.gQ + (size_t)node * p.ldgq + (size_t)(p.k_base + k) * p.H + c, o);
+          stv_nt<VEC>(p.gQ + row_off(node, p.ldgq) + (size_t)(p.k_base + k) * p.H + c, o);
         }
-        const Vec<VEC> g0 = p.first_pass ? ldv_nt<VEC>(p.gxs + (size_t)node * p.ldgx + c)
-                                         : ldv<VEC>(p.gx + (size_t)node * p.ldgxo + c);
+        Vec<VEC> g0;
+        if (EPI) {
+          g0 = gxd;              // zero for a halo source (no target role)
+          if (!p.first_pass) {
+            const Vec<VEC> prev = ldv<VEC>(p.gx + row_off(node, p.ldgxo) + c);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) g0.v[i] += prev.v[i];
+          }
+        } else {
+          g0 = p.first_pass ? ldv_nt<VEC>(p.gxs + row_off(node, p.ldgx) + c) : ldv<VEC>(p.gx + row_off(node, p.ldgxo) + c);
+        }
         Vec<VEC> o;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) o.v[i] = g0.v[i] + ax.v[i];
-        stv_nt<VEC>(p.gx + (size_t)node * p.ldgxo + c, o);
+        stv_nt<VEC>(p.gx + row_off(node, p.ldgxo) + c, o);
       } else {
         float* ps = p.partial + (size_t)slot * p.pstride;
 #pragma unroll
@@ -594,6 +682,7 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void nc_bwd_finalize_kernel(const NcBwdParams p, const int4* hubs, int64_t n_hubs) {
   const int per_row = (p.H + VEC - 1) / VEC;
+  const bool epi = p.T != nullptr;
   const int64_t total = n_hubs * (p.K_total + 1) * per_row;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(idx % per_row) * VEC;
@@ -614,20 +703,40 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_finalize_kernel(const NcBwdPara
       }
     }
     const int node = hub.x;
+    const bool tgt = epi && (int64_t)node < p.n_targets;
     Vec<VEC> o;
     if (k < p.K_total) {
       const Vec<VEC> xj = ldv<VEC>(p.x + (size_t)node * p.ldx + c);
+      float mxq = 0.f;
+      if (tgt) nc_bwd_epilogue<VEC>(p, node, c, k, 1, mxq);            // gP of this mask (the direct term is formed by the k == K thread)
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o.v[i] = xj.v[i] * s.v[i];
       stv_nt<VEC>(p.gQ + (size_t)node * p.ldgq + (size_t)k * p.H + c, o);
       if (p.rowmax) {
-        float mxq = 0.f;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) mxq = fmaxf(mxq, fabsf(o.v[i]));
         if (mxq > 0.f) atomicMax(p.rowmax + node, __float_as_uint(mxq));
       }
     } else {
-      const Vec<VEC> g0 = ldv<VEC>(p.gxs + (size_t)node * p.ldgx + c);
+      Vec<VEC> g0 = vzero<VEC>();
+      if (tgt) {
+        // sum_k g * dm/dx_i over ALL masks: the epilogue's direct term without its stores
+        const Vec<VEC> g = ldv<VEC>(p.g + row_off(node, p.ldgg) + c);
+        const float* crow = p.crow + row_off(node, p.ldc);
+        const float inv_deg = crow[0];
+        for (int kk = 0; kk < p.K_total; ++kk) {
+          const uint32_t sslot = sel_slot_of(p.sel_slots, kk);
+          const uint32_t ck = sslot != 0xFu ? ldb<VEC>(reinterpret_cast<const uint8_t*>(crow + 4 + (size_t)sslot * p.HQ) + c) : 0u;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            float fs, fx;
+            combine_grad_tf(kind_of(p.kinds, kk), (ck >> (8 * i)) & 0xFFu, inv_deg, fs, fx);
+            g0.v[i] = fmaf(g.v[i], fx, g0.v[i]);
+          }
+        }
+      } else if (!epi) {
+        g0 = ldv<VEC>(p.gxs + (size_t)node * p.ldgx + c);
+      }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o.v[i] = g0.v[i] + s.v[i];
       stv<VEC>(p.gx + (size_t)node * p.ldgxo + c, o);
@@ -654,13 +763,14 @@ static int pack_codes(const uint8_t* kind_host, const uint8_t* act_host, int K, 
   return 0;
 }
 
-// sel-kinds (max/min/softmax/softmin) get consecutive code slots in the packed aux row; returns the row length in floats
-static int64_t fill_sel_slots(const uint8_t* kind_host, int K, int H, uint8_t* slots) {
+// sel-kinds (max/min/softmax/softmin) get consecutive code slots in the packed code row (4 bits per mask, 0xF = none); returns the
+// row length in floats: [ 1/d_i, 0, 0, 0 | n_sel * ceil(H/4) words of codes ], rounded up to a multiple of 4
+static int64_t fill_sel_slots(const uint8_t* kind_host, int K, int H, uint32_t* slots) {
   int n = 0;
-  for (int k = 0; k < MMA_MAX_K; ++k) slots[k] = 0xFF;
+  *slots = 0xFFFFFFFFu;
   for (int k = 0; k < K; ++k)
-    if (kind_host[k] >= MMA_KIND_MAX) slots[k] = (uint8_t)n++;
-  return (((int64_t)H + 4 + (int64_t)n * (((int64_t)H + 3) / 4)) + 3) & ~(int64_t)3;      // 64-bit: H comes straight from the caller
+    if (kind_host[k] >= MMA_KIND_MAX) { *slots = (*slots & ~(0xFu << (4 * k))) | ((uint32_t)n << (4 * k)); ++n; }
+  return ((4 + (int64_t)n * (((int64_t)H + 3) / 4)) + 3) & ~(int64_t)3;      // 64-bit: H comes straight from the caller
 }
 
 static int make_drop(int32_t mode, uint32_t thr, uint64_t seed, const uint64_t* seed_dev, int64_t edge_base, const uint8_t* keep,
@@ -696,44 +806,46 @@ static dim3 item_grid(int64_t n_items, int chunks, int items_per_wave = 1) {
 }
 
 template <int K, int VEC, bool MULTI>
-static void launch_fwd(const NcFwdParams& p, dim3 grid, bool save, bool drop, hipStream_t st) {
+static void launch_fwd(const NcFwdParams& p, dim3 grid, bool save, int dm, hipStream_t st) {
+#define MMA_FWD(SAVE, DM) hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, SAVE, DM, MULTI>), grid, dim3(kBlock), 0, st, p)
   if (save) {
-    if (drop) hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, true, true, MULTI>), grid, dim3(kBlock), 0, st, p);
-    else hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, true, false, MULTI>), grid, dim3(kBlock), 0, st, p);
+    if (dm == MMA_DROP_HASH) MMA_FWD(true, MMA_DROP_HASH); else if (dm == MMA_DROP_EXPLICIT) MMA_FWD(true, MMA_DROP_EXPLICIT); else MMA_FWD(true, MMA_DROP_NONE);
   } else {
-    if (drop) hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, false, true, MULTI>), grid, dim3(kBlock), 0, st, p);
-    else hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, false, false, MULTI>), grid, dim3(kBlock), 0, st, p);
+    if (dm == MMA_DROP_HASH) MMA_FWD(false, MMA_DROP_HASH); else if (dm == MMA_DROP_EXPLICIT) MMA_FWD(false, MMA_DROP_EXPLICIT); else MMA_FWD(false, MMA_DROP_NONE);
   }
+#undef MMA_FWD
 }
 template <int VEC, bool MULTI>
-static void launch_fwd_k(int Ks, const NcFwdParams& p, dim3 grid, bool save, bool drop, hipStream_t st) {
+static void launch_fwd_k(int Ks, const NcFwdParams& p, dim3 grid, bool save, int dm, hipStream_t st) {
   switch (Ks) {
-    case 1: launch_fwd<1, VEC, MULTI>(p, grid, save, drop, st); break;
-    case 2: launch_fwd<2, VEC, MULTI>(p, grid, save, drop, st); break;
-    case 3: launch_fwd<3, VEC, MULTI>(p, grid, save, drop, st); break;
-    case 4: launch_fwd<4, VEC, MULTI>(p, grid, save, drop, st); break;
-    default: launch_fwd<8, VEC, MULTI>(p, grid, save, drop, st); break;
+    case 1: launch_fwd<1, VEC, MULTI>(p, grid, save, dm, st); break;
+    case 2: launch_fwd<2, VEC, MULTI>(p, grid, save, dm, st); break;
+    case 3: launch_fwd<3, VEC, MULTI>(p, grid, save, dm, st); break;
+    case 4: launch_fwd<4, VEC, MULTI>(p, grid, save, dm, st); break;
+    default: launch_fwd<8, VEC, MULTI>(p, grid, save, dm, st); break;
   }
 }
 template <int K, int VEC, bool MULTI>
-static void launch_bwd(const NcBwdParams& p, dim3 grid, bool drop, hipStream_t st) {
+static void launch_bwd(const NcBwdParams& p, dim3 grid, int dm, hipStream_t st) {
   const bool shared = p.gs == nullptr;
-  if (shared) {
-    if (drop) hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, true, true, MULTI>), grid, dim3(kBlock), 0, st, p);
-    else hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, false, true, MULTI>), grid, dim3(kBlock), 0, st, p);
-  } else {
-    if (drop) hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, true, false, MULTI>), grid, dim3(kBlock), 0, st, p);
-    else hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, false, false, MULTI>), grid, dim3(kBlock), 0, st, p);
-  }
+  const bool epi = p.T != nullptr;
+#define MMA_BWD(DM, SHARED, EPI) hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, DM, SHARED, MULTI, EPI>), grid, dim3(kBlock), 0, st, p)
+#define MMA_BWD_DM(SHARED, EPI) \
+  do { if (dm == MMA_DROP_HASH) MMA_BWD(MMA_DROP_HASH, SHARED, EPI); else if (dm == MMA_DROP_EXPLICIT) MMA_BWD(MMA_DROP_EXPLICIT, SHARED, EPI); \
+       else MMA_BWD(MMA_DROP_NONE, SHARED, EPI); } while (0)
+  if (shared) { if (epi) MMA_BWD_DM(true, true); else MMA_BWD_DM(true, false); }
+  else MMA_BWD_DM(false, false);
+#undef MMA_BWD_DM
+#undef MMA_BWD
 }
 template <int VEC, bool MULTI>
-static void launch_bwd_k(int Ks, const NcBwdParams& p, dim3 grid, bool drop, hipStream_t st) {
+static void launch_bwd_k(int Ks, const NcBwdParams& p, dim3 grid, int dm, hipStream_t st) {
   switch (Ks) {
-    case 1: launch_bwd<1, VEC, MULTI>(p, grid, drop, st); break;
-    case 2: launch_bwd<2, VEC, MULTI>(p, grid, drop, st); break;
-    case 3: launch_bwd<3, VEC, MULTI>(p, grid, drop, st); break;
-    case 4: launch_bwd<4, VEC, MULTI>(p, grid, drop, st); break;
-    default: launch_bwd<8, VEC, MULTI>(p, grid, drop, st); break;
+    case 1: launch_bwd<1, VEC, MULTI>(p, grid, dm, st); break;
+    case 2: launch_bwd<2, VEC, MULTI>(p, grid, dm, st); break;
+    case 3: launch_bwd<3, VEC, MULTI>(p, grid, dm, st); break;
+    case 4: launch_bwd<4, VEC, MULTI>(p, grid, dm, st); break;
+    default: launch_bwd<8, VEC, MULTI>(p, grid, dm, st); break;
   }
 }
 
@@ -754,6 +866,7 @@ extern "C" int mma_nc_fused_fwd(
     const int32_t* rowptr, const int32_t* col,
     const int32_t* items, int64_t n_items, int64_t n_wave_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots, float* m, float* m_sum, int64_t ldms, float* T, uint8_t* sel, int64_t ldt,
+    float* crow, int64_t ldc,
     int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* kind_host, const uint8_t* act_host,
     int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, int64_t drop_edge_base, const uint8_t* keep,
     void* stream) {
@@ -761,8 +874,10 @@ extern "C" int mma_nc_fused_fwd(
   MMA_REQUIRE(H >= 1 && K >= 1 && K <= MMA_MAX_K, "H=%d K=%d unsupported (1<=K<=%d)", H, K, MMA_MAX_K);
   MMA_REQUIRE(ldx >= H && ldp >= (int64_t)K * H && ldq >= (int64_t)K * H, "row pitch too small: ldx=%lld ldp=%lld ldq=%lld",
               (long long)ldx, (long long)ldp, (long long)ldq);
-  MMA_REQUIRE((T == nullptr) == (sel == nullptr), "T and sel must both be given or both be NULL");
+  MMA_REQUIRE(T != nullptr || (sel == nullptr && crow == nullptr), "sel / crow are saved next to T: give T too");
+  MMA_REQUIRE(T == nullptr || sel != nullptr || crow != nullptr, "T needs the selection state beside it: sel (N,K*H), crow (N,ldc), or both");
   MMA_REQUIRE(T == nullptr || ldt >= (int64_t)K * H, "ldt=%lld too small", (long long)ldt);
+  MMA_REQUIRE(ldx < (1LL << 31) && ldp < (1LL << 31) && ldq < (1LL << 31) && ldt < (1LL << 31) && ldc < (1LL << 31), "row pitch out of range");
   MMA_REQUIRE(n_items >= 0 && n_hubs >= 0 && n_slots >= 0 && n_items < (1LL << 31) && n_wave_items >= 0, "negative or oversize item counts");
   MMA_REQUIRE(n_slots == 0 || (partial != nullptr && hubs != nullptr && n_hubs > 0), "hub slots without partial/hubs buffers");
   if (N == 0 || n_items == 0) return 0;
@@ -775,16 +890,22 @@ extern "C" int mma_nc_fused_fwd(
   if (int rc = pack_codes(kind_host, act_host, K, &kinds, &acts)) return rc;
   NcFwdParams p{};
   if (int rc = make_drop(drop_mode, drop_thr, seed, seed_dev, drop_edge_base, keep, E, &p.drop)) return rc;
-  const bool drop = drop_mode != MMA_DROP_NONE && !(drop_mode == MMA_DROP_HASH && drop_thr == 0);
+  const int dm = (drop_mode == MMA_DROP_HASH && drop_thr == 0) ? MMA_DROP_NONE : drop_mode;
   const bool save = T != nullptr;
+  if (crow) {
+    const int64_t crow_len = fill_sel_slots(kind_host, K, H, &p.sel_slots);
+    MMA_REQUIRE(ldc >= crow_len && ldc % 4 == 0 && aligned16(crow), "crow needs a 16-byte aligned pitch >= %lld floats (mma_nc_crow_floats)",
+                (long long)crow_len);
+  }
   const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldp % 4 == 0) && (ldq % 4 == 0) && (!save || ldt % 4 == 0) && aligned16(x) &&
-                  aligned16(P) && aligned16(Q) && (!m || aligned16(m)) && (!m_sum || (aligned16(m_sum) && ldms % 4 == 0)) && (!save || (aligned16(T) && aligned16(sel))) &&
-                  (partial == nullptr || aligned16(partial));
+                  aligned16(P) && aligned16(Q) && (!m || aligned16(m)) && (!m_sum || (aligned16(m_sum) && ldms % 4 == 0)) &&
+                  (!save || (aligned16(T) && (!sel || aligned16(sel)))) && (partial == nullptr || aligned16(partial));
   const Geometry g = geometry(H, v4);
   p.x = x; p.ldx = ldx; p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.rowptr = rowptr; p.col = col;
   p.items = reinterpret_cast<const int4*>(items); p.n_items = n_items;
   p.partial = partial; p.pstride = 2LL * K * H;
   p.m = m; p.m_kstride = N * (int64_t)H; p.msum = m_sum; p.ldms = ldms; p.T = T; p.sel = sel; p.ldt = ldt;
+  p.crow = crow; p.ldc = ldc;
   p.H = H; p.HQ = (H + 3) / 4; p.K_total = K; p.lpr_log = g.lpr_log; p.kinds = kinds; p.acts = acts;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // items [0, n_wave_items): one per wavefront; items [n_wave_items, n_items): one per LPR-lane group (short segments)
@@ -800,8 +921,8 @@ extern "C" int mma_nc_fused_fwd(
     for (int k0 = 0; k0 < K;) {
       const int ks = next_slice(K - k0);
       p.k_base = k0;
-      if (g.vec == 4) { if (part == 0) launch_fwd_k<4, false>(ks, p, grid, save, drop, st); else launch_fwd_k<4, true>(ks, p, grid, save, drop, st); }
-      else { if (part == 0) launch_fwd_k<1, false>(ks, p, grid, save, drop, st); else launch_fwd_k<1, true>(ks, p, grid, save, drop, st); }
+      if (g.vec == 4) { if (part == 0) launch_fwd_k<4, false>(ks, p, grid, save, dm, st); else launch_fwd_k<4, true>(ks, p, grid, save, dm, st); }
+      else { if (part == 0) launch_fwd_k<1, false>(ks, p, grid, save, dm, st); else launch_fwd_k<1, true>(ks, p, grid, save, dm, st); }
       k0 += ks;
     }
   }
@@ -822,31 +943,32 @@ extern "C" int mma_nc_fused_fwd(
   return 0;
 }
 
-extern "C" int64_t mma_nc_aux_row_floats(int32_t H, int32_t K, const uint8_t* kind_host) {
+extern "C" int64_t mma_nc_crow_floats(int32_t H, int32_t K, const uint8_t* kind_host) {
   if (H < 1 || K < 1 || K > MMA_MAX_K || !kind_host) return -1;
-  uint8_t slots[MMA_MAX_K];
-  return fill_sel_slots(kind_host, K, H, slots);
+  for (int k = 0; k < K; ++k) if (kind_host[k] > MMA_KIND_SOFTMIN) return -1;
+  uint32_t slots;
+  return fill_sel_slots(kind_host, K, H, &slots);
 }
 
 extern "C" int mma_nc_bwd_node(
     const float* g, int64_t g_kstride, int64_t ldgr, const uint8_t* sel, const float* T, int64_t ldt, const int32_t* rowptr,
-    float* gs, int64_t ldgs, float* aux, int64_t ldaux, float* gP, int64_t ldgp, float* gxs, int64_t ldgx, float* row_max,
+    float* gs, int64_t ldgs, const float* crow, int64_t ldc, float* gP, int64_t ldgp, float* gxs, int64_t ldgx, float* row_max,
     int64_t N, int32_t H, int32_t K, const uint8_t* kind_host, void* stream) {
   MMA_REQUIRE(N >= 0 && N < (1LL << 31) && H >= 1 && K >= 1 && K <= MMA_MAX_K, "N=%lld H=%d K=%d unsupported", (long long)N, H, K);
   MMA_REQUIRE(ldt >= (int64_t)K * H && (!gs || ldgs >= (int64_t)K * H) && ldgp >= (int64_t)K * H && ldgx >= H && ldgr >= H &&
               g_kstride >= 0, "row pitch too small");
   if (N == 0) return 0;
-  MMA_REQUIRE(g && sel && T && rowptr && gP && gxs && kind_host, "NULL argument");
+  MMA_REQUIRE(g && (sel || crow) && T && rowptr && gP && gxs && kind_host, "NULL argument (the selection state is sel or crow)");
   uint32_t kinds, acts;
   if (int rc = pack_codes(kind_host, nullptr, K, &kinds, &acts)) return rc;
   NcBwdNodeParams p{g, g_kstride, ldgr, sel, T, ldt, rowptr, gs, ldgs, gP, ldgp, gxs, ldgx, N, H, K, kinds};
   p.rowmax = reinterpret_cast<uint32_t*>(row_max);
-  p.aux = aux; p.ldaux = ldaux; p.HQ = (H + 3) / 4;
-  const int64_t aux_len = fill_sel_slots(kind_host, K, H, p.sel_slot);
-  MMA_REQUIRE(!aux || (g_kstride == 0 && ldaux >= aux_len && ldaux % 4 == 0 && aligned16(aux)),
-              "aux needs the shared-gradient form (g_kstride 0) and a 16-byte aligned pitch >= %lld floats", (long long)aux_len);
+  p.crow = crow; p.ldc = ldc; p.HQ = (H + 3) / 4;
+  const int64_t crow_len = fill_sel_slots(kind_host, K, H, &p.sel_slots);
+  MMA_REQUIRE(!crow || (ldc >= crow_len && ldc % 4 == 0 && aligned16(crow)),
+              "crow needs a 16-byte aligned pitch >= %lld floats (mma_nc_crow_floats)", (long long)crow_len);
   const bool v4 = (H % 4 == 0) && (ldt % 4 == 0) && (!gs || ldgs % 4 == 0) && (ldgp % 4 == 0) && (ldgx % 4 == 0) &&
-                  (ldgr % 4 == 0) && (g_kstride % 4 == 0) && aligned16(g) && aligned16(sel) &&
+                  (ldgr % 4 == 0) && (g_kstride % 4 == 0) && aligned16(g) && (crow || aligned16(sel)) &&
                   aligned16(T) && (!gs || aligned16(gs)) && aligned16(gP) && aligned16(gxs);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int per_row = v4 ? H / 4 : H;
@@ -860,7 +982,8 @@ extern "C" int mma_nc_bwd_node(
 
 extern "C" int mma_nc_fused_bwd(
     const float* x, int64_t ldx, const float* P, int64_t ldp, const float* Q, int64_t ldq,
-    const float* gs, int64_t ldg, const float* aux, int64_t ldaux, const uint8_t* kind_host, const float* gxs, int64_t ldgx,
+    const float* gs, int64_t ldg, const float* g, int64_t ldgg, const float* crow, int64_t ldc, const uint8_t* kind_host,
+    const float* gxs, int64_t ldgx, const float* T, int64_t ldt, float* gP, int64_t ldgp, int64_t n_targets,
     const int32_t* t_col, const int32_t* t_eid,
     const int32_t* items, int64_t n_items, int64_t n_wave_items, const int32_t* hubs, int64_t n_hubs,
     float* partial, int64_t n_slots, float* gQ, int64_t ldgq, float* gx, int64_t ldgxo, float* row_max,
@@ -870,36 +993,46 @@ extern "C" int mma_nc_fused_bwd(
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31), "N=%lld E=%lld out of int32 range", (long long)N, (long long)E);
   MMA_REQUIRE(H >= 1 && K >= 1 && K <= MMA_MAX_K, "H=%d K=%d unsupported (1<=K<=%d)", H, K, MMA_MAX_K);
   MMA_REQUIRE(ldx >= H && ldp >= (int64_t)K * H && ldq >= (int64_t)K * H && (!gs || ldg >= (int64_t)K * H) && ldgq >= (int64_t)K * H &&
-              ldgx >= H && ldgxo >= H, "row pitch too small");
+              ldgxo >= H, "row pitch too small");
+  MMA_REQUIRE(ldx < (1LL << 31) && ldp < (1LL << 31) && ldq < (1LL << 31) && ldg < (1LL << 31) && ldgg < (1LL << 31) && ldc < (1LL << 31) &&
+              ldt < (1LL << 31) && ldgp < (1LL << 31) && ldgq < (1LL << 31) && ldgx < (1LL << 31) && ldgxo < (1LL << 31), "row pitch out of range");
   MMA_REQUIRE(n_items >= 0 && n_hubs >= 0 && n_slots >= 0 && n_items < (1LL << 31) && n_wave_items >= 0, "negative or oversize item counts");
   MMA_REQUIRE(n_slots == 0 || (partial != nullptr && hubs != nullptr && n_hubs > 0), "hub slots without partial/hubs buffers");
   if (N == 0 || n_items == 0) return 0;       // an empty shard: nothing to do (its zero-row buffers are NULL)
-  MMA_REQUIRE(gs != nullptr || (aux && kind_host), "give gs (N,K*H), or the shared-gradient form: aux rows from mma_nc_bwd_node + kinds");
-  MMA_REQUIRE(x && P && Q && gxs && items && gQ && gx && act_host, "NULL argument");
+  const bool shared = gs == nullptr;
+  const bool epi = T != nullptr;
+  MMA_REQUIRE(!shared || (g && crow && kind_host && ldgg >= H),
+              "give gs (n_targets,K*H), or the shared-gradient form: g (n_targets,H), the code rows crow K1 wrote, and kinds");
+  MMA_REQUIRE(!epi || (shared && gP && ldt >= (int64_t)K * H && ldgp >= (int64_t)K * H && n_targets >= 0 && n_targets <= N),
+              "the fused node-level epilogue (T given) needs the shared-gradient form, gP and 0 <= n_targets <= N");
+  MMA_REQUIRE(epi || (gxs && ldgx >= H), "gxs (N,H) from mma_nc_bwd_node is needed unless the epilogue is fused (T given)");
+  MMA_REQUIRE(x && P && Q && items && gQ && gx && act_host, "NULL argument");
   MMA_REQUIRE(E == 0 || (t_col != nullptr && t_eid != nullptr), "NULL transposed CSR");
   MMA_REQUIRE(aligned16(items) && (hubs == nullptr || aligned16(hubs)), "items/hubs must be 16-byte aligned int32 quadruples");
   uint32_t kinds, acts;
-  if (int rc = pack_codes(gs ? nullptr : kind_host, act_host, K, &kinds, &acts)) return rc;
+  if (int rc = pack_codes(shared ? kind_host : nullptr, act_host, K, &kinds, &acts)) return rc;
   NcBwdParams p{};
   if (int rc = make_drop(drop_mode, drop_thr, seed, seed_dev, drop_edge_base, keep, E, &p.drop)) return rc;
-  const bool drop = drop_mode != MMA_DROP_NONE && !(drop_mode == MMA_DROP_HASH && drop_thr == 0);
-  const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldp % 4 == 0) && (ldq % 4 == 0) && (ldgx % 4 == 0) && (ldgq % 4 == 0) &&
-                  (gs ? (ldg % 4 == 0 && aligned16(gs)) : (ldaux % 4 == 0 && aligned16(aux))) &&
-                  (ldgxo % 4 == 0) && aligned16(x) && aligned16(P) && aligned16(Q) && aligned16(gxs) &&
+  const int dm = (drop_mode == MMA_DROP_HASH && drop_thr == 0) ? MMA_DROP_NONE : drop_mode;
+  const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldp % 4 == 0) && (ldq % 4 == 0) && (epi || (ldgx % 4 == 0 && aligned16(gxs))) && (ldgq % 4 == 0) &&
+                  (shared ? (ldgg % 4 == 0 && aligned16(g) && ldc % 4 == 0 && aligned16(crow)) : (ldg % 4 == 0 && aligned16(gs))) &&
+                  (!epi || (ldt % 4 == 0 && aligned16(T) && ldgp % 4 == 0 && aligned16(gP))) &&
+                  (ldgxo % 4 == 0) && aligned16(x) && aligned16(P) && aligned16(Q) &&
                   aligned16(gQ) && aligned16(gx) && (partial == nullptr || aligned16(partial));
-  const Geometry g = geometry(H, v4);
+  const Geometry geo = geometry(H, v4);
   p.x = x; p.ldx = ldx; p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.gs = gs; p.ldg = ldg; p.gxs = gxs; p.ldgx = ldgx;
-  p.aux = aux; p.ldaux = ldaux; p.kinds = kinds;
-  if (!gs) {
-    const int64_t aux_len = fill_sel_slots(kind_host, K, H, p.sel_slot);
-    MMA_REQUIRE(ldaux >= aux_len, "ldaux=%lld < %lld", (long long)ldaux, (long long)aux_len);
+  p.g = g; p.ldgg = ldgg; p.crow = crow; p.ldc = ldc; p.kinds = kinds;
+  p.T = T; p.ldt = ldt; p.gP = gP; p.ldgp = ldgp; p.n_targets = n_targets;
+  if (shared) {
+    const int64_t crow_len = fill_sel_slots(kind_host, K, H, &p.sel_slots);
+    MMA_REQUIRE(ldc >= crow_len, "ldc=%lld < %lld", (long long)ldc, (long long)crow_len);
   }
   p.t_col = t_col; p.t_eid = t_eid; p.items = reinterpret_cast<const int4*>(items); p.n_items = n_items;
   p.partial = partial; p.pstride = (int64_t)(K + 1) * H; p.gQ = gQ; p.ldgq = ldgq; p.gx = gx; p.ldgxo = ldgxo;
   p.rowmax = reinterpret_cast<uint32_t*>(row_max);
-  p.H = H; p.HQ = (H + 3) / 4; p.K_total = K; p.lpr_log = g.lpr_log; p.acts = acts;
+  p.H = H; p.HQ = (H + 3) / 4; p.K_total = K; p.lpr_log = geo.lpr_log; p.acts = acts;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int ipw = kWave >> g.lpr_log;
+  const int ipw = kWave >> geo.lpr_log;
   if (ipw == 1 || n_wave_items > n_items) n_wave_items = n_items;
   const int4* all_items = p.items;
   for (int part = 0; part < 2; ++part) {
@@ -907,21 +1040,21 @@ extern "C" int mma_nc_fused_bwd(
     if (cnt <= 0) continue;
     p.items = all_items + (part == 0 ? 0 : n_wave_items);
     p.n_items = cnt;
-    const dim3 grid = item_grid(cnt, g.chunks, part == 0 ? 1 : ipw);
+    const dim3 grid = item_grid(cnt, geo.chunks, part == 0 ? 1 : ipw);
     for (int k0 = 0; k0 < K;) {
       const int ks = next_slice(K - k0);
       p.k_base = k0; p.first_pass = (k0 == 0);
-      if (g.vec == 4) { if (part == 0) launch_bwd_k<4, false>(ks, p, grid, drop, st); else launch_bwd_k<4, true>(ks, p, grid, drop, st); }
-      else { if (part == 0) launch_bwd_k<1, false>(ks, p, grid, drop, st); else launch_bwd_k<1, true>(ks, p, grid, drop, st); }
+      if (geo.vec == 4) { if (part == 0) launch_bwd_k<4, false>(ks, p, grid, dm, st); else launch_bwd_k<4, true>(ks, p, grid, dm, st); }
+      else { if (part == 0) launch_bwd_k<1, false>(ks, p, grid, dm, st); else launch_bwd_k<1, true>(ks, p, grid, dm, st); }
       k0 += ks;
     }
   }
   if (int rc = check_launch("nc_bwd_kernel")) return rc;
   if (n_hubs > 0) {
-    const int per_row = (H + g.vec - 1) / g.vec;
+    const int per_row = (H + geo.vec - 1) / geo.vec;
     const dim3 fg((unsigned)elementwise_grid(n_hubs * (K + 1) * per_row));
     const int4* hb = reinterpret_cast<const int4*>(hubs);
-    if (g.vec == 4) hipLaunchKernelGGL((nc_bwd_finalize_kernel<4>), fg, dim3(kBlock), 0, st, p, hb, n_hubs);
+    if (geo.vec == 4) hipLaunchKernelGGL((nc_bwd_finalize_kernel<4>), fg, dim3(kBlock), 0, st, p, hb, n_hubs);
     else hipLaunchKernelGGL((nc_bwd_finalize_kernel<1>), fg, dim3(kBlock), 0, st, p, hb, n_hubs);
     if (int rc = check_launch("nc_bwd_finalize_kernel")) return rc;
   }

@@ -1,6 +1,8 @@
 """autograd wrappers over the C ABI (include/mma_amd.h).  Tensors are plumbing: every FLOP and byte of the
 hot path moves inside libmma_amd.so; torch only owns the memory, the stream and the autograd tape."""
 
+import os
+
 import torch
 
 from . import _lib
@@ -11,6 +13,10 @@ from ._lib import call, host_codes, ptr, require_gpu, stream_ptr
 # 4 KB gathered per edge at K=4, H=128 (C4: 5.5 vs 6.7 ms with dropout, 5.2 vs 6.8 ms without; K2a 1.3 vs 1.8 ms).
 # False: gather a materialised (N,K*H) gs.  Both forms are covered by the parity tests.
 SHARED_GRAD_BWD = True
+# Round 3: with the shared-gradient form K1 leaves the packed code rows itself (no aux rows written by K2a), and the node-level
+# backward (K2a: gP = g dm/ds T, the direct term of dL/dx) runs in K2b's per-source epilogue - no K2a launch, no gxs round trip.
+# False: K2a stays a launch of its own (reading the code rows).  Both forms are covered by the parity tests.
+FUSE_NODE_BWD = os.environ.get("MMA_FUSE_NODE_BWD", "1") != "0"
 TIMER = None   # bench.py installs an object with .span(name) -> context manager (HIP events around the calls)
 
 
@@ -60,11 +66,18 @@ class DropoutSpec:
         return self.mode, self.thr, self.seed, ptr(self.seed_tensor), ptr(self.keep)
 
 
-def nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, save):
-    """K1 on prepared operands -> (m or msum, T, sel).  No autograd; shared by _NCFused and the sharded layer."""
+def crow_floats(H, kinds):
+    return _lib.query("mma_nc_crow_floats", H, len(kinds), host_codes(kinds))
+
+
+def nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, save, shared=None):
+    """K1 on prepared operands -> (m or msum, T, sel, crow).  No autograd; shared by _NCFused and the sharded layer.
+    shared (default: reduce_k and SHARED_GRAD_BWD): the backward will take the shared-gradient form, so the selection state is
+    saved as the packed code rows `crow` (N, ldc) K2b gathers per edge instead of the (N,K*H) byte array `sel`."""
     K = len(kinds)
     S, H = x_src.shape
     N = graph.N
+    shared = (reduce_k and SHARED_GRAD_BWD) if shared is None else shared
     assert x_src.dtype == torch.float32 and P.dtype == torch.float32 and Q.dtype == torch.float32
     assert S == graph.n_src and P.shape == (N, K * H) and Q.shape == (S, K * H) and 1 <= K <= 8
     assert x_src.is_contiguous() and P.stride(1) == 1 and Q.stride(1) == 1
@@ -72,7 +85,12 @@ def nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, save):
     m = None if reduce_k else torch.empty((K, N, H), device=dev, dtype=torch.float32)
     msum = torch.empty((N, H), device=dev, dtype=torch.float32) if reduce_k else None
     T = torch.empty((N, K * H), device=dev, dtype=torch.float32) if save else None
-    sel = torch.empty((N, K * H), device=dev, dtype=torch.uint8) if save else None
+    sel = torch.empty((N, K * H), device=dev, dtype=torch.uint8) if save and not shared else None
+    crow = None
+    if save and shared:
+        ldc = crow_floats(H, kinds)
+        # zeros: the padding of a row (and, for H % 4 != 0, the tail of a code word) is never written by the kernel
+        crow = (torch.zeros if H % 4 else torch.empty)((N, ldc), device=dev, dtype=torch.float32)
     partial = torch.empty((graph.n_slots, 2 * K * H), device=dev, dtype=torch.float32) if graph.n_slots else None
     if drop.keep is not None:
         assert drop.keep.dtype == torch.uint8 and drop.keep.is_contiguous() and drop.keep.is_cuda and \
@@ -82,21 +100,18 @@ def nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, save):
         call("mma_nc_fused_fwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
              ptr(graph.rowptr), ptr(graph.col), ptr(graph.items), graph.items.shape[0], graph.n_wave_items,
              ptr(graph.hubs) if graph.n_slots else None, graph.hubs.shape[0], ptr(partial), graph.n_slots,
-             ptr(m), ptr(msum), H, ptr(T), ptr(sel), K * H, N, graph.E, H, K, host_codes(kinds), host_codes(acts),
+             ptr(m), ptr(msum), H, ptr(T), ptr(sel), K * H, ptr(crow), crow.stride(0) if crow is not None else 0,
+             N, graph.E, H, K, host_codes(kinds), host_codes(acts),
              mode, thr, seed, seed_dev, graph.edge_base, keep, stream_ptr())
-    return (msum if reduce_k else m), T, sel
+    return (msum if reduce_k else m), T, sel, crow
 
 
-def nc_bwd_node_launch(g, reduce_k, sel, T, graph, kinds, H, shared, gP=None, row_max=None):
-    """K2a -> (gs or None, aux or None, ldaux, gP (N,K*H), gxs (n_src,H) with zero halo rows).
-    gP may be a (N,K*H) column block of a wider buffer (row pitch = its stride(0))."""
+def nc_bwd_node_launch(g, reduce_k, sel, crow, T, graph, kinds, H, shared, gP=None, row_max=None):
+    """K2a -> (gs or None, gP (N,K*H), gxs (n_src,H) with zero halo rows).  The selection state is `crow` (shared-gradient form)
+    or `sel`.  gP may be a (N,K*H) column block of a wider buffer (row pitch = its stride(0))."""
     K, N, S = len(kinds), graph.N, graph.n_src
     dev = g.device
     gs = None if shared else torch.empty((N, K * H), device=dev, dtype=torch.float32)
-    aux, ldaux = None, 0
-    if shared:
-        ldaux = _lib.query("mma_nc_aux_row_floats", H, K, host_codes(kinds))
-        aux = torch.empty((N, ldaux), device=dev, dtype=torch.float32)
     if gP is None:
         gP = torch.empty((N, K * H), device=dev, dtype=torch.float32)
     gxs = torch.empty((S, H), device=dev, dtype=torch.float32)
@@ -104,12 +119,14 @@ def nc_bwd_node_launch(g, reduce_k, sel, T, graph, kinds, H, shared, gP=None, ro
         gxs[N:].zero_()
     with _span("nc_bwd_node"):
         call("mma_nc_bwd_node", ptr(g), 0 if reduce_k else N * H, H, ptr(sel), ptr(T), K * H, ptr(graph.rowptr),
-             ptr(gs), K * H, ptr(aux), ldaux, ptr(gP), gP.stride(0), ptr(gxs), H, ptr(row_max), N, H, K, host_codes(kinds), stream_ptr())
-    return gs, aux, ldaux, gP, gxs
+             ptr(gs), K * H, ptr(crow), crow.stride(0) if crow is not None else 0, ptr(gP), gP.stride(0), ptr(gxs), H, ptr(row_max),
+             N, H, K, host_codes(kinds), stream_ptr())
+    return gs, gP, gxs
 
 
-def nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, part=None, row_max=None):
-    """K2b over the transposed CSR; `part` = (items, n_wave_items, hubs) restricts it to a subset of the sources."""
+def nc_bwd_edges_launch(x_src, P, Q, gs, g, crow, gxs, graph, kinds, acts, drop, gQ, gx, partial, part=None, row_max=None, T=None, gP=None):
+    """K2b over the transposed CSR; `part` = (items, n_wave_items, hubs) restricts it to a subset of the sources.
+    gs given: materialised dL/ds rows; else the shared-gradient form on (g, crow); with T and gP: K2a fused into the epilogue."""
     K = len(acts)
     S, H = x_src.shape
     items, n_wave, hubs = part if part is not None else (graph.t_items, graph.t_n_wave_items, graph.t_hubs)
@@ -117,7 +134,9 @@ def nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, dr
     mode, thr, seed, seed_dev, keep = drop.args()
     with _span("nc_fused_bwd"):
         call("mma_nc_fused_bwd", ptr(x_src), x_src.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0),
-             ptr(gs), K * H, ptr(aux), ldaux, host_codes(kinds) if shared else None, ptr(gxs), H,
+             ptr(gs), K * H, ptr(g) if shared else None, g.stride(0) if shared else 0,
+             ptr(crow) if shared else None, crow.stride(0) if shared else 0, host_codes(kinds) if shared else None,
+             ptr(gxs), H, ptr(T), K * H if T is not None else 0, ptr(gP), gP.stride(0) if gP is not None else 0, graph.N,
              ptr(graph.t_col), ptr(graph.t_eid), ptr(items), items.shape[0], n_wave,
              ptr(hubs) if hubs.shape[0] else None, hubs.shape[0], ptr(partial), graph.t_n_slots if hubs.shape[0] else 0,
              ptr(gQ), gQ.stride(0), ptr(gx), H, ptr(row_max), S, graph.E, H, K, host_codes(acts), mode, thr, seed, seed_dev, graph.edge_base,
@@ -139,26 +158,30 @@ class _NCFused(torch.autograd.Function):
             P = P.contiguous()
         if Q.stride(1) != 1:
             Q = Q.contiguous()
-        out, T, sel = nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, any(ctx.needs_input_grad[:3]))
+        out, T, sel, crow = nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, any(ctx.needs_input_grad[:3]))
         ctx.graph, ctx.kinds, ctx.acts, ctx.drop, ctx.reduce_k = graph, kinds, acts, drop, reduce_k
-        ctx.save_for_backward(x_src, P, Q, T, sel)
+        ctx.save_for_backward(x_src, P, Q, T, sel, crow)
         return out
 
     @staticmethod
     def backward(ctx, g):
         graph, kinds, acts, drop, reduce_k = ctx.graph, ctx.kinds, ctx.acts, ctx.drop, ctx.reduce_k
-        shared = reduce_k and SHARED_GRAD_BWD
-        x_src, P, Q, T, sel = ctx.saved_tensors
+        x_src, P, Q, T, sel, crow = ctx.saved_tensors
+        shared = crow is not None
         K = len(kinds)
         H, S = x_src.shape[1], graph.n_src
         g = g.contiguous()
         dev = g.device
-        gs, aux, ldaux, gP, gxs = nc_bwd_node_launch(g, reduce_k, sel, T, graph, kinds, H, shared)
         gQ = torch.empty((S, K * H), device=dev, dtype=torch.float32)
         gx = torch.empty((S, H), device=dev, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32)
                    if graph.t_n_slots else None)
-        nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial)
+        if shared and FUSE_NODE_BWD:
+            gP = torch.empty((graph.N, K * H), device=dev, dtype=torch.float32)
+            nc_bwd_edges_launch(x_src, P, Q, None, g, crow, None, graph, kinds, acts, drop, gQ, gx, partial, T=T, gP=gP)
+        else:
+            gs, gP, gxs = nc_bwd_node_launch(g, reduce_k, sel, crow, T, graph, kinds, H, shared)
+            nc_bwd_edges_launch(x_src, P, Q, gs, g, crow, gxs, graph, kinds, acts, drop, gQ, gx, partial)
         return gx, gP, gQ, None, None, None, None, None
 
 
@@ -179,16 +202,16 @@ class _NCLocalLayer(torch.autograd.Function):
         need = any(ctx.needs_input_grad[:3])
         box = [] if need else None                                          # row maxima of x, when the forward GEMM forms them: the
         mm_into(x, wcat, PQ, row_max_box=box)                               # weight-gradient product's row scales (three-product TN form)
-        msum, T, sel = nc_fwd_launch(x, PQ[:, :KH], PQ[:, KH:], graph, kinds, acts, drop, True, need)
+        msum, T, sel, crow = nc_fwd_launch(x, PQ[:, :KH], PQ[:, KH:], graph, kinds, acts, drop, True, need)
         ctx.graph, ctx.kinds, ctx.acts, ctx.drop = graph, kinds, acts, drop
-        ctx.save_for_backward(x, PQ, T, sel, wcat, box[0] if box else None)
+        ctx.save_for_backward(x, PQ, T, sel, crow, wcat, box[0] if box else None)
         return msum
 
     @staticmethod
     def backward(ctx, g):
         from .dense import rows_mm_add_, xt_g
         graph, kinds, acts, drop = ctx.graph, ctx.kinds, ctx.acts, ctx.drop
-        x, PQ, T, sel, wcat, x_row_max = ctx.saved_tensors
+        x, PQ, T, sel, crow, wcat, x_row_max = ctx.saved_tensors
         N, H = x.shape
         K = len(kinds)
         KH = K * H
@@ -197,12 +220,17 @@ class _NCLocalLayer(torch.autograd.Function):
         gPQ = torch.empty((N, 2 * KH), device=g.device, dtype=torch.float32)
         # the three-product dL/dx GEMM scales every row of [gP|gQ] by a power of two: K2a and K2b leave the row maxima here
         row_max = torch.zeros((N,), device=g.device, dtype=torch.float32) if dense.f16x2_n128_ok(N, 2 * KH, H) and K <= 8 else None
-        gs, aux, ldaux, gP, gxs = nc_bwd_node_launch(g, True, sel, T, graph, kinds, H, SHARED_GRAD_BWD, gP=gPQ[:, :KH], row_max=row_max)
         gx = torch.empty((N, H), device=g.device, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=g.device, dtype=torch.float32)
                    if graph.t_n_slots else None)
-        nc_bwd_edges_launch(x, PQ[:, :KH], PQ[:, KH:], gs, aux, ldaux, gxs, graph, kinds, acts, drop, gPQ[:, KH:], gx, partial,
-                            row_max=row_max)
+        shared = crow is not None
+        if shared and FUSE_NODE_BWD:         # K2a inside K2b's epilogue: gP lands in the left half of [gP | gQ] from the same launch
+            nc_bwd_edges_launch(x, PQ[:, :KH], PQ[:, KH:], None, g, crow, None, graph, kinds, acts, drop, gPQ[:, KH:], gx, partial,
+                                row_max=row_max, T=T, gP=gPQ[:, :KH])
+        else:
+            gs, gP, gxs = nc_bwd_node_launch(g, True, sel, crow, T, graph, kinds, H, shared, gP=gPQ[:, :KH], row_max=row_max)
+            nc_bwd_edges_launch(x, PQ[:, :KH], PQ[:, KH:], gs, g, crow, gxs, graph, kinds, acts, drop, gPQ[:, KH:], gx, partial,
+                                row_max=row_max)
         dense.rows_mm_add_scaled_(gx, gPQ, wcat.t(), row_max)                # direct + through P and Q in one GEMM (C += A B)
         gw = xt_g(x, gPQ, x_row_max, row_max) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
         return gx, (gw[:, :KH] if gw is not None else None), (gw[:, KH:] if gw is not None else None), None, None, None, None

@@ -286,16 +286,16 @@ class _ShardedAggregate(torch.autograd.Function):
             h.wait()
         mm_into(x_src[n:], wbot, PQ[n:, KH:], row_max_box=box_halo)
         P, Q = PQ[:n, :KH], PQ[:, KH:]
-        msum, T, sel = Fn.nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, True, need)
+        msum, T, sel, crow = Fn.nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, True, need)
         ctx.mod, ctx.kinds, ctx.acts, ctx.drop = mod, kinds, acts, drop
-        ctx.save_for_backward(x_src, PQ, T, sel, wcat, box_own[0] if box_own else None, box_halo[0] if box_halo else None)
+        ctx.save_for_backward(x_src, PQ, T, sel, crow, wcat, box_own[0] if box_own else None, box_halo[0] if box_halo else None)
         return msum
 
     @staticmethod
     def backward(ctx, g):
         mod, kinds, acts, drop = ctx.mod, ctx.kinds, ctx.acts, ctx.drop
         plan, graph = mod.plan, mod.graph
-        x_src, PQ, T, sel, wcat, xrm_own, xrm_halo = ctx.saved_tensors
+        x_src, PQ, T, sel, crow, wcat, xrm_own, xrm_halo = ctx.saved_tensors
         n, S, H = plan.n_own, plan.n_src, x_src.shape[1]
         K = len(kinds)
         KH = K * H
@@ -303,12 +303,16 @@ class _ShardedAggregate(torch.autograd.Function):
         wbot = wcat[:, KH:]
         dev = g.device
         g = g.contiguous()
-        shared = Fn.SHARED_GRAD_BWD
+        shared = crow is not None
+        fuse = shared and Fn.FUSE_NODE_BWD          # K2a in the epilogue of the OWN-source launch (halo sources have no target role)
         gPQ = torch.empty((S, 2 * KH), device=dev, dtype=torch.float32)          # [dL/dP | dL/dQ], halo rows: Q half only
         from .dense import f16x2_n128_ok, rows_mm_add_scaled_
         # row maxima of [gP|gQ] for the three-product dL/dx GEMMs (own rows: both halves; halo rows: the Q half only)
         row_max = torch.zeros((S,), device=dev, dtype=torch.float32) if f16x2_n128_ok(max(n, S - n), KH, H) and K <= 8 else None
-        gs, aux, ldaux, gP, gxs = Fn.nc_bwd_node_launch(g, True, sel, T, graph, kinds, H, shared, gP=gPQ[:n, :KH], row_max=row_max)
+        gs = gxs = None
+        if not fuse:
+            gs, _gP, gxs = Fn.nc_bwd_node_launch(g, True, sel, crow, T, graph, kinds, H, shared, gP=gPQ[:n, :KH], row_max=row_max)
+        epi = dict(T=T, gP=gPQ[:n, :KH]) if fuse else {}
         gQ = gPQ[:, KH:]
         gx = torch.empty((S, H), device=dev, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32) if graph.t_n_slots else None)
@@ -318,14 +322,14 @@ class _ShardedAggregate(torch.autograd.Function):
         back = None
         if S > n:
             halo_part, own_part = graph.t_parts
-            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, halo_part, row_max=row_max)
+            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, g, crow, gxs, graph, kinds, acts, drop, gQ, gx, partial, halo_part, row_max=row_max, **epi)
             gxh = rows_mm_add_scaled_(gx[n:], gQ[n:], wbot.t(), row_max[n:] if row_max is not None else None)   # halo rows: direct + via Q
             back = all_to_all_rows_start(gxh, plan.recv_counts, plan.send_counts, plan.group)
-            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, own_part, row_max=row_max)
+            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, g, crow, gxs, graph, kinds, acts, drop, gQ, gx, partial, own_part, row_max=row_max, **epi)
         else:
             if plan.world > 1:
                 back = all_to_all_rows_start(gx[n:], plan.recv_counts, plan.send_counts, plan.group)    # sends (0,H), still receives
-            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, aux, ldaux, gxs, graph, kinds, acts, drop, gQ, gx, partial, row_max=row_max)
+            Fn.nc_bwd_edges_launch(x_src, P, Q, gs, g, crow, gxs, graph, kinds, acts, drop, gQ, gx, partial, row_max=row_max, **epi)
         gx_own = rows_mm_add_scaled_(gx[:n], gPQ[:n], wcat.t(), row_max[:n] if row_max is not None else None)   # own rows, one GEMM
         gwtop = gwbot = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:

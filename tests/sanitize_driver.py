@@ -61,12 +61,13 @@ def recipe(lib, name, rng, keep):
                  act_host=codes([rng.randrange(0, 2) for _ in range(K)]), drop_mode=rng.choice([0, 1, 2]), drop_thr=rng.choice([0, 128, 255]),
                  drop_edge_base=rng.choice([0, 0, 1 << 20]), g_kstride=rng.choice([0, 4 * ((N * H + 3) // 4)]), ldgr=H + pad, ldgs=K * H,
                  ldgp=K * H, ldgx=H + pad, ldg=K * H, ldgq=K * H, ldgxo=H + pad)
-        lib.mma_nc_aux_row_floats.restype = ctypes.c_int64
-        d["ldaux"] = int(lib.mma_nc_aux_row_floats(H, K, d["kind_host"]))
+        lib.mma_nc_crow_floats.restype = ctypes.c_int64
+        d["ldc"] = int(lib.mma_nc_crow_floats(H, K, d["kind_host"]))
+        d.update(ldgg=H + pad, n_targets=rng.choice([0, N // 2, N]))
         if not hubs:
             d.update(hubs=None, partial=None)
         if rng.random() < 0.3:
-            d.update(T=None, sel=None)
+            d.update(T=None, sel=None, crow=None)
         return d
     if name.startswith("mma_gr_fused"):
         T, F = rng.choice([(1, 1), (1, 4), (2, 3), (5, 76), (5, 75), (1, 128), (4, 16), (8, 8)])
