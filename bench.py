@@ -379,7 +379,8 @@ def gr_config(tag, n_graphs, dev, reps=20, replay=True, categorical=False):
     spans = t.summary(); Fn.TIMER = prev
     r = {"config": tag, "graphs": n_graphs, "nodes": N, "edges": E, "towers": 5, "F": 75, "ms_per_step_eager": ms,
          "edges_per_s_eager": E / ms * 1e3,
-         "kernels": _kernel_table(spans, reps, gr_algorithmic_bytes(N, E, 5, 75, 2, 3, "categorical" if categorical else True))}
+         "kernels": _kernel_table(spans, reps, gr_algorithmic_bytes(N, E, 5, 75, 2, 1 if __import__("mma_amd").mma_conv.FACTOR_SCALERS else 3,
+                                                                    "categorical" if categorical else True))}
     if replay:
         conv.graph_capturable = True
         gms = graph_replay_ms(step, 20)
@@ -742,7 +743,9 @@ def run_c2l(args, dev, rank=0, world=1, barrier=None):
         return
     E_all, N_all = int(tot[0].item()), int(tot[1].item())
     T, F, K, S = 5, 75, 2, 3
-    ab = gr_algorithmic_bytes(N, E, T, F, K, S)
+    from mma_amd import mma_conv as _mc
+    # with the degree scalers factored into the post-NN (round 3) the fused kernels move the K UNSCALED aggregates: S = 1 in their bytes
+    ab = gr_algorithmic_bytes(N, E, T, F, K, 1 if _mc.FACTOR_SCALERS else S)
     kernels = _kernel_table(timer.summary(), args.steps, ab)
     roofs = {}
     for n in ("gr_fused_fwd", "gr_fused_bwd"):

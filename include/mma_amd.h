@@ -213,6 +213,12 @@ int mma_gemm_f16x2_n128(const float* A, int64_t lda, const float* row_max, const
 int64_t mma_gemm_bf16x3_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC);
 int mma_gemm_bf16x3_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, float* C, float* ws, int64_t ws_floats,
                        int64_t M, int32_t KA, int32_t NC, void* stream);
+/* B independent TN products in one launch: C (B,KA,NC), C[b] = X_b^T G_b with X_b = X + b*xb and G_b = G + b*gb - column blocks of
+ * wider rows (the per-tower weight gradients of MMAConv's post-NN: mma_tower_post_bwd's gys and K3's aggregates).  Six-product form,
+ * same shape rules as mma_gemm_bf16x3_tn; ws: mma_gemm_bf16x3_tn_batched_workspace_floats(M, KA, NC, B) floats. */
+int64_t mma_gemm_bf16x3_tn_batched_workspace_floats(int64_t M, int32_t KA, int32_t NC, int32_t B);
+int mma_gemm_bf16x3_tn_batched(const float* X, int64_t ldx, int64_t xb, const float* G, int64_t ldg, int64_t gb, float* C, float* ws,
+                               int64_t ws_floats, int64_t M, int32_t KA, int32_t NC, int32_t B, void* stream);
 /* The TN product in the three-product fp16 x 2 form (half the MFMAs).  The reduction runs over the rows, so the power-of-two scales
  * are per ROW of both operands, balanced between them (x_i 2^a and g_i 2^-a leave x_i g_i unchanged) so that ONE un-scaling serves
  * the whole product; they are derived on the device from the row maxima: x_row_max / g_row_max (M,) >= max |.| of every row of X /
@@ -255,6 +261,46 @@ int mma_col_sum(const float* g, int64_t ldg, int64_t R, int32_t C, float* out, f
 int64_t mma_tower_linear_bwd_blocks(int64_t N);
 int mma_tower_linear_bwd(const float* gy, const float* a, const float* W, float* ga, float* part, int64_t n_blocks,
                          int64_t N, int32_t T, int32_t O, int32_t C, void* stream);
+
+/* ---- K13 / K14: MMAConv's per-tower post-NN on the UNSCALED aggregates, degree scalers applied as row factors (ABI 27) -------------
+ * mma_conv.py:181-196 builds out (N,T,S*K*F) = cat_q(agg * prod_{q' <= q} scaler_q'(deg)) and :132-134 applies post_nns[t] to cat[x, out].
+ * The scalers are per-target row factors, so with pre_q = the running product (reference order) of the S scalers at deg = clamp(d_n, 1):
+ *   fwd: y[n, t*O + o]      = sum_q pre_q sum_kf agg[n, t*KF + kf] Wa[t][kf][q*16 + o]        (agg (N, lda): K3 with the identity scaler)
+ *   bwd: gagg[n, t*KF + kf] = sum_q pre_q sum_o gy[n, t*O + o] Wb[t][q*16 + o][kf]            (what K4 takes as its upstream gradient)
+ *        gys[n, (t*S + q)*16 + o] = pre_q gy[n, t*O + o]   (optional: the left operand of gW[t] = gys_t^T agg_t, a TN product)
+ * on the matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain).  The caller lays the post-NN weight columns
+ * Wo[t][o][(q*K + k)*F + f] out twice, zero-padded: Wa (T, KFp, S*16) and Wb (T, S*16, KFp + 16) with KFp = mma_tower_post_kfp(KF);
+ * KF = K*F <= 512, O <= 16, S <= 5; rowptr: the CSR-by-target row pointers (degrees).  Neither `out` nor its
+ * gradient is ever materialised. */
+int64_t mma_tower_post_kfp(int32_t KF);
+int mma_tower_post_fwd(const float* agg, int64_t lda, const int32_t* rowptr, const float* Wa, float* y, int64_t ldy,
+                       int64_t N, int32_t T, int32_t KF, int32_t S, int32_t O, const uint8_t* scaler_host, float avg_log, float avg_lin,
+                       void* stream);
+int mma_tower_post_bwd(const float* gy, int64_t ldg, const int32_t* rowptr, const float* Wb, float* gagg, int64_t lda,
+                       float* gys, int64_t ldgs,
+                       float* pre_out,              /* optional (N, 8): pre_q of every node, the table mma_tower_post_gw reads */
+                       int64_t N, int32_t T, int32_t KF, int32_t S, int32_t O,
+                       const uint8_t* scaler_host, float avg_log, float avg_lin, void* stream);
+/* K15: the weight gradient of the same product, part (n_chunks, T, S*16, KFp16) with KFp16 = KF rounded up to 16 and n_chunks =
+ * mma_tower_post_gw_chunks(N, T): part[c][t][q*16 + o][kf] = sum over the nodes n of chunk c of pre_q(deg_n) gy[n, t*O + o] agg[n, t*KF + kf]
+ * (exact fp32 on the matrix cores, the node is the reduction index); summing the chunks in order (mma_col_sum over the n_chunks rows)
+ * gives gW[t][q*16 + o][kf] = the gradient of Wb.  Rows o >= O and columns kf >= KF are zero. */
+int64_t mma_tower_post_gw_chunks(int64_t N, int32_t T);
+int mma_tower_post_gw(const float* gy, int64_t ldg, const float* agg, int64_t lda,
+                      const float* pre,            /* (N, 8) from mma_tower_post_bwd */
+                      float* part, int64_t n_chunks,
+                      int64_t N, int32_t T, int32_t KF, int32_t S, int32_t O, const uint8_t* scaler_host, float avg_log, float avg_lin,
+                      void* stream);
+
+/* ---- K16: a plain skinny Linear on the K13 / K14 kernels (exact fp32 on the matrix cores): the 75 -> 75 Linear layers around MMAConv's
+ * fused kernels (x-part of the post-NN and `lin`, mma_conv.py:99-105,132-136; F.linear in the reference) --------------------------------
+ *   fwd:    y (N,O)  = x (N,K) W^T + bias            Wa (KFp, S*16): Wa[k][o] = W[o][k], zero-padded, S = ceil(O/16), KFp = mma_tower_post_kfp(K)
+ *   bwd_dx: gx (N,K) = gy (N,O) W                    Wb (S*16, KFp + 16): Wb[o][k] = W[o][k], zero-padded
+ * O <= 80, K <= 512, any row pitches (16-byte aligned rows take the float4 path).  bias may be NULL. */
+int mma_skinny_linear_fwd(const float* x, int64_t ldx, const float* Wa, const float* bias, float* y, int64_t ldy,
+                          int64_t N, int32_t K, int32_t O, void* stream);
+int mma_skinny_linear_bwd_dx(const float* gy, int64_t ldg, const float* Wb, float* gx, int64_t ldx,
+                             int64_t N, int32_t K, int32_t O, void* stream);
 
 /* ---- K10: fused log_softmax + nll_loss of the training step (models.py:68 F.log_softmax(x, dim=1) + train.py:77
  * F.nll_loss(output[idx_train], labels[idx_train])) ------------------------------------------------------------------------

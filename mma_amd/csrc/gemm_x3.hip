@@ -856,6 +856,9 @@ struct TnParams {
   const uint16_t* sgh;         // (M,) the same for the G rows
   const int* state;            // {max t, min t, bad, unscale exponent}: see tn_scale_* below.  state != NULL: the kernel runs only
   int want_bad;                //   if (state[2] != 0) == want_bad (the two forms are launched back to back, one of them leaves at once)
+  // batched form (blockIdx.y = b): X + b*xb and G + b*gb (column offsets inside wider rows: the towers of MMAConv), partial tiles
+  // (splits, batch, KA, NC); zero for a single product
+  int64_t xb, gb, part_ss;
 };
 
 constexpr int kTnKC = 32;                        // rows of X / G per chunk
@@ -906,9 +909,10 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_tn_kernel(const TnParams p)
   const int ldg_b = (int)p.ldg * 4, ldx_b = (int)p.ldx * 4;                    // row pitches in bytes
   const int rows = (int)(r1 > r0 ? r1 - r0 : 0);
   const int64_t rbase = r1 > r0 ? r0 : 0;                                      // an empty split still gets a valid base
-  const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G + rbase * p.ldg + gcol0), 0,
+  const int64_t bz = (int64_t)blockIdx.y;                                      // batch index (0 for a single product)
+  const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G + bz * p.gb + rbase * p.ldg + gcol0), 0,
                                                         rows ? (rows - 1) * ldg_b + min(128, p.NC - gcol0) * 4 : 0, 0x00020000);
-  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + rbase * p.ldx), 0,
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + bz * p.xb + rbase * p.ldx), 0,
                                                         rows ? (rows - 1) * ldx_b + p.KA * 4 : 0, 0x00020000);
   const int g_voff = skg * 8 * ldg_b + scol * 4;     // per lane: first row of its k-group, its column
   const int x_voff = 8 * h * ldx_b + xcol * 4;
@@ -1023,7 +1027,8 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_x3_tn_kernel(const TnParams p)
 #undef MMA_TN_PUBLISH
 
   if (wave_active) {   // acc reg r holds X column 32*wave + (r&3) + 8*(r>>2) + 4*h, G column gcol0 + 32*ct + r31
-    float* out = p.part + ((size_t)split * p.KA + (size_t)wave * 32) * p.NC + gcol0 + r31;
+    float* out = p.part + (size_t)split * (p.part_ss ? (size_t)p.part_ss : (size_t)p.KA * p.NC) + (size_t)bz * p.KA * p.NC +
+                 (size_t)wave * 32 * p.NC + gcol0 + r31;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       if (ct < n_ct) {
@@ -1171,9 +1176,10 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_f16x2_tn_kernel(const TnParams
   const int ldg_b = (int)p.ldg * 4, ldx_b = (int)p.ldx * 4;
   const int rows = (int)(r1 > r0 ? r1 - r0 : 0);
   const int64_t rbase = r1 > r0 ? r0 : 0;
-  const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G + rbase * p.ldg + gcol0), 0,
+  const int64_t bz = (int64_t)blockIdx.y;                                      // batch index (0 for a single product)
+  const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G + bz * p.gb + rbase * p.ldg + gcol0), 0,
                                                         rows ? (rows - 1) * ldg_b + min(128, p.NC - gcol0) * 4 : 0, 0x00020000);
-  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + rbase * p.ldx), 0,
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + bz * p.xb + rbase * p.ldx), 0,
                                                         rows ? (rows - 1) * ldx_b + p.KA * 4 : 0, 0x00020000);
   // the scale vectors of this split's rows (rows past the split read as scale 0: their values read as 0 as well)
   const int rows_pad = (rows + kTnKC - 1) / kTnKC * kTnKC;   // the arrays are padded to whole chunks (scale 0), rbase % 32 == 0
@@ -1466,6 +1472,46 @@ extern "C" int mma_gemm_bf16x3_tn(const float* X, int64_t ldx, const float* G, i
   if (int rc = check_launch("gemm_x3_tn_kernel")) return rc;
   if (s == 1) return 0;
   return mma_col_sum(ws, (int64_t)KA * NC, s, KA * NC, C, nullptr, 0, stream);      // <= 512 rows: one pass, fixed order
+}
+
+// B independent TN products in ONE launch: C[b] (KA,NC) = X_b^T G_b with X_b = X + b*xb, G_b = G + b*gb (column blocks of wider rows).
+// The per-tower weight gradients of MMAConv's post-NN (5 products of 48 x 152 over 2 * 10^5 rows at ZINC's shape) were five
+// launches + five reductions of 0.08 ms each; the row ranges are cut for the whole batch (splits * column blocks * B workgroups).
+static int tn_splits_batched(int64_t M, int NC, int B) {
+  const int64_t n_cb = ((int64_t)NC + 127) / 128;
+  int64_t s = 512 / (n_cb * B);
+  const int64_t max_s = M / (8 * kTnKC) + 1;
+  if (s > max_s) s = max_s;
+  if (s >= 8) s = s / 8 * 8;
+  return (int)(s < 1 ? 1 : s);
+}
+extern "C" int64_t mma_gemm_bf16x3_tn_batched_workspace_floats(int64_t M, int32_t KA, int32_t NC, int32_t B) {
+  if (M <= 0 || KA <= 0 || NC <= 0 || B <= 0) return 0;
+  const int s = tn_splits_batched(M, NC, B);
+  return s > 1 ? (int64_t)s * B * KA * NC : 0;
+}
+extern "C" int mma_gemm_bf16x3_tn_batched(const float* X, int64_t ldx, int64_t xb, const float* G, int64_t ldg, int64_t gb, float* C, float* ws,
+                                          int64_t ws_floats, int64_t M, int32_t KA, int32_t NC, int32_t B, void* stream) {
+  MMA_REQUIRE(M >= 1 && KA >= 1 && KA <= 128 && NC >= 1 && B >= 1 && B <= 65535 && (int64_t)KA * NC * B < (1LL << 31),
+              "M=%lld KA=%d NC=%d B=%d: need 1 <= KA <= 128, NC >= 1, 1 <= B <= 65535", (long long)M, KA, NC, B);
+  MMA_REQUIRE(X && G && C && xb >= 0 && gb >= 0 && ldx >= xb * (B - 1) + KA && ldg >= gb * (B - 1) + NC && ldx < (1 << 24) && ldg < (1 << 24),
+              "NULL argument, or the B column blocks do not fit the row pitch");
+  MMA_REQUIRE((reinterpret_cast<uintptr_t>(X) & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & 3) == 0, "misaligned argument");
+  const int s = tn_splits_batched(M, NC, B);
+  MMA_REQUIRE(s == 1 || (ws && ws_floats >= (int64_t)s * B * KA * NC), "workspace too small: %lld floats, need %lld",
+              (long long)ws_floats, (long long)s * B * KA * NC);
+  int64_t rps = (M + s - 1) / s;
+  rps = (rps + kTnKC - 1) / kTnKC * kTnKC;
+  MMA_REQUIRE((rps + kTnKC) * (ldx > ldg ? ldx : ldg) * 4 < (1LL << 31), "row range of one split exceeds a 2 GB buffer window");
+  TnParams p{X, ldx, G, ldg, s == 1 ? C : ws, M, rps, KA, NC, s};
+  p.xb = xb; p.gb = gb; p.part_ss = (int64_t)B * KA * NC;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(((NC + 127) / 128) * s), (unsigned)B);
+  if (NC % 128 == 0 && KA % 32 == 0) hipLaunchKernelGGL(gemm_x3_tn_kernel<true>, grid, dim3(kBlock), 0, st, p);
+  else hipLaunchKernelGGL(gemm_x3_tn_kernel<false>, grid, dim3(kBlock), 0, st, p);
+  if (int rc = check_launch("gemm_x3_tn_kernel (batched)")) return rc;
+  if (s == 1) return 0;
+  return mma_col_sum(ws, (int64_t)B * KA * NC, s, B * KA * NC, C, nullptr, 0, stream);      // <= 512 rows: one pass, fixed order
 }
 
 static int64_t tn_pad32(int64_t M) { return (M + 31) / 32 * 32; }

@@ -869,9 +869,14 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
     const int f = c - (int)t * p.F;
     const float* go = p.gout + ((size_t)node * p.T + t) * ((size_t)p.S * p.K * p.F) + f;
     // one batch of loads: the K*S gradient blocks (slots past K*S re-read the last one and are dropped) + the arg bytes
+    // (round 3: blocks past K*S are not loaded at all - with the scalers factored out of `out`, K*S is 2 at ZINC's shape and the six
+    // clamped re-reads of the last block were most of this batch)
     Vec<4> gv[kBlkMaxKS];
 #pragma unroll
-    for (int i = 0; i < kBlkMaxKS; ++i) gv[i] = ldv_nt<4>(go + (size_t)min(i, KS - 1) * p.F);
+    for (int i = 0; i < kBlkMaxKS; ++i) {
+      gv[i] = vzero<4>();
+      if (i < KS) gv[i] = ldv_nt<4>(go + (size_t)i * p.F);          // wave-uniform condition
+    }
     uint32_t wn = 0xFFFFFFFFu, wx = 0xFFFFFFFFu;
     if ((NEEDS & NEED_MIN) && p.amin8) wn = ldb<4>(p.amin8 + (size_t)node * p.ldsave + c);     // NULL: no min in the aggregator list
     if ((NEEDS & NEED_MAX) && p.amax8) wx = ldb<4>(p.amax8 + (size_t)node * p.ldsave + c);

@@ -1,0 +1,522 @@
+// K13 / K14: MMAConv's per-tower post-NN Linear on the aggregates with the degree scalers FACTORED OUT of the aggregate tensor
+// (reference graph_regression/mma_conv.py:181-196 builds out = cat_q(agg * prod_{q' <= q} scaler_q'(deg)) of width S*K*F per tower,
+// then :132-134 applies post_nns[t] = Linear((K*S+1)*F -> F_out) to cat[x, out]).  The scalers are per-TARGET row factors, so
+//     y[n,t,o] = sum_q pre_q(deg_n) * sum_{k,f} agg[n,t,k,f] * Wo[t][o][(q*K+k)*F+f],     pre_q = prod_{q' <= q} scaler_q'
+// and neither the (N,T,S*K*F) tensor `out` nor its gradient ever exists: K3 runs with the identity scaler only and leaves the K
+// unscaled aggregates (N,T,K*F) - a third of the bytes at ZINC's S = 3 -, K4 takes their gradient.
+//   K13  mma_tower_post_fwd : y from agg                                  (replaces the strided-batched library GEMM)
+//   K14  mma_tower_post_bwd : gagg[n,t,kf] = sum_q pre_q sum_o gy[n,t,o] Wo[..], and gys[n,t,q,o] = pre_q gy[n,t,o], the left operand
+//                             of the weight gradient gW[t][q][o][kf] = sum_n gys[n,t,q,o] agg[n,t,kf] (a TN product on the matrix
+//                             cores: mma_gemm_bf16x3_tn per tower)                (replaces K9 tower_bwd_kernel)
+// Both are small GEMMs per (64 nodes, tower) with a 16-wide output dimension per scaler - run on the matrix cores in EXACT fp32:
+// v_mfma_f32_16x16x4_f32 (one rounding per product, fp32 accumulate: a k-ordered fmaf chain; 64 FLOP/clk/SIMD like the VALU, but
+// one VGPR per operand and no broadcast traffic).  A 16-row tile IS one scaler q (rows = its 16 padded outputs), so S*16 rows tile
+// exactly; a wavefront owns 64 nodes = four 16-column tiles.
+//   forward : D_q[o][node] = sum_kf Wa[kf][q*16+o] * agg[node][kf];  epilogue y[o] = sum_q pre_q[node] D_q[o][node]: the C/D map puts
+//             the node on the lane (column) and 4 consecutive o in its 4 registers - the scaler sum never leaves the lane;
+//   backward: D[kf][node] = sum_r Wb[r][kf] * gys[node][r], r = (q,o): the B fragments are the lane's own scaled gradients (registers).
+// The tower's weights sit in LDS for the whole workgroup (30 KB at ZINC's shape), aggregate rows enter / leave as whole 128-byte row
+// segments through a wave-private LDS tile.  (A first version kept lane = node on the VALU with the 16 weights of a (q, kf) as SGPR
+// operands from s_load_dwordx16: 0.41 / 1.02 ms at C2L - the 29 KB weight sweep of every wave thrashes the 16 KB scalar cache.)
+#include "common.h"
+
+namespace mma {
+
+constexpr int kPostO = 16;        // outputs per tower, padded (ZINC: 15)
+constexpr int kPostMaxS = 5;      // scalers (identity, amplification, attenuation, linear, inverse_linear)
+constexpr int kPostTile = 32;     // kf columns per LDS tile round
+constexpr int kPostPrePitch = 8;   // floats per node in the table of scaler products K14 leaves for K15
+constexpr int kPostPitch = 34;    // tile pitch: (j*34 + k) mod 32 is distinct over the 16 x 2 lanes one ds_read_b32 group covers
+typedef float post_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float post_scaler(int code, float deg, float avg_log, float avg_lin) {
+  switch (code) {       // mma_conv.py:183-192
+    case MMA_SC_AMPLIFICATION: return logf(deg + 1.f) / avg_log;
+    case MMA_SC_ATTENUATION: return avg_log / logf(deg + 1.f);
+    case MMA_SC_LINEAR: return deg / avg_lin;
+    case MMA_SC_INVERSE_LINEAR: return avg_lin / deg;
+    default: return 1.f;
+  }
+}
+
+struct PostParams {
+  int64_t N; int T, KF, KFp, S, O;          // KFp: KF rounded up to kPostTile (the padded weight rows / columns are zero)
+  int64_t lda, ldy, ldg, ldgs;
+  uint32_t scaler_pack; float avg_log, avg_lin;
+  int vec4;                 // rows of agg / gagg are 16-byte aligned (pitch % 4 == 0, KF % 4 == 0): float4 row segments; else dwords
+  const float* bias;        // PLAIN forward only, may be NULL
+};
+
+// running products of the scalers for one node, in the reference's multiplication order ((v f0) f1) ...
+template <int S>
+__device__ __forceinline__ void post_pre(const PostParams& p, const int32_t* __restrict__ rowptr, int64_t node, bool valid, float (&pre)[S]) {
+  const float deg = valid ? (float)max(rowptr[node + 1] - rowptr[node], 1) : 1.f;      // degree(...).clamp_(1), mma_conv.py:178-179
+  float run = 1.f;
+#pragma unroll
+  for (int q = 0; q < S; ++q) {
+    run = run * post_scaler((int)((p.scaler_pack >> (4 * q)) & 15u), deg, p.avg_log, p.avg_lin);
+    pre[q] = run;
+  }
+}
+
+// The aggregate tiles are WAVE-private: a wave's LDS accesses execute in order, so its own writes are visible to its own later reads
+// without a workgroup barrier; only the compiler has to keep the order.  (With __syncthreads() per tile round the four waves load,
+// multiply and store in lockstep - nobody multiplies while anybody loads: 0.35 ms; free-running waves overlap each other's phases.)
+__device__ __forceinline__ void post_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void post_stage_weights(float* dst, const float* __restrict__ src, int n_floats) {
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  for (int i = threadIdx.x; i < n_floats / 4; i += kBlock) d4[i] = s4[i];
+}
+
+// rows n0..n0+63, columns [kf0, kf0+32) of tower t -> registers (coalesced 128-byte row segments; 8 lanes per node row) -> the wave's LDS tile
+__device__ __forceinline__ void post_tile_fetch(const PostParams& p, const float* __restrict__ agg, int64_t n0, int t, int kf0, bool tvalid,
+                                                int lane, float4 (&v)[8]) {
+  const int lrow = lane >> 3, lq = lane & 7;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int row = r * 8 + lrow;
+    const int col = kf0 + lq * 4;
+    v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tvalid && n0 + row < p.N && col < p.KF) {
+      const float* src = agg + (size_t)(n0 + row) * p.lda + (size_t)t * p.KF + col;
+      if (p.vec4) {                                            // KF % 4 == 0: a quad is inside or outside
+        v[r] = *reinterpret_cast<const float4*>(src);
+      } else {                                                 // odd widths / pitches (the 75-wide Linear layers): dwords, guarded
+        v[r].x = src[0];
+        if (col + 1 < p.KF) v[r].y = src[1];
+        if (col + 2 < p.KF) v[r].z = src[2];
+        if (col + 3 < p.KF) v[r].w = src[3];
+      }
+    }
+  }
+}
+__device__ __forceinline__ void post_tile_put(float* tile, int lane, const float4 (&v)[8]) {
+  const int lrow = lane >> 3, lq = lane & 7;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float2* d = reinterpret_cast<float2*>(tile + (r * 8 + lrow) * kPostPitch + lq * 4);   // pitch 34: 8-byte aligned
+    d[0] = make_float2(v[r].x, v[r].y); d[1] = make_float2(v[r].z, v[r].w);
+  }
+}
+
+// y[n, t*O + o] = sum_q pre_q sum_kf agg[n, t*KF + kf] * Wa[t][kf][q*16 + o]
+// PLAIN: a plain skinny Linear, y[n, r] = bias[r] + sum_kf x[n, kf] * Wa[kf][r] for r < O <= S*16 - every 16-row tile is 16 more
+// outputs instead of one more scaler (the 75 -> 75 Linear layers around the fused kernels: x-part of the post-NN, `lin`)
+template <int S, bool PLAIN>
+__global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams p, const float* __restrict__ agg, const int32_t* __restrict__ rowptr,
+                                                                const float* __restrict__ Wa, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float post_smem[];
+  constexpr int R = S * kPostO;                                // weight columns per kf row
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* Wl = post_smem;                                       // (KFp, R)
+  float* tile = post_smem + (size_t)p.KFp * R + wave * (kWave * kPostPitch);
+  const int t = (int)blockIdx.y;
+  const int64_t nblk = (int64_t)blockIdx.x * (kBlock / kWave) + wave;
+  const bool tvalid = nblk * kWave < p.N;                      // wave-uniform; the block-wide barriers below are still joined
+  const int64_t n0 = (tvalid ? nblk : 0) * kWave;
+  post_stage_weights(Wl, Wa + (size_t)t * p.KFp * R, p.KFp * R);      // visible after the barrier below
+  const int j = lane & 15, kq = lane >> 4;                     // MFMA 16x16x4 operand lane: row/column j, k index kq
+  post_f32x4 acc[4][S];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int q = 0; q < S; ++q) acc[nt][q] = post_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 nxt[8];
+  post_tile_fetch(p, agg, n0, t, 0, tvalid, lane, nxt);
+  __syncthreads();                                             // weights staged
+  for (int kf0 = 0; kf0 < p.KFp; kf0 += kPostTile) {
+    post_tile_put(tile, lane, nxt);
+    post_wave_sync();
+    if (kf0 + kPostTile < p.KFp) post_tile_fetch(p, agg, n0, t, kf0 + kPostTile, tvalid, lane, nxt);   // in flight behind the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < kPostTile / 4; ++ks) {
+      const int kf = kf0 + 4 * ks + kq;
+      float a[S], b[4];
+#pragma unroll
+      for (int q = 0; q < S; ++q) a[q] = Wl[kf * R + q * kPostO + j];               // A[i = o][k = kf]
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) b[nt] = tile[(nt * 16 + j) * kPostPitch + 4 * ks + kq];   // B[k = kf][j = node]
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int q = 0; q < S; ++q) acc[nt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[nt], acc[nt][q], 0, 0, 0);
+    }
+    post_wave_sync();
+  }
+  // C/D map of 16x16: column = lane & 15 (the node), row = 4 * (lane >> 4) + reg (the output o): y[o] = sum_q pre_q D_q[o]
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int64_t node = n0 + nt * 16 + j;
+    const bool valid = tvalid && node < p.N;
+    if (PLAIN) {
+      if (valid) {
+#pragma unroll
+        for (int q = 0; q < S; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int col = q * kPostO + 4 * kq + r;
+            if (col < p.O) y[(size_t)node * p.ldy + col] = acc[nt][q][r] + (p.bias ? p.bias[col] : 0.f);
+          }
+      }
+      continue;
+    }
+    float pre[S];
+    post_pre<S>(p, rowptr, node, valid, pre);
+    float yv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < S; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yv[r] = fmaf(pre[q], acc[nt][q][r], yv[r]);
+    if (valid) {
+      float* yr = y + (size_t)node * p.ldy + (size_t)t * p.O + 4 * kq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * kq + r < p.O) yr[r] = yv[r];
+    }
+  }
+}
+
+// gagg[n, t*KF + kf] = sum_r gys[n][r] * Wb[t][r][kf],  r = q*16 + o,  gys[n][r] = pre_q gy[n, t*O + o]   (also stored, optional)
+// PLAIN: gx[n, kf] = sum_r gy[n, r] * Wb[r][kf], r < O <= S*16 (the dL/dx of the plain skinny Linear)
+template <int S, bool PLAIN>
+__global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams p, const float* __restrict__ gy, const int32_t* __restrict__ rowptr,
+                                                                const float* __restrict__ Wb, int wb_pitch, float* __restrict__ gagg,
+                                                                float* __restrict__ gys, float* __restrict__ pre_out) {
+  extern __shared__ __attribute__((aligned(16))) float post_smem[];
+  constexpr int R = S * kPostO;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* Wl = post_smem;                                       // (R, wb_pitch): pitch = KFp + 16, so that k and k+1 fall on different banks
+  float* tile = post_smem + (size_t)R * wb_pitch + wave * (kWave * kPostPitch);
+  const int t = (int)blockIdx.y;
+  const int64_t nblk = (int64_t)blockIdx.x * (kBlock / kWave) + wave;
+  const bool tvalid = nblk * kWave < p.N;
+  const int64_t n0 = (tvalid ? nblk : 0) * kWave;
+  post_stage_weights(Wl, Wb + (size_t)t * R * wb_pitch, R * wb_pitch);
+  const int j = lane & 15, kq = lane >> 4;
+  // B fragments: this lane's node (per 16-node tile nt) and its k index kq: gys[node][4*s + kq], s = 0 .. R/4 - 1
+  float bf[4][R / 4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int64_t node = n0 + nt * 16 + j;
+    const bool valid = tvalid && node < p.N;
+    if (PLAIN) {
+#pragma unroll
+      for (int s = 0; s < R / 4; ++s) bf[nt][s] = (valid && 4 * s + kq < p.O) ? gy[(size_t)node * p.ldg + 4 * s + kq] : 0.f;
+      continue;
+    }
+    float pre[S];
+    post_pre<S>(p, rowptr, node, valid, pre);
+    if (pre_out && valid && kq == 0 && blockIdx.y == 0) {      // the scaler products of every node, once: K15 reads them per k-step
+#pragma unroll
+      for (int q = 0; q < S; ++q) pre_out[(size_t)node * kPostPrePitch + q] = pre[q];
+    }
+    // r = 4*s + kq  ->  o = r % 16 = 4*(s % 4) + kq,  q = s / 4: the lane needs gy[o] for o = kq, 4 + kq, 8 + kq, 12 + kq
+    float g4[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) g4[m] = (valid && 4 * m + kq < p.O) ? gy[(size_t)node * p.ldg + (size_t)t * p.O + 4 * m + kq] : 0.f;
+#pragma unroll
+    for (int s = 0; s < R / 4; ++s) bf[nt][s] = pre[s / 4] * g4[s % 4];
+    if (gys && valid) {          // the left operand of the weight-gradient product; 4-byte stores, 16 lanes of a node tile cover 64 B runs
+#pragma unroll
+      for (int s = 0; s < R / 4; ++s) gys[(size_t)node * p.ldgs + (size_t)t * R + 4 * s + kq] = bf[nt][s];
+    }
+  }
+  __syncthreads();               // weights staged
+
+  for (int kf0 = 0; kf0 < p.KFp; kf0 += kPostTile) {
+    post_f32x4 acc[2][4];        // two 16-row kf tiles x four node tiles
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[c][nt] = post_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < R / 4; ++s) {
+      const float* wr = Wl + (size_t)(4 * s + kq) * wb_pitch + kf0 + j;              // A[i = kf][k = r]
+      const float a0 = wr[0], a1 = wr[16];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf[nt][s], acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf[nt][s], acc[1][nt], 0, 0, 0);
+      }
+    }
+    // D: column = the node (lane & 15), row = 4 * kq + reg = the kf inside the 16-row tile  ->  tile[node][kf_local]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(nt * 16 + j) * kPostPitch + c * 16 + 4 * kq + r] = acc[c][nt][r];
+    post_wave_sync();
+    {
+      const int lrow = lane >> 3, lq = lane & 7;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = r * 8 + lrow;
+        const int col = kf0 + lq * 4;
+        if (tvalid && n0 + row < p.N && col < p.KF) {
+          const float* sp = tile + row * kPostPitch + lq * 4;
+          float* dst = gagg + (size_t)(n0 + row) * p.lda + (size_t)t * p.KF + col;
+          if (p.vec4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+          } else {
+            dst[0] = sp[0];
+            if (col + 1 < p.KF) dst[1] = sp[1];
+            if (col + 2 < p.KF) dst[2] = sp[2];
+            if (col + 3 < p.KF) dst[3] = sp[3];
+          }
+        }
+      }
+    }
+    post_wave_sync();
+  }
+}
+
+// K15: the weight gradient of the factored post-NN, gW[t][q*16 + o][kf] = sum_n pre_q(deg_n) gy[n, t*O + o] agg[n, t*KF + kf], as a TN
+// product on the fp32 matrix cores with the NODE as the reduction index (v_mfma_f32_16x16x4_f32: four nodes per instruction).  A wave
+// walks its own contiguous node range and keeps S x G accumulator tiles (G = 5 or 10 kf tiles of 16 columns per pass) for the
+// whole range; both operands come straight from memory in the MFMA's own lane order - A[i = o][k = node] = pre_q gy (16 lanes read 64
+// consecutive bytes of a gy row, the scalers are re-evaluated per node), B[k = node][j = kf] = agg (64-byte runs of four rows) - no
+// LDS, no scaled copy of gy (round 3's first form wrote gys (N, T*S*16) and ran five TN launches of the bf16x3 kernel: 0.4-0.5 ms).
+// The per-wave partial tiles are summed in a fixed order by mma_col_sum.
+template <int S>
+__global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams p, const float* __restrict__ gy, const float* __restrict__ agg,
+                                                               const float* __restrict__ pre_tab, float* __restrict__ part, int64_t npw,
+                                                               int kfp16) {
+  constexpr int G = S <= 2 ? 10 : 5;                           // kf tiles per pass: S*G accumulator tiles + two operand groups in flight
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int t = (int)blockIdx.y;
+  const int64_t chunk = (int64_t)blockIdx.x * (kBlock / kWave) + wave;
+  const int64_t nb = chunk * npw, ne = min(p.N, nb + npw);
+  const int j = lane & 15, kq = lane >> 4;
+  const int n_kft = kfp16 / 16;
+  float* out = part + ((size_t)chunk * p.T + t) * (size_t)(S * kPostO) * kfp16;
+  const int jo = j < p.O ? j : 0;                              // clamped column of gy (the value is zeroed by a select)
+  const int64_t nlast = p.N - 1;
+  for (int kt0 = 0; kt0 < n_kft; kt0 += G) {
+    post_f32x4 acc[S][G];
+#pragma unroll
+    for (int q = 0; q < S; ++q)
+#pragma unroll
+      for (int c = 0; c < G; ++c) acc[q][c] = post_f32x4{0.f, 0.f, 0.f, 0.f};
+    // The raw operands of a k-step (4 nodes) are requested a whole step AHEAD of the MFMAs that use them, by UNCONDITIONAL loads from
+    // clamped addresses (zeroed by selects at use): a conditional load sits in its own exec branch and the first dependent use - the
+    // row pointers of the first version, whose scaler products were re-evaluated here - made the wave wait for every load it had just
+    // issued (one memory round trip per k-step: 0.43 ms, the matrix pipe idle three quarters of the time).  The scaler products come
+    // from the table K14 wrote.
+    struct Raw { float g; float pre[S]; float b[G]; bool valid; };
+    auto fetch = [&](int64_t n4, Raw& r) {
+      const int64_t node = n4 + kq;
+      r.valid = node < ne;
+      const int64_t nc = node < nlast ? node : nlast;
+      r.g = gy[(size_t)nc * p.ldg + (size_t)t * p.O + jo];
+#pragma unroll
+      for (int q = 0; q < S; ++q) r.pre[q] = pre_tab[(size_t)nc * kPostPrePitch + q];
+#pragma unroll
+      for (int c = 0; c < G; ++c) {
+        const int col = min((kt0 + c) * 16 + j, p.KF - 1);
+        r.b[c] = agg[(size_t)nc * p.lda + (size_t)t * p.KF + col];
+      }
+    };
+    auto multiply = [&](const Raw& r) {
+      const float g = (r.valid && j < p.O) ? r.g : 0.f;
+      float b[G];
+#pragma unroll
+      for (int c = 0; c < G; ++c) b[c] = (r.valid && (kt0 + c) * 16 + j < p.KF) ? r.b[c] : 0.f;
+#pragma unroll
+      for (int q = 0; q < S; ++q) {
+        const float a = r.pre[q] * g;
+#pragma unroll
+        for (int c = 0; c < G; ++c) acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c], acc[q][c], 0, 0, 0);
+      }
+    };
+    Raw r0, r1;                                                // two operand sets used in turn (no register copies: a copy of a set
+    fetch(nb, r0);                                             // that is still in flight is a wait for it in the middle of the MFMAs)
+    for (int64_t n4 = nb; n4 < ne; n4 += 8) {
+      fetch(n4 + 4, r1);
+      __builtin_amdgcn_sched_barrier(0);                       // the scheduler otherwise sinks these loads to their first use
+      multiply(r0);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(n4 + 8, r0);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(r1);                                            // past the range: valid is false, the operands are zeros
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // D: row = 4 * kq + reg = o, column = lane & 15 = kf inside the tile
+#pragma unroll
+    for (int q = 0; q < S; ++q)
+#pragma unroll
+      for (int c = 0; c < G; ++c) {
+        if (kt0 + c < n_kft) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[(size_t)(q * kPostO + 4 * kq + r) * kfp16 + (kt0 + c) * 16 + j] = acc[q][c][r];
+        }
+      }
+  }
+}
+
+static int64_t post_gw_npw(int64_t N, int T) {
+  // about two waves per SIMD over the whole grid (1024 SIMDs), node ranges in multiples of 64
+  int64_t waves = 2048 / (T < 1 ? 1 : T);
+  if (waves < 4) waves = 4;
+  int64_t npw = (N + waves - 1) / waves;
+  npw = (npw + 63) / 64 * 64;
+  return npw < 64 ? 64 : npw;
+}
+
+static int post_fill(PostParams* p, int64_t N, int T, int KF, int S, int O, const uint8_t* scaler_host, float avg_log, float avg_lin) {
+  MMA_REQUIRE(N >= 0 && N < (1LL << 31) && T >= 1 && T <= 65535 && KF >= 1 && KF <= 512 && S >= 1 && S <= kPostMaxS &&
+              O >= 1 && (scaler_host ? O <= kPostO : O <= S * kPostO), "N=%lld T=%d KF=%d S=%d O=%d unsupported (KF <= 512, S <= %d, O <= %d)",
+              (long long)N, T, KF, S, O, kPostMaxS, kPostO);
+  p->scaler_pack = 0;
+  for (int q = 0; scaler_host && q < S; ++q) {
+    MMA_REQUIRE(scaler_host[q] <= MMA_SC_INVERSE_LINEAR, "scaler[%d]=%d is not an MMA_SC_* code", q, (int)scaler_host[q]);
+    p->scaler_pack |= (uint32_t)scaler_host[q] << (4 * q);
+  }
+  p->N = N; p->T = T; p->KF = KF; p->KFp = (KF + kPostTile - 1) / kPostTile * kPostTile; p->S = S; p->O = O; p->avg_log = avg_log; p->avg_lin = avg_lin;
+  return 0;
+}
+
+static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+static unsigned post_lds_bytes(int KFp, int S, bool bwd) {
+  const int R = S * kPostO;
+  return (unsigned)(((size_t)(bwd ? R * (KFp + 16) : KFp * R) + (size_t)(kBlock / kWave) * kWave * kPostPitch) * sizeof(float));
+}
+
+}  // namespace mma
+
+using namespace mma;
+
+#define MMA_POST_LAUNCH(KERNEL, LDS, ...)                                                                              \
+  switch (S) {                                                                                                         \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;                       \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;                       \
+    case 3: hipLaunchKernelGGL((KERNEL<3>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;                       \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;                       \
+    default: hipLaunchKernelGGL((KERNEL<5>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;                      \
+  }
+#define MMA_POST_LAUNCH2(KERNEL, PLAIN, LDS, ...)                                                                      \
+  switch (S) {                                                                                                         \
+    case 1: hipLaunchKernelGGL((KERNEL<1, PLAIN>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;                \
+    case 2: hipLaunchKernelGGL((KERNEL<2, PLAIN>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;                \
+    case 3: hipLaunchKernelGGL((KERNEL<3, PLAIN>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;                \
+    case 4: hipLaunchKernelGGL((KERNEL<4, PLAIN>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;                \
+    default: hipLaunchKernelGGL((KERNEL<5, PLAIN>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;               \
+  }
+
+// padded weight shapes the caller prepares: forward Wa (T, KFp, S*16), backward Wb (T, S*16, KFp + 16), KFp = mma_tower_post_kfp(KF)
+extern "C" int64_t mma_tower_post_kfp(int32_t KF) { return KF < 1 ? -1 : ((int64_t)KF + kPostTile - 1) / kPostTile * kPostTile; }
+
+extern "C" int mma_tower_post_fwd(const float* agg, int64_t lda, const int32_t* rowptr, const float* Wa, float* y, int64_t ldy,
+                                  int64_t N, int32_t T, int32_t KF, int32_t S, int32_t O, const uint8_t* scaler_host, float avg_log,
+                                  float avg_lin, void* stream) {
+  PostParams p{};
+  if (int rc = post_fill(&p, N, T, KF, S, O, scaler_host, avg_log, avg_lin)) return rc;
+  if (N == 0) return 0;
+  MMA_REQUIRE(scaler_host != nullptr, "NULL scaler codes");
+  MMA_REQUIRE(agg && rowptr && Wa && y && al16(Wa) && lda >= (int64_t)T * KF && ldy >= (int64_t)T * O && (reinterpret_cast<uintptr_t>(agg) & 3) == 0,
+              "NULL / misaligned argument or row pitch too small");
+  p.lda = lda; p.ldy = ldy; p.vec4 = (KF % 4 == 0 && lda % 4 == 0 && al16(agg)) ? 1 : 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned lds = post_lds_bytes(p.KFp, S, false);
+  MMA_REQUIRE(lds <= 160 * 1024, "the tower's weights (%u bytes with the tiles) do not fit the LDS", lds);
+  // tower = blockIdx.y; 256 nodes (four waves x 64) per workgroup
+  const dim3 grid((unsigned)(((N + kWave - 1) / kWave + kBlock / kWave - 1) / (kBlock / kWave)), (unsigned)T);
+  MMA_POST_LAUNCH2(tower_post_fwd_kernel, false, lds, agg, rowptr, Wa, y)
+  return check_launch("tower_post_fwd_kernel");
+}
+
+extern "C" int64_t mma_tower_post_gw_chunks(int64_t N, int32_t T) {
+  if (N <= 0 || T <= 0) return 0;
+  const int64_t npw = post_gw_npw(N, T);
+  return ((N + npw - 1) / npw + kBlock / kWave - 1) / (kBlock / kWave) * (kBlock / kWave);        // whole workgroups of four waves
+}
+
+extern "C" int mma_tower_post_gw(const float* gy, int64_t ldg, const float* agg, int64_t lda, const float* pre, float* part,
+                                 int64_t n_chunks, int64_t N, int32_t T, int32_t KF, int32_t S, int32_t O, const uint8_t* scaler_host,
+                                 float avg_log, float avg_lin, void* stream) {
+  PostParams p{};
+  if (int rc = post_fill(&p, N, T, KF, S, O, scaler_host, avg_log, avg_lin)) return rc;
+  MMA_REQUIRE(n_chunks == mma_tower_post_gw_chunks(N, T), "n_chunks=%lld, expected mma_tower_post_gw_chunks(N, T)=%lld", (long long)n_chunks,
+              (long long)mma_tower_post_gw_chunks(N, T));
+  if (N == 0) return 0;
+  MMA_REQUIRE(gy && agg && pre && part && lda >= (int64_t)T * KF && ldg >= (int64_t)T * O, "NULL argument or row pitch too small");
+  p.lda = lda; p.ldg = ldg;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int kfp16 = (KF + 15) / 16 * 16;
+  const int64_t npw = post_gw_npw(N, T);
+  const dim3 grid((unsigned)(n_chunks / (kBlock / kWave)), (unsigned)T);
+  MMA_POST_LAUNCH(tower_post_gw_kernel, 0, gy, agg, pre, part, npw, kfp16)
+  return check_launch("tower_post_gw_kernel");
+}
+
+extern "C" int mma_tower_post_bwd(const float* gy, int64_t ldg, const int32_t* rowptr, const float* Wb, float* gagg, int64_t lda,
+                                  float* gys, int64_t ldgs, float* pre_out, int64_t N, int32_t T, int32_t KF, int32_t S, int32_t O,
+                                  const uint8_t* scaler_host, float avg_log, float avg_lin, void* stream) {
+  PostParams p{};
+  if (int rc = post_fill(&p, N, T, KF, S, O, scaler_host, avg_log, avg_lin)) return rc;
+  if (N == 0) return 0;
+  MMA_REQUIRE(scaler_host != nullptr, "NULL scaler codes");
+  MMA_REQUIRE(gy && rowptr && Wb && gagg && al16(Wb) && lda >= (int64_t)T * KF && ldg >= (int64_t)T * O && (reinterpret_cast<uintptr_t>(gagg) & 3) == 0,
+              "NULL / misaligned argument or row pitch too small");
+  MMA_REQUIRE(!gys || ldgs >= (int64_t)T * S * kPostO, "gys needs a pitch >= T*S*16 floats");
+  p.lda = lda; p.ldg = ldg; p.ldgs = ldgs; p.vec4 = (KF % 4 == 0 && lda % 4 == 0 && al16(gagg)) ? 1 : 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned lds = post_lds_bytes(p.KFp, S, true);
+  MMA_REQUIRE(lds <= 160 * 1024, "the tower's weights (%u bytes with the tiles) do not fit the LDS", lds);
+  const int wb_pitch = p.KFp + 16;
+  const dim3 grid((unsigned)(((N + kWave - 1) / kWave + kBlock / kWave - 1) / (kBlock / kWave)), (unsigned)T);
+  MMA_POST_LAUNCH2(tower_post_bwd_kernel, false, lds, gy, rowptr, Wb, wb_pitch, gagg, gys, pre_out)
+  return check_launch("tower_post_bwd_kernel");
+}
+
+// ---- K16: a plain skinny Linear on the same kernels (PLAIN): y (N,O) = x (N,K) Wa + bias, gx (N,K) = gy (N,O) Wb, O <= 80, K <= 512 --
+// The 75 -> 75 Linear layers around MMAConv's fused kernels (the x-part of the post-NN, `lin`: mma_conv.py:99-105,132-136) are four
+// library GEMMs per layer step at ~0.11 ms each for 61 MB in / 61 MB out (rocBLAS picks a 16x256 macro tile for a 75-wide output).
+// Wa (KFp, S*16) / Wb (S*16, KFp + 16) zero-padded as for mma_tower_post_*, S = ceil(O / 16), KFp = mma_tower_post_kfp(K).
+extern "C" int mma_skinny_linear_fwd(const float* x, int64_t ldx, const float* Wa, const float* bias, float* y, int64_t ldy,
+                                     int64_t N, int32_t K, int32_t O, void* stream) {
+  MMA_REQUIRE(O >= 1 && O <= kPostMaxS * kPostO, "O=%d unsupported (<= %d)", O, kPostMaxS * kPostO);
+  const int S = (O + kPostO - 1) / kPostO;
+  PostParams p{};
+  if (int rc = post_fill(&p, N, 1, K, S, O, nullptr, 1.f, 1.f)) return rc;
+  if (N == 0) return 0;
+  MMA_REQUIRE(x && Wa && y && al16(Wa) && ldx >= K && ldy >= O && (reinterpret_cast<uintptr_t>(x) & 3) == 0, "NULL / misaligned argument or row pitch too small");
+  p.lda = ldx; p.ldy = ldy; p.bias = bias; p.vec4 = (K % 4 == 0 && ldx % 4 == 0 && al16(x)) ? 1 : 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned lds = post_lds_bytes(p.KFp, S, false);
+  MMA_REQUIRE(lds <= 160 * 1024, "the weights (%u bytes with the tiles) do not fit the LDS", lds);
+  const dim3 grid((unsigned)(((N + kWave - 1) / kWave + kBlock / kWave - 1) / (kBlock / kWave)), 1u);
+  const int32_t* rowptr = nullptr;
+  MMA_POST_LAUNCH2(tower_post_fwd_kernel, true, lds, x, rowptr, Wa, y)
+  return check_launch("tower_post_fwd_kernel (plain)");
+}
+
+extern "C" int mma_skinny_linear_bwd_dx(const float* gy, int64_t ldg, const float* Wb, float* gx, int64_t ldx,
+                                        int64_t N, int32_t K, int32_t O, void* stream) {
+  MMA_REQUIRE(O >= 1 && O <= kPostMaxS * kPostO, "O=%d unsupported (<= %d)", O, kPostMaxS * kPostO);
+  const int S = (O + kPostO - 1) / kPostO;
+  PostParams p{};
+  if (int rc = post_fill(&p, N, 1, K, S, O, nullptr, 1.f, 1.f)) return rc;
+  if (N == 0) return 0;
+  MMA_REQUIRE(gy && Wb && gx && al16(Wb) && ldx >= K && ldg >= O && (reinterpret_cast<uintptr_t>(gx) & 3) == 0, "NULL / misaligned argument or row pitch too small");
+  p.lda = ldx; p.ldg = ldg; p.vec4 = (K % 4 == 0 && ldx % 4 == 0 && al16(gx)) ? 1 : 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned lds = post_lds_bytes(p.KFp, S, true);
+  MMA_REQUIRE(lds <= 160 * 1024, "the weights (%u bytes with the tiles) do not fit the LDS", lds);
+  const int wb_pitch = p.KFp + 16;
+  const dim3 grid((unsigned)(((N + kWave - 1) / kWave + kBlock / kWave - 1) / (kBlock / kWave)), 1u);
+  const int32_t* rowptr = nullptr;
+  float* gys = nullptr;
+  float* pre_out = nullptr;
+  MMA_POST_LAUNCH2(tower_post_bwd_kernel, true, lds, gy, rowptr, Wb, wb_pitch, gx, gys, pre_out)
+  return check_launch("tower_post_bwd_kernel (plain)");
+}

@@ -279,6 +279,27 @@ def xt_g(x, g, x_row_max=None, g_row_max=None):
     return out
 
 
+def xt_g_batched(x, ka, g, nc, B):
+    """(B, ka, nc): out[b] = x[:, b*ka:(b+1)*ka]^T @ g[:, b*nc:(b+1)*nc] - B independent TN products over the same rows in ONE launch
+    (mma_gemm_bf16x3_tn_batched) where the shape allows, else one xt_g per block."""
+    M = x.shape[0]
+    ok = (USE_BF16X3 and x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32 and M >= _MIN_ROWS_X3 and 8 <= ka <= 128
+          and nc >= 32 and x.stride(1) == 1 and g.stride(1) == 1 and max(x.stride(0), g.stride(0)) < (1 << 24))
+    if ok:
+        n_ws = int(_lib.lib().mma_gemm_bf16x3_tn_batched_workspace_floats(M, ka, nc, B))
+        splits = max(1, n_ws // (B * ka * nc))
+        rows = -(-(-(-M // splits)) // 32) * 32
+        ok = (rows + 32) * max(x.stride(0), g.stride(0)) * 4 < 2 ** 31          # one split's rows through a 32-bit buffer window
+    if not ok:
+        return torch.stack([xt_g(x[:, b * ka:(b + 1) * ka], g[:, b * nc:(b + 1) * nc]) for b in range(B)])
+    out = torch.empty((B, ka, nc), device=x.device, dtype=torch.float32)
+    ws = torch.empty((n_ws,), device=x.device, dtype=torch.float32) if n_ws else None
+    with _span("gemm_x3_tn"):
+        call("mma_gemm_bf16x3_tn_batched", ptr(x), x.stride(0), ka, ptr(g), g.stride(0), nc, ptr(out), ptr(ws), n_ws, M, ka, nc, B,
+             stream_ptr())
+    return out
+
+
 def mm(x, w):
     """x @ w with the split-reduction weight gradient."""
     return _MM.apply(x, w)
@@ -299,26 +320,68 @@ def col_sum(g):
     return out
 
 
+USE_SKINNY = __import__("os").environ.get("MMA_SKINNY_LINEAR", "1") != "0"
+_SKINNY_MIN_ROWS = 4096
+
+
+def _skinny_ok(x2, weight):
+    """K16: tall fp32 rows through a narrow Linear (out <= 80, in <= 512): the 75 -> 75 layers of graph regression.  rocBLAS runs
+    them at ~0.11 ms per GEMM on 2e5 rows (61 MB in, 61 MB out); the fp32 matrix-core kernels stream them."""
+    O, K = weight.shape
+    return (USE_SKINNY and x2.is_cuda and x2.dtype == torch.float32 and weight.dtype == torch.float32 and x2.dim() == 2
+            and x2.shape[0] >= _SKINNY_MIN_ROWS and O <= 80 and K <= 512 and x2.stride(1) == 1)
+
+
+def _skinny_weights(weight):
+    """(Wa (KFp, S*16), Wb (S*16, KFp+16)) zero-padded copies of W (O, K) in the layouts the kernels stage into LDS."""
+    O, K = weight.shape
+    S = -(-O // 16)
+    kfp = int(_lib.lib().mma_tower_post_kfp(K))
+    Wb = torch.zeros((S * 16, kfp + 16), device=weight.device, dtype=torch.float32)
+    Wb[:O, :K] = weight
+    return Wb[:, :kfp].t().contiguous(), Wb
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b over the last dimension (torch_geometric Linear / F.linear: mma_conv.py:82,99-105, mask_aggr.py:50).
-    Forward is the library GEMM; backward replaces autograd's two weak spots for tall inputs: the weight gradient is the
-    split-reduction GEMM (xt_g) and the bias gradient the K8 column sum."""
+    Forward is the library GEMM - or, for tall rows through a narrow layer, the K16 fp32 matrix-core kernel; backward replaces
+    autograd's weak spots for tall inputs: the weight gradient is the split-reduction GEMM (xt_g), the bias gradient the K8 column
+    sum, dL/dx the K16 kernel again."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.skinny = _skinny_ok(x2, weight)
+        if ctx.skinny:
+            O, K = weight.shape
+            Wa, Wb = _skinny_weights(weight)
+            y = torch.empty((x2.shape[0], O), device=x.device, dtype=torch.float32)
+            with _span("skinny_linear_fwd"):
+                call("mma_skinny_linear_fwd", ptr(x2), x2.stride(0), ptr(Wa), ptr(bias.contiguous() if bias is not None else None), ptr(y), O,
+                     x2.shape[0], K, O, stream_ptr())
+            ctx.save_for_backward(x, weight, Wb)
+            return y.view(x.shape[:-1] + (O,))
+        ctx.save_for_backward(x, weight)
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, g):
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors[:2]
         g2 = g.reshape(-1, g.shape[-1])
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.mm(g2, weight).view(x.shape)
+            if ctx.skinny:
+                O, K = weight.shape
+                g2 = g2 if g2.stride(1) == 1 else g2.contiguous()
+                gx2 = torch.empty((g2.shape[0], K), device=g.device, dtype=torch.float32)
+                with _span("skinny_linear_bwd"):
+                    call("mma_skinny_linear_bwd_dx", ptr(g2), g2.stride(0), ptr(ctx.saved_tensors[2]), ptr(gx2), K, g2.shape[0], K, O, stream_ptr())
+                gx = gx2.view(x.shape)
+            else:
+                gx = torch.mm(g2, weight).view(x.shape)
         x2 = x.reshape(-1, x.shape[-1])
-        if ctx.has_bias and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and x2.shape[0] >= 4 * _ROWS_PER_BATCH:
+        if ctx.has_bias and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and x2.shape[0] >= 4 * _ROWS_PER_BATCH and not ctx.skinny:
             # tall input: the bias gradient rides on the weight-gradient GEMM as the row of a ones column appended to x, so the
             # (rows, out) gradient is read once instead of twice (C2L: 2 x 0.13 ms of column sums over 0.62 / 0.65 GB)
             gw1 = xt_g(g2, torch.cat([x2, x2.new_ones((x2.shape[0], 1))], 1))               # (out, in + 1)

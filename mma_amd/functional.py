@@ -518,6 +518,67 @@ class _GRAggregate(torch.autograd.Function):
         return (None, gUV, gz) + (None,) * 10
 
 
+class _TowerPost(torch.autograd.Function):
+    """MMAConv's per-tower post-NN on the UNSCALED aggregates (K13 forward, K14 + one TN product per tower backward):
+        y[n, t*O + o] = sum_q pre_q(deg_n) sum_kf agg[n,t,kf] Wo[t][o][q*KF + kf]
+    = post_nns[t] applied to the `out` of mma_conv.py:181-196 without ever forming that (N,T,S*K*F) tensor or its gradient: the
+    degree scalers are per-target row factors (pre_q = their running product), so they move from the aggregates to the products."""
+
+    @staticmethod
+    def forward(ctx, agg, Wo, rowptr, scalers, avg_log, avg_lin):
+        require_gpu(agg, Wo)
+        N, T, KF = agg.shape
+        O, S = Wo.shape[1], len(scalers)
+        assert Wo.shape == (T, O, S * KF) and O <= 16 and KF % 4 == 0 and S <= 5
+        agg = agg if agg.is_contiguous() else agg.contiguous()
+        KFp = int(_lib.lib().mma_tower_post_kfp(KF))
+        # the weight columns twice, zero-padded: Wa (T, KFp, S*16) [kf][q*16+o] for the forward, Wb (T, S*16, KFp+16) [q*16+o][kf]
+        # for the backward (the tower's weights are staged in LDS in exactly these layouts)
+        Wb = torch.zeros((T, S * 16, KFp + 16), device=agg.device, dtype=torch.float32)
+        Wb.view(T, S, 16, KFp + 16)[:, :, :O, :KF] = Wo.view(T, O, S, KF).permute(0, 2, 1, 3)
+        Wa = Wb[:, :, :KFp].transpose(1, 2).contiguous()
+        y = torch.empty((N, T * O), device=agg.device, dtype=torch.float32)
+        with _span("tower_post_fwd"):
+            call("mma_tower_post_fwd", ptr(agg), T * KF, ptr(rowptr), ptr(Wa), ptr(y), T * O, N, T, KF, S, O, host_codes(scalers),
+                 float(avg_log), float(avg_lin), stream_ptr())
+        ctx.save_for_backward(agg, Wb, rowptr)
+        ctx.cfg = (O, scalers, avg_log, avg_lin)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import dense
+        agg, Wb, rowptr = ctx.saved_tensors
+        O, scalers, avg_log, avg_lin = ctx.cfg
+        N, T, KF = agg.shape
+        S = len(scalers)
+        gy = gy.contiguous()
+        gagg = torch.empty_like(agg)
+        need_w = ctx.needs_input_grad[1]
+        pre = torch.empty((N, 8), device=agg.device, dtype=torch.float32) if need_w else None     # pre_q of every node: K14 -> K15
+        with _span("tower_post_bwd"):
+            call("mma_tower_post_bwd", ptr(gy), T * O, ptr(rowptr), ptr(Wb), ptr(gagg), T * KF, None, 0, ptr(pre), N, T, KF, S, O,
+                 host_codes(scalers), float(avg_log), float(avg_lin), stream_ptr())
+        gWo = None
+        if need_w:
+            # K15: gW[t][q*16+o][kf] = sum_n pre_q gy agg on the fp32 matrix cores (node = reduction index), per-wave partial tiles
+            # summed in a fixed order by K8
+            kfp16 = -(-KF // 16) * 16
+            n_chunks = int(_lib.lib().mma_tower_post_gw_chunks(N, T))
+            part = torch.empty((n_chunks, T * S * 16 * kfp16), device=agg.device, dtype=torch.float32)
+            with _span("tower_post_gw"):
+                call("mma_tower_post_gw", ptr(gy), T * O, ptr(agg), T * KF, ptr(pre), ptr(part), n_chunks, N, T, KF, S, O,
+                     host_codes(scalers), float(avg_log), float(avg_lin), stream_ptr())
+                gWq = dense.col_sum(part).view(T, S, 16, kfp16)
+            gWo = gWq[:, :, :O, :KF].permute(0, 2, 1, 3).reshape(T, O, S * KF)
+        return gagg, gWo, None, None, None, None
+
+
+def tower_post(agg, Wo, rowptr, scalers, avg_log, avg_lin):
+    """agg (N,T,K*F) unscaled aggregates, Wo (T,O,S*K*F) post-NN weight columns of `out` (q-major, then k, then f) -> y (N, T*O)."""
+    return _TowerPost.apply(agg, Wo, rowptr, tuple(GR_SCALER[s] for s in scalers), avg_log, avg_lin)
+
+
 def gr_aggregate(inputs, graph, aggregators, scalers, avg_log, avg_lin):
     """aggregate() on given messages (E,T,F) -> (N,T,S*K*F)."""
     E, T, F = inputs.shape

@@ -27,6 +27,7 @@ from .mask_aggr import MaskAggregateLinear
 from .pyg_compat import Linear, reset
 
 _SCATTER_REDUCE = ("sum", "mean", "min", "max")
+FACTOR_SCALERS = __import__("os").environ.get("MMA_FACTOR_SCALERS", "1") != "0"     # 0: materialise `out` (N,T,S*K*F) as in round 2
 
 
 class CategoricalEdges:
@@ -184,9 +185,15 @@ class MMAConv(torch.nn.Module):
                     z_index = edge_attr.types_by_position(graph)
                 else:
                     Z = dense.linear_tall(Fn.rows_by_position(edge_attr, graph), wz, bz)                         # (E, T*Fw) by position
-            out = Fn.gr_fused_conv(UV, Z, graph, T, Fw, self.aggregators, self.scalers,
+            # Round 3: when the post-NN is a single small Linear, the degree scalers - per-target row factors - move from the
+            # aggregates into it (Fn.tower_post): K3 then runs with the identity scaler only and leaves the K UNSCALED aggregates
+            # (N,T,K*Fw), a third of `out` at S = 3; the (N,T,S*K*F) tensor of mma_conv.py:196 and its gradient never exist
+            factored = FACTOR_SCALERS and self.post_layers == 1 and self.F_out <= 16 and len(self.scalers) <= 5 and \
+                all(s_ in Fn.GR_SCALER for s_ in self.scalers)
+            out = Fn.gr_fused_conv(UV, Z, graph, T, Fw, self.aggregators, ["identity"] if factored else self.scalers,
                                    self.avg_deg['log'], self.avg_deg['lin'], self._drop(x.device), z_by_pos=True, z_index=z_index)
         else:
+            factored = False
             src, dst = edge_index[0], edge_index[1]
             if isinstance(edge_attr, CategoricalEdges):
                 edge_attr = edge_attr.dense()
@@ -201,7 +208,10 @@ class MMAConv(torch.nn.Module):
             bp = torch.cat([seq[0].bias for seq in self.post_nns])                       # (T*F_out,)
             Wx = Wp[:, :, :Fi]
             Wo = self._pad_dim(Wp[:, :, Fi:].reshape(T, self.F_out, KS, Fi), 3, Fw).reshape(T, self.F_out, KS * Fw)
-            y = dense.tower_linear(out, Wo)                                              # (N, T, F_out), no copy of `out`
+            if factored:
+                y = Fn.tower_post(out, Wo, graph.by_target.rowptr, self.scalers, self.avg_deg['log'], self.avg_deg['lin']).view(N, T, self.F_out)
+            else:
+                y = dense.tower_linear(out, Wo)                                          # (N, T, F_out), no copy of `out`
             if self.divide_input:
                 y = y + torch.bmm(x.transpose(0, 1), Wx.transpose(1, 2)).transpose(0, 1)
                 out = dense.bias_add(y.reshape(N, T * self.F_out), bp)
