@@ -265,7 +265,7 @@ def nc_config(tag, fixture, H, names, C, p, dev, reps=50, replay=True):
     from mma_amd import functional as Fn
     rowptr, col = golden_csr(fixture)
     N, E, K = len(rowptr) - 1, len(col), len(names)
-    graph = mma_amd.NCGraph(rowptr, col, dev)
+    graph = mma_amd.NCGraph(rowptr, col, dev, H=H)
     layer = make_layer(mma_amd, graph, H, C, names, p, dev)
     dst = np.repeat(np.arange(N), np.diff(rowptr))
     adj = mma_amd.graph.SpmmGraph(dst, col, None, N, N, dev)

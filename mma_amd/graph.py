@@ -11,8 +11,11 @@ SPMM_CHUNK = 512       # the same for the SpMM plans (64-byte rows: as tuned in 
 SPMM_GROUP_BELOW = 64  # SpMM rows shorter than this run one per C/4-lane group (a group walks its row alone, four gathers in flight)
 
 
-def auto_plan(E):
-    """(chunk, group_below, t_group_below) for a graph (or shard) of E edges.  chunk: a hub chunk is walked by ONE wavefront, ~0.4 us
+SMALL_GRAPH_EDGES = 1_000_000
+
+
+def auto_plan(E, H=None):
+    """(chunk, group_below, t_group_below) for a graph (or shard) of E edges; H: the feature width, when the caller knows it.  chunk: a hub chunk is walked by ONE wavefront, ~0.4 us
     per edge, so it must stay a small part of the kernel's time - which scales with E; group_below / t_group_below: items shorter
     than this run one per H/4-lane group (several per wavefront) in the forward (by-target) / backward (by-source) lists.
     Swept on the C4 R-MAT graph and on its 2 / 4 / 8-way shards after the nt policy went in (ms per step, same box each):
@@ -24,7 +27,25 @@ def auto_plan(E):
         return 1024, 48, 64
     if E >= 4_000_000:
         return 512, 48, 64
+    if E < SMALL_GRAPH_EDGES and H is not None:
+        # Small graphs (Cora 10.6 k edges, Pubmed 88.6 k: BASELINE configs[0], [2]) move a few MB per kernel: the kernel's time is the
+        # LONGEST serial chain of dependent gathers any wavefront walks, not bytes.  A wavefront gathers EPG = 64 / (H/4 lanes per row)
+        # rows per step, a grouped item (one H/4-lane group) ONE row per step: the 256-edge chunks above leave Cora's 168-edge hub as one
+        # wavefront's 42-step walk (K1 60 us for 11.6 MB), and Pubmed's 31-edge items as 31-step walks of a 4-lane group (K2b 110 us).
+        # So: chunks of 16 wavefront steps, grouped items below 4 edges.  Swept on the Cora / Pubmed structures (round 3, HIP-event spans
+        # of the K1 / K2b calls in us, eager; (steps, group)):  Cora H=64: old plan 58.9 / 70.5, (4,4) 40.3 / 40.5, (8,4) 44.0 / 45.1,
+        # (16,4) 44.1 / 47.8, (8,16) 47.6 / 51.9;  Pubmed H=16: old 68.7 / 76.4, (4,4) 62.1 / 43.4, (8,4) 67.8 / 43.3, (16,4) 51.0 / 37.7,
+        # (16,16) 64.6 / 54.4.  Layer replay as one hipGraph: Cora 0.249 -> 0.197 ms, Pubmed 0.371 -> 0.319 ms.
+        lpr = 1
+        while lpr < min(-(-H // 4), 64):
+            lpr *= 2
+        epg = 64 // lpr
+        return max(16, SMALL_STEPS * epg), SMALL_GROUP_BELOW, SMALL_GROUP_BELOW
     return 256, 32, 32
+
+
+SMALL_STEPS = int(__import__("os").environ.get("MMA_SMALL_STEPS", "16"))
+SMALL_GROUP_BELOW = int(__import__("os").environ.get("MMA_SMALL_GROUP", "4"))
 
 
 
@@ -77,7 +98,7 @@ def transpose_csr(rowptr, col, n_src):
 class NCGraph:
     """Device-resident plan.  n_src >= N allows extra source rows (halo rows in the sharded path)."""
 
-    def __init__(self, rowptr, col, device, n_src=None, chunk=DEFAULT_CHUNK, edge_base=0, group_below=None, t_group_below=None):
+    def __init__(self, rowptr, col, device, n_src=None, chunk=DEFAULT_CHUNK, edge_base=0, group_below=None, t_group_below=None, H=None):
         rowptr = np.asarray(rowptr, dtype=np.int64)
         col = np.asarray(col, dtype=np.int64)
         self.N = len(rowptr) - 1
@@ -85,7 +106,7 @@ class NCGraph:
         self.n_src = self.N if n_src is None else int(n_src)
         assert len(col) == self.E and (self.E == 0 or (col.min() >= 0 and col.max() < self.n_src)), "bad CSR"
         assert self.n_src < 2 ** 31 and self.E < 2 ** 31
-        auto = auto_plan(self.E)
+        auto = auto_plan(self.E, H)
         chunk = auto[0] if chunk is None else chunk
         group_below = auto[1] if group_below is None else group_below
         t_group_below = auto[2] if t_group_below is None else t_group_below
@@ -120,12 +141,12 @@ class NCGraph:
         self.inv_deg = torch.from_numpy((1.0 / np.maximum(deg, 1)).astype(np.float32)).to(dev)   # mean-kind backward
 
     @classmethod
-    def from_add_all(cls, add_all, device, chunk=DEFAULT_CHUNK):
+    def from_add_all(cls, add_all, device, chunk=DEFAULT_CHUNK, H=None):
         rowptr = np.zeros(len(add_all) + 1, dtype=np.int64)
         rowptr[1:] = np.cumsum([len(a) for a in add_all])
         col = (np.concatenate([np.asarray(a, dtype=np.int64) for a in add_all])
                if len(add_all) and rowptr[-1] > 0 else np.zeros(0, np.int64))
-        return cls(rowptr, col, device, chunk=chunk)
+        return cls(rowptr, col, device, chunk=chunk, H=H)
 
 
 class SpmmGraph:

@@ -164,7 +164,7 @@ class MMA(Module):
     # ---- plan -------------------------------------------------------------------------------------------
     def graph(self, device):
         if self._graph is None or self._graph.device != device:
-            self._graph = NCGraph.from_add_all(self.add_all, device, chunk=self._chunk)
+            self._graph = NCGraph.from_add_all(self.add_all, device, chunk=self._chunk, H=self.in_features)
         return self._graph
 
     def _scaler_factor(self, N, device):
