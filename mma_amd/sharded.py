@@ -256,8 +256,12 @@ class _ShardedAggregate(torch.autograd.Function):
     """Fused K-mask aggregate on a shard, with the halo traffic hidden behind independent work.
 
     forward : pack -> all-to-all of x halo rows (async) || P = x_own Wtop, Q_own = x_own Wbot ;  wait ;  Q_halo = x_halo Wbot ;  K1
-    backward: K2a ; K2b on the HALO sources ; their dL/dx (direct + through Q) -> reverse all-to-all (async) ||
-              K2b on the own sources, dL/dx_own, dL/dWtop, dL/dWbot ;  wait ;  unpack-add at the owner."""
+    backward: K2b on the HALO sources ; their dL/dx (direct + through Q) -> reverse all-to-all (async) ||
+              K2b on the own sources (node-level backward in its epilogue), dL/dx_own, dL/dWtop, dL/dWbot ;  wait ;  unpack-add.
+    Memory (round 3): P (n, K*H) and Q (S, K*H) are SEPARATE tables - a halo row has no target role, so its P half (and dL/dP half) was
+    never read: one (S, 2*K*H) buffer each way wasted 2 x n_halo x K*H floats per rank (2 x 25 GB at C5, where a rank's halo is ~3x its
+    own rows).  The own rows of x are not copied either when the caller's tensor already heads the (S, H) source table
+    (ShardedMMA.feature_buffer())."""
 
     @staticmethod
     def forward(ctx, x_own, wtop, wbot, mod, kinds, acts, drop):
@@ -267,53 +271,50 @@ class _ShardedAggregate(torch.autograd.Function):
         K = len(kinds)
         dev = x_own.device
         x_own = x_own.contiguous()
-        x_src = torch.empty((S, H), device=dev, dtype=torch.float32)
+        x_src = mod.source_table(x_own)                          # (S,H); its first n rows ARE x_own when the caller used feature_buffer()
         n_send = int(plan.send_counts.sum())
         send = torch.empty((n_send, H), device=dev, dtype=torch.float32)
         with Fn._span("halo_pack"):
             call("mma_pack_rows", ptr(x_own), H, ptr(mod.send_idx), n_send, ptr(send), H, H, stream_ptr())
         h = all_to_all_rows_start(send, plan.send_counts, plan.recv_counts, plan.group, out=x_src[n:])
-        x_src[:n].copy_(x_own)
-        # one (S, 2KH) buffer: row i = [P_i | Q_i]; own rows come out of ONE GEMM with [Wtop | Wbot], halo rows only get
-        # their Q half (their P half is never read).  K1/K2b take P and Q as strided views of it.
+        if x_src.data_ptr() != x_own.data_ptr():
+            x_src[:n].copy_(x_own)
         KH = K * H
-        PQ = torch.empty((S, 2 * KH), device=dev, dtype=torch.float32)
-        wcat = torch.cat([wtop, wbot], 1)                                   # (H, 2KH)
+        P = torch.empty((n, KH), device=dev, dtype=torch.float32)
+        Q = torch.empty((S, KH), device=dev, dtype=torch.float32)
         need = any(ctx.needs_input_grad[:3])
         box_own, box_halo = ([], []) if need else (None, None)              # row maxima of x from the forward GEMMs (three-product TN form)
-        mm_into(x_own, wcat, PQ[:n], row_max_box=box_own)
+        mm_into(x_own, wtop, P, row_max_box=box_own)
+        mm_into(x_own, wbot, Q[:n])
         with Fn._span("halo_wait"):
             h.wait()
-        mm_into(x_src[n:], wbot, PQ[n:, KH:], row_max_box=box_halo)
-        P, Q = PQ[:n, :KH], PQ[:, KH:]
+        mm_into(x_src[n:], wbot, Q[n:], row_max_box=box_halo)
         msum, T, sel, crow = Fn.nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, True, need)
         ctx.mod, ctx.kinds, ctx.acts, ctx.drop = mod, kinds, acts, drop
-        ctx.save_for_backward(x_src, PQ, T, sel, crow, wcat, box_own[0] if box_own else None, box_halo[0] if box_halo else None)
+        ctx.save_for_backward(x_src, P, Q, T, sel, crow, wtop, wbot, box_own[0] if box_own else None, box_halo[0] if box_halo else None)
         return msum
 
     @staticmethod
     def backward(ctx, g):
         mod, kinds, acts, drop = ctx.mod, ctx.kinds, ctx.acts, ctx.drop
         plan, graph = mod.plan, mod.graph
-        x_src, PQ, T, sel, crow, wcat, xrm_own, xrm_halo = ctx.saved_tensors
+        x_src, P, Q, T, sel, crow, wtop, wbot, xrm_own, xrm_halo = ctx.saved_tensors
         n, S, H = plan.n_own, plan.n_src, x_src.shape[1]
         K = len(kinds)
         KH = K * H
-        P, Q = PQ[:n, :KH], PQ[:, KH:]
-        wbot = wcat[:, KH:]
         dev = g.device
         g = g.contiguous()
         shared = crow is not None
         fuse = shared and Fn.FUSE_NODE_BWD          # K2a in the epilogue of the OWN-source launch (halo sources have no target role)
-        gPQ = torch.empty((S, 2 * KH), device=dev, dtype=torch.float32)          # [dL/dP | dL/dQ], halo rows: Q half only
+        gP = torch.empty((n, KH), device=dev, dtype=torch.float32)
+        gQ = torch.empty((S, KH), device=dev, dtype=torch.float32)
         from .dense import f16x2_n128_ok, rows_mm_add_scaled_
-        # row maxima of [gP|gQ] for the three-product dL/dx GEMMs (own rows: both halves; halo rows: the Q half only)
+        # row maxima of gP / gQ for the three-product dL/dx GEMMs (own rows: the larger of both; halo rows: gQ only)
         row_max = torch.zeros((S,), device=dev, dtype=torch.float32) if f16x2_n128_ok(max(n, S - n), KH, H) and K <= 8 else None
         gs = gxs = None
         if not fuse:
-            gs, _gP, gxs = Fn.nc_bwd_node_launch(g, True, sel, crow, T, graph, kinds, H, shared, gP=gPQ[:n, :KH], row_max=row_max)
-        epi = dict(T=T, gP=gPQ[:n, :KH]) if fuse else {}
-        gQ = gPQ[:, KH:]
+            gs, _gP, gxs = Fn.nc_bwd_node_launch(g, True, sel, crow, T, graph, kinds, H, shared, gP=gP, row_max=row_max)
+        epi = dict(T=T, gP=gP) if fuse else {}
         gx = torch.empty((S, H), device=dev, dtype=torch.float32)
         partial = (torch.empty((graph.t_n_slots, (K + 1) * H), device=dev, dtype=torch.float32) if graph.t_n_slots else None)
         # The reverse exchange is a COLLECTIVE: every rank of a multi-rank plan joins it, also one that has no halo rows of
@@ -330,12 +331,14 @@ class _ShardedAggregate(torch.autograd.Function):
             if plan.world > 1:
                 back = all_to_all_rows_start(gx[n:], plan.recv_counts, plan.send_counts, plan.group)    # sends (0,H), still receives
             Fn.nc_bwd_edges_launch(x_src, P, Q, gs, g, crow, gxs, graph, kinds, acts, drop, gQ, gx, partial, row_max=row_max, **epi)
-        gx_own = rows_mm_add_scaled_(gx[:n], gPQ[:n], wcat.t(), row_max[:n] if row_max is not None else None)   # own rows, one GEMM
+        rm_own = row_max[:n] if row_max is not None else None
+        gx_own = rows_mm_add_scaled_(gx[:n], gP, wtop.t(), rm_own)             # own rows: direct + through P ...
+        gx_own = rows_mm_add_scaled_(gx_own, gQ[:n], wbot.t(), rm_own)         # ... + through Q
         gwtop = gwbot = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            rm = row_max if row_max is not None else None        # K2a / K2b's row maxima also scale the three-product TN form
-            gw = xt_g(x_src[:n], gPQ[:n], xrm_own, rm[:n] if rm is not None else None)   # (H, 2KH) = [dL/dWtop | own part of dL/dWbot]
-            gwtop, gwbot = gw[:, :KH], gw[:, KH:]
+            rm = row_max                                          # K2b's row maxima also scale the three-product TN form
+            gwtop = xt_g(x_src[:n], gP, xrm_own, rm[:n] if rm is not None else None)
+            gwbot = xt_g(x_src[:n], gQ[:n], xrm_own, rm[:n] if rm is not None else None)
             if S > n:
                 gwbot = gwbot + xt_g(x_src[n:], gQ[n:], xrm_halo, rm[n:] if rm is not None else None)
         if back is not None:
@@ -375,6 +378,20 @@ class ShardedMMA(torch.nn.Module):
         self.local_edges = int(plan.rowptr[-1])
         self.n_total = plan.n_total  # global node count: the scalers' quirk Q1 evaluates its factor with N, on every rank alike
         self.drop_override = None
+        self._x_src = None           # (S,H) source table [own | halo], kept between calls when the caller writes into feature_buffer()
+
+    def feature_buffer(self):
+        """A leaf tensor (n_own, H) that HEADS this rank's (S, H) source table: put the shard's features here (copy_ under
+        no_grad, or hand it to the producing op as `out=`) and pass it to forward() - the halo rows are then received right behind
+        it and K1 reads [own | halo] as one table without the per-call copy of the own rows (0.3 ms per layer call at C5)."""
+        if self._x_src is None:
+            self._x_src = torch.empty((self.plan.n_src, self.H), device=self.weight.device, dtype=torch.float32)
+        return self._x_src[:self.plan.n_own].detach().requires_grad_(True)
+
+    def source_table(self, x_own):
+        if self._x_src is not None and x_own.data_ptr() == self._x_src.data_ptr() and x_own.shape[0] == self.plan.n_own:
+            return self._x_src
+        return torch.empty((self.plan.n_src, x_own.shape[1]), device=x_own.device, dtype=torch.float32)
 
     @classmethod
     def build(cls, rowptr, col, rank, world, device, H, C, names, dropout, seed=42, chunk=DEFAULT_CHUNK, group=None,

@@ -85,12 +85,30 @@ def run_cpu(rank, world):
              ("no edges", 9, (np.zeros(10, np.int64), np.zeros(0, np.int64)))]
     for tag, N, (rowptr, col) in cases:
         check_cpu(rank, world, tag, N, rowptr.astype(np.int64), col.astype(np.int64))
+    # BASELINE configs[4] in miniature: K = 8 masks and the S = 5 compounding true-degree scalers (mma_conv.py:181-196), whose row
+    # factor needs the GLOBAL degree means on every rank
+    check_cpu(rank, world, "c5 miniature (K=8, S=5)", 211, *[a.astype(np.int64) for a in graph(9, 211, 5)],
+              names=["sum", "mean", "max", "min", "sum2", "mean2", "max2", "min2"],
+              scalers=["identity", "amplification", "attenuation", "linear", "inverse_linear"])
 
 
-def check_cpu(rank, world, tag, N, rowptr, col):
+def true_degree_factor(deg, scalers, avg_log, avg_lin):
+    """Row factor sum_s prod_{q<=s} f_q(d) of the compounding scalers (mma_conv.py:181-196), numpy restatement for this test."""
+    d = np.maximum(deg, 1).astype(np.float64)
+    lg = np.log(d + 1)
+    f = {"identity": np.ones_like(d), "amplification": lg / avg_log, "attenuation": avg_log / lg, "linear": d / avg_lin,
+         "inverse_linear": avg_lin / d}
+    total, run = np.zeros_like(d), np.ones_like(d)
+    for name in scalers:
+        run = run * f[name]
+        total = total + run
+    return torch.from_numpy(total.astype(np.float32)).unsqueeze(1)
+
+
+def check_cpu(rank, world, tag, N, rowptr, col, names=("sum", "mean", "max", "min"), scalers=None):
     from mma_amd.sharded import HaloPlan, all_to_all_rows, partition_bounds
     from oracle import nc_oracle as O
-    H, C, names, act = 12, 5, ["sum", "mean", "max", "min"], "new_sigmoid"
+    H, C, names, act = 12, 5, list(names), "new_sigmoid"
     g = torch.Generator().manual_seed(0)
     x = torch.relu(torch.randn(N, H, generator=g))
     Ws, weight, bias = O.init_like_reference(H, C, names, 1)
@@ -98,7 +116,15 @@ def check_cpu(rank, world, tag, N, rowptr, col):
     dst = np.repeat(np.arange(N), np.diff(rowptr))
     # unsharded oracle
     xf = x.clone().requires_grad_(True)
-    out_f = O.mma_forward(names, xf, Ws, weight, bias, rowptr, col, dst, col, np.ones(len(col), np.float32), act)
+    deg_all = np.diff(rowptr)
+    if scalers is None:
+        out_f = O.mma_forward(names, xf, Ws, weight, bias, rowptr, col, dst, col, np.ones(len(col), np.float32), act)
+    else:       # true-degree scalers: sum_k A ((R m_k) W) + b with the row factor R from the global degree means
+        d1 = np.maximum(deg_all, 1).astype(np.float64)
+        avg_log, avg_lin = float(np.log(d1 + 1).mean()), float(d1.mean())
+        Rf = true_degree_factor(deg_all, scalers, avg_log, avg_lin)
+        Sf = sum((O.aggregate(a, xf, Ws[a], rowptr, col, act) @ weight) * Rf for a in names)
+        out_f = torch.zeros(N, C).index_add(0, torch.from_numpy(dst), Sf.index_select(0, torch.from_numpy(col))) + bias
     gx_f, = torch.autograd.grad((out_f * cot).sum(), [xf])
 
     bounds = partition_bounds(rowptr, world)
@@ -128,8 +154,11 @@ def check_cpu(rank, world, tag, N, rowptr, col):
     n = plan.n_own
     rp_pad = np.concatenate([plan.rowptr, np.full(plan.n_halo, plan.rowptr[-1])])      # halo rows: degree 0
     ms = [O.aggregate(a, x_src, Ws[a], rp_pad, plan.col, act)[:n] for a in names]
-    amp, att = O.scaler_factors(N)
-    S = sum((m @ weight) * (1.0 + amp[:1] + att[:1]) for m in ms)
+    if scalers is None:
+        amp, att = O.scaler_factors(N)
+        S = sum((m @ weight) * (1.0 + amp[:1] + att[:1]) for m in ms)
+    else:       # a rank owns ALL in-edges of its targets: its local degrees are the true ones; the means are global
+        S = sum((m @ weight) * true_degree_factor(np.diff(plan.rowptr), scalers, avg_log, avg_lin) for m in ms)
     S_src = torch.cat([S, Exchange.apply(S)], 0)
     dl = np.repeat(np.arange(n), np.diff(plan.rowptr))
     out = torch.zeros(n, C).index_add(0, torch.from_numpy(dl), S_src.index_select(0, torch.from_numpy(plan.col))) + bias
@@ -149,6 +178,9 @@ def run_gpu(rank, world, variant="hub"):
                                 ("no edges", 9, (np.zeros(10, np.int64), np.zeros(0, np.int64)), {}),
                                 ("true-degree scalers", 157, graph(3, 157, 4),
                                  dict(strict_reference=False, scalers=["identity", "amplification", "linear"], compound_scalers=True)),
+                                ("c5 miniature: K=8 masks, S=5 true-degree scalers", 211, graph(9, 211, 5),
+                                 dict(H=32, names=["sum", "mean", "max", "min", "sum2", "mean2", "max2", "min2"], strict_reference=False,
+                                      scalers=["identity", "amplification", "attenuation", "linear", "inverse_linear"], compound_scalers=True)),
                                 ("tall shards: three-product GEMMs with K2a/K2b row maxima", 150000 * world, big_graph(150000 * world), dict(H=128))):
             check_gpu(rank, world, tag, n_, gr[0].astype(np.int64), gr[1].astype(np.int64), kw)
         return
@@ -213,7 +245,7 @@ def check_gpu(rank, world, tag, N, rowptr, col, kw):
     from mma_amd.sharded import ShardedMMA
     dev = "cuda:0"
     kw = dict(kw)
-    H, C, names, p, seed = kw.pop("H", 16), 4, ["sum", "mean3", "max", "min2"], 0.5, 0x1234ABCD77
+    H, C, names, p, seed = kw.pop("H", 16), 4, kw.pop("names", ["sum", "mean3", "max", "min2"]), 0.5, 0x1234ABCD77
     g = torch.Generator().manual_seed(1)
     x = torch.relu(torch.randn(N, H, generator=g))
     cot = torch.randn(N, C, generator=g)
@@ -240,6 +272,18 @@ def check_gpu(rank, world, tag, N, rowptr, col, kw):
     of.backward(cot.to(dev))
     close(out, of[sh.lo:sh.hi], "%s: out rank %d" % (tag, rank))
     close(xo.grad if xo.grad is not None else torch.zeros_like(xo), xf.grad[sh.lo:sh.hi], "%s: gx rank %d" % (tag, rank))
+    # the same call with the features written into the head of the rank's source table (no per-call copy of the own rows): bit-equal
+    xb = sh.feature_buffer()
+    with torch.no_grad():
+        xb.copy_(x[sh.lo:sh.hi].to(dev))
+    out_b = sh(xb)
+    out_b.backward(cot[sh.lo:sh.hi].to(dev))
+    assert torch.equal(out_b, out), tag + ": feature_buffer() forward differs"
+    assert xo.grad is None or torch.equal(xb.grad, xo.grad), tag + ": feature_buffer() gradient differs"
+    for prm in sh.owned:            # the second backward accumulated onto the (already all-reduced) gradients: halve is wrong - recompute
+        prm.grad = None
+    sh(xo.detach().requires_grad_(True)).backward(cot[sh.lo:sh.hi].to(dev))
+    sh.allreduce_grads()
     close(sh.weight.grad, w.grad, tag + ": gweight")
     close(sh.bias.grad, b.grad, tag + ": gbias")
     for n_ in names:
