@@ -6,6 +6,7 @@ graph on the host with numpy and then lives in HBM as int32."""
 import numpy as np
 import torch
 
+DEVICE_PLAN = __import__("os").environ.get("MMA_DEVICE_PLAN", "1") != "0"     # 0: the host numpy builders (round 2)
 DEFAULT_CHUNK = None   # edges per work item (longer segments - hubs - are split and summed in a second pass); None: by graph size
 SPMM_CHUNK = 512       # the same for the SpMM plans (64-byte rows: as tuned in round 1)
 SPMM_GROUP_BELOW = 64  # SpMM rows shorter than this run one per C/4-lane group (a group walks its row alone, four gathers in flight)
@@ -146,11 +147,127 @@ class NCGraph:
         rowptr[1:] = np.cumsum([len(a) for a in add_all])
         col = (np.concatenate([np.asarray(a, dtype=np.int64) for a in add_all])
                if len(add_all) and rowptr[-1] > 0 else np.zeros(0, np.int64))
+        if DEVICE_PLAN and torch.device(device).type == "cuda":       # the neighbour lists go up once; the plan is built in HBM
+            assert len(col) == 0 or (col.min() >= 0 and col.max() < len(add_all)), "bad neighbour lists"
+            return cls.from_device_csr(torch.from_numpy(rowptr).to(device), torch.from_numpy(col).to(device), chunk=chunk, H=H)
         return cls(rowptr, col, device, chunk=chunk, H=H)
+
+
+# ---- device-side plan builders (graph ingest without host preprocessing) -----------------------------------------------
+# The same plans as above, bit for bit, from a CSR that already lives in HBM: the two groupings (edges by source; work items by
+# length) are stable radix sorts of K6 (mma_build_csr, rocPRIM), everything else is scans and gathers.  The host only reads back
+# four counts (items, hub slots, the per-wavefront / grouped split points).
+def _i64(t):
+    return t.to(torch.int64)
+
+
+def device_make_items(rowptr, chunk):
+    """make_items() on the device: (items (n,4) int32, hubs (h,4) int32, n_slots, lens (n,) int64 sorted like items)."""
+    from .functional import DeviceCSR
+    dev = rowptr.device
+    rp = _i64(rowptr)
+    N = rp.numel() - 1
+    deg = rp[1:] - rp[:-1]
+    nch = torch.clamp((deg + (chunk - 1)) // chunk, min=1)
+    csum = torch.cumsum(nch, 0)
+    total = int(csum[-1]) if N else 0
+    node = torch.repeat_interleave(torch.arange(N, device=dev), nch, output_size=total)
+    first = csum - nch
+    ci = torch.arange(total, device=dev) - first[node]
+    ebeg = rp[node] + ci * chunk
+    eend = torch.minimum(ebeg + chunk, rp[node + 1])
+    is_hub = nch[node] > 1
+    hub_rank = torch.cumsum(is_hub.to(torch.int64), 0)
+    slot = torch.where(is_hub, hub_rank - 1, torch.full_like(hub_rank, -1))
+    items = torch.stack([node, ebeg, eend, slot], 1)
+    lens = eend - ebeg
+    n_slots = int(hub_rank[-1]) if total else 0
+    if total:
+        # longest first, stable (equal lengths keep ascending node / chunk order): radix sort of (max_len - len) by K6
+        mx = int(lens.max())
+        order = DeviceCSR((mx - lens).contiguous(), None, mx + 1).perm[:total].long()
+        items, lens = items[order], lens[order]
+    hub_nodes = torch.nonzero(nch > 1).flatten()
+    if hub_nodes.numel():
+        hn = nch[hub_nodes]
+        sb = torch.cumsum(hn, 0) - hn
+        hubs = torch.stack([hub_nodes, sb, sb + hn, torch.zeros_like(sb)], 1)
+    else:
+        hubs = torch.zeros((0, 4), dtype=torch.int64, device=dev)
+    return items.to(torch.int32).contiguous(), hubs.to(torch.int32).contiguous(), n_slots, lens
+
+
+def device_transpose_csr(rowptr, col, n_src):
+    """transpose_csr() on the device: edges grouped by source with a stable radix sort (K6): (t_rowptr, t_col, t_eid) int32."""
+    from .functional import DeviceCSR
+    rp = _i64(rowptr)
+    N, E = rp.numel() - 1, int(col.numel())
+    if E == 0:
+        z = torch.zeros((0,), dtype=torch.int32, device=rowptr.device)
+        return torch.zeros((n_src + 1,), dtype=torch.int32, device=rowptr.device), z, z
+    dst = torch.repeat_interleave(torch.arange(N, device=rowptr.device), rp[1:] - rp[:-1], output_size=E)
+    t = DeviceCSR(_i64(col).contiguous(), dst, n_src)
+    return t.rowptr, t.other[:E].contiguous(), t.perm[:E].contiguous()
+
+
+def _ncgraph_from_device_csr(cls, rowptr, col, n_src=None, chunk=DEFAULT_CHUNK, edge_base=0, group_below=None, t_group_below=None, H=None):
+    """NCGraph from a CSR by target that already lives on the GPU (rowptr (N+1), col (E), any integer dtype): the plan of
+    NCGraph.__init__ bit for bit, built on the device."""
+    assert rowptr.is_cuda and col.is_cuda
+    g = object.__new__(cls)
+    dev = rowptr.device
+    g.N = rowptr.numel() - 1
+    g.E = int(col.numel())
+    g.n_src = g.N if n_src is None else int(n_src)
+    assert g.n_src < 2 ** 31 and g.E < 2 ** 31
+    if g.E:
+        torch._assert_async(((col >= 0) & (col < g.n_src)).all())
+    auto = auto_plan(g.E, H)
+    chunk = auto[0] if chunk is None else chunk
+    group_below = auto[1] if group_below is None else group_below
+    t_group_below = auto[2] if t_group_below is None else t_group_below
+    g.chunk, g.edge_base, g.device = int(chunk), int(edge_base), dev
+    g.rowptr, g.col = rowptr.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
+    g.items, g.hubs, g.n_slots, lens = device_make_items(g.rowptr, g.chunk)
+    g.t_rowptr, g.t_col, g.t_eid = device_transpose_csr(g.rowptr, g.col, g.n_src)
+    g.t_items, g.t_hubs, g.t_n_slots, t_lens = device_make_items(g.t_rowptr, g.chunk)
+    g.n_wave_items = int((lens >= group_below).sum())
+    g.t_n_wave_items = int((t_lens >= t_group_below).sum())
+    g.t_parts = None
+    if g.n_src > g.N:
+        parts = []
+        for sel_halo in (True, False):
+            mi = (g.t_items[:, 0] >= g.N) == sel_halo
+            mh = (g.t_hubs[:, 0] >= g.N) == sel_halo
+            parts.append((g.t_items[mi].contiguous(), int(((t_lens >= t_group_below) & mi).sum()), g.t_hubs[mh].contiguous()))
+        g.t_parts = parts
+    deg = (g.rowptr[1:] - g.rowptr[:-1])
+    g.max_degree = int(deg.max()) if g.N else 0
+    g.inv_deg = (1.0 / torch.clamp(deg, min=1).to(torch.float64)).to(torch.float32)          # as the numpy plan: fp64 reciprocal, rounded once
+    return g
+
+
+NCGraph.from_device_csr = classmethod(_ncgraph_from_device_csr)
 
 
 class SpmmGraph:
     """CSR (and its transpose) of the adjacency the reference hands to torch.spmm (layers.py:861-862)."""
+
+    @classmethod
+    def from_device_csr(cls, rowptr, col, n_cols=None):
+        """The plan of an all-ones adjacency that is already a CSR by row on the GPU with ascending columns inside a row (the raw
+        0/1 adjacency of utils.py:71,114: MMA.forward's `adj` is the same CSR as its `add_all`): built on the device."""
+        g = object.__new__(cls)
+        g.n_rows = rowptr.numel() - 1
+        g.n_cols = g.n_rows if n_cols is None else int(n_cols)
+        g.rowptr, g.col = rowptr.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
+        g.val = g.t_val = None
+        g.t_rowptr, g.t_col, _ = device_transpose_csr(g.rowptr, g.col, g.n_cols)
+        g.items, g.hubs, g.n_slots, lens = device_make_items(g.rowptr, SPMM_CHUNK)
+        g.n_wave_items = int((lens >= SPMM_GROUP_BELOW).sum())
+        g.t_items, g.t_hubs, g.t_n_slots, t_lens = device_make_items(g.t_rowptr, SPMM_CHUNK)
+        g.t_n_wave_items = int((t_lens >= SPMM_GROUP_BELOW).sum())
+        return g
 
     def __init__(self, row, col, val, n_rows, n_cols, device):
         row = np.asarray(row, dtype=np.int64); col = np.asarray(col, dtype=np.int64)
@@ -179,5 +296,12 @@ class SpmmGraph:
         """`device`: where the plan lives (the layer passes its input's device: a CPU sparse adj next to GPU features must
         not hand host pointers to the kernels)."""
         a = adj.coalesce()
+        dev = torch.device(adj.device if device is None else device)
+        if DEVICE_PLAN and dev.type == "cuda" and a.values().numel() and bool((a.values() == 1).all()):
+            # the raw 0/1 adjacency of utils.py:71,114: coalesced COO = sorted by (row, col) -> its CSR is one scan away, on the device
+            idx = a.indices().to(dev)
+            rowptr = torch.zeros(a.shape[0] + 1, dtype=torch.int64, device=dev)
+            rowptr[1:] = torch.cumsum(torch.bincount(idx[0], minlength=a.shape[0]), 0)
+            return cls.from_device_csr(rowptr, idx[1], n_cols=a.shape[1])
         idx = a.indices().cpu().numpy()
-        return cls(idx[0], idx[1], a.values().cpu().numpy(), a.shape[0], a.shape[1], adj.device if device is None else device)
+        return cls(idx[0], idx[1], a.values().cpu().numpy(), a.shape[0], a.shape[1], dev)

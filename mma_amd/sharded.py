@@ -28,6 +28,9 @@ from .layers import _AGG
 from .scalers import scaler_row_factor, true_degree_row_factor
 
 
+DEVICE_PLAN = __import__("os").environ.get("MMA_DEVICE_PLAN", "1") != "0"     # 0: the host numpy plan builders (round 2)
+
+
 def partition_bounds(rowptr, world, row_cost=0.0):
     """Contiguous target ranges with (nearly) equal cost: bounds[r] .. bounds[r+1].  cost(node) = in-degree + row_cost;
     row_cost = 0 balances the edges alone (the default: under a locality-free node order every range then also holds ~N/world
@@ -142,25 +145,40 @@ def allreduce_grads(params, group=None, average=False, bucket_bytes=256 << 20):
 class HaloPlan:
     """Who sends which rows to whom, for one rank.  Built once per (graph, partition) with one index exchange."""
 
-    def __init__(self, rowptr_own, col_global, bounds, rank, world, comm_device="cpu", group=None):
+    def __init__(self, rowptr_own, col_global, bounds, rank, world, comm_device="cpu", group=None, plan_device=None):
+        """plan_device (a cuda device): the shard's heavy index work - the distinct remote sources (sort-unique), the local column
+        ids (binary search), the reverse-exchange lists (stable radix sort) - runs on the GPU and the local CSR stays there
+        (`rowptr_dev`, `col_dev`: ShardedMMA then builds its NCGraph / SpmmGraph plans on the device too).  Default: host numpy."""
         bounds = np.asarray(bounds, dtype=np.int64)
         self.rank, self.world, self.group = rank, world, group
         self.lo, self.hi = int(bounds[rank]), int(bounds[rank + 1])
         self.n_own = self.hi - self.lo
         rowptr_own = np.asarray(rowptr_own, dtype=np.int64)
-        col_global = np.asarray(col_global, dtype=np.int64)
         assert len(rowptr_own) == self.n_own + 1 and rowptr_own[0] == 0 and rowptr_own[-1] == len(col_global)
-        own = (col_global >= self.lo) & (col_global < self.hi)
-        self.halo_ids = np.unique(col_global[~own])                       # ascending => grouped by owner
+        self.rowptr_dev = self.col_dev = None
+        self.plan_device = torch.device(plan_device) if plan_device is not None else None
+        if self.plan_device is not None and self.plan_device.type == "cuda":
+            pd = self.plan_device
+            cg = torch.from_numpy(np.ascontiguousarray(col_global, dtype=np.int64)).to(pd)
+            own = (cg >= self.lo) & (cg < self.hi)
+            halo_t = torch.unique(cg[~own])                                # sorted => grouped by owner
+            col_local = torch.where(own, cg - self.lo, self.n_own + torch.searchsorted(halo_t, cg))
+            self.halo_ids = halo_t.cpu().numpy()
+            self.col_dev, self.rowptr_dev = col_local, torch.from_numpy(rowptr_own).to(pd)
+            self.rowptr, self.col = rowptr_own, None                      # the local columns live on the device only
+        else:
+            col_global = np.asarray(col_global, dtype=np.int64)
+            own = (col_global >= self.lo) & (col_global < self.hi)
+            self.halo_ids = np.unique(col_global[~own])                   # ascending => grouped by owner
+            # local column ids: own rows first, then halo rows in halo_ids order
+            col_local = np.where(own, col_global - self.lo, 0)
+            col_local[~own] = self.n_own + np.searchsorted(self.halo_ids, col_global[~own])
+            self.rowptr, self.col = rowptr_own, col_local
         self.n_halo = len(self.halo_ids)
         self.n_src = self.n_own + self.n_halo
         owner = np.searchsorted(bounds, self.halo_ids, side="right") - 1
         self.recv_counts = np.bincount(owner, minlength=world).astype(np.int64)
         assert self.recv_counts[rank] == 0
-        # local column ids: own rows first, then halo rows in halo_ids order
-        col_local = np.where(own, col_global - self.lo, 0)
-        col_local[~own] = self.n_own + np.searchsorted(self.halo_ids, col_global[~own])
-        self.rowptr, self.col = rowptr_own, col_local
         # index exchange: tell every owner which of its rows this rank needs
         dev = torch.device(comm_device)
         rc = torch.from_numpy(self.recv_counts).to(dev)
@@ -180,6 +198,18 @@ class HaloPlan:
     def build_unpack(self):
         """The reverse exchange in ONE launch: every local row that is sent to anyone, with the positions of its copies in the
         concatenated receive buffer (ascending = by peer rank: a fixed summation order) - mma_unpack_add_rows_csr."""
+        pd = getattr(self, "plan_device", None)
+        if pd is not None and pd.type == "cuda" and len(self.send_idx):
+            # the same lists from ONE stable radix sort of the send positions by local row (K6): rows with at least one copy, the
+            # segment of each in the sorted order, the positions themselves
+            t = Fn.DeviceCSR(torch.from_numpy(self.send_idx).to(pd), None, max(self.n_own, 1))
+            rp = t.rowptr.long()
+            cnt = rp[1:] - rp[:-1]
+            rows = torch.nonzero(cnt > 0).flatten()
+            self.unpack_rows = rows.cpu().numpy().astype(np.int64)
+            self.unpack_segptr = torch.cat([rp[rows], rp[-1:]]).cpu().numpy().astype(np.int64)
+            self.unpack_pos = t.perm[:len(self.send_idx)].cpu().numpy().astype(np.int64)
+            return
         order = np.argsort(self.send_idx, kind="stable")
         self.unpack_rows, first = np.unique(self.send_idx[order], return_index=True)
         self.unpack_segptr = np.concatenate([first, [len(order)]]).astype(np.int64)
@@ -352,7 +382,8 @@ class ShardedMMA(torch.nn.Module):
     """The MMA layer (layers.py:54-872 semantics, as mma_amd.MMA) on this rank's shard of the graph."""
 
     def __init__(self, plan, device, H, C, names, masks, weight, bias, dropout, activation="new_sigmoid", edge_base=0,
-                 chunk=DEFAULT_CHUNK, adj_val=None, strict_reference=True, scalers=None, compound_scalers=False, avg_d=None):
+                 chunk=DEFAULT_CHUNK, adj_val=None, strict_reference=True, scalers=None, compound_scalers=False, avg_d=None,
+                 group_below=None, t_group_below=None):
         super().__init__()
         # strict_reference=False: true-degree scalers as in mma_amd.MMA; avg_d must then hold the GLOBAL means {'log','lin'}
         self.strict_reference, self.scaler_names, self.compound_scalers, self.avg_d = strict_reference, scalers, compound_scalers, avg_d
@@ -362,13 +393,28 @@ class ShardedMMA(torch.nn.Module):
         self.H, self.C = H, C
         self.lo, self.hi = plan.lo, plan.hi
         dev = torch.device(device)
-        self.graph = NCGraph(plan.rowptr, plan.col, dev, n_src=plan.n_src, chunk=chunk, edge_base=edge_base)
-        dst = np.repeat(np.arange(plan.n_own, dtype=np.int64), np.diff(plan.rowptr))
-        # the tail SpMM in two parts: own sources (runs while the S rows of the halo are on the wire) and halo sources
-        own = plan.col < plan.n_own
-        val = None if adj_val is None else np.asarray(adj_val, dtype=np.float32)
-        self.sg_own = SpmmGraph(dst[own], plan.col[own], None if val is None else val[own], plan.n_own, plan.n_own, dev)
-        self.sg_halo = SpmmGraph(dst[~own], plan.col[~own] - plan.n_own, None if val is None else val[~own], plan.n_own, plan.n_halo, dev)
+        col_dev = getattr(plan, "col_dev", None)
+        if col_dev is not None and adj_val is None:
+            # the shard's plans on the device (K6 sorts + scans), from the local CSR the HaloPlan left in HBM
+            rp = plan.rowptr_dev.to(dev).long()
+            cl = col_dev.to(dev)
+            self.graph = NCGraph.from_device_csr(rp, cl, n_src=plan.n_src, chunk=chunk, edge_base=edge_base, H=H, group_below=group_below,
+                                                  t_group_below=t_group_below)
+            own = cl < plan.n_own
+            cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=cl.device), torch.cumsum(own.to(torch.int64), 0)])
+            rp_own = cs[rp]                                            # edges with an own source in front of each row
+            self.sg_own = SpmmGraph.from_device_csr(rp_own, cl[own], n_cols=plan.n_own)
+            self.sg_halo = SpmmGraph.from_device_csr(rp - rp_own, cl[~own] - plan.n_own, n_cols=plan.n_halo)
+        else:
+            col_np = plan.col if plan.col is not None else col_dev.cpu().numpy()
+            self.graph = NCGraph(plan.rowptr, col_np, dev, n_src=plan.n_src, chunk=chunk, edge_base=edge_base, H=H, group_below=group_below,
+                                 t_group_below=t_group_below)
+            dst = np.repeat(np.arange(plan.n_own, dtype=np.int64), np.diff(plan.rowptr))
+            # the tail SpMM in two parts: own sources (runs while the S rows of the halo are on the wire) and halo sources
+            own = col_np < plan.n_own
+            val = None if adj_val is None else np.asarray(adj_val, dtype=np.float32)
+            self.sg_own = SpmmGraph(dst[own], col_np[own], None if val is None else val[own], plan.n_own, plan.n_own, dev)
+            self.sg_halo = SpmmGraph(dst[~own], col_np[~own] - plan.n_own, None if val is None else val[~own], plan.n_own, plan.n_halo, dev)
         i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
         self.send_idx = i32(plan.send_idx)
         self.unpack_rows, self.unpack_segptr, self.unpack_pos = i32(plan.unpack_rows), i32(plan.unpack_segptr), i32(plan.unpack_pos)
@@ -395,7 +441,7 @@ class ShardedMMA(torch.nn.Module):
 
     @classmethod
     def build(cls, rowptr, col, rank, world, device, H, C, names, dropout, seed=42, chunk=DEFAULT_CHUNK, group=None,
-              strict_reference=True, scalers=None, compound_scalers=False):
+              strict_reference=True, scalers=None, compound_scalers=False, group_below=None, t_group_below=None):
         """Convenience for bench/tests: every rank holds the full CSR and slices its shard; parameters are
         initialised identically on all ranks (layers.py:143-198 distributions)."""
         rowptr = np.asarray(rowptr, dtype=np.int64)
@@ -403,7 +449,8 @@ class ShardedMMA(torch.nn.Module):
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         e0, e1 = int(rowptr[lo]), int(rowptr[hi])
         comm_dev = "cpu" if _backend(group) == "gloo" else device
-        plan = HaloPlan(rowptr[lo:hi + 1] - e0, np.asarray(col[e0:e1]), bounds, rank, world, comm_dev, group)
+        plan = HaloPlan(rowptr[lo:hi + 1] - e0, np.asarray(col[e0:e1]), bounds, rank, world, comm_dev, group,
+                        plan_device=device if (DEVICE_PLAN and torch.device(device).type == "cuda") else None)
         g = torch.Generator().manual_seed(seed)
         b = 1.0 / np.sqrt(H)
         P = lambda *s: torch.nn.Parameter(((torch.rand(*s, generator=g) * 2 - 1) * b).to(device))
@@ -414,7 +461,8 @@ class ShardedMMA(torch.nn.Module):
             d = np.maximum(np.diff(rowptr), 1).astype(np.float32)
             avg_d = {"log": float(torch.log(torch.from_numpy(d) + 1).mean()), "lin": float(torch.from_numpy(d).mean())}
         return cls(plan, device, H, C, names, masks, weight, bias, dropout, edge_base=e0, chunk=chunk,
-                   strict_reference=strict_reference, scalers=scalers, compound_scalers=compound_scalers, avg_d=avg_d)
+                   strict_reference=strict_reference, scalers=scalers, compound_scalers=compound_scalers, avg_d=avg_d,
+                   group_below=group_below, t_group_below=t_group_below)
 
     def _drop(self):
         return self.drop_override if self.drop_override is not None else Fn.DropoutSpec(self.dropout)

@@ -249,7 +249,25 @@ def check_gpu(rank, world, tag, N, rowptr, col, kw):
     g = torch.Generator().manual_seed(1)
     x = torch.relu(torch.randn(N, H, generator=g))
     cot = torch.randn(N, C, generator=g)
-    sh = ShardedMMA.build(rowptr, col, rank, world, dev, H, C, names, p, seed=7, chunk=16, **kw)
+    # The SAME work-item plan on both sides (chunks of 16 edges, items below 8 edges grouped): a segment then takes the same kernel
+    # path and summation order in the shard and in the whole graph.  With different plans the sums differ in the last bit and a
+    # max / min mask flips its selection on a near tie now and then - a legitimate discontinuity of the reference's max(x_i, s), but
+    # one flipped element moves a whole row of dL/dx through the mask-weight GEMM (seen: 5 rows of 450 000 at 1 %).
+    PLAN = dict(chunk=16, group_below=8, t_group_below=8)
+    sh = ShardedMMA.build(rowptr, col, rank, world, dev, H, C, names, p, seed=7, **PLAN, **kw)
+    # the device-built shard plan (HaloPlan(plan_device=...), NCGraph.from_device_csr) against the host numpy one, list by list
+    from mma_amd.sharded import HaloPlan, partition_bounds
+    import mma_amd.graph as G
+    assert sh.plan.col_dev is not None, "ShardedMMA.build did not take the device plan path"
+    bnd = partition_bounds(rowptr, world)
+    e0_, e1_ = int(rowptr[sh.lo]), int(rowptr[sh.hi])
+    hp = HaloPlan(rowptr[sh.lo:sh.hi + 1] - e0_, col[e0_:e1_], bnd, rank, world, "cpu" if dist.get_backend() == "gloo" else dev)
+    assert np.array_equal(hp.halo_ids, sh.plan.halo_ids) and np.array_equal(hp.col, sh.plan.col_dev.cpu().numpy()), tag + ": halo ids / local columns"
+    for f_ in ("send_idx", "send_counts", "recv_counts", "unpack_rows", "unpack_segptr", "unpack_pos"):
+        assert np.array_equal(getattr(hp, f_), getattr(sh.plan, f_)), tag + ": " + f_
+    gh = G.NCGraph(hp.rowptr, hp.col, dev, n_src=hp.n_src, edge_base=e0_, H=H, **PLAN)
+    for f_ in ("rowptr", "col", "items", "hubs", "t_rowptr", "t_col", "t_eid", "t_items", "t_hubs"):
+        assert torch.equal(getattr(gh, f_), getattr(sh.graph, f_)), tag + ": graph." + f_
     sh.drop_override = Fn.DropoutSpec(p, seed=seed)
     xo = x[sh.lo:sh.hi].to(dev).requires_grad_(True)
     out = sh(xo)
@@ -258,8 +276,8 @@ def check_gpu(rank, world, tag, N, rowptr, col, kw):
     PP = lambda t: torch.nn.Parameter(t.detach().clone())
     masks = {n_: PP(sh.masks[n_]) if n_ in names else torch.nn.Parameter(torch.zeros(2, 1, device=dev)) for n_ in _MASK_NAMES}
     w, b = PP(sh.weight), PP(sh.bias)
-    add_all = [col[rowptr[i]:rowptr[i + 1]] for i in range(N)]
-    ref = mma_amd.MMA(add_all, "new_sigmoid", 2, H, C, w, b, *[masks[n_] for n_ in _MASK_NAMES], p, names, dev, chunk=16, **kw)
+    ref = mma_amd.MMA(G.NCGraph(rowptr, col, dev, H=H, **PLAN), "new_sigmoid", 2, H, C, w, b, *[masks[n_] for n_ in _MASK_NAMES], p, names,
+                      dev, **kw)
     with torch.no_grad():
         for n_ in names:
             masks[n_].copy_(sh.masks[n_])

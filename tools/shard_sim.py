@@ -106,8 +106,15 @@ def run(rank, world, steps=5):
     sp = t.summary(); Fn.TIMER = None
     ks = {k: round(v[1] / 3, 3) for k, v in sp.items()}
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    # the same shard plan built on the device (what ShardedMMA.build does through HaloPlan(plan_device=...)), timed beside the host one
+    rp_d, cl_d = torch.from_numpy(plan.rowptr).to(dev), torch.from_numpy(plan.col).to(dev)
+    mma_amd.NCGraph.from_device_csr(rp_d, cl_d, n_src=plan.n_src, edge_base=e0, H=H)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mma_amd.NCGraph.from_device_csr(rp_d, cl_d, n_src=plan.n_src, edge_base=e0, H=H)
+    torch.cuda.synchronize(); t_graph_dev = time.perf_counter() - t0
+    del rp_d, cl_d
     print(f"world {world} rank {rank}: own {plan.n_own} halo {plan.n_halo} send {int(plan.send_counts.sum())} edges {sh.local_edges}  "
-          f"{dt:.2f} ms/step  peak {peak:.1f} GiB  plan {t_plan:.1f} s + graph {t_graph:.1f} s (host numpy)  {ks}", flush=True)
+          f"{dt:.2f} ms/step  peak {peak:.1f} GiB  plan {t_plan:.1f} s + graph {t_graph:.1f} s (host numpy; the graph plan on the device: {t_graph_dev:.3f} s)  {ks}", flush=True)
     del sh, x, cot
     torch.cuda.empty_cache()
     return dt
