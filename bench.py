@@ -388,7 +388,7 @@ def gr_config(tag, n_graphs, dev, reps=20, replay=True, categorical=False):
     return r
 
 
-def gr_model_config(tag, n_graphs, dev, reps=10, n_batches=3):
+def gr_model_config(tag, n_graphs, dev, reps=10, n_batches=3, graphed=False):
     """BASELINE configs[1] at model level: one TRAINING step of the reference's graph-regression Net (mma.py:63-127: atom / bond
     embeddings, 4 x (MMAConv 75->75, towers=5, edge_dim=50 + BatchNorm + ReLU), add-pooling, MLP) with its L1 loss (mma.py:156)
     and Adam - forward, fused loss, backward, fused optimizer step - on a FRESH batch every step (rotating pre-generated
@@ -425,10 +425,31 @@ def gr_model_config(tag, n_graphs, dev, reps=10, n_batches=3):
     ms = wall_ms(step, reps)
     last = step().item()
     E_mean = float(np.mean([b["E"] for b in batches]))
-    return {"config": tag, "graphs_per_batch": n_graphs, "nodes": int(np.mean([b["N"] for b in batches])), "edges": int(E_mean),
-            "conv_layers": 4, "ms_per_step_eager": ms, "graphs_per_s": n_graphs / ms * 1e3, "edges_per_s_eager": 4 * E_mean / ms * 1e3,
-            "loss_first_steps": first, "loss_after": last,
-            "note": "whole Net training step (4 MMAConv layer calls): edges/s counts E x 4 layer calls per step"}
+    res = {"config": tag, "graphs_per_batch": n_graphs, "nodes": int(np.mean([b["N"] for b in batches])), "edges": int(E_mean),
+           "conv_layers": 4, "ms_per_step_eager": ms, "graphs_per_s": n_graphs / ms * 1e3, "edges_per_s_eager": 4 * E_mean / ms * 1e3,
+           "loss_first_steps": first, "loss_after": last,
+           "note": "whole Net training step (4 MMAConv layer calls): edges/s counts E x 4 layer calls per step"}
+    if graphed:
+        # the same training step as ONE hipGraph over padded static-shape buffers (mma_amd.GraphedNetStep): a fresh batch is copied into
+        # the bucket every step and its CSR is built inside the graph
+        n_pad = -(-(max(b["N"] for b in batches) + 1) // 64) * 64
+        e_pad = -(-max(b["E"] for b in batches) // 128) * 128
+        torch.manual_seed(0)
+        net2 = Net(["min", "max"], ["identity", "amplification", "linear"], torch.tensor(hist)).to(dev)
+        opt2 = mma_amd.FusedAdam([q for q in net2.parameters() if q.requires_grad], lr=1e-3)
+        gstep = mma_amd.GraphedNetStep(net2, opt2, n_graphs, n_pad, e_pad, dev)
+        st2 = {"i": 0}
+
+        def gs():
+            b = batches[st2["i"] % n_batches]
+            st2["i"] += 1
+            return gstep(b["x"], b["ei"], b["ea"], b["batch"], b["y"])
+        l0 = [gs().item() for _ in range(3)]
+        gms = wall_ms(gs, max(reps, 30))
+        res.update(ms_per_step_hipgraph=gms, graphs_per_s_hipgraph=n_graphs / gms * 1e3, edges_per_s_hipgraph=4 * E_mean / gms * 1e3,
+                   bucket={"n_pad": n_pad, "e_pad": e_pad}, loss_first_steps_hipgraph=l0, loss_after_hipgraph=gs().item(),
+                   speedup_over_eager=ms / gms)
+    return res
 
 
 def c5_shard_config(dev, reps=3):
@@ -480,7 +501,8 @@ def extra_configs(dev):
                                                         "min,min2,min3,min4, dropout 0.5", "pubmed_h16", 500, 0.10, 16, ["min", "min2", "min3", "min4"], 3,
                                                         0.5, 60, dev)),
                     ("C2", lambda: gr_config("C2: ZINC-like batch of 64 molecules, MMAConv T=5 F=75 min,max x id,amp,lin", 64, dev)),
-                    ("C2net", lambda: gr_model_config("C2 model: Net (mma.py:63-127) training step, batch 64 (mma.py:52-54 hard-codes 64)", 64, dev, reps=20)),
+                    ("C2net", lambda: gr_model_config("C2 model: Net (mma.py:63-127) training step, batch 64 (mma.py:52-54 hard-codes 64)", 64, dev, reps=20,
+                                                      graphed=True)),
                     ("C2net128", lambda: gr_model_config("C2 model at batch 128 (not a reference setting; round-2 entry kept for comparison)", 128, dev,
                                                          reps=20)),
                     ("C2Lnet", lambda: gr_model_config("C2L model: the same training step on 10 000 molecules per batch", 10000, dev, reps=5)),

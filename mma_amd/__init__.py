@@ -10,7 +10,7 @@ from .functional import nc_fused_aggregate, csr_spmm  # noqa: F401
 from .layers import MMA, GraphConvolution  # noqa: F401
 from .mask_aggr import MaskAggregateLinear  # noqa: F401
 from .mma_conv import CategoricalEdges, MMAConv  # noqa: F401
-from .train_step import FusedAdam, GraphedTrainStep, fused_l1_loss, fused_nll_loss  # noqa: F401
+from .train_step import FusedAdam, GraphedNetStep, GraphedTrainStep, fused_l1_loss, fused_nll_loss  # noqa: F401
 
 __all__ = ["MMA", "GraphConvolution", "MMAConv", "CategoricalEdges", "MaskAggregateLinear", "NCGraph", "nc_fused_aggregate", "csr_spmm",
-           "GraphedTrainStep", "FusedAdam", "fused_nll_loss", "fused_l1_loss"]
+           "GraphedTrainStep", "GraphedNetStep", "FusedAdam", "fused_nll_loss", "fused_l1_loss"]

@@ -49,7 +49,9 @@ class CategoricalEdges:
         """(E,) uint8 in target-sorted position order (the order K3/K4 walk the edges in)."""
         key = (id(graph), self.types.data_ptr(), self.types._version)
         if self._by_pos is None or self._by_pos[0] != key:
-            if self.types.numel():        # an out-of-range type would read past the table inside the kernel: device-side check, no sync
+            if self.types.numel() and not torch.cuda.is_current_stream_capturing():
+                # an out-of-range type would read past the table inside the kernel: device-side check, no sync (skipped inside a
+                # hipGraph capture, whose eager warm-up has just run it on the same buffers)
                 torch._assert_async(((self.types >= 0) & (self.types < self.table.shape[0])).all())
             t = self.types.to(torch.uint8)
             self._by_pos = (key, t if graph.E == 0 else t.index_select(0, graph.perm.long()).contiguous())

@@ -10,7 +10,80 @@ from .mma_conv import CategoricalEdges, MMAConv
 
 def global_add_pool(x, batch, size=None):
     size = int(batch.max()) + 1 if size is None else size
+    if x.is_cuda and x.dtype == torch.float32:
+        return _SegmentPool.apply(x, batch, size)
     return torch.zeros((size, x.shape[1]), device=x.device, dtype=x.dtype).index_add_(0, batch, x)
+
+
+class _SegmentPool(torch.autograd.Function):
+    """global_add_pool (mma.py:124) for a SORTED batch vector (PyG mini-batches number their nodes graph by graph): the pooled row
+    of a graph is the sum of one contiguous node range - the K5 segment-sum kernel in a fixed order instead of index_add_'s float
+    atomics, whose summation order changes from run to run (and between a hipGraph replay and the eager step it was captured from)."""
+
+    @staticmethod
+    def forward(ctx, x, batch, size):
+        from . import functional as Fn
+        from ._lib import call, ptr, stream_ptr
+        x = x.contiguous()
+        N, C = x.shape
+        if N > 1 and not torch.cuda.is_current_stream_capturing():
+            torch._assert_async((batch[1:] >= batch[:-1]).all())       # the contiguous-range form needs the batch vector sorted
+        rowptr = torch.searchsorted(batch, torch.arange(size + 1, device=x.device, dtype=batch.dtype)).to(torch.int32)
+        col = torch.arange(N, device=x.device, dtype=torch.int32)
+        out = torch.empty((size, C), device=x.device, dtype=torch.float32)
+        with Fn._span("pool_segsum"):
+            call("mma_csr_spmm", ptr(rowptr), ptr(col), None, ptr(x), C, N, 1, None, ptr(out), C, size, C, stream_ptr())
+        ctx.save_for_backward(batch)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        batch, = ctx.saved_tensors
+        return g.index_select(0, batch), None, None
+
+
+class _EmbedRows(torch.autograd.Function):
+    """Embedding lookup (mma.py:87,116 node_emb) whose weight gradient is a fixed-order one-hot TN product (as for the bond-type
+    table, functional.GRGraph.type_onehot) instead of torch's scatter: deterministic, so a replayed step equals the eager one."""
+
+    @staticmethod
+    def forward(ctx, idx, weight):
+        ctx.save_for_backward(idx)
+        ctx.n_types = weight.shape[0]
+        return weight.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import dense
+        idx, = ctx.saved_tensors
+        width = -(-ctx.n_types // 32) * 32
+        oh = torch.zeros((idx.numel(), width), device=g.device, dtype=torch.float32)
+        oh.scatter_(1, idx.unsqueeze(1), 1.0)
+        return None, dense.xt_g(oh, g.contiguous())[:ctx.n_types]
+
+
+def masked_batch_norm(x, bn, n_valid):
+    """BatchNorm1d over the first n_valid rows of x (n_valid: 0-dim device tensor): the padded rows of a static-shape batch neither
+    enter the statistics nor the running averages (PyG's BatchNorm = torch's BatchNorm1d on the real nodes, mma.py:97,121).  The
+    padded rows are normalised with the same statistics (their values are never read by a real node or graph)."""
+    cnt = n_valid.to(torch.float32)
+    w = (torch.arange(x.shape[0], device=x.device) < n_valid).to(torch.float32).unsqueeze(1)
+    if bn.training or not bn.track_running_stats:
+        mean = (x * w).sum(0) / cnt
+        d = (x - mean) * w
+        var = (d * d).sum(0) / cnt
+        if bn.track_running_stats:
+            with torch.no_grad():
+                m = bn.momentum if bn.momentum is not None else 0.1
+                bn.running_mean.mul_(1 - m).add_(mean.detach() * m)
+                bn.running_var.mul_(1 - m).add_(var.detach() * (cnt / torch.clamp(cnt - 1, min=1)) * m)
+                bn.num_batches_tracked.add_(1)
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    y = (x - mean) * torch.rsqrt(var + bn.eps)
+    if bn.affine:
+        y = y * bn.weight + bn.bias
+    return y
 
 
 class Net(torch.nn.Module):
@@ -29,13 +102,18 @@ class Net(torch.nn.Module):
             self.batch_norms.append(BatchNorm1d(75))
         self.mlp = Sequential(Linear(75, 50), ReLU(), Linear(50, 25), ReLU(), Linear(25, 1))
 
-    def forward(self, x, edge_index, edge_attr, batch):
-        x = self.node_emb(x.squeeze())
+    def forward(self, x, edge_index, edge_attr, batch, n_valid=None, n_graphs=None):
+        """mma.py:103-127.  n_valid / n_graphs (extension, used by train_step.GraphedNetStep): the batch is PADDED to a static shape -
+        rows [n_valid, N) are dummy nodes of a dummy graph with id n_graphs; BatchNorm then takes its statistics over the real rows
+        only and the pooled output has n_graphs + 1 rows, the last one the dummy graph's."""
+        idx = x.squeeze(-1) if x.dim() > 1 else x
+        x = _EmbedRows.apply(idx, self.node_emb.weight) if idx.is_cuda else self.node_emb(idx)
         if self.categorical_edges and x.is_cuda and edge_attr.dim() == 1:
             edge_attr = CategoricalEdges(edge_attr, self.edge_emb.weight)     # = self.edge_emb(edge_attr), never materialised
         else:
             edge_attr = self.edge_emb(edge_attr)
         for conv, batch_norm in zip(self.convs, self.batch_norms):
-            x = F.relu(batch_norm(conv(x, edge_index, edge_attr)))
-        x = global_add_pool(x, batch)
+            h = conv(x, edge_index, edge_attr)
+            x = F.relu(batch_norm(h) if n_valid is None else masked_batch_norm(h, batch_norm, n_valid))
+        x = global_add_pool(x, batch, None if n_graphs is None else n_graphs + 1)
         return self.mlp(x)

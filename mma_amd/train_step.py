@@ -248,3 +248,93 @@ class GraphedTrainStep:
     def __call__(self):
         self.graph.replay()
         return self.loss
+
+
+class GraphedNetStep:
+    """One TRAINING step of the graph-regression Net (graph_regression/mma.py:150-160: forward, L1 loss, backward, Adam) as ONE
+    hipGraph over PADDED, static-shape batch buffers - so the per-batch CSR build (K6) is inside the graph too.
+
+    A ZINC mini-batch of 64 molecules (mma.py:52-54) is ~1 500 nodes / 3 200 edges: every kernel of the step moves a few hundred KB
+    and the eager step is ~700 launches of 5-10 us host time each (7 ms).  Molecule batches change shape every step, which a captured
+    graph cannot; so the batch is copied into buffers of a fixed bucket size (n_pad nodes, e_pad edges) and padded with DUMMY nodes
+    that belong to a dummy graph (id = n_graphs) and dummy self-loop edges on those nodes:
+      * a dummy node is isolated from every real node, so no real aggregate, message or gradient sees it;
+      * BatchNorm takes its statistics over the first n_valid rows only (net.masked_batch_norm);
+      * pooling yields n_graphs + 1 rows, the loss reads the first n_graphs.
+    The result for the real graphs is what the unpadded step computes (up to BatchNorm's reduction order); `step_eager()` runs the
+    SAME padded step without the graph - the replay equals it bit for bit (tests/test_graph_capture_gpu.py).
+
+        step = GraphedNetStep(net, optimizer, n_graphs=64, n_pad=1792, e_pad=3840)
+        for data in loader:
+            loss = step(data.x, data.edge_index, data.edge_attr, data.batch, data.y)     # 0-dim device tensor
+    A batch that does not fit the bucket (or has another graph count) raises; use one step object per bucket."""
+
+    def __init__(self, net, optimizer, n_graphs, n_pad, e_pad, device="cuda:0", warmup=3):
+        from . import functional as Fn
+        self.net, self.optimizer, self.n_graphs, self.n_pad, self.e_pad = net, optimizer, int(n_graphs), int(n_pad), int(e_pad)
+        dev = torch.device(device)
+        for g in optimizer.param_groups:
+            if "capturable" in g and not g["capturable"]:
+                raise ValueError("GraphedNetStep needs a capturable optimizer (mma_amd.FusedAdam, or torch.optim.Adam(capturable=True))")
+        self.x = torch.zeros((n_pad, 1), dtype=torch.int64, device=dev)
+        self.ei = torch.zeros((2, e_pad), dtype=torch.int64, device=dev)
+        self.ea = torch.zeros((e_pad,), dtype=torch.int64, device=dev)
+        self.batch = torch.full((n_pad,), self.n_graphs, dtype=torch.int64, device=dev)
+        self.y = torch.zeros((self.n_graphs,), dtype=torch.float32, device=dev)
+        self.n_valid = torch.zeros((), dtype=torch.int64, device=dev)
+        self._fn = Fn
+        self.graph = None
+        self._warmup = warmup
+        _set_capturable(net, True)
+
+    def load(self, x, edge_index, edge_attr, batch, y):
+        """Copy a batch into the static buffers and pad it (device-side copies on the current stream, no sync)."""
+        N, E = int(x.shape[0]), int(edge_index.shape[1])
+        if N + 1 > self.n_pad or E > self.e_pad or int(y.numel()) != self.n_graphs:
+            raise ValueError("batch of %d nodes / %d edges / %d graphs does not fit the bucket (%d, %d, %d graphs); one dummy node is needed"
+                             % (N, E, int(y.numel()), self.n_pad, self.e_pad, self.n_graphs))
+        self.x[:N].copy_(x.reshape(N, 1)); self.x[N:].zero_()
+        self.batch[:N].copy_(batch); self.batch[N:].fill_(self.n_graphs)
+        self.ei[:, :E].copy_(edge_index); self.ea[:E].copy_(edge_attr); self.ea[E:].zero_()
+        if E < self.e_pad:       # dummy self-loops, dealt round-robin over the dummy nodes (short segments: the block kernels' shape)
+            d = N + torch.arange(self.e_pad - E, device=self.ei.device) % (self.n_pad - N)
+            self.ei[0, E:] = d; self.ei[1, E:] = d
+        self.y.copy_(y.reshape(-1).to(torch.float32))
+        self.n_valid.fill_(N)
+
+    def forward_backward(self):
+        """Loss and gradients of the loaded (padded) batch, no optimizer step."""
+        self._fn._GR_GRAPHS.clear()            # the CSR of THIS batch is built inside the step (and inside the captured graph)
+        self.optimizer.zero_grad(set_to_none=False)
+        out = self.net(self.x, self.ei, self.ea, self.batch, n_valid=self.n_valid, n_graphs=self.n_graphs)
+        loss = fused_l1_loss(out[:self.n_graphs].squeeze(-1), self.y)
+        loss.backward()
+        return loss.detach()
+
+    def _step(self):
+        loss = self.forward_backward()
+        self.optimizer.step()
+        return loss
+
+    def step_eager(self):
+        """The padded step without the graph (what the captured graph replays)."""
+        return self._step()
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self._warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._step()
+
+    def __call__(self, x=None, edge_index=None, edge_attr=None, batch=None, y=None):
+        if x is not None:
+            self.load(x, edge_index, edge_attr, batch, y)
+        if self.graph is None:
+            self._capture()          # NOTE: the warm-up steps are real optimizer steps on the loaded batch (the capture itself runs nothing)
+        self.graph.replay()
+        return self.loss
