@@ -312,6 +312,20 @@ int mma_logsoftmax_nll_fwd(const float* x, int64_t ldx, const int64_t* idx, cons
 int mma_logsoftmax_nll_bwd(const float* logp, int64_t ldo, const int64_t* idx, const int64_t* labels, int64_t n_idx,
                            const float* gloss, float* gx, int64_t ldg, int64_t N, int32_t C, void* stream);
 
+/* ---- K17: BatchNorm1d (training mode) + ReLU over the first *n_valid rows of a padded batch (mma.py:121 F.relu(batch_norm(conv(...)))
+ * inside the graphed Net step, where batches are padded to a static shape) ---------------------------------------------------------
+ * fwd: per column, mean / biased variance over rows [0, *n_valid) (n_valid: DEVICE int64 scalar, clamped to [1, N]); y = relu?(gamma
+ *      (x - mean) rstd + beta) for ALL N rows; mean_out / rstd_out (C,) saved for backward; running_mean / running_var (both or neither)
+ *      updated with `momentum` (the unbiased variance, like torch) and *n_tracked incremented (may be NULL).  gamma / beta may be NULL.
+ * bwd: g = gy [y > 0] (if relu); gx = gamma rstd (g - sum g / n - xhat sum(g xhat) / n), ggamma = sum g xhat, gbeta = sum g (may be NULL);
+ *      the sums run over all N rows (rows past n_valid belong to the dummy graph the loss never reads: their g is 0). */
+int mma_masked_bn_relu_fwd(const float* x, int64_t ldx, const int64_t* n_valid, const float* gamma, const float* beta, float* y, int64_t ldy,
+                           float* mean_out, float* rstd_out, float* running_mean, float* running_var, int64_t* n_tracked, float momentum,
+                           float eps, int64_t N, int32_t C, int32_t relu, void* stream);
+int mma_masked_bn_relu_bwd(const float* gy, int64_t ldg, const float* y, int64_t ldy, const float* x, int64_t ldx, const float* mean,
+                           const float* rstd, const float* gamma, const int64_t* n_valid, float* gx, int64_t ldgx, float* ggamma, float* gbeta,
+                           int64_t N, int32_t C, int32_t relu, void* stream);
+
 /* ---- K12: the graph-regression loss of the training step (graph_regression/mma.py:156 (out.squeeze() - data.y).abs().mean()) ----
  * fwd: loss (DEVICE scalar) = mean_i |pred[i] - target[i]| over n >= 1 contiguous values, fixed summation order.
  * bwd: gpred[i] = gloss * sign(pred[i] - target[i]) / n with sign(0) = 0 (torch's abs backward); gloss: DEVICE scalar. */

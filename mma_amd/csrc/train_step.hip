@@ -132,6 +132,92 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(const AdamTensor* tab, int
 }
 __global__ void adam_tick_kernel(float* step) { *step += 1.f; }
 
+// ---- K17: BatchNorm1d (training mode) + ReLU over the first n_valid rows of a padded batch, one launch each way ------------------
+// mma.py:121 `x = F.relu(batch_norm(conv(...)))` inside the graphed Net step (train_step.GraphedNetStep): the batch is padded to a
+// static shape, so the statistics run over the first *n_valid rows (a DEVICE scalar: the captured graph replays on batches of any
+// size) while every row is normalised.  As torch ops the masked form is ~30 small launches per layer and direction.
+// One workgroup owns 16 columns: 16 row lanes x 16 columns, fixed summation order (a strided partial sum per row lane, then a tree).
+constexpr int kBnCols = 16, kBnRows = kBlock / kBnCols;
+
+__device__ __forceinline__ float bn_block_sum(float v, float (*red)[kBnCols], int r, int c) {
+  __syncthreads();
+  red[r][c] = v;
+  __syncthreads();
+  for (int o = kBnRows / 2; o > 0; o >>= 1) {
+    if (r < o) red[r][c] += red[r + o][c];
+    __syncthreads();
+  }
+  return red[0][c];
+}
+
+__global__ __launch_bounds__(kBlock) void masked_bn_relu_fwd_kernel(const float* x, int64_t ldx, const int64_t* n_valid, const float* gamma,
+                                                                    const float* beta, float* y, int64_t ldy, float* mean_out, float* rstd_out,
+                                                                    float* run_mean, float* run_var, int64_t* n_tracked, float momentum,
+                                                                    float eps, int64_t N, int C, int relu) {
+  __shared__ float red[kBnRows][kBnCols];
+  const int c = threadIdx.x % kBnCols, r = threadIdx.x / kBnCols;
+  const int col = (int)blockIdx.x * kBnCols + c;
+  const bool cv = col < C;
+  const int64_t nv = min(max(*n_valid, (int64_t)1), N);
+  const float cnt = (float)nv;
+  float s = 0.f;
+  for (int64_t i = r; i < nv; i += kBnRows) s += cv ? x[i * ldx + col] : 0.f;
+  const float mean = bn_block_sum(s, red, r, c) / cnt;
+  float q = 0.f;
+  for (int64_t i = r; i < nv; i += kBnRows) { const float d = cv ? x[i * ldx + col] - mean : 0.f; q += d * d; }
+  const float var = bn_block_sum(q, red, r, c) / cnt;                  // biased: what normalises (torch BatchNorm training mode)
+  const float rstd = rsqrtf(var + eps);
+  if (cv) {
+    const float g = gamma ? gamma[col] : 1.f, b = beta ? beta[col] : 0.f;
+    for (int64_t i = r; i < N; i += kBnRows) {
+      const float v = (x[i * ldx + col] - mean) * rstd * g + b;
+      y[i * ldy + col] = relu ? fmaxf(v, 0.f) : v;
+    }
+    if (r == 0) {
+      mean_out[col] = mean; rstd_out[col] = rstd;
+      if (run_mean) {                                                  // running averages: the UNBIASED variance, like torch
+        run_mean[col] = (1.f - momentum) * run_mean[col] + momentum * mean;
+        run_var[col] = (1.f - momentum) * run_var[col] + momentum * var * (cnt / fmaxf(cnt - 1.f, 1.f));
+      }
+    }
+  }
+  if (n_tracked && blockIdx.x == 0 && threadIdx.x == 0) *n_tracked += 1;
+}
+
+// g = gy * [y > 0] (ReLU);  gx = gamma rstd (g - sum(g)/n - xhat sum(g xhat)/n);  ggamma = sum(g xhat), gbeta = sum(g): sums over ALL rows -
+// the rows past n_valid belong to the dummy graph the loss never reads, their g is exactly 0
+__global__ __launch_bounds__(kBlock) void masked_bn_relu_bwd_kernel(const float* gy, int64_t ldg, const float* y, int64_t ldy, const float* x,
+                                                                    int64_t ldx, const float* mean_in, const float* rstd_in, const float* gamma,
+                                                                    const int64_t* n_valid, float* gx, int64_t ldgx, float* ggamma, float* gbeta,
+                                                                    int64_t N, int C, int relu) {
+  __shared__ float red[kBnRows][kBnCols];
+  const int c = threadIdx.x % kBnCols, r = threadIdx.x / kBnCols;
+  const int col = (int)blockIdx.x * kBnCols + c;
+  const bool cv = col < C;
+  const int64_t nv = min(max(*n_valid, (int64_t)1), N);
+  const float cnt = (float)nv;
+  const float mean = cv ? mean_in[col] : 0.f, rstd = cv ? rstd_in[col] : 0.f;
+  float sg = 0.f, sgx = 0.f;
+  for (int64_t i = r; i < N; i += kBnRows) {
+    if (cv) {
+      const float g = (relu && !(y[i * ldy + col] > 0.f)) ? 0.f : gy[i * ldg + col];
+      sg += g; sgx += g * ((x[i * ldx + col] - mean) * rstd);
+    }
+  }
+  const float tg = bn_block_sum(sg, red, r, c);
+  const float tgx = bn_block_sum(sgx, red, r, c);
+  if (cv) {
+    const float k = (gamma ? gamma[col] : 1.f) * rstd;
+    for (int64_t i = r; i < N; i += kBnRows) {
+      const float g = (relu && !(y[i * ldy + col] > 0.f)) ? 0.f : gy[i * ldg + col];
+      const float xh = (x[i * ldx + col] - mean) * rstd;
+      // the statistics depend on the first nv rows only: a padded row's x reaches nothing but its own y
+      gx[i * ldgx + col] = i < nv ? k * (g - tg / cnt - xh * (tgx / cnt)) : k * g;
+    }
+    if (r == 0) { if (ggamma) ggamma[col] = tgx; if (gbeta) gbeta[col] = tg; }
+  }
+}
+
 }  // namespace mma
 
 using namespace mma;
@@ -202,4 +288,24 @@ extern "C" int mma_l1_loss_bwd(const float* pred, const float* target, int64_t n
   if (blocks > kMaxGrid) blocks = kMaxGrid;
   hipLaunchKernelGGL(l1_mean_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), pred, target, n, gloss, gpred);
   return check_launch("l1_mean_bwd_kernel");
+}
+
+extern "C" int mma_masked_bn_relu_fwd(const float* x, int64_t ldx, const int64_t* n_valid, const float* gamma, const float* beta, float* y,
+                                      int64_t ldy, float* mean_out, float* rstd_out, float* running_mean, float* running_var,
+                                      int64_t* n_tracked, float momentum, float eps, int64_t N, int32_t C, int32_t relu, void* stream) {
+  MMA_REQUIRE(N >= 1 && C >= 1 && ldx >= C && ldy >= C && momentum >= 0.f && momentum <= 1.f && eps >= 0.f, "N=%lld C=%d unsupported", (long long)N, C);
+  MMA_REQUIRE(x && n_valid && y && mean_out && rstd_out && ((running_mean == nullptr) == (running_var == nullptr)), "NULL argument");
+  hipLaunchKernelGGL(masked_bn_relu_fwd_kernel, dim3((unsigned)((C + kBnCols - 1) / kBnCols)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     x, ldx, n_valid, gamma, beta, y, ldy, mean_out, rstd_out, running_mean, running_var, n_tracked, momentum, eps, N, (int)C, (int)relu);
+  return check_launch("masked_bn_relu_fwd_kernel");
+}
+
+extern "C" int mma_masked_bn_relu_bwd(const float* gy, int64_t ldg, const float* y, int64_t ldy, const float* x, int64_t ldx, const float* mean,
+                                      const float* rstd, const float* gamma, const int64_t* n_valid, float* gx, int64_t ldgx, float* ggamma,
+                                      float* gbeta, int64_t N, int32_t C, int32_t relu, void* stream) {
+  MMA_REQUIRE(N >= 1 && C >= 1 && ldx >= C && ldy >= C && ldg >= C && ldgx >= C, "N=%lld C=%d unsupported", (long long)N, C);
+  MMA_REQUIRE(gy && y && x && mean && rstd && n_valid && gx, "NULL argument");
+  hipLaunchKernelGGL(masked_bn_relu_bwd_kernel, dim3((unsigned)((C + kBnCols - 1) / kBnCols)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     gy, ldg, y, ldy, x, ldx, mean, rstd, gamma, n_valid, gx, ldgx, ggamma, gbeta, N, (int)C, (int)relu);
+  return check_launch("masked_bn_relu_bwd_kernel");
 }

@@ -86,6 +86,51 @@ def masked_batch_norm(x, bn, n_valid):
     return y
 
 
+class _MaskedBNReLU(torch.autograd.Function):
+    """K17: training-mode BatchNorm1d over the first n_valid rows + ReLU, one launch each way (running statistics updated in place)."""
+
+    @staticmethod
+    def forward(ctx, x, n_valid, weight, bias, bn):
+        from ._lib import call, ptr, stream_ptr
+        x = x.contiguous()
+        N, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((C,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty((C,), device=x.device, dtype=torch.float32)
+        track = bn.track_running_stats
+        m = bn.momentum if bn.momentum is not None else 0.1
+        call("mma_masked_bn_relu_fwd", ptr(x), C, ptr(n_valid), ptr(weight), ptr(bias), ptr(y), C, ptr(mean), ptr(rstd),
+             ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None, ptr(bn.num_batches_tracked) if track else None,
+             float(m), float(bn.eps), N, C, 1, stream_ptr())
+        ctx.save_for_backward(x, y, mean, rstd, weight, n_valid)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from ._lib import call, ptr, stream_ptr
+        x, y, mean, rstd, weight, n_valid = ctx.saved_tensors
+        N, C = x.shape
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        gw = torch.empty((C,), device=x.device, dtype=torch.float32) if weight is not None else None
+        gb = torch.empty((C,), device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        call("mma_masked_bn_relu_bwd", ptr(gy), C, ptr(y), C, ptr(x), C, ptr(mean), ptr(rstd), ptr(weight), ptr(n_valid), ptr(gx), C,
+             ptr(gw), ptr(gb), N, C, 1, stream_ptr())
+        return gx, None, gw, gb, None
+
+
+def masked_bn_relu(x, bn, n_valid):
+    """F.relu(batch_norm(x)) with the statistics over the first n_valid rows: the fused K17 kernels in training mode on the GPU, the
+    torch formulation (masked_batch_norm) otherwise."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and (bn.training or not bn.track_running_stats) and FUSED_BN:
+        return _MaskedBNReLU.apply(x, n_valid, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn)
+    return F.relu(masked_batch_norm(x, bn, n_valid))
+
+
+FUSED_BN = __import__("os").environ.get("MMA_FUSED_BN", "1") != "0"
+
+
 class Net(torch.nn.Module):
     categorical_edges = True      # hand the bond types and the embedding table to the layers (same math as the embedded rows)
 
@@ -114,6 +159,6 @@ class Net(torch.nn.Module):
             edge_attr = self.edge_emb(edge_attr)
         for conv, batch_norm in zip(self.convs, self.batch_norms):
             h = conv(x, edge_index, edge_attr)
-            x = F.relu(batch_norm(h) if n_valid is None else masked_batch_norm(h, batch_norm, n_valid))
+            x = F.relu(batch_norm(h)) if n_valid is None else masked_bn_relu(h, batch_norm, n_valid)
         x = global_add_pool(x, batch, None if n_graphs is None else n_graphs + 1)
         return self.mlp(x)

@@ -193,3 +193,38 @@ def test_graphed_net_step_refuses_a_batch_that_does_not_fit():
     st = mma_amd.GraphedNetStep(net, opt, 8, b["N"], b["E"], DEV)       # no room for the dummy node
     with pytest.raises(ValueError, match="does not fit"):
         st.load(b["x"], b["ei"], b["ea"], b["batch"], b["y"])
+
+
+def test_fused_masked_bn_relu_equals_the_torch_formulation():
+    """K17 against net.masked_batch_norm + relu (torch ops) and, on the valid rows, against torch's own BatchNorm1d on the unpadded
+    rows: outputs, input / weight / bias gradients, running statistics."""
+    from mma_amd import net as NN
+    g = torch.Generator().manual_seed(3)
+    N, nv, C = 333, 301, 75
+    x0 = (torch.randn(N, C, generator=g) * 2 + 0.5).to(DEV)
+    cot = torch.randn(N, C, generator=g).to(DEV)
+    cot[nv:] = 0                                      # rows of the dummy graph: the loss never reads them
+    n_valid = torch.tensor(nv, device=DEV)
+    res = []
+    for fused in (True, False):
+        NN.FUSED_BN = fused
+        bn = torch.nn.BatchNorm1d(C).to(DEV)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.5, 0.5, C))
+        x = x0.clone().requires_grad_(True)
+        y = NN.masked_bn_relu(x, bn, n_valid)
+        y.backward(cot)
+        res.append((y.detach(), x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)))
+    NN.FUSED_BN = True
+    assert torch.equal(res[0][1][nv:], torch.zeros(N - nv, C, device=DEV))        # padded rows: no gradient (their g is 0)
+    for a, b, what in zip(res[0][:6], res[1][:6], ("y", "gx", "gweight", "gbias", "running_mean", "running_var")):
+        assert torch.allclose(a, b, rtol=2e-5, atol=2e-5), (what, (a - b).abs().max().item())
+    assert res[0][6] == res[1][6] == 1
+    bn = torch.nn.BatchNorm1d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.5, 0.5, C))
+    xr = x0[:nv].clone().requires_grad_(True)
+    yr = torch.relu(bn(xr)); yr.backward(cot[:nv])
+    assert torch.allclose(res[0][0][:nv], yr.detach(), rtol=2e-5, atol=2e-5) and torch.allclose(res[0][1][:nv], xr.grad, rtol=2e-5, atol=2e-5)
+    assert torch.allclose(res[0][4], bn.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(res[0][5], bn.running_var, rtol=1e-5, atol=1e-6)
