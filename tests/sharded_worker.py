@@ -172,7 +172,7 @@ def run_gpu(rank, world, variant="hub"):
     from mma_amd import functional as Fn
     from mma_amd.layers import _MASK_NAMES
     from mma_amd.sharded import ShardedMMA, partition_bounds
-    dev = "cuda:0"
+    dev = "cuda:%d" % torch.cuda.current_device()
     if variant == "sweep":        # the remaining graph shapes of the CPU test + the true-degree scalers, one launch
         for tag, n_, gr, kw in (("messy", 131, messy_graph(5, 131), {}), ("fewer nodes than ranks", 2, (np.array([0, 1, 2]), np.array([1, 0])), {}),
                                 ("no edges", 9, (np.zeros(10, np.int64), np.zeros(0, np.int64)), {}),
@@ -243,7 +243,7 @@ def check_gpu(rank, world, tag, N, rowptr, col, kw):
     from mma_amd import functional as Fn
     from mma_amd.layers import _MASK_NAMES
     from mma_amd.sharded import ShardedMMA
-    dev = "cuda:0"
+    dev = "cuda:%d" % torch.cuda.current_device()
     kw = dict(kw)
     H, C, names, p, seed = kw.pop("H", 16), 4, kw.pop("names", ["sum", "mean3", "max", "min2"]), 0.5, 0x1234ABCD77
     g = torch.Generator().manual_seed(1)
@@ -332,9 +332,10 @@ def run_grads(rank, world):
 
 if __name__ == "__main__":
     mode = sys.argv[1]
-    if mode == "nccl":          # the real RCCL code path (device-side index exchange, all_to_all_single on GPU tensors) at world size 1
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    if mode in ("nccl", "nccl_multi"):   # the real RCCL code path (device-side index exchange, all_to_all_single on GPU tensors)
+        lr = int(os.environ.get("LOCAL_RANK", 0)) if mode == "nccl_multi" else 0      # nccl: world size 1 on cuda:0; nccl_multi: one GPU per rank
+        torch.cuda.set_device(lr)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
     else:
         dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -347,6 +348,9 @@ if __name__ == "__main__":
             elif mode == "nccl":
                 run_gpu(rank, world, "hub")
                 run_gpu(rank, world, "sweep")
+            elif mode == "nccl_multi":          # async RCCL all-to-all-v with uneven and zero counts, comm stream vs compute stream
+                for variant in ("hub", "directed", "sweep") + (("empty",) if world == 3 else ()):
+                    run_gpu(rank, world, variant)
             else:
                 run_gpu(rank, world, sys.argv[2] if len(sys.argv) > 2 else "hub")
         except BaseException:

@@ -59,6 +59,19 @@ def test_sharded_on_the_rccl_backend_single_rank():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_on_rccl_one_gpu_per_rank(world):
+    """the overlapped exchanges (async all_to_all_single handles on RCCL's stream beside the compute stream, send / receive
+    buffer lifetimes, uneven and zero counts) with world > 1 on the REAL backend - hub, directed (a rank without halo), sweep
+    (messy / tiny / empty graphs, true-degree scalers, K=8 / S=5, tall shards) and, at world 3, an empty shard.  Needs one GPU per
+    rank: skipped on the single-GPU test box (RCCL refuses two ranks on one device), runs wherever the driver has a multi-GPU node."""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs (this box has %d)" % (world, torch.cuda.device_count()))
+    _launch("nccl_multi", world)
+
+
+@pytest.mark.gpu
 def test_sharded_gpu_two_ranks_one_device():
     _launch("gpu", 2)
 
