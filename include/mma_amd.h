@@ -270,15 +270,17 @@ int mma_tower_linear_bwd(const float* gy, const float* a, const float* W, float*
  *        gys[n, (t*S + q)*16 + o] = pre_q gy[n, t*O + o]   (optional: the left operand of gW[t] = gys_t^T agg_t, a TN product)
  * on the matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain).  The caller lays the post-NN weight columns
  * Wo[t][o][(q*K + k)*F + f] out twice, zero-padded: Wa (T, KFp, S*16) and Wb (T, S*16, KFp + 16) with KFp = mma_tower_post_kfp(KF);
- * KF = K*F <= 512, O <= 16, S <= 5; rowptr: the CSR-by-target row pointers (degrees).  Neither `out` nor its
+ * KF = K*F <= 512, O <= 16, S <= 5; pre: the table of mma_tower_post_pre (from the CSR-by-target row pointers = degrees).  Neither `out` nor its
  * gradient is ever materialised. */
 int64_t mma_tower_post_kfp(int32_t KF);
-int mma_tower_post_fwd(const float* agg, int64_t lda, const int32_t* rowptr, const float* Wa, float* y, int64_t ldy,
+/* pre (N, 8): pre[n][q] = prod_{q' <= q} scaler_q'(clamp(rowptr[n+1] - rowptr[n], 1)), q < S - the table the three kernels below read */
+int mma_tower_post_pre(const int32_t* rowptr, float* pre, int64_t N, int32_t S, const uint8_t* scaler_host, float avg_log, float avg_lin,
+                       void* stream);
+int mma_tower_post_fwd(const float* agg, int64_t lda, const float* pre, const float* Wa, float* y, int64_t ldy,
                        int64_t N, int32_t T, int32_t KF, int32_t S, int32_t O, const uint8_t* scaler_host, float avg_log, float avg_lin,
                        void* stream);
-int mma_tower_post_bwd(const float* gy, int64_t ldg, const int32_t* rowptr, const float* Wb, float* gagg, int64_t lda,
+int mma_tower_post_bwd(const float* gy, int64_t ldg, const float* pre, const float* Wb, float* gagg, int64_t lda,
                        float* gys, int64_t ldgs,
-                       float* pre_out,              /* optional (N, 8): pre_q of every node, the table mma_tower_post_gw reads */
                        int64_t N, int32_t T, int32_t KF, int32_t S, int32_t O,
                        const uint8_t* scaler_host, float avg_log, float avg_lin, void* stream);
 /* K15: the weight gradient of the same product, part (n_chunks, T, S*16, KFp16) with KFp16 = KF rounded up to 16 and n_chunks =
@@ -287,7 +289,7 @@ int mma_tower_post_bwd(const float* gy, int64_t ldg, const int32_t* rowptr, cons
  * gives gW[t][q*16 + o][kf] = the gradient of Wb.  Rows o >= O and columns kf >= KF are zero. */
 int64_t mma_tower_post_gw_chunks(int64_t N, int32_t T);
 int mma_tower_post_gw(const float* gy, int64_t ldg, const float* agg, int64_t lda,
-                      const float* pre,            /* (N, 8) from mma_tower_post_bwd */
+                      const float* pre,            /* (N, 8) from mma_tower_post_pre */
                       float* part, int64_t n_chunks,
                       int64_t N, int32_t T, int32_t KF, int32_t S, int32_t O, const uint8_t* scaler_host, float avg_log, float avg_lin,
                       void* stream);

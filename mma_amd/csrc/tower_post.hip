@@ -43,6 +43,7 @@ struct PostParams {
   int64_t N; int T, KF, KFp, S, O;          // KFp: KF rounded up to kPostTile (the padded weight rows / columns are zero)
   int64_t lda, ldy, ldg, ldgs;
   uint32_t scaler_pack; float avg_log, avg_lin;
+  int tiles_per_wave;       // 64-node tiles a wavefront walks with the tower's weights staged once
   int vec4;                 // rows of agg / gagg are 16-byte aligned (pitch % 4 == 0, KF % 4 == 0): float4 row segments; else dwords
   const float* bias;        // PLAIN forward only, may be NULL
 };
@@ -68,31 +69,44 @@ __device__ __forceinline__ void post_wave_sync() {
 }
 
 __device__ __forceinline__ void post_stage_weights(float* dst, const float* __restrict__ src, int n_floats) {
+  // eight loads in flight per thread, then eight LDS stores: as a plain copy loop every 16-byte piece was a load -> wait -> store round
+  // trip (30 of them per thread for ZINC's 30 KB: most of a workgroup's life, PMC: the matrix pipe busy 45 % of the kernel)
   const float4* s4 = reinterpret_cast<const float4*>(src);
   float4* d4 = reinterpret_cast<float4*>(dst);
-  for (int i = threadIdx.x; i < n_floats / 4; i += kBlock) d4[i] = s4[i];
+  const int n4 = n_floats / 4;
+  for (int i0 = threadIdx.x; i0 < n4; i0 += kBlock * 8) {
+    float4 v[8];           // indices past the end are clamped for the load AND the store (every such lane rewrites the last piece with its own value)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = s4[min(i0 + u * kBlock, n4 - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d4[min(i0 + u * kBlock, n4 - 1)] = v[u];
+  }
 }
 
-// rows n0..n0+63, columns [kf0, kf0+32) of tower t -> registers (coalesced 128-byte row segments; 8 lanes per node row) -> the wave's LDS tile
-__device__ __forceinline__ void post_tile_fetch(const PostParams& p, const float* __restrict__ agg, int64_t n0, int t, int kf0, bool tvalid,
-                                                int lane, float4 (&v)[8]) {
+// rows n0..n0+63, columns [kf0, kf0+32) of tower t -> registers (coalesced 128-byte row segments; 8 lanes per node row) -> the wave's LDS tile.
+// Unconditional loads from clamped addresses, zeroed by selects (a conditional load is an exec branch of its own: eight of them in a row
+// kept the scheduler from batching the tile's loads)
+template <bool VEC4>
+__device__ __forceinline__ void post_tile_fetch(const PostParams& p, const float* __restrict__ agg, int64_t n0, int t, int kf0, int lane,
+                                                float4 (&v)[8]) {
   const int lrow = lane >> 3, lq = lane & 7;
+  const int col = kf0 + lq * 4;
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const int row = r * 8 + lrow;
-    const int col = kf0 + lq * 4;
-    v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tvalid && n0 + row < p.N && col < p.KF) {
-      const float* src = agg + (size_t)(n0 + row) * p.lda + (size_t)t * p.KF + col;
-      if (p.vec4) {                                            // KF % 4 == 0: a quad is inside or outside
-        v[r] = *reinterpret_cast<const float4*>(src);
-      } else {                                                 // odd widths / pitches (the 75-wide Linear layers): dwords, guarded
-        v[r].x = src[0];
-        if (col + 1 < p.KF) v[r].y = src[1];
-        if (col + 2 < p.KF) v[r].z = src[2];
-        if (col + 3 < p.KF) v[r].w = src[3];
-      }
+    const int64_t row = min(n0 + r * 8 + lrow, p.N - 1);
+    const float* base = agg + (size_t)row * p.lda + (size_t)t * p.KF;
+    if (VEC4) {                                                // KF % 4 == 0: a quad is inside or outside
+      v[r] = *reinterpret_cast<const float4*>(base + min(col, p.KF - 4));
+    } else {                                                   // odd widths / pitches (the 75-wide Linear layers): dwords
+      v[r].x = base[min(col, p.KF - 1)]; v[r].y = base[min(col + 1, p.KF - 1)];
+      v[r].z = base[min(col + 2, p.KF - 1)]; v[r].w = base[min(col + 3, p.KF - 1)];
     }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const bool rv = n0 + r * 8 + lrow < p.N;
+    v[r].x = (rv && col < p.KF) ? v[r].x : 0.f; v[r].y = (rv && col + 1 < p.KF) ? v[r].y : 0.f;
+    v[r].z = (rv && col + 2 < p.KF) ? v[r].z : 0.f; v[r].w = (rv && col + 3 < p.KF) ? v[r].w : 0.f;
   }
 }
 __device__ __forceinline__ void post_tile_put(float* tile, int lane, const float4 (&v)[8]) {
@@ -104,11 +118,23 @@ __device__ __forceinline__ void post_tile_put(float* tile, int lane, const float
   }
 }
 
+// the scaler products of every node, once per call: pre[n][q] = prod_{q' <= q} scaler_q'(clamp(deg_n, 1)) - K13, K14 and K15 read the table
+// (each re-evaluating them - a logarithm, two divisions and a switch per scaler - put a chain of ~60 branches into every epilogue)
+template <int S>
+__global__ __launch_bounds__(kBlock) void tower_post_pre_kernel(const PostParams p, const int32_t* __restrict__ rowptr, float* __restrict__ pre_out) {
+  const int64_t node = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (node >= p.N) return;
+  float pre[S];
+  post_pre<S>(p, rowptr, node, true, pre);
+#pragma unroll
+  for (int q = 0; q < S; ++q) pre_out[(size_t)node * kPostPrePitch + q] = pre[q];
+}
+
 // y[n, t*O + o] = sum_q pre_q sum_kf agg[n, t*KF + kf] * Wa[t][kf][q*16 + o]
 // PLAIN: a plain skinny Linear, y[n, r] = bias[r] + sum_kf x[n, kf] * Wa[kf][r] for r < O <= S*16 - every 16-row tile is 16 more
 // outputs instead of one more scaler (the 75 -> 75 Linear layers around the fused kernels: x-part of the post-NN, `lin`)
-template <int S, bool PLAIN>
-__global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams p, const float* __restrict__ agg, const int32_t* __restrict__ rowptr,
+template <int S, bool PLAIN, bool VEC4>
+__global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams p, const float* __restrict__ agg, const float* __restrict__ pre_tab,
                                                                 const float* __restrict__ Wa, float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float post_smem[];
   constexpr int R = S * kPostO;                                // weight columns per kf row
@@ -117,11 +143,14 @@ __global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams
   float* Wl = post_smem;                                       // (KFp, R)
   float* tile = post_smem + (size_t)p.KFp * R + wave * (kWave * kPostPitch);
   const int t = (int)blockIdx.y;
-  const int64_t nblk = (int64_t)blockIdx.x * (kBlock / kWave) + wave;
-  const bool tvalid = nblk * kWave < p.N;                      // wave-uniform; the block-wide barriers below are still joined
-  const int64_t n0 = (tvalid ? nblk : 0) * kWave;
-  post_stage_weights(Wl, Wa + (size_t)t * p.KFp * R, p.KFp * R);      // visible after the barrier below
+  post_stage_weights(Wl, Wa + (size_t)t * p.KFp * R, p.KFp * R);
+  __syncthreads();                                             // weights staged: the only workgroup barrier
   const int j = lane & 15, kq = lane >> 4;                     // MFMA 16x16x4 operand lane: row/column j, k index kq
+  for (int rt = 0; rt < p.tiles_per_wave; ++rt) {
+  const int64_t nblk = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * p.tiles_per_wave + rt;
+  const bool tvalid = nblk * kWave < p.N;                      // wave-uniform
+  if (!tvalid) break;
+  const int64_t n0 = nblk * kWave;
   post_f32x4 acc[4][S];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
@@ -129,12 +158,11 @@ __global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams
     for (int q = 0; q < S; ++q) acc[nt][q] = post_f32x4{0.f, 0.f, 0.f, 0.f};
 
   float4 nxt[8];
-  post_tile_fetch(p, agg, n0, t, 0, tvalid, lane, nxt);
-  __syncthreads();                                             // weights staged
+  post_tile_fetch<VEC4>(p, agg, n0, t, 0, lane, nxt);
   for (int kf0 = 0; kf0 < p.KFp; kf0 += kPostTile) {
     post_tile_put(tile, lane, nxt);
     post_wave_sync();
-    if (kf0 + kPostTile < p.KFp) post_tile_fetch(p, agg, n0, t, kf0 + kPostTile, tvalid, lane, nxt);   // in flight behind the MFMAs
+    if (kf0 + kPostTile < p.KFp) post_tile_fetch<VEC4>(p, agg, n0, t, kf0 + kPostTile, lane, nxt);   // in flight behind the MFMAs
 #pragma unroll
     for (int ks = 0; ks < kPostTile / 4; ++ks) {
       const int kf = kf0 + 4 * ks + kq;
@@ -168,7 +196,8 @@ __global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams
       continue;
     }
     float pre[S];
-    post_pre<S>(p, rowptr, node, valid, pre);
+#pragma unroll
+    for (int q = 0; q < S; ++q) pre[q] = pre_tab[(size_t)min(node, p.N - 1) * kPostPrePitch + q];      // the table of mma_tower_post_pre
     float yv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < S; ++q)
@@ -181,14 +210,15 @@ __global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams
         if (4 * kq + r < p.O) yr[r] = yv[r];
     }
   }
+  }   // tiles of this wave
 }
 
 // gagg[n, t*KF + kf] = sum_r gys[n][r] * Wb[t][r][kf],  r = q*16 + o,  gys[n][r] = pre_q gy[n, t*O + o]   (also stored, optional)
 // PLAIN: gx[n, kf] = sum_r gy[n, r] * Wb[r][kf], r < O <= S*16 (the dL/dx of the plain skinny Linear)
 template <int S, bool PLAIN>
-__global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams p, const float* __restrict__ gy, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams p, const float* __restrict__ gy, const float* __restrict__ pre_tab,
                                                                 const float* __restrict__ Wb, int wb_pitch, float* __restrict__ gagg,
-                                                                float* __restrict__ gys, float* __restrict__ pre_out) {
+                                                                float* __restrict__ gys) {
   extern __shared__ __attribute__((aligned(16))) float post_smem[];
   constexpr int R = S * kPostO;
   const int lane = threadIdx.x & (kWave - 1);
@@ -196,11 +226,14 @@ __global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams
   float* Wl = post_smem;                                       // (R, wb_pitch): pitch = KFp + 16, so that k and k+1 fall on different banks
   float* tile = post_smem + (size_t)R * wb_pitch + wave * (kWave * kPostPitch);
   const int t = (int)blockIdx.y;
-  const int64_t nblk = (int64_t)blockIdx.x * (kBlock / kWave) + wave;
-  const bool tvalid = nblk * kWave < p.N;
-  const int64_t n0 = (tvalid ? nblk : 0) * kWave;
   post_stage_weights(Wl, Wb + (size_t)t * R * wb_pitch, R * wb_pitch);
+  __syncthreads();               // weights staged: the only workgroup barrier
   const int j = lane & 15, kq = lane >> 4;
+  for (int rt = 0; rt < p.tiles_per_wave; ++rt) {
+  const int64_t nblk = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * p.tiles_per_wave + rt;
+  const bool tvalid = nblk * kWave < p.N;
+  if (!tvalid) break;
+  const int64_t n0 = nblk * kWave;
   // B fragments: this lane's node (per 16-node tile nt) and its k index kq: gys[node][4*s + kq], s = 0 .. R/4 - 1
   float bf[4][R / 4];
 #pragma unroll
@@ -213,11 +246,8 @@ __global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams
       continue;
     }
     float pre[S];
-    post_pre<S>(p, rowptr, node, valid, pre);
-    if (pre_out && valid && kq == 0 && blockIdx.y == 0) {      // the scaler products of every node, once: K15 reads them per k-step
 #pragma unroll
-      for (int q = 0; q < S; ++q) pre_out[(size_t)node * kPostPrePitch + q] = pre[q];
-    }
+    for (int q = 0; q < S; ++q) pre[q] = pre_tab[(size_t)min(node, p.N - 1) * kPostPrePitch + q];
     // r = 4*s + kq  ->  o = r % 16 = 4*(s % 4) + kq,  q = s / 4: the lane needs gy[o] for o = kq, 4 + kq, 8 + kq, 12 + kq
     float g4[4];
 #pragma unroll
@@ -229,8 +259,6 @@ __global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams
       for (int s = 0; s < R / 4; ++s) gys[(size_t)node * p.ldgs + (size_t)t * R + 4 * s + kq] = bf[nt][s];
     }
   }
-  __syncthreads();               // weights staged
-
   for (int kf0 = 0; kf0 < p.KFp; kf0 += kPostTile) {
     post_f32x4 acc[2][4];        // two 16-row kf tiles x four node tiles
 #pragma unroll
@@ -277,6 +305,7 @@ __global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams
     }
     post_wave_sync();
   }
+  }   // tiles of this wave
 }
 
 // K15: the weight gradient of the factored post-NN, gW[t][q*16 + o][kf] = sum_n pre_q(deg_n) gy[n, t*O + o] agg[n, t*KF + kf], as a TN
@@ -382,7 +411,33 @@ static int post_fill(PostParams* p, int64_t N, int T, int KF, int S, int O, cons
     p->scaler_pack |= (uint32_t)scaler_host[q] << (4 * q);
   }
   p->N = N; p->T = T; p->KF = KF; p->KFp = (KF + kPostTile - 1) / kPostTile * kPostTile; p->S = S; p->O = O; p->avg_log = avg_log; p->avg_lin = avg_lin;
+  p->tiles_per_wave = 1;
   return 0;
+}
+
+// tiles per wave: the tower's weights are staged once per workgroup, so a workgroup should walk many node tiles - but the grid must
+// still fill the chip (>= ~4 workgroups per CU over all towers)
+static int post_tiles_per_wave(int64_t N, int T) {
+  // Two workgroups fit a CU (65 KB of LDS each): 512 run at a time.  A workgroup's fixed costs (dispatch, staging 30 KB of weights, the
+  // first tile's round trip, the epilogue stores: ~13 us at C2L against 7 us of MFMAs per tile) are paid once per workgroup, so a wave
+  // should walk several tiles - but only in a way that keeps the number of workgroup ROUNDS integral: 4000 workgroups at one tile per
+  // wave are 8 rounds, 1000 at four tiles are 2 rounds of 4 tiles (the same 8 tile-times, a quarter of the fixed costs); three tiles
+  // per wave would be 2.6 rounds, i.e. 9 tile-times.
+  const int64_t blocks1 = ((N + kWave - 1) / kWave + kBlock / kWave - 1) / (kBlock / kWave) * (int64_t)T;     // workgroups at one tile per wave
+  int best = 1;
+  int64_t best_cost = ((blocks1 + 511) / 512);
+  for (int r = 2; r <= 8; ++r) {
+    const int64_t blocks = (blocks1 + r - 1) / r;
+    if (blocks < 512) break;                                   // never leave CUs without a workgroup
+    const int64_t cost = ((blocks + 511) / 512) * r;
+    if (cost <= best_cost) { best = r; best_cost = cost; }
+  }
+  return best;
+}
+static dim3 post_grid(const PostParams& p, int T) {
+  const int64_t tiles = (p.N + kWave - 1) / kWave;
+  const int64_t per_block = (int64_t)(kBlock / kWave) * p.tiles_per_wave;
+  return dim3((unsigned)((tiles + per_block - 1) / per_block), (unsigned)T);
 }
 
 static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -403,6 +458,14 @@ using namespace mma;
     case 4: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;                       \
     default: hipLaunchKernelGGL((KERNEL<5>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;                      \
   }
+#define MMA_POST_LAUNCH3(KERNEL, PLAIN, V4, LDS, ...)                                                                  \
+  switch (S) {                                                                                                         \
+    case 1: hipLaunchKernelGGL((KERNEL<1, PLAIN, V4>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;            \
+    case 2: hipLaunchKernelGGL((KERNEL<2, PLAIN, V4>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;            \
+    case 3: hipLaunchKernelGGL((KERNEL<3, PLAIN, V4>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;            \
+    case 4: hipLaunchKernelGGL((KERNEL<4, PLAIN, V4>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;            \
+    default: hipLaunchKernelGGL((KERNEL<5, PLAIN, V4>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;           \
+  }
 #define MMA_POST_LAUNCH2(KERNEL, PLAIN, LDS, ...)                                                                      \
   switch (S) {                                                                                                         \
     case 1: hipLaunchKernelGGL((KERNEL<1, PLAIN>), grid, dim3(kBlock), LDS, st, p, __VA_ARGS__); break;                \
@@ -415,22 +478,36 @@ using namespace mma;
 // padded weight shapes the caller prepares: forward Wa (T, KFp, S*16), backward Wb (T, S*16, KFp + 16), KFp = mma_tower_post_kfp(KF)
 extern "C" int64_t mma_tower_post_kfp(int32_t KF) { return KF < 1 ? -1 : ((int64_t)KF + kPostTile - 1) / kPostTile * kPostTile; }
 
-extern "C" int mma_tower_post_fwd(const float* agg, int64_t lda, const int32_t* rowptr, const float* Wa, float* y, int64_t ldy,
+extern "C" int mma_tower_post_pre(const int32_t* rowptr, float* pre, int64_t N, int32_t S, const uint8_t* scaler_host, float avg_log, float avg_lin,
+                                  void* stream) {
+  PostParams p{};
+  if (int rc = post_fill(&p, N, 1, 4, S, 1, scaler_host, avg_log, avg_lin)) return rc;
+  MMA_REQUIRE(scaler_host != nullptr, "NULL scaler codes");
+  if (N == 0) return 0;
+  MMA_REQUIRE(rowptr && pre, "NULL argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)((N + kBlock - 1) / kBlock));
+  MMA_POST_LAUNCH(tower_post_pre_kernel, 0, rowptr, pre)
+  return check_launch("tower_post_pre_kernel");
+}
+
+extern "C" int mma_tower_post_fwd(const float* agg, int64_t lda, const float* pre, const float* Wa, float* y, int64_t ldy,
                                   int64_t N, int32_t T, int32_t KF, int32_t S, int32_t O, const uint8_t* scaler_host, float avg_log,
                                   float avg_lin, void* stream) {
   PostParams p{};
   if (int rc = post_fill(&p, N, T, KF, S, O, scaler_host, avg_log, avg_lin)) return rc;
   if (N == 0) return 0;
   MMA_REQUIRE(scaler_host != nullptr, "NULL scaler codes");
-  MMA_REQUIRE(agg && rowptr && Wa && y && al16(Wa) && lda >= (int64_t)T * KF && ldy >= (int64_t)T * O && (reinterpret_cast<uintptr_t>(agg) & 3) == 0,
+  MMA_REQUIRE(agg && pre && Wa && y && al16(Wa) && lda >= (int64_t)T * KF && ldy >= (int64_t)T * O && (reinterpret_cast<uintptr_t>(agg) & 3) == 0,
               "NULL / misaligned argument or row pitch too small");
   p.lda = lda; p.ldy = ldy; p.vec4 = (KF % 4 == 0 && lda % 4 == 0 && al16(agg)) ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned lds = post_lds_bytes(p.KFp, S, false);
   MMA_REQUIRE(lds <= 160 * 1024, "the tower's weights (%u bytes with the tiles) do not fit the LDS", lds);
-  // tower = blockIdx.y; 256 nodes (four waves x 64) per workgroup
-  const dim3 grid((unsigned)(((N + kWave - 1) / kWave + kBlock / kWave - 1) / (kBlock / kWave)), (unsigned)T);
-  MMA_POST_LAUNCH2(tower_post_fwd_kernel, false, lds, agg, rowptr, Wa, y)
+  // tower = blockIdx.y; 256 * tiles_per_wave nodes (four waves x 64 x tiles) per workgroup
+  p.tiles_per_wave = post_tiles_per_wave(N, T);
+  const dim3 grid = post_grid(p, T);
+  if (p.vec4) { MMA_POST_LAUNCH3(tower_post_fwd_kernel, false, true, lds, agg, pre, Wa, y) } else { MMA_POST_LAUNCH3(tower_post_fwd_kernel, false, false, lds, agg, pre, Wa, y) }
   return check_launch("tower_post_fwd_kernel");
 }
 
@@ -458,14 +535,14 @@ extern "C" int mma_tower_post_gw(const float* gy, int64_t ldg, const float* agg,
   return check_launch("tower_post_gw_kernel");
 }
 
-extern "C" int mma_tower_post_bwd(const float* gy, int64_t ldg, const int32_t* rowptr, const float* Wb, float* gagg, int64_t lda,
-                                  float* gys, int64_t ldgs, float* pre_out, int64_t N, int32_t T, int32_t KF, int32_t S, int32_t O,
+extern "C" int mma_tower_post_bwd(const float* gy, int64_t ldg, const float* pre, const float* Wb, float* gagg, int64_t lda,
+                                  float* gys, int64_t ldgs, int64_t N, int32_t T, int32_t KF, int32_t S, int32_t O,
                                   const uint8_t* scaler_host, float avg_log, float avg_lin, void* stream) {
   PostParams p{};
   if (int rc = post_fill(&p, N, T, KF, S, O, scaler_host, avg_log, avg_lin)) return rc;
   if (N == 0) return 0;
   MMA_REQUIRE(scaler_host != nullptr, "NULL scaler codes");
-  MMA_REQUIRE(gy && rowptr && Wb && gagg && al16(Wb) && lda >= (int64_t)T * KF && ldg >= (int64_t)T * O && (reinterpret_cast<uintptr_t>(gagg) & 3) == 0,
+  MMA_REQUIRE(gy && pre && Wb && gagg && al16(Wb) && lda >= (int64_t)T * KF && ldg >= (int64_t)T * O && (reinterpret_cast<uintptr_t>(gagg) & 3) == 0,
               "NULL / misaligned argument or row pitch too small");
   MMA_REQUIRE(!gys || ldgs >= (int64_t)T * S * kPostO, "gys needs a pitch >= T*S*16 floats");
   p.lda = lda; p.ldg = ldg; p.ldgs = ldgs; p.vec4 = (KF % 4 == 0 && lda % 4 == 0 && al16(gagg)) ? 1 : 0;
@@ -473,8 +550,9 @@ extern "C" int mma_tower_post_bwd(const float* gy, int64_t ldg, const int32_t* r
   const unsigned lds = post_lds_bytes(p.KFp, S, true);
   MMA_REQUIRE(lds <= 160 * 1024, "the tower's weights (%u bytes with the tiles) do not fit the LDS", lds);
   const int wb_pitch = p.KFp + 16;
-  const dim3 grid((unsigned)(((N + kWave - 1) / kWave + kBlock / kWave - 1) / (kBlock / kWave)), (unsigned)T);
-  MMA_POST_LAUNCH2(tower_post_bwd_kernel, false, lds, gy, rowptr, Wb, wb_pitch, gagg, gys, pre_out)
+  p.tiles_per_wave = post_tiles_per_wave(N, T);
+  const dim3 grid = post_grid(p, T);
+  MMA_POST_LAUNCH2(tower_post_bwd_kernel, false, lds, gy, pre, Wb, wb_pitch, gagg, gys)
   return check_launch("tower_post_bwd_kernel");
 }
 
@@ -494,9 +572,10 @@ extern "C" int mma_skinny_linear_fwd(const float* x, int64_t ldx, const float* W
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned lds = post_lds_bytes(p.KFp, S, false);
   MMA_REQUIRE(lds <= 160 * 1024, "the weights (%u bytes with the tiles) do not fit the LDS", lds);
-  const dim3 grid((unsigned)(((N + kWave - 1) / kWave + kBlock / kWave - 1) / (kBlock / kWave)), 1u);
-  const int32_t* rowptr = nullptr;
-  MMA_POST_LAUNCH2(tower_post_fwd_kernel, true, lds, x, rowptr, Wa, y)
+  p.tiles_per_wave = post_tiles_per_wave(N, 1);
+  const dim3 grid = post_grid(p, 1);
+  const float* pre = nullptr;
+  if (p.vec4) { MMA_POST_LAUNCH3(tower_post_fwd_kernel, true, true, lds, x, pre, Wa, y) } else { MMA_POST_LAUNCH3(tower_post_fwd_kernel, true, false, lds, x, pre, Wa, y) }
   return check_launch("tower_post_fwd_kernel (plain)");
 }
 
@@ -513,10 +592,10 @@ extern "C" int mma_skinny_linear_bwd_dx(const float* gy, int64_t ldg, const floa
   const unsigned lds = post_lds_bytes(p.KFp, S, true);
   MMA_REQUIRE(lds <= 160 * 1024, "the weights (%u bytes with the tiles) do not fit the LDS", lds);
   const int wb_pitch = p.KFp + 16;
-  const dim3 grid((unsigned)(((N + kWave - 1) / kWave + kBlock / kWave - 1) / (kBlock / kWave)), 1u);
-  const int32_t* rowptr = nullptr;
+  p.tiles_per_wave = post_tiles_per_wave(N, 1);
+  const dim3 grid = post_grid(p, 1);
+  const float* pre = nullptr;
   float* gys = nullptr;
-  float* pre_out = nullptr;
-  MMA_POST_LAUNCH2(tower_post_bwd_kernel, true, lds, gy, rowptr, Wb, wb_pitch, gx, gys, pre_out)
+  MMA_POST_LAUNCH2(tower_post_bwd_kernel, true, lds, gy, pre, Wb, wb_pitch, gx, gys)
   return check_launch("tower_post_bwd_kernel (plain)");
 }

@@ -529,7 +529,7 @@ class _TowerPost(torch.autograd.Function):
         require_gpu(agg, Wo)
         N, T, KF = agg.shape
         O, S = Wo.shape[1], len(scalers)
-        assert Wo.shape == (T, O, S * KF) and O <= 16 and KF % 4 == 0 and S <= 5
+        assert Wo.shape == (T, O, S * KF) and O <= 16 and KF % 4 == 0 and S <= 5       # (MMAConv pads the tower width to 4 floats)
         agg = agg if agg.is_contiguous() else agg.contiguous()
         KFp = int(_lib.lib().mma_tower_post_kfp(KF))
         # the weight columns twice, zero-padded: Wa (T, KFp, S*16) [kf][q*16+o] for the forward, Wb (T, S*16, KFp+16) [q*16+o][kf]
@@ -538,26 +538,27 @@ class _TowerPost(torch.autograd.Function):
         Wb.view(T, S, 16, KFp + 16)[:, :, :O, :KF] = Wo.view(T, O, S, KF).permute(0, 2, 1, 3)
         Wa = Wb[:, :, :KFp].transpose(1, 2).contiguous()
         y = torch.empty((N, T * O), device=agg.device, dtype=torch.float32)
+        pre = torch.empty((N, 8), device=agg.device, dtype=torch.float32)       # the scaler products of every node, once: K13 / K14 / K15 read them
         with _span("tower_post_fwd"):
-            call("mma_tower_post_fwd", ptr(agg), T * KF, ptr(rowptr), ptr(Wa), ptr(y), T * O, N, T, KF, S, O, host_codes(scalers),
+            call("mma_tower_post_pre", ptr(rowptr), ptr(pre), N, S, host_codes(scalers), float(avg_log), float(avg_lin), stream_ptr())
+            call("mma_tower_post_fwd", ptr(agg), T * KF, ptr(pre), ptr(Wa), ptr(y), T * O, N, T, KF, S, O, host_codes(scalers),
                  float(avg_log), float(avg_lin), stream_ptr())
-        ctx.save_for_backward(agg, Wb, rowptr)
+        ctx.save_for_backward(agg, Wb, pre)
         ctx.cfg = (O, scalers, avg_log, avg_lin)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         from . import dense
-        agg, Wb, rowptr = ctx.saved_tensors
+        agg, Wb, pre = ctx.saved_tensors
         O, scalers, avg_log, avg_lin = ctx.cfg
         N, T, KF = agg.shape
         S = len(scalers)
         gy = gy.contiguous()
         gagg = torch.empty_like(agg)
         need_w = ctx.needs_input_grad[1]
-        pre = torch.empty((N, 8), device=agg.device, dtype=torch.float32) if need_w else None     # pre_q of every node: K14 -> K15
         with _span("tower_post_bwd"):
-            call("mma_tower_post_bwd", ptr(gy), T * O, ptr(rowptr), ptr(Wb), ptr(gagg), T * KF, None, 0, ptr(pre), N, T, KF, S, O,
+            call("mma_tower_post_bwd", ptr(gy), T * O, ptr(pre), ptr(Wb), ptr(gagg), T * KF, None, 0, N, T, KF, S, O,
                  host_codes(scalers), float(avg_log), float(avg_lin), stream_ptr())
         gWo = None
         if need_w:
