@@ -198,7 +198,8 @@ class _NCLocalLayer(torch.autograd.Function):
         K = len(kinds)
         KH = K * H
         PQ = torch.empty((N, 2 * KH), device=x.device, dtype=torch.float32)
-        wcat = torch.cat([wtop, wbot], 1)                                   # (H, 2*K*H)
+        ctx.cat_given = wbot is None                                        # wtop IS [Wtop | Wbot] (H, 2*K*H): mask_weights()
+        wcat = wtop if ctx.cat_given else torch.cat([wtop, wbot], 1)        # (H, 2*K*H)
         need = any(ctx.needs_input_grad[:3])
         box = [] if need else None                                          # row maxima of x, when the forward GEMM forms them: the
         mm_into(x, wcat, PQ, row_max_box=box)                               # weight-gradient product's row scales (three-product TN form)
@@ -233,13 +234,39 @@ class _NCLocalLayer(torch.autograd.Function):
                                 row_max=row_max)
         dense.rows_mm_add_scaled_(gx, gPQ, wcat.t(), row_max)                # direct + through P and Q in one GEMM (C += A B)
         gw = xt_g(x, gPQ, x_row_max, row_max) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
+        if ctx.cat_given:
+            return gx, gw, None, None, None, None, None
         return gx, (gw[:, :KH] if gw is not None else None), (gw[:, KH:] if gw is not None else None), None, None, None, None
 
 
 def nc_local_layer(x, wtop, wbot, graph, kinds, acts, drop=None):
-    """sum_k m_k (graph.N, H) straight from the features and the concatenated mask weights (unsharded graphs)."""
+    """sum_k m_k (graph.N, H) straight from the features and the concatenated mask weights (unsharded graphs).
+    wbot=None: `wtop` is already [Wtop | Wbot] (H, 2*K*H), e.g. from mask_weights()."""
     assert graph.n_src == graph.N
     return _NCLocalLayer.apply(x, wtop, wbot, graph, tuple(kinds), tuple(acts), drop or DropoutSpec(0.0))
+
+
+class _MaskWeights(torch.autograd.Function):
+    """[W_1[:H] .. W_K[:H] | W_1[H:] .. W_K[H:]] (H, 2*K*H) from the K caller-owned (2H,H) mask weights in two launches, and their
+    gradients back in one: as slices + torch.cat the forward is 3 launches and autograd's backward ~5 per mask (zero-fill + slice copy
+    per half, an add, the accumulation) - on Cora, where every kernel of the layer is a few microseconds, a fifth of the replay."""
+
+    @staticmethod
+    def forward(ctx, *masks):
+        K = len(masks)
+        H = masks[0].shape[1]
+        ctx.shape = (K, H)
+        return torch.stack(masks).view(K, 2, H, H).permute(2, 1, 0, 3).reshape(H, 2 * K * H)
+
+    @staticmethod
+    def backward(ctx, g):
+        K, H = ctx.shape
+        gm = g.view(H, 2, K, H).permute(2, 1, 0, 3).reshape(K, 2 * H, H)       # one copy; the K gradients are row blocks of it
+        return tuple(gm[k] for k in range(K))
+
+
+def mask_weights(masks):
+    return _MaskWeights.apply(*masks)
 
 
 def nc_fused_aggregate(x, P, Q, graph, kinds, acts, drop=None, reduce_k=False):

@@ -208,10 +208,10 @@ class MMA(Module):
         kinds, acts = self._codes(names)
         masks = [getattr(self, "mask_" + n) for n in names]
         # [x_i || x_j] @ W_k  ==  x_i @ W_k[:H] + x_j @ W_k[H:]: dense GEMMs (matrix cores) shared by all K masks
-        wtop, wbot = torch.cat([w[:H] for w in masks], 1), torch.cat([w[H:] for w in masks], 1)      # (H, K*H) each
         graph = self.graph(input.device)
         if reduce_k:
-            return Fn.nc_local_layer(input, wtop, wbot, graph, kinds, acts, drop or self._drop(names, input.device))
+            return Fn.nc_local_layer(input, Fn.mask_weights(masks), None, graph, kinds, acts, drop or self._drop(names, input.device))
+        wtop, wbot = torch.cat([w[:H] for w in masks], 1), torch.cat([w[H:] for w in masks], 1)      # (H, K*H) each
         return Fn.nc_fused_aggregate(input, mm(input, wtop), mm(input, wbot), graph, kinds, acts,
                                      drop or self._drop(names, input.device))
 
