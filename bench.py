@@ -274,6 +274,7 @@ def nc_config(tag, fixture, H, names, C, p, dev, reps=50, replay=True):
 
     def step():
         x.grad = None
+        layer.zero_grad(set_to_none=True)        # train.py:73 optimizer.zero_grad(): gradients are written, not accumulated
         layer(x, adj).backward(cot)
     ms = wall_ms(step, reps)
     prev = Fn.TIMER

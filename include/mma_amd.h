@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 27
+#define MMA_ABI_VERSION 28
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -89,6 +89,11 @@ int mma_nc_fused_fwd(
                                                     dropout bits without re-capture, the host only rewrites 8 bytes */
     int64_t drop_edge_base,                      /* HASH key = edge position + base */
     const uint8_t* keep,                         /* EXPLICIT: (K,E,H), else NULL */
+    int32_t* sync,                               /* optional DEVICE counter, zero before the first call and left zero by every call:
+                                                    with it a small plan (H % 4 == 0, H <= 256, K in {1,2,3,4,8}, no EXPLICIT mask,
+                                                    few hubs) runs as ONE launch - wave items, grouped items and the hub sums, the
+                                                    last workgroup to finish doing the latter.  Same results.  One counter per
+                                                    stream of calls (calls sharing it must not overlap). */
     void* stream);
 
 /* ---- K2a: node-level backward of the combine (element-wise) -------------------------------------
@@ -142,6 +147,7 @@ int mma_nc_fused_bwd(
     int64_t N, int64_t E, int32_t H, int32_t K,
     const uint8_t* act_host,
     int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, int64_t drop_edge_base, const uint8_t* keep,
+    int32_t* sync,                               /* optional, as in mma_nc_fused_fwd (shared-gradient form only): ONE launch */
     void* stream);
 
 /* ---- K5: CSR SpMM over a K-times column-stacked adjacency ----------------------------------------
@@ -327,6 +333,14 @@ int mma_masked_bn_relu_fwd(const float* x, int64_t ldx, const int64_t* n_valid, 
 int mma_masked_bn_relu_bwd(const float* gy, int64_t ldg, const float* y, int64_t ldy, const float* x, int64_t ldx, const float* mean,
                            const float* rstd, const float* gamma, const int64_t* n_valid, float* gx, int64_t ldgx, float* ggamma, float* gbeta,
                            int64_t N, int32_t C, int32_t relu, void* stream);
+
+/* ---- dropout seeds of a captured (hipGraph) step -------------------------------------------------------------------------------
+ * seeds: DEVICE (2n,) uint64 - [0,n) the seeds the fused kernels read through their `seed_dev` argument (one per launch group of 8
+ * masks), [n,2n) the splitmix64 states behind them (initialised by the caller from its own generator).  Each call advances every
+ * state by the golden-ratio increment and writes the finalised value: a fresh seed per replay from ONE captured launch (the
+ * reference redraws its F.dropout masks from torch's generator on every forward, layers.py:223; a generator op inside a captured
+ * graph costs two extra fills ahead of every replay). */
+int mma_seed_advance(uint64_t* seeds, int32_t n, void* stream);
 
 /* ---- K12: the graph-regression loss of the training step (graph_regression/mma.py:156 (out.squeeze() - data.y).abs().mean()) ----
  * fwd: loss (DEVICE scalar) = mean_i |pred[i] - target[i]| over n >= 1 contiguous values, fixed summation order.

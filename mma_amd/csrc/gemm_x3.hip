@@ -25,6 +25,7 @@
 // LDS slab shared by the 4 waves, prefetched one tile ahead.  K > 128 is processed in chunks of 128 with the (at most
 // four) accumulator tiles kept in registers, so either K == 128 or N <= 128 is required.
 #include <algorithm>
+#include <cstdlib>
 #include "common.h"
 
 namespace mma {
@@ -1311,7 +1312,10 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_f16x2_tn_kernel(const TnParams
 static int tn_splits(int64_t M, int NC) {
   const int64_t n_cb = ((int64_t)NC + 127) / 128;
   int64_t s = 512 / n_cb;                               // ~2 workgroups per CU in total
-  const int64_t max_s = M / (8 * kTnKC) + 1;            // at least 8 chunks per split (no M + const: M comes from the caller)
+  static const int min_chunks_small = getenv("MMA_TN_MIN_CHUNKS") ? atoi(getenv("MMA_TN_MIN_CHUNKS")) : 2;
+  // at least 8 chunks per split - 2 on small problems, where the launch is latency-bound and 16 workgroups walking 11 chunks each
+  // (Cora: 2 708 rows) take twice as long as 80 walking 3 (no M + const: M comes from the caller)
+  const int64_t max_s = M / ((M >= 65536 ? 8 : min_chunks_small) * kTnKC) + 1;
   if (s > max_s) s = max_s;
   if (s >= 8) s = s / 8 * 8;                            // multiples of 8: the XCD-local id mapping of the kernel
   return (int)(s < 1 ? 1 : s);

@@ -37,6 +37,8 @@ struct NcFwdParams {
   int H, HQ, K_total, k_base, lpr_log;
   uint32_t kinds, acts;              // 4 bits / 1 bit per mask, indexed by absolute k
   DropParams drop;
+  // one-launch form (nc_fwd_small_kernel): the hub list and the ticket counter of the chunk partials
+  const int4* hubs; int64_t n_hubs; unsigned* sync; unsigned n_slots;
 };
 
 // row * pitch as ONE v_mad_u64_u32: rows and pitches are < 2^31 (checked on the host), so the 64-bit product needs neither the
@@ -114,8 +116,15 @@ __device__ __forceinline__ void nc_msum_store(const NcFwdParams& p, int node, in
 //                latency chain (item -> indices -> rows -> store) dominates and more items in flight is what pays.
 // DM: dropout mode as a TEMPLATE parameter (MMA_DROP_NONE / HASH / EXPLICIT) - as a run-time field every mask of every edge step
 // carried a scalar branch between the hash and the explicit-mask code, which cut the step into basic blocks
-template <int K, int VEC, bool SAVE, int DM, bool MULTI>
-__global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_kernel(const NcFwdParams p) {
+template <int VEC, bool SAVE>
+__device__ __forceinline__ void nc_fwd_finalize_body(const NcFwdParams& p, const int4* hubs, int64_t n_hubs, const int64_t first, const int64_t step);
+
+// ONE (the one-launch form, nc_fwd_small_kernel): a wavefront that has written a hub chunk's partial takes a ticket on p.sync after a
+// release fence at device scope (the L2s of the 8 XCDs are not coherent with each other: the fence writes the partial back), and the
+// wavefront that draws the LAST of the n_slots tickets sums the partials of every hub (slot order: same bits as the finalize launch)
+// and leaves the counter at zero.  The chunk items head the longest-first list, so this happens while the short items still run.
+template <int K, int VEC, bool SAVE, int DM, bool MULTI, bool ONE = false>
+__device__ __forceinline__ void nc_fwd_body(const NcFwdParams& p, const int bx, const int nbx) {
   const DropParams dp = DM == MMA_DROP_HASH ? drop_resolve(p.drop) : p.drop;
   uint32_t mult[K];
 #pragma unroll
@@ -136,10 +145,10 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_k
   const bool fvalid = c < p.H;
   const int cc = fvalid ? c : 0;  // masked lanes read column 0 (valid memory), results are discarded
   const int waves_per_block = kBlock / kWave;
-  const int64_t stride = (int64_t)gridDim.x * waves_per_block;
+  const int64_t stride = (int64_t)nbx * waves_per_block;
   const int64_t n_witems = (p.n_items + gpw - 1) / gpw;
 
-  for (int64_t it0 = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); it0 < n_witems; it0 += stride) {
+  for (int64_t it0 = (int64_t)bx * waves_per_block + (threadIdx.x >> 6); it0 < n_witems; it0 += stride) {
     int node, ebeg, eend, slot;
     bool ivalid = true;
     if (MULTI) {
@@ -260,15 +269,33 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_k
         }
       }
     }
+    if (ONE) {
+      const bool wrote = ivalid && slot >= 0;
+      if (__builtin_amdgcn_ballot_w64(wrote) != 0) {            // wave-uniform from here on
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        unsigned ticket = 0u;
+        if (wrote && gl == 0) ticket = atomicAdd(p.sync, 1u) + 1u;
+        if (__builtin_amdgcn_ballot_w64(ticket == p.n_slots) != 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          nc_fwd_finalize_body<VEC, SAVE>(p, p.hubs, p.n_hubs, lane, kWave);
+          if (lane == 0) *p.sync = 0u;
+        }
+      }
+    }
   }
+}
+
+template <int K, int VEC, bool SAVE, int DM, bool MULTI>
+__global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_kernel(const NcFwdParams p) {
+  nc_fwd_body<K, VEC, SAVE, DM, MULTI>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // hub nodes: sum the chunk partials in slot order, then the same epilogue
 template <int VEC, bool SAVE>
-__global__ __launch_bounds__(kBlock) void nc_fwd_finalize_kernel(const NcFwdParams p, const int4* hubs, int64_t n_hubs) {
+__device__ __forceinline__ void nc_fwd_finalize_body(const NcFwdParams& p, const int4* hubs, int64_t n_hubs, const int64_t first, const int64_t step) {
   const int per_row = (p.H + VEC - 1) / VEC;
   const int64_t total = n_hubs * per_row;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t idx = first; idx < total; idx += step) {
     const int c = (int)(idx % per_row) * VEC;
     const int4 hub = hubs[idx / per_row];
     const int node = hub.x;
@@ -306,6 +333,28 @@ __global__ __launch_bounds__(kBlock) void nc_fwd_finalize_kernel(const NcFwdPara
     }
     if (p.msum) nc_msum_store<VEC>(p, node, c, ms, false);
     if (SAVE && p.crow && c == 0) p.crow[(size_t)node * p.ldc] = 1.f / deg;
+  }
+}
+template <int VEC, bool SAVE>
+__global__ __launch_bounds__(kBlock) void nc_fwd_finalize_kernel(const NcFwdParams p, const int4* hubs, int64_t n_hubs) {
+  nc_fwd_finalize_body<VEC, SAVE>(p, hubs, n_hubs, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+// Small graphs (Cora, PubMed: every kernel of the layer is a few microseconds, the launches ARE the step): the wave items, the
+// grouped items and the hub sums of one call in ONE launch.  Blocks [0, blocks_a) walk the wave items, the rest the grouped items;
+// the hub sums are done by the wavefront that stores the last chunk partial (ONE in nc_fwd_body).
+struct NcSmallPlan { int64_t n_wave_items; int blocks_a; };
+
+template <int K, int VEC, bool SAVE, int DM>
+__global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_fwd_small_kernel(const NcFwdParams p, const NcSmallPlan sp) {
+  if ((int)blockIdx.x < sp.blocks_a) {
+    NcFwdParams q = p;
+    q.n_items = sp.n_wave_items;
+    nc_fwd_body<K, VEC, SAVE, DM, false, true>(q, (int)blockIdx.x, sp.blocks_a);
+  } else {
+    NcFwdParams q = p;
+    q.items = p.items + sp.n_wave_items; q.n_items = p.n_items - sp.n_wave_items;
+    nc_fwd_body<K, VEC, SAVE, DM, true, true>(q, (int)blockIdx.x - sp.blocks_a, (int)gridDim.x - sp.blocks_a);
   }
 }
 
@@ -421,6 +470,7 @@ struct NcBwdParams {
   DropParams drop;
   int first_pass;  // k_base == 0: gx starts from gxs (or the epilogue's direct term); later K-slices accumulate onto gx
   uint32_t* rowmax;  // optional: max |gQ| (EPI: and |gP|) per source row (see NcBwdNodeParams::rowmax)
+  const int4* hubs; int64_t n_hubs; unsigned* sync; unsigned n_slots;      // one-launch form, as in NcFwdParams
 };
 
 // the K2a work of one (node, VEC columns) for the masks [k0, k0 + nk): stores gP, returns the direct term sum_k g * dm/dx_i and
@@ -459,8 +509,11 @@ __device__ __forceinline__ Vec<VEC> nc_bwd_epilogue(const NcBwdParams& p, int no
   return gxd;
 }
 
-template <int K, int VEC, int DM, bool SHARED, bool MULTI, bool EPI>
-__global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_kernel(const NcBwdParams p) {
+template <int VEC>
+__device__ __forceinline__ void nc_bwd_finalize_body(const NcBwdParams& p, const int4* hubs, int64_t n_hubs, const int64_t first, const int64_t step);
+
+template <int K, int VEC, int DM, bool SHARED, bool MULTI, bool EPI, bool ONE = false>
+__device__ __forceinline__ void nc_bwd_body(const NcBwdParams& p, const int bx, const int nbx) {
   constexpr bool DROP = DM != MMA_DROP_NONE;
   const DropParams dp = DM == MMA_DROP_HASH ? drop_resolve(p.drop) : p.drop;
   uint32_t mult[K];
@@ -480,10 +533,10 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
   const bool fvalid = c < p.H;
   const int cc = fvalid ? c : 0;
   const int waves_per_block = kBlock / kWave;
-  const int64_t stride = (int64_t)gridDim.x * waves_per_block;
+  const int64_t stride = (int64_t)nbx * waves_per_block;
   const int64_t n_witems = (p.n_items + gpw - 1) / gpw;
 
-  for (int64_t it0 = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); it0 < n_witems; it0 += stride) {
+  for (int64_t it0 = (int64_t)bx * waves_per_block + (threadIdx.x >> 6); it0 < n_witems; it0 += stride) {
     int node, ebeg, eend, slot;     // node = the SOURCE j
     bool ivalid = true;
     if (MULTI) {
@@ -676,15 +729,33 @@ __global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_k
         }
       }
     }
+    if (ONE) {                                                   // see nc_fwd_body
+      const bool wrote = ivalid && slot >= 0;
+      if (__builtin_amdgcn_ballot_w64(wrote) != 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        unsigned ticket = 0u;
+        if (wrote && gl == 0) ticket = atomicAdd(p.sync, 1u) + 1u;
+        if (__builtin_amdgcn_ballot_w64(ticket == p.n_slots) != 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          nc_bwd_finalize_body<VEC>(p, p.hubs, p.n_hubs, lane, kWave);
+          if (lane == 0) *p.sync = 0u;
+        }
+      }
+    }
   }
 }
 
+template <int K, int VEC, int DM, bool SHARED, bool MULTI, bool EPI>
+__global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_kernel(const NcBwdParams p) {
+  nc_bwd_body<K, VEC, DM, SHARED, MULTI, EPI>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void nc_bwd_finalize_kernel(const NcBwdParams p, const int4* hubs, int64_t n_hubs) {
+__device__ __forceinline__ void nc_bwd_finalize_body(const NcBwdParams& p, const int4* hubs, int64_t n_hubs, const int64_t first, const int64_t step) {
   const int per_row = (p.H + VEC - 1) / VEC;
   const bool epi = p.T != nullptr;
   const int64_t total = n_hubs * (p.K_total + 1) * per_row;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t idx = first; idx < total; idx += step) {
     const int c = (int)(idx % per_row) * VEC;
     const int k = (int)((idx / per_row) % (p.K_total + 1));
     const int4 hub = hubs[idx / ((int64_t)per_row * (p.K_total + 1))];
@@ -741,6 +812,24 @@ __global__ __launch_bounds__(kBlock) void nc_bwd_finalize_kernel(const NcBwdPara
       for (int i = 0; i < VEC; ++i) o.v[i] = g0.v[i] + s.v[i];
       stv<VEC>(p.gx + (size_t)node * p.ldgxo + c, o);
     }
+  }
+}
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void nc_bwd_finalize_kernel(const NcBwdParams p, const int4* hubs, int64_t n_hubs) {
+  nc_bwd_finalize_body<VEC>(p, hubs, n_hubs, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+// one launch for a small graph's backward (see nc_fwd_small_kernel); shared-gradient form only
+template <int K, int VEC, int DM, bool EPI>
+__global__ __launch_bounds__(kBlock, (K <= 4 ? MMA_MIN_WAVES : 1)) void nc_bwd_small_kernel(const NcBwdParams p, const NcSmallPlan sp) {
+  if ((int)blockIdx.x < sp.blocks_a) {
+    NcBwdParams q = p;
+    q.n_items = sp.n_wave_items;
+    nc_bwd_body<K, VEC, DM, true, false, EPI, true>(q, (int)blockIdx.x, sp.blocks_a);
+  } else {
+    NcBwdParams q = p;
+    q.items = p.items + sp.n_wave_items; q.n_items = p.n_items - sp.n_wave_items;
+    nc_bwd_body<K, VEC, DM, true, true, EPI, true>(q, (int)blockIdx.x - sp.blocks_a, (int)gridDim.x - sp.blocks_a);
   }
 }
 
@@ -849,6 +938,38 @@ static void launch_bwd_k(int Ks, const NcBwdParams& p, dim3 grid, int dm, hipStr
   }
 }
 
+// the one-launch form (VEC = 4, hash / no dropout, one K-slice)
+template <int K>
+static void launch_fwd_small(const NcFwdParams& p, const NcSmallPlan& sp, dim3 grid, bool save, int dm, hipStream_t st) {
+#define MMA_FWD_S(SAVE, DM) hipLaunchKernelGGL((nc_fwd_small_kernel<K, 4, SAVE, DM>), grid, dim3(kBlock), 0, st, p, sp)
+  if (save) { if (dm == MMA_DROP_HASH) MMA_FWD_S(true, MMA_DROP_HASH); else MMA_FWD_S(true, MMA_DROP_NONE); }
+  else { if (dm == MMA_DROP_HASH) MMA_FWD_S(false, MMA_DROP_HASH); else MMA_FWD_S(false, MMA_DROP_NONE); }
+#undef MMA_FWD_S
+}
+template <int K>
+static void launch_bwd_small(const NcBwdParams& p, const NcSmallPlan& sp, dim3 grid, int dm, hipStream_t st) {
+  const bool epi = p.T != nullptr;
+#define MMA_BWD_S(DM, EPI) hipLaunchKernelGGL((nc_bwd_small_kernel<K, 4, DM, EPI>), grid, dim3(kBlock), 0, st, p, sp)
+  if (epi) { if (dm == MMA_DROP_HASH) MMA_BWD_S(MMA_DROP_HASH, true); else MMA_BWD_S(MMA_DROP_NONE, true); }
+  else { if (dm == MMA_DROP_HASH) MMA_BWD_S(MMA_DROP_HASH, false); else MMA_BWD_S(MMA_DROP_NONE, false); }
+#undef MMA_BWD_S
+}
+// Is the one-launch form possible?  Fills the plan (grid = blocks_a + blocks_b) when it is.  The hub sums are done by ONE wavefront
+// (the one that stores the last chunk partial), so they must be few: `finalize_elems` = (hubs) x (vectors per row) [x (K+1)].
+static bool small_plan(int32_t* sync, int K, const Geometry& g, int dm, int64_t n_items, int64_t n_wave_items, int64_t n_hubs, int64_t n_slots,
+                       int64_t finalize_elems, NcSmallPlan* sp, dim3* grid) {
+  const bool one_slice = K <= 4 || K == 8;
+  if (!sync || !one_slice || g.vec != 4 || g.chunks != 1 || dm == MMA_DROP_EXPLICIT || finalize_elems > 4096 || n_slots >= (1LL << 31)) return false;
+  const int64_t n_group = n_items - n_wave_items;
+  if (n_hubs == 0 && (n_wave_items == 0 || n_group == 0)) return false;       // already a single launch
+  const int ipw = kWave >> g.lpr_log;
+  const unsigned ba = n_wave_items > 0 ? item_grid(n_wave_items, 1, 1).x : 0u;
+  const unsigned bb = n_group > 0 ? item_grid(n_group, 1, ipw).x : 0u;
+  *sp = NcSmallPlan{n_wave_items, (int)ba};
+  *grid = dim3(ba + bb, 1, 1);
+  return true;
+}
+
 // K in 1..8 is issued as slices the kernels are instantiated for: 8 | 4+{1,2,3} | {1,2,3,4}
 static int next_slice(int remaining) { return remaining >= 8 ? 8 : (remaining >= 4 ? 4 : remaining); }
 
@@ -869,7 +990,7 @@ extern "C" int mma_nc_fused_fwd(
     float* crow, int64_t ldc,
     int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* kind_host, const uint8_t* act_host,
     int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, int64_t drop_edge_base, const uint8_t* keep,
-    void* stream) {
+    int32_t* sync, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31), "N=%lld E=%lld out of int32 range", (long long)N, (long long)E);
   MMA_REQUIRE(H >= 1 && K >= 1 && K <= MMA_MAX_K, "H=%d K=%d unsupported (1<=K<=%d)", H, K, MMA_MAX_K);
   MMA_REQUIRE(ldx >= H && ldp >= (int64_t)K * H && ldq >= (int64_t)K * H, "row pitch too small: ldx=%lld ldp=%lld ldq=%lld",
@@ -912,6 +1033,21 @@ extern "C" int mma_nc_fused_fwd(
   const int ipw = kWave >> g.lpr_log;
   if (ipw == 1 || n_wave_items > n_items) n_wave_items = n_items;
   const int4* all_items = p.items;
+  {
+    NcSmallPlan sp; dim3 sgrid;
+    if (small_plan(sync, K, g, dm, n_items, n_wave_items, n_hubs, n_slots, n_hubs * ((H + 3) / 4), &sp, &sgrid)) {
+      p.k_base = 0;
+      p.hubs = reinterpret_cast<const int4*>(hubs); p.n_hubs = n_hubs; p.sync = reinterpret_cast<unsigned*>(sync); p.n_slots = (unsigned)n_slots;
+      switch (K) {
+        case 1: launch_fwd_small<1>(p, sp, sgrid, save, dm, st); break;
+        case 2: launch_fwd_small<2>(p, sp, sgrid, save, dm, st); break;
+        case 3: launch_fwd_small<3>(p, sp, sgrid, save, dm, st); break;
+        case 4: launch_fwd_small<4>(p, sp, sgrid, save, dm, st); break;
+        default: launch_fwd_small<8>(p, sp, sgrid, save, dm, st); break;
+      }
+      return check_launch("nc_fwd_small_kernel");
+    }
+  }
   for (int part = 0; part < 2; ++part) {
     const int64_t cnt = part == 0 ? n_wave_items : n_items - n_wave_items;
     if (cnt <= 0) continue;
@@ -989,7 +1125,7 @@ extern "C" int mma_nc_fused_bwd(
     float* partial, int64_t n_slots, float* gQ, int64_t ldgq, float* gx, int64_t ldgxo, float* row_max,
     int64_t N, int64_t E, int32_t H, int32_t K, const uint8_t* act_host,
     int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, int64_t drop_edge_base, const uint8_t* keep,
-    void* stream) {
+    int32_t* sync, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31), "N=%lld E=%lld out of int32 range", (long long)N, (long long)E);
   MMA_REQUIRE(H >= 1 && K >= 1 && K <= MMA_MAX_K, "H=%d K=%d unsupported (1<=K<=%d)", H, K, MMA_MAX_K);
   MMA_REQUIRE(ldx >= H && ldp >= (int64_t)K * H && ldq >= (int64_t)K * H && (!gs || ldg >= (int64_t)K * H) && ldgq >= (int64_t)K * H &&
@@ -1035,6 +1171,21 @@ extern "C" int mma_nc_fused_bwd(
   const int ipw = kWave >> geo.lpr_log;
   if (ipw == 1 || n_wave_items > n_items) n_wave_items = n_items;
   const int4* all_items = p.items;
+  {
+    NcSmallPlan sp; dim3 sgrid;
+    if (shared && small_plan(sync, K, geo, dm, n_items, n_wave_items, n_hubs, n_slots, n_hubs * (K + 1) * ((H + 3) / 4), &sp, &sgrid)) {
+      p.k_base = 0; p.first_pass = 1;
+      p.hubs = reinterpret_cast<const int4*>(hubs); p.n_hubs = n_hubs; p.sync = reinterpret_cast<unsigned*>(sync); p.n_slots = (unsigned)n_slots;
+      switch (K) {
+        case 1: launch_bwd_small<1>(p, sp, sgrid, dm, st); break;
+        case 2: launch_bwd_small<2>(p, sp, sgrid, dm, st); break;
+        case 3: launch_bwd_small<3>(p, sp, sgrid, dm, st); break;
+        case 4: launch_bwd_small<4>(p, sp, sgrid, dm, st); break;
+        default: launch_bwd_small<8>(p, sp, sgrid, dm, st); break;
+      }
+      return check_launch("nc_bwd_small_kernel");
+    }
+  }
   for (int part = 0; part < 2; ++part) {
     const int64_t cnt = part == 0 ? n_wave_items : n_items - n_wave_items;
     if (cnt <= 0) continue;

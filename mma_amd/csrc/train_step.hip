@@ -218,6 +218,18 @@ __global__ __launch_bounds__(kBlock) void masked_bn_relu_bwd_kernel(const float*
   }
 }
 
+// Dropout seeds of a captured step: seeds[0..n) are what the fused kernels read (DropParams::seed_dev), seeds[n..2n) the splitmix64
+// states behind them.  One launch replaces torch's captured random_() (a philox kernel plus two fills of its seed / offset tensors
+// that torch enqueues ahead of EVERY replay of a graph that holds a generator op).
+__global__ void seed_advance_kernel(uint64_t* seeds, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t z = (seeds[n + i] += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  seeds[i] = z ^ (z >> 31);
+}
+
 }  // namespace mma
 
 using namespace mma;
@@ -308,4 +320,12 @@ extern "C" int mma_masked_bn_relu_bwd(const float* gy, int64_t ldg, const float*
   hipLaunchKernelGGL(masked_bn_relu_bwd_kernel, dim3((unsigned)((C + kBnCols - 1) / kBnCols)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                      gy, ldg, y, ldy, x, ldx, mean, rstd, gamma, n_valid, gx, ldgx, ggamma, gbeta, N, (int)C, (int)relu);
   return check_launch("masked_bn_relu_bwd_kernel");
+}
+
+extern "C" int mma_seed_advance(uint64_t* seeds, int32_t n, void* stream) {
+  MMA_REQUIRE(n >= 0, "n < 0");
+  if (n == 0) return 0;
+  MMA_REQUIRE(seeds, "NULL argument");
+  hipLaunchKernelGGL(seed_advance_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), seeds, (int)n);
+  return check_launch("seed_advance_kernel");
 }

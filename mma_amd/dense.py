@@ -18,6 +18,7 @@ def _span(name):
 _ROWS_PER_BATCH = 8192
 USE_BF16X3 = True     # fp32-accurate GEMM on the bf16 matrix cores (csrc/gemm_x3.hip) where the shape allows
 _MIN_ROWS_X3 = 4096
+_MIN_COLS_TN = int(__import__("os").environ.get("MMA_MIN_COLS_TN", "1"))
 _MIN_ROWS_TN = int(__import__("os").environ.get("MMA_MIN_ROWS_TN", "1024"))    # the TN kernel from here on (Cora's 2 708 rows: the library's
                                                                               # 128 x 256 x 2708 TN product takes 22-25 us, a fifth of the layer replay)
 
@@ -211,10 +212,11 @@ class _MM(torch.autograd.Function):
 
 def _x3_tn_ok(x, g):
     """The kernel takes up to 128 x columns (any count: ragged tiles are guarded); wider x (hidden width 256: C5) runs as
-    128-column blocks of x.  Any g width from 32 columns on (the odd-width Linear layers of graph regression: 75 x 76)."""
+    128-column blocks of x.  Any g width (the odd-width Linear layers of graph regression: 75 x 76; the 3- / 7-class output
+    weights of node classification, where the library's TN product takes 22 us on Cora and 80 us on PubMed)."""
     KA = x.shape[1]
     ok = (USE_BF16X3 and x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32 and x.shape[0] >= _MIN_ROWS_TN
-          and (8 <= KA <= 128 or KA % 128 == 0) and g.shape[1] >= 32 and x.stride(1) == 1 and g.stride(1) == 1)
+          and (8 <= KA <= 128 or KA % 128 == 0) and g.shape[1] >= _MIN_COLS_TN and x.stride(1) == 1 and g.stride(1) == 1)
     if not ok:
         return False
     # the kernel addresses one row range through a 32-bit buffer window: (rows per split) x (row pitch) must stay < 2 GB

@@ -102,7 +102,7 @@ def nc_fwd_launch(x_src, P, Q, graph, kinds, acts, drop, reduce_k, save, shared=
              ptr(graph.hubs) if graph.n_slots else None, graph.hubs.shape[0], ptr(partial), graph.n_slots,
              ptr(m), ptr(msum), H, ptr(T), ptr(sel), K * H, ptr(crow), crow.stride(0) if crow is not None else 0,
              N, graph.E, H, K, host_codes(kinds), host_codes(acts),
-             mode, thr, seed, seed_dev, graph.edge_base, keep, stream_ptr())
+             mode, thr, seed, seed_dev, graph.edge_base, keep, ptr(graph.sync(0)), stream_ptr())
     return (msum if reduce_k else m), T, sel, crow
 
 
@@ -140,7 +140,7 @@ def nc_bwd_edges_launch(x_src, P, Q, gs, g, crow, gxs, graph, kinds, acts, drop,
              ptr(graph.t_col), ptr(graph.t_eid), ptr(items), items.shape[0], n_wave,
              ptr(hubs) if hubs.shape[0] else None, hubs.shape[0], ptr(partial), graph.t_n_slots if hubs.shape[0] else 0,
              ptr(gQ), gQ.stride(0), ptr(gx), H, ptr(row_max), S, graph.E, H, K, host_codes(acts), mode, thr, seed, seed_dev, graph.edge_base,
-             keep, stream_ptr())
+             keep, ptr(graph.sync(1)) if part is None else None, stream_ptr())
 
 
 class _NCFused(torch.autograd.Function):
@@ -244,6 +244,24 @@ def nc_local_layer(x, wtop, wbot, graph, kinds, acts, drop=None):
     wbot=None: `wtop` is already [Wtop | Wbot] (H, 2*K*H), e.g. from mask_weights()."""
     assert graph.n_src == graph.N
     return _NCLocalLayer.apply(x, wtop, wbot, graph, tuple(kinds), tuple(acts), drop or DropoutSpec(0.0))
+
+
+class DeviceSeeds:
+    """Dropout seeds of a graph-capturable module: n device seeds (`.seeds`, what DropoutSpec(seed_tensor=) takes) advanced by ONE
+    captured launch per step (mma_seed_advance: splitmix64 streams whose states are drawn once from torch's generator)."""
+
+    def __init__(self, n, device):
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.MMALibraryError("mma_amd: run one warm-up step before capturing a graph (the dropout seed states are drawn on the first step)")
+        self.n = n
+        self.buf = torch.empty(2 * n, dtype=torch.int64, device=device)
+        self.buf.random_()
+        self.seeds = self.buf[:n]
+        self.device = self.buf.device
+
+    def advance(self):
+        call("mma_seed_advance", ptr(self.buf), self.n, stream_ptr())
+        return self.seeds
 
 
 class _MaskWeights(torch.autograd.Function):

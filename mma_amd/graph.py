@@ -47,6 +47,7 @@ def auto_plan(E, H=None):
 
 SMALL_STEPS = int(__import__("os").environ.get("MMA_SMALL_STEPS", "16"))
 SMALL_GROUP_BELOW = int(__import__("os").environ.get("MMA_SMALL_GROUP", "4"))
+ONE_LAUNCH = __import__("os").environ.get("MMA_ONE_LAUNCH", "1") != "0"
 
 
 
@@ -140,6 +141,14 @@ class NCGraph:
         deg = np.diff(rowptr)
         self.max_degree = int(deg.max()) if self.N else 0
         self.inv_deg = torch.from_numpy((1.0 / np.maximum(deg, 1)).astype(np.float32)).to(dev)   # mean-kind backward
+
+    def sync(self, which):
+        """Device counter for the one-launch form of K1 (which = 0) / K2b (1) on small graphs (mma_amd.h `sync`), else None."""
+        if not ONE_LAUNCH or self.E >= SMALL_GRAPH_EDGES or self.n_src != self.N:
+            return None
+        if getattr(self, "_sync", None) is None:
+            self._sync = torch.zeros(2, dtype=torch.int32, device=self.device)
+        return self._sync[which:]
 
     @classmethod
     def from_add_all(cls, add_all, device, chunk=DEFAULT_CHUNK, H=None):

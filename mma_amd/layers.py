@@ -146,8 +146,9 @@ class MMA(Module):
         self._sg = None         # (adj object, SpmmGraph) cache for the tail spmm
         self.drop_override = None   # tests: a DropoutSpec (explicit keep mask / fixed seed) used instead of p
         # hipGraph capture (torch.cuda.graph) of the layer: the dropout seed then lives in a device buffer that is re-drawn
-        # by a captured random_() on every replay, instead of being baked into the kernel arguments at capture time
+        # by one captured launch (Fn.DeviceSeeds) on every replay, instead of being baked into the kernel arguments at capture time
         self.graph_capturable = False
+        self._seeds = None
         self._seed_buf = None
 
     def reset_parameters(self):
@@ -195,10 +196,10 @@ class MMA(Module):
             return self.drop_override
         if self.graph_capturable and self.dropout > 0 and device is not None:
             n_groups = -(-len(names) // 8)      # one device seed per 8-mask launch group: groups must not share dropout bits
-            if self._seed_buf is None or self._seed_buf.device != device or self._seed_buf.numel() != n_groups:
-                self._seed_buf = torch.zeros(n_groups, dtype=torch.int64, device=device)
-            self._seed_buf.random_()
-            return Fn.DropoutSpec(self.dropout, seed_tensor=self._seed_buf)
+            if self._seeds is None or self._seeds.device != device or self._seeds.n != n_groups:
+                self._seeds = Fn.DeviceSeeds(n_groups, device)
+                self._seed_buf = self._seeds.seeds
+            return Fn.DropoutSpec(self.dropout, seed_tensor=self._seeds.advance())
         return Fn.DropoutSpec(self.dropout)
 
     def _aggregate(self, names, input, drop=None, reduce_k=False):

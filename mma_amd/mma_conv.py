@@ -92,6 +92,7 @@ class MMAConv(torch.nn.Module):
 
         self.drop_override = None     # tests: a functional.DropoutSpec with a fixed seed
         self.graph_capturable = False  # True: the dropout seed is re-drawn on the device each call (hipGraph replays)
+        self._seeds = None
         self._seed_buf = None
 
     def _pre_stack(self, aggr):
@@ -137,10 +138,10 @@ class MMAConv(torch.nn.Module):
         if self.drop_override is not None:
             return self.drop_override
         if self.graph_capturable and device is not None:
-            if self._seed_buf is None or self._seed_buf.device != device:
-                self._seed_buf = torch.zeros(1, dtype=torch.int64, device=device)
-            self._seed_buf.random_()
-            return Fn.DropoutSpec(self.dropout, seed_tensor=self._seed_buf)
+            if self._seeds is None or self._seeds.device != device:
+                self._seeds = Fn.DeviceSeeds(1, device)
+                self._seed_buf = self._seeds.seeds
+            return Fn.DropoutSpec(self.dropout, seed_tensor=self._seeds.advance())
         return Fn.DropoutSpec(self.dropout)
 
     # ---- forward ------------------------------------------------------------------------------------------

@@ -68,6 +68,8 @@ def recipe(lib, name, rng, keep):
             d.update(hubs=None, partial=None)
         if rng.random() < 0.3:
             d.update(T=None, sel=None, crow=None)
+        if rng.random() < 0.5:
+            d.update(sync=None)          # else a fake counter: the one-launch plan is laid out on the host
         return d
     if name.startswith("mma_gr_fused"):
         T, F = rng.choice([(1, 1), (1, 4), (2, 3), (5, 76), (5, 75), (1, 128), (4, 16), (8, 8)])

@@ -89,7 +89,9 @@ def test_linear_backward_matches_torch():
 
 @pytest.mark.parametrize("M,KA,NC,padx,padg", [(5000, 128, 1024, 0, 0), (4097, 64, 96, 0, 32), (70001, 128, 512, 128, 0),
                                                (33, 32, 32, 0, 0), (262144 + 17, 96, 160, 0, 0), (6000, 256, 512, 0, 0),
-                                               (204552, 75, 76, 0, 0), (5001, 9, 33, 3, 1), (7000, 128, 129, 0, 0), (4100, 1, 200, 0, 0)])
+                                               (204552, 75, 76, 0, 0), (5001, 9, 33, 3, 1), (7000, 128, 129, 0, 0), (4100, 1, 200, 0, 0),
+                                               (2708, 64, 7, 0, 0), (19717, 16, 3, 0, 0), (2708, 64, 256, 0, 0), (1500, 50, 25, 0, 0),
+                                               (3000, 25, 1, 0, 3)])
 def test_gemm_bf16x3_tn_accuracy(M, KA, NC, padx, padg):
     """x^T g on the TN kernel: error at the level of an fp32 GEMM's against fp64, repeatable, row-strided operands."""
     from mma_amd import dense

@@ -60,7 +60,7 @@ def test_argument_checks_run_on_host_without_gpu():
     # a bad shape must be refused before any launch (works with no GPU present)
     with pytest.raises(_lib.MMALibraryError, match="K="):
         _lib.call("mma_nc_fused_fwd", None, 4, None, 4, None, 4, None, None, None, 0, 0, None, 0, None, 0, None, None, 4, None, None, 4, None, 0,
-                  10, 10, 4, 99, None, None, 0, 0, 0, None, 0, None, None)
+                  10, 10, 4, 99, None, None, 0, 0, 0, None, 0, None, None, None)
     with pytest.raises(_lib.MMALibraryError, match="pitch"):
         _lib.call("mma_csr_spmm", None, None, None, None, 2, 5, 1, None, None, 2, 5, 4, None)
 

@@ -365,3 +365,44 @@ def test_true_degree_scalers_vs_oracle(compound, scalers):
     assert not torch.allclose(ref(xg, adj), out)
     with pytest.raises(ValueError):
         mma_amd.MMA(add_all, act, 2, H, C, w, b, *[mp[n] for n in _MASK_NAMES], 0.0, names, DEV, scalers=["linear"])
+
+
+@pytest.mark.parametrize("N,H,names,p,chunk,hub", [
+    (400, 64, ["mean", "mean2"], 0.75, 16, 170),                                   # Cora's layer: hubs split into 11 chunks
+    (300, 16, ["min", "min2", "min3", "min4"], 0.5, 64, 200),
+    (257, 128, ["sum", "mean", "max", "min"], 0.5, 32, 300),
+    (200, 32, ["sum", "mean", "max", "min", "sum2", "mean2", "max2", "softmax"], 0.0, 8, 90),      # K = 8
+    (150, 64, ["max"], 0.25, 512, 0),                                              # no hubs: wave + grouped items only
+])
+def test_one_launch_form_equals_the_separate_launches(N, H, names, p, chunk, hub, monkeypatch):
+    """Small graphs run K1 / K2b as ONE launch each (wave items + grouped items + the hub sums by the wavefront that stores the last
+    chunk partial, mma_amd.h `sync`): bit for bit the results of the separate launches, forward and backward, repeatedly (the
+    ticket counter must be back at zero after every call)."""
+    import mma_amd
+    from mma_amd import functional as Fn, graph as G
+    from oracle import nc_oracle as O
+    rng = np.random.default_rng(N + H + len(names))
+    rowptr, col = random_graph(rng, N, 4, hub)
+    graph = mma_amd.NCGraph(rowptr, col, DEV, chunk=chunk, group_below=4, t_group_below=4)
+    assert (graph.n_slots > 0) == bool(hub) and 0 < graph.n_wave_items < graph.items.shape[0]
+    K = len(names)
+    x = torch.from_numpy(np.maximum(rng.standard_normal((N, H)), 0).astype(np.float32)).to(DEV)
+    wcat = torch.from_numpy(((rng.random((H, 2 * K * H)) * 2 - 1) / np.sqrt(H)).astype(np.float32)).to(DEV)
+    cot = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(DEV)
+    kinds = [Fn.KIND[O.AGGREGATORS[n][0]] for n in names]
+    acts = [Fn.ACT_RAW if O.uses_raw_logits(n, "new_sigmoid") else Fn.ACT_SIGMOID for n in names]
+
+    def run():
+        xg, wg = x.clone().requires_grad_(True), wcat.clone().requires_grad_(True)
+        out = Fn.nc_local_layer(xg, wg, None, graph, kinds, acts, Fn.DropoutSpec(p, seed=77))
+        return (out.detach(),) + torch.autograd.grad((out * cot).sum(), [xg, wg])
+    monkeypatch.setattr(G, "ONE_LAUNCH", False)
+    assert graph.sync(0) is None
+    ref = run()
+    monkeypatch.setattr(G, "ONE_LAUNCH", True)
+    assert graph.sync(0) is not None
+    for _ in range(3):
+        got = run()
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        assert int(graph._sync.abs().sum()) == 0
