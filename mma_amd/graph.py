@@ -46,7 +46,7 @@ def auto_plan(E, H=None):
 
 
 SMALL_STEPS = int(__import__("os").environ.get("MMA_SMALL_STEPS", "16"))
-SMALL_GROUP_BELOW = int(__import__("os").environ.get("MMA_SMALL_GROUP", "4"))
+SMALL_GROUP_BELOW = int(__import__("os").environ.get("MMA_SMALL_GROUP", "8"))
 ONE_LAUNCH = __import__("os").environ.get("MMA_ONE_LAUNCH", "1") != "0"
 
 

@@ -15,6 +15,8 @@ the K9 kernel backward; `aggregate()` on given messages uses the same K3.  Refer
 """
 from typing import Dict, List, Optional
 
+import math
+
 import torch
 import torch.nn.functional as F
 from torch import Tensor
@@ -58,6 +60,67 @@ class CategoricalEdges:
         return self._by_pos[1]
 
 
+class _WeightPlan:
+    """The block table of K18 (mma_pack_blocks) for one MMAConv: which (row, column) block of which Parameter lands where in the padded
+    matrices the fused path takes, and the same blocks addressed inside ONE flat gradient buffer for the way back."""
+
+    def __init__(self, params, blocks, outs, device):
+        # params: the source Parameters; blocks: (param index, column offset, rows, cols, out index, b_off, ldb, b_rows, b_cols);
+        # outs: shapes of the packed outputs (index = out index)
+        self.ptrs = tuple(q.data_ptr() for q in params)
+        self.shapes = [tuple(q.shape) for q in params]
+        self.g_off = [0]
+        for q in params:
+            self.g_off.append(self.g_off[-1] + q.numel())
+        fwd, bwd = [], []
+        for (pi, c0, rows, cols, oi, b_off, ldb, b_rows, b_cols) in blocks:
+            q = params[pi]
+            assert q.is_contiguous() and q.dtype == torch.float32
+            lda = q.shape[-1]
+            fwd.append([q.data_ptr() + 4 * c0, lda, rows, cols, oi, b_off, ldb, b_rows, b_cols, 0])
+            bwd.append([self.g_off[pi] + c0, lda, rows, cols, oi, b_off, ldb, b_rows, b_cols, 0])
+        self.n_blocks = len(blocks)
+        self.used = {blk[4] for blk in blocks}                                # outputs some block lands in (the rest are placeholders)
+        self.fwd = torch.tensor(fwd, dtype=torch.int64).to(device)
+        self.bwd = torch.tensor(bwd, dtype=torch.int64).to(device)
+        self.outs = outs
+        self.o_off = [0]
+        for shp in outs:
+            n = 1
+            for d in shp:
+                n *= d
+            self.o_off.append(self.o_off[-1] + (n + 3) // 4 * 4)          # 16-byte aligned outputs
+
+
+class _PackWeights(torch.autograd.Function):
+    """The padded matrices of the fused path from the layer's Parameters, one launch; their gradients back into the Parameters'
+    layout, one launch (K18) - instead of stack / slice / pad / cat and the zero-fill + copy + add each of those costs in backward."""
+
+    @staticmethod
+    def forward(ctx, plan, *params):
+        from ._lib import call, ptr, stream_ptr
+        flat = torch.empty((plan.o_off[-1],), device=params[0].device, dtype=torch.float32)
+        outs = [flat[plan.o_off[i]:plan.o_off[i] + math.prod(shp)].view(shp) for i, shp in enumerate(plan.outs)]
+        b = [ptr(o) for o in outs] + [None] * (8 - len(outs))
+        call("mma_pack_blocks", ptr(plan.fwd), plan.n_blocks, None, *b, 0, stream_ptr())
+        ctx.plan = plan
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        from ._lib import call, ptr, stream_ptr
+        plan = ctx.plan
+        gouts = [(torch.zeros(shp, device=plan.fwd.device) if i in plan.used else None) if g is None else g.contiguous()
+                 for i, (g, shp) in enumerate(zip(gouts, plan.outs))]
+        flat = torch.empty((plan.g_off[-1],), device=plan.fwd.device, dtype=torch.float32)
+        b = gouts + [None] * (8 - len(gouts))
+        call("mma_pack_blocks", ptr(plan.bwd), plan.n_blocks, ptr(flat), *b, 1, stream_ptr())
+        return (None,) + tuple(flat[plan.g_off[i]:plan.g_off[i + 1]].view(shp) for i, shp in enumerate(plan.shapes))
+
+
+PACK_WEIGHTS = __import__("os").environ.get("MMA_PACK_WEIGHTS", "1") != "0"
+
+
 class MMAConv(torch.nn.Module):
     def __init__(self, in_channels: int, out_channels: int, aggregators: List[str], scalers: List[str], deg: Tensor,
                  edge_dim: Optional[int] = None, towers: int = 1, pre_layers: int = 1, post_layers: int = 1,
@@ -94,6 +157,7 @@ class MMAConv(torch.nn.Module):
         self.graph_capturable = False  # True: the dropout seed is re-drawn on the device each call (hipGraph replays)
         self._seeds = None
         self._seed_buf = None
+        self._wplan = None
 
     def _pre_stack(self, aggr):
         """Sequential(MaskAggregateLinear([x_i|x_j|e] -> F_in), (ReLU, MaskAggregateLinear) x (pre_layers-1))."""
@@ -144,6 +208,40 @@ class MMAConv(torch.nn.Module):
             return Fn.DropoutSpec(self.dropout, seed_tensor=self._seeds.advance())
         return Fn.DropoutSpec(self.dropout)
 
+    # ---- weight plumbing (K18) ----------------------------------------------------------------------------
+    def _packed_weights(self, lins, has_edge, device):
+        """(Wij (2*T*Fw, F), b2 (2*T*Fw,) | None, We (T*Fw, F) | None, Wx (T*F_out, F), Wo (T, F_out, K*S*Fw), bp (T*F_out,)) - the
+        matrices forward() builds from the per-tower Linears, zero padding included - in one launch (and one for all their gradients)."""
+        T, Fi, Fw, Fo = self.towers, self.F_in, self.fused_width(), self.F_out
+        KS = len(self.aggregators) * len(self.scalers)
+        TF = T * Fw
+        posts = [seq[0] for seq in self.post_nns]
+        has_b = lins[0].bias is not None
+        params = [l.weight for l in lins] + ([l.bias for l in lins] if has_b else []) + [q.weight for q in posts] + [q.bias for q in posts]
+        key = (str(device), has_edge, tuple(q.data_ptr() for q in params))
+        if self._wplan is None or self._wplan[0] != key:
+            iw, ib = 0, T
+            ipw = T + (T if has_b else 0)
+            ipb = ipw + T
+            outs = [(2 * TF, Fi), (2 * TF,) if has_b else (4,), (TF, Fi) if has_edge else (4,), (T * Fo, Fi), (T, Fo, KS * Fw), (T * Fo,)]
+            blocks = []
+            for t in range(T):
+                blocks.append((iw + t, 0, Fi, Fi, 0, t * Fw * Fi, Fi, Fw, Fi))                       # Wi rows of tower t
+                blocks.append((iw + t, Fi, Fi, Fi, 0, (TF + t * Fw) * Fi, Fi, Fw, Fi))               # Wj
+                if has_edge:
+                    blocks.append((iw + t, 2 * Fi, Fi, Fi, 2, t * Fw * Fi, Fi, Fw, Fi))              # We
+                if has_b:
+                    blocks.append((ib + t, 0, 1, Fi, 1, t * Fw, Fw, 1, Fw))                          # the bias lands in U only
+                blocks.append((ipw + t, 0, Fo, Fi, 3, t * Fo * Fi, Fi, Fo, Fi))                      # Wx
+                for ks in range(KS):
+                    blocks.append((ipw + t, (1 + ks) * Fi, Fo, Fi, 4, t * Fo * KS * Fw + ks * Fw, KS * Fw, Fo, Fw))
+                blocks.append((ipb + t, 0, 1, Fo, 5, t * Fo, Fo, 1, Fo))
+            if has_b:
+                blocks.append((0, 0, 0, 0, 1, TF, TF, 1, TF))                                        # V's half of the bias: zeros
+            self._wplan = (key, _WeightPlan(params, blocks, outs, device))
+        Wij, b2, We, Wx, Wo, bp = _PackWeights.apply(self._wplan[1], *params)
+        return Wij, (b2 if has_b else None), (We if has_edge else None), Wx, Wo, bp
+
     # ---- forward ------------------------------------------------------------------------------------------
     def forward(self, x: Tensor, edge_index, edge_attr: Optional[Tensor] = None) -> Tensor:
         require_gpu(x)
@@ -161,25 +259,32 @@ class MMAConv(torch.nn.Module):
             lins = [seq[0].active_linear() for seq in self.pre_nns[last]]       # T Linears (F_in, 3F|2F)
             TF = T * Fw
 
-            Wall = torch.stack([l.weight for l in lins])                        # (T, F, 3F|2F): ONE stack, then three slices
+            packed = None
+            if PACK_WEIGHTS and self.post_layers == 1 and not self.divide_input and self.post_nns[0][0].bias is not None:
+                packed = self._packed_weights(lins, edge_attr is not None, x.device)        # K18: one launch each way
+            Wall = None if packed else torch.stack([l.weight for l in lins])    # (T, F, 3F|2F): ONE stack, then three slices
 
             def rows(lo, hi):       # the T per-tower (F, hi-lo) weight blocks as rows of one (T*Fw, hi-lo) matrix
                 return self._pad_dim(Wall[:, :, lo:hi], 1, Fw).reshape(TF, hi - lo)
-            Wi, Wj = rows(0, Fi), rows(Fi, 2 * Fi)
             has_b = lins[0].bias is not None
-            b = self._pad_dim(torch.stack([l.bias for l in lins]), 1, Fw).reshape(TF) if has_b else None   # lands in U only
-            if self.divide_input:
+            if packed:
+                UV = dense.linear_tall(x2, packed[0], packed[1])
+            elif self.divide_input:
+                Wi, Wj = rows(0, Fi), rows(Fi, 2 * Fi)
+                b = self._pad_dim(torch.stack([l.bias for l in lins]), 1, Fw).reshape(TF) if has_b else None   # lands in U only
                 U = torch.einsum('ntf,tgf->ntg', x, Wi.view(T, Fw, Fi)).reshape(N, TF)
                 V = torch.einsum('ntf,tgf->ntg', x, Wj.view(T, Fw, Fi)).reshape(N, TF)
                 UV = torch.cat([dense.bias_add(U, b) if has_b else U, V], 1)
             else:                                                               # towers share x -> ONE GEMM for U | V
+                Wi, Wj = rows(0, Fi), rows(Fi, 2 * Fi)
+                b = self._pad_dim(torch.stack([l.bias for l in lins]), 1, Fw).reshape(TF) if has_b else None
                 UV = dense.linear_tall(x2, torch.cat([Wi, Wj]), torch.cat([b, torch.zeros_like(b)]) if has_b else None)
             Z = z_index = None
             if edge_attr is not None:
                 # enc(e) W_e^T = e (W_e W_enc)^T + W_e b_enc: the (E,F) encoding never materialises (mma_conv.py:141-146)
                 # The (E, edge_dim) rows are put in target-sorted position order BEFORE the GEMM (50 floats per edge), so that Z
                 # - and in backward the (E, T*Fw) message gradients - stream contiguously through K3/K4.
-                We, enc = rows(2 * Fi, 3 * Fi), self.edge_encoder
+                We, enc = (packed[2] if packed else rows(2 * Fi, 3 * Fi)), self.edge_encoder
                 wz, bz = We @ enc.weight, (We @ enc.bias if enc.bias is not None else None)
                 if isinstance(edge_attr, CategoricalEdges):
                     # edge_attr = table[types] (an Embedding: mma.py:88,103): Z has only n_types distinct rows, so the kernels get
@@ -196,7 +301,7 @@ class MMAConv(torch.nn.Module):
             out = Fn.gr_fused_conv(UV, Z, graph, T, Fw, self.aggregators, ["identity"] if factored else self.scalers,
                                    self.avg_deg['log'], self.avg_deg['lin'], self._drop(x.device), z_by_pos=True, z_index=z_index)
         else:
-            factored = False
+            factored, packed = False, None
             src, dst = edge_index[0], edge_index[1]
             if isinstance(edge_attr, CategoricalEdges):
                 edge_attr = edge_attr.dense()
@@ -207,10 +312,13 @@ class MMAConv(torch.nn.Module):
         if self.post_layers == 1:
             # post_nns[t](cat[x_t, out_t]) = x_t Wx_t^T + out_t Wo_t^T + b_t  (mma_conv.py:132-134) as ONE strided-batched
             # GEMM over the towers: neither the (N,T,(K*S+1)*F) concatenation nor the per-tower slices are materialised.
-            Wp = torch.stack([seq[0].weight for seq in self.post_nns])                   # (T, F_out, (K*S+1)*F_in)
-            bp = torch.cat([seq[0].bias for seq in self.post_nns])                       # (T*F_out,)
-            Wx = Wp[:, :, :Fi]
-            Wo = self._pad_dim(Wp[:, :, Fi:].reshape(T, self.F_out, KS, Fi), 3, Fw).reshape(T, self.F_out, KS * Fw)
+            if packed:
+                Wx, Wo, bp = packed[3].view(T, self.F_out, Fi), packed[4], packed[5]
+            else:
+                Wp = torch.stack([seq[0].weight for seq in self.post_nns])               # (T, F_out, (K*S+1)*F_in)
+                bp = torch.cat([seq[0].bias for seq in self.post_nns])                   # (T*F_out,)
+                Wx = Wp[:, :, :Fi]
+                Wo = self._pad_dim(Wp[:, :, Fi:].reshape(T, self.F_out, KS, Fi), 3, Fw).reshape(T, self.F_out, KS * Fw)
             if factored:
                 y = Fn.tower_post(out, Wo, graph.by_target.rowptr, self.scalers, self.avg_deg['log'], self.avg_deg['lin']).view(N, T, self.F_out)
             else:

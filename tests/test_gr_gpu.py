@@ -317,3 +317,32 @@ def test_categorical_edges_equal_the_embedded_rows(n_graphs, p):
         if a is not None:
             assert a.shape == b.shape
             assert (a - b).abs().max().item() <= (1e-3 if tall else 2e-5) * b.abs().max().item() + 1e-5, ((a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.parametrize("edge_dim,n_graphs", [(50, 64), (None, 20)])
+def test_packed_weights_equal_the_torch_plumbing(edge_dim, n_graphs, monkeypatch):
+    """K18 (mma_pack_blocks): the padded [Wi;Wj], We, Wx, Wo and bias matrices built from the per-tower Linears in one launch - and all
+    their gradients scattered back in one - are the matrices (and gradients) of the stack / slice / pad / cat formulation, bit for
+    bit: layer output, dL/dx, every registered parameter and the unregistered pre-NN Linears."""
+    from mma_amd import functional as Fn, mma_conv as MC
+    rng = np.random.default_rng(3)
+    ei, N = molecule_batch(rng, n_graphs)
+    E = ei.shape[1]
+    conv = make_conv(["min", "max"], ["identity", "amplification", "linear"], towers=5, F=75, edge_dim=edge_dim)
+    conv.drop_override = Fn.DropoutSpec(0.5, seed=0xABCDEF)
+    x = torch.from_numpy(rng.standard_normal((N, 75)).astype(np.float32)).to(DEV)
+    ea = torch.from_numpy(rng.standard_normal((E, edge_dim)).astype(np.float32)).to(DEV) if edge_dim else None
+    cot = torch.from_numpy(rng.standard_normal((N, conv.out_channels)).astype(np.float32)).to(DEV)
+    eig = torch.from_numpy(ei).to(DEV)
+    lins = [seq[0].active_linear() for seq in conv.pre_nns[conv.aggregators[-1]]]
+    prm = [q for q in conv.parameters() if q.requires_grad] + [l.weight for l in lins] + [l.bias for l in lins]
+    res = []
+    for packed in (False, True):
+        monkeypatch.setattr(MC, "PACK_WEIGHTS", packed)
+        xg = x.clone().requires_grad_(True)
+        out = conv(xg, eig, ea)
+        res.append((out.detach(), torch.autograd.grad((out * cot).sum(), [xg] + prm)))
+    (o0, g0), (o1, g1) = res
+    assert conv._wplan is not None and torch.equal(o0, o1)
+    for a, b in zip(g0, g1):
+        assert a.shape == b.shape and torch.equal(a, b)

@@ -10,7 +10,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 RT=$(find /opt/rocm/lib/llvm/lib/clang -name 'libclang_rt.asan-x86_64.so' | head -1)
 [ -n "$RT" ] || { echo "no ASan runtime under /opt/rocm/lib/llvm"; exit 3; }
 cd "$ROOT/mma_amd/csrc"
-printf "%s\n" abi nc_fused spmm_rows gr_fused gemm_x3 tower tower_post train_step | xargs -P 8 -I{} $HIPCC -O1 -g -std=c++17 -fPIC -ffp-contract=off \
+printf "%s\n" abi nc_fused spmm_rows gr_fused gemm_x3 tower tower_post train_step pack | xargs -P 8 -I{} $HIPCC -O1 -g -std=c++17 -fPIC -ffp-contract=off \
   --offload-arch=gfx950 -fno-gpu-rdc -fsanitize=address,undefined -fno-gpu-sanitize -fno-sanitize-recover=undefined -Wno-unused-function \
   -c {}.hip -o "$OUT/{}.o"
 $HIPCC -shared -fPIC --offload-arch=gfx950 -fsanitize=address,undefined -fno-gpu-sanitize -o "$OUT/libmma_amd.so" "$OUT"/*.o
