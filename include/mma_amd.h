@@ -337,11 +337,13 @@ int mma_masked_bn_relu_bwd(const float* gy, int64_t ldg, const float* y, int64_t
 /* ---- K18: block pack / unpack (the weight plumbing of one MMAConv call, mma_conv.py:96-118 Parameters -> the padded matrices the
  * fused kernels take, and their gradients back) ------------------------------------------------------------------------------------
  * table: DEVICE (n_blocks, 10) int64, one 2-D block per row:
- *     [ a, lda, rows, cols, b_index, b_off, ldb, b_rows, b_cols, 0 ]
- *   a: the A side - an absolute device address of fp32 data when a_base is NULL, else a float offset from a_base;
+ *     [ a, lda, rows, cols, b_index, b_off, ldb, b_rows, b_cols, flags ]
+ *   a: the A side - an absolute device address of fp32 data when a_base is NULL or flags & 1, else a float offset from a_base;
+ *   flags & 2: unpack ADDS onto A (a gradient buffer that outlives the call: the reference's unregistered mask Linears, G2, are
+ *   never zeroed by optimizer.zero_grad(), so their .grad accumulates over the whole training run);
  *   b_index in [0,8): which of b0..b7 holds the B side, at float offset b_off with row pitch ldb.
  * unpack == 0:  B[r*ldb + c] = (r < rows && c < cols) ? A[r*lda + c] : 0   for r < b_rows, c < b_cols   (zero padding written here)
- * unpack != 0:  A[r*lda + c] = B[r*ldb + c]                                 for r < rows,   c < cols
+ * unpack != 0:  A[r*lda + c] (+)= B[r*ldb + c]                              for r < rows,   c < cols
  * One workgroup per block, no overlap checks: blocks of one call must not write the same element.  The table is trusted (addresses
  * are the caller's): a wrong entry is an out-of-bounds access, as with any pointer argument. */
 int mma_pack_blocks(const int64_t* table, int64_t n_blocks, float* a_base, float* b0, float* b1, float* b2, float* b3, float* b4,

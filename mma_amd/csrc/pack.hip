@@ -5,12 +5,14 @@
 // ~35 per backward (zero-fill + copy per slice gradient, an add per accumulation): at ZINC's batch of 64 molecules, where every
 // kernel of the layer is ~5 us, more than half of the replayed step.  Here: a table of 2-D blocks, one workgroup per block.
 //   pack:    B[b][off + r*ldb + c] = (r < rows && c < cols) ? A[r*lda + c] : 0      for r < b_rows, c < b_cols  (zero padding)
-//   unpack:  A[r*lda + c]          = B[b][off + r*ldb + c]                          for r < rows,   c < cols    (the gradients)
+//   unpack:  A[r*lda + c]     (+)= B[b][off + r*ldb + c]                          for r < rows,   c < cols    (the gradients)
 #include "common.h"
 
 namespace mma {
 
-constexpr int kPackFields = 10;     // int64 per block: a (address, or float offset from a_base), lda, rows, cols, b index, b offset, ldb, b_rows, b_cols, 0
+constexpr int kPackFields = 10;     // int64 per block: a (address, or float offset from a_base), lda, rows, cols, b index, b offset, ldb, b_rows, b_cols, flags
+constexpr int64_t kPackAbsolute = 1;     // flags: `a` is an absolute address even though a_base is given
+constexpr int64_t kPackAccumulate = 2;   //        unpack adds onto A (gradient accumulation into a buffer that outlives the call)
 constexpr int kPackBases = 8;
 
 struct PackParams { const int64_t* table; float* a_base; float* b[kPackBases]; };
@@ -18,7 +20,8 @@ struct PackParams { const int64_t* table; float* a_base; float* b[kPackBases]; }
 template <bool UNPACK>
 __global__ __launch_bounds__(kBlock) void pack_blocks_kernel(const PackParams p) {
   const int64_t* e = p.table + (int64_t)blockIdx.x * kPackFields;
-  float* a = p.a_base ? p.a_base + e[0] : reinterpret_cast<float*>(static_cast<uintptr_t>(e[0]));
+  const int64_t flags = e[9];
+  float* a = (p.a_base && !(flags & kPackAbsolute)) ? p.a_base + e[0] : reinterpret_cast<float*>(static_cast<uintptr_t>(e[0]));
   const int64_t lda = e[1];
   const int rows = (int)e[2], cols = (int)e[3];
   float* b = p.b[e[4]] + e[5];
@@ -28,7 +31,8 @@ __global__ __launch_bounds__(kBlock) void pack_blocks_kernel(const PackParams p)
     const int total = rows * cols;
     for (int i = threadIdx.x; i < total; i += kBlock) {
       const int r = i / cols, c = i - r * cols;
-      a[r * lda + c] = b[r * ldb + c];
+      if (flags & kPackAccumulate) a[r * lda + c] += b[r * ldb + c];
+      else a[r * lda + c] = b[r * ldb + c];
     }
   } else {
     const int total = b_rows * b_cols;

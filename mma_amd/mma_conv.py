@@ -64,21 +64,31 @@ class _WeightPlan:
     """The block table of K18 (mma_pack_blocks) for one MMAConv: which (row, column) block of which Parameter lands where in the padded
     matrices the fused path takes, and the same blocks addressed inside ONE flat gradient buffer for the way back."""
 
-    def __init__(self, params, blocks, outs, device):
+    def __init__(self, params, blocks, outs, device, n_acc=0):
         # params: the source Parameters; blocks: (param index, column offset, rows, cols, out index, b_off, ldb, b_rows, b_cols);
         # outs: shapes of the packed outputs (index = out index)
+        # n_acc: the first n_acc params are the UNREGISTERED mask Linears (G2).  Nobody zeroes their .grad (optimizer.zero_grad() does
+        # not know them), so it accumulates for the whole run - here inside the unpack launch, onto one persistent buffer whose views
+        # are their .grad, instead of one add launch per tensor per step
         self.ptrs = tuple(q.data_ptr() for q in params)
         self.shapes = [tuple(q.shape) for q in params]
+        self.n_acc = n_acc
         self.g_off = [0]
         for q in params:
             self.g_off.append(self.g_off[-1] + q.numel())
+        self.acc = torch.zeros((self.g_off[n_acc],), device=device, dtype=torch.float32) if n_acc else None
+        self.acc_views = [self.acc[self.g_off[i]:self.g_off[i + 1]].view(self.shapes[i]) for i in range(n_acc)]
+        self.params = list(params)
         fwd, bwd = [], []
         for (pi, c0, rows, cols, oi, b_off, ldb, b_rows, b_cols) in blocks:
             q = params[pi]
             assert q.is_contiguous() and q.dtype == torch.float32
             lda = q.shape[-1]
             fwd.append([q.data_ptr() + 4 * c0, lda, rows, cols, oi, b_off, ldb, b_rows, b_cols, 0])
-            bwd.append([self.g_off[pi] + c0, lda, rows, cols, oi, b_off, ldb, b_rows, b_cols, 0])
+            if pi < n_acc:
+                bwd.append([self.acc.data_ptr() + 4 * (self.g_off[pi] + c0), lda, rows, cols, oi, b_off, ldb, b_rows, b_cols, 3])
+            else:
+                bwd.append([self.g_off[pi] - self.g_off[n_acc] + c0, lda, rows, cols, oi, b_off, ldb, b_rows, b_cols, 0])
         self.n_blocks = len(blocks)
         self.used = {blk[4] for blk in blocks}                                # outputs some block lands in (the rest are placeholders)
         self.fwd = torch.tensor(fwd, dtype=torch.int64).to(device)
@@ -112,13 +122,23 @@ class _PackWeights(torch.autograd.Function):
         plan = ctx.plan
         gouts = [(torch.zeros(shp, device=plan.fwd.device) if i in plan.used else None) if g is None else g.contiguous()
                  for i, (g, shp) in enumerate(zip(gouts, plan.outs))]
-        flat = torch.empty((plan.g_off[-1],), device=plan.fwd.device, dtype=torch.float32)
+        n_acc, base = plan.n_acc, plan.g_off[plan.n_acc]
+        for q, view in zip(plan.params[:n_acc], plan.acc_views):      # the accumulating .grad of the unregistered Linears
+            if q.grad is not view:
+                if q.grad is None:
+                    view.zero_()                                       # somebody reset it: start again from zero
+                else:
+                    view.copy_(q.grad)                                 # somebody else's running sum: carry it over
+                q.grad = view
+        flat = torch.empty((plan.g_off[-1] - base,), device=plan.fwd.device, dtype=torch.float32)
         b = gouts + [None] * (8 - len(gouts))
         call("mma_pack_blocks", ptr(plan.bwd), plan.n_blocks, ptr(flat), *b, 1, stream_ptr())
-        return (None,) + tuple(flat[plan.g_off[i]:plan.g_off[i + 1]].view(shp) for i, shp in enumerate(plan.shapes))
+        return (None,) * (1 + n_acc) + tuple(flat[plan.g_off[i] - base:plan.g_off[i + 1] - base].view(plan.shapes[i])
+                                             for i in range(n_acc, len(plan.shapes)))
 
 
 PACK_WEIGHTS = __import__("os").environ.get("MMA_PACK_WEIGHTS", "1") != "0"
+ACCUMULATE_UNREGISTERED = __import__("os").environ.get("MMA_ACC_UNREGISTERED", "1") != "0"
 
 
 class MMAConv(torch.nn.Module):
@@ -238,7 +258,7 @@ class MMAConv(torch.nn.Module):
                 blocks.append((ipb + t, 0, 1, Fo, 5, t * Fo, Fo, 1, Fo))
             if has_b:
                 blocks.append((0, 0, 0, 0, 1, TF, TF, 1, TF))                                        # V's half of the bias: zeros
-            self._wplan = (key, _WeightPlan(params, blocks, outs, device))
+            self._wplan = (key, _WeightPlan(params, blocks, outs, device, n_acc=ipw if ACCUMULATE_UNREGISTERED else 0))
         Wij, b2, We, Wx, Wo, bp = _PackWeights.apply(self._wplan[1], *params)
         return Wij, (b2 if has_b else None), (We if has_edge else None), Wx, Wo, bp
 

@@ -328,6 +328,7 @@ def test_packed_weights_equal_the_torch_plumbing(edge_dim, n_graphs, monkeypatch
     rng = np.random.default_rng(3)
     ei, N = molecule_batch(rng, n_graphs)
     E = ei.shape[1]
+    monkeypatch.setattr(MC, "ACCUMULATE_UNREGISTERED", False)     # torch.autograd.grad below asks for the mask Linears' gradients
     conv = make_conv(["min", "max"], ["identity", "amplification", "linear"], towers=5, F=75, edge_dim=edge_dim)
     conv.drop_override = Fn.DropoutSpec(0.5, seed=0xABCDEF)
     x = torch.from_numpy(rng.standard_normal((N, 75)).astype(np.float32)).to(DEV)
@@ -346,3 +347,39 @@ def test_packed_weights_equal_the_torch_plumbing(edge_dim, n_graphs, monkeypatch
     assert conv._wplan is not None and torch.equal(o0, o1)
     for a, b in zip(g0, g1):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_unregistered_mask_linears_accumulate_their_gradient_like_the_reference(monkeypatch):
+    """G2: the per-aggregation Linears live in a plain dict, optimizer.zero_grad() never sees them, so in the reference their .grad is
+    the running sum over every backward().  The packed path adds into one persistent buffer inside the unpack launch (no add launch
+    per tensor): after two steps .grad equals the sum torch's own accumulation gives, and a manual reset (grad = None) starts over."""
+    from mma_amd import functional as Fn, mma_conv as MC
+    rng = np.random.default_rng(5)
+    ei, N = molecule_batch(rng, 16)
+    E = ei.shape[1]
+    x = torch.from_numpy(rng.standard_normal((N, 75)).astype(np.float32)).to(DEV)
+    ea = torch.from_numpy(rng.standard_normal((E, 50)).astype(np.float32)).to(DEV)
+    cots = [torch.from_numpy(rng.standard_normal((N, 375)).astype(np.float32)).to(DEV) for _ in range(2)]
+    eig = torch.from_numpy(ei).to(DEV)
+    res = []
+    for acc in (False, True):
+        monkeypatch.setattr(MC, "ACCUMULATE_UNREGISTERED", acc)
+        torch.manual_seed(0)
+        conv = make_conv(["min", "max"], ["identity", "amplification", "linear"], towers=5, F=75, edge_dim=50)
+        conv.drop_override = Fn.DropoutSpec(0.5, seed=0x77)
+        lins = [seq[0].active_linear() for seq in conv.pre_nns["max"]]
+        snaps = []
+        for step, cot in enumerate(cots + cots[:1]):
+            if step == 2:
+                for l in lins:
+                    l.weight.grad = None
+                    l.bias.grad = None
+            conv.zero_grad(set_to_none=True)            # the registered parameters only, as an optimizer would
+            conv(x, eig, ea).backward(cot)
+            snaps.append([l.weight.grad.clone() for l in lins] + [l.bias.grad.clone() for l in lins] + [conv.lin.weight.grad.clone()])
+        res.append(snaps)
+        assert (conv._wplan[1].n_acc > 0) == acc
+    for s0, s1 in zip(*res):
+        for a, b in zip(s0, s1):
+            assert torch.equal(a, b)
+    assert not torch.equal(res[1][0][0], res[1][1][0]) and torch.equal(res[1][0][0], res[1][2][0])     # accumulated, then restarted
