@@ -323,7 +323,7 @@ extern "C" int mma_masked_bn_relu_bwd(const float* gy, int64_t ldg, const float*
 }
 
 extern "C" int mma_seed_advance(uint64_t* seeds, int32_t n, void* stream) {
-  MMA_REQUIRE(n >= 0, "n < 0");
+  MMA_REQUIRE(n >= 0 && n <= (1 << 24), "n=%d out of range (0 .. 2^24)", n);
   if (n == 0) return 0;
   MMA_REQUIRE(seeds, "NULL argument");
   hipLaunchKernelGGL(seed_advance_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), seeds, (int)n);
