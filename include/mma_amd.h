@@ -367,12 +367,19 @@ int mma_l1_loss_bwd(const float* pred, const float* target, int64_t n, const flo
  * torch.optim.Adam semantics (no amsgrad; weight decay added to the gradient; bias-corrected).  table (DEVICE memory,
  * mma_adam_table_bytes(n_tensors, total_chunks) bytes): n_tensors records {float* p; const float* g; float* m; float* v;
  * int64 n; int64 chunk0} followed by total_chunks int32 tensor ids, one per workgroup chunk of mma_adam_chunks(1) = 4096
- * elements (tensor t owns chunks [chunk0, chunk0 + mma_adam_chunks(n))).  step: DEVICE float, the number of steps taken so
- * far; incremented by the call (so a captured hipGraph replays correctly). */
+ * elements (tensor t owns chunks [chunk0, chunk0 + mma_adam_chunks(n))), followed by one int32 ZERO (the ticket counter of the
+ * launch: the last workgroup to finish moves `step`; left at zero).  step: DEVICE float, the number of steps taken so far;
+ * incremented by the call (so a captured hipGraph replays correctly).
+ * mma_adam_step_grads: the gradient pointers come with the CALL - grad_ptrs_host = n_tensors little-endian 8-byte device addresses in
+ * HOST memory, n_tensors <= mma_adam_max_grads_by_value() - and the table's g fields are ignored: the caller may hand over fresh
+ * gradient tensors every step (optimizer.zero_grad(set_to_none=True): no zero-fill, no accumulating add per parameter). */
 int64_t mma_adam_table_bytes(int64_t n_tensors, int64_t total_chunks);
 int64_t mma_adam_chunks(int64_t n_elements);
 int mma_adam_step(const void* table, int64_t n_tensors, int64_t total_chunks, float* step, double lr, double beta1, double beta2,
                   float eps, float weight_decay, void* stream);   /* lr, betas: double, like torch's Python floats (1 - 0.999f != 1e-3) */
+int64_t mma_adam_max_grads_by_value(void);
+int mma_adam_step_grads(const void* table, int64_t n_tensors, int64_t total_chunks, float* step, double lr, double beta1, double beta2,
+                        float eps, float weight_decay, const uint8_t* grad_ptrs_host, void* stream);
 
 /* ---- K6: CSR by key, built on the device (graph-regression batches change every call) ----------------
  * Stable radix sort (rocPRIM) of edge positions by key[e] (int64 node ids as PyG's edge_index holds them):

@@ -109,8 +109,16 @@ __global__ void l1_mean_bwd_kernel(const float* pred, const float* target, int64
 struct AdamTensor { float* p; const float* g; float* m; float* v; int64_t n; int64_t chunk0; };   // chunk0: first chunk id of the tensor
 constexpr int64_t kAdamChunk = 4096;     // elements per workgroup
 
+constexpr int kAdamByValue = 120;        // gradient pointers that fit the kernel arguments (960 of the 4096 bytes)
+struct AdamGrads { const float* g[kAdamByValue]; };
+
+// BY_VALUE: the gradient pointers come with the launch instead of from the table: autograd may hand over FRESH gradient tensors
+// every step (optimizer.zero_grad(set_to_none=True) - no zero-fill and no accumulating add per parameter), and a captured graph
+// keeps the pointers of its capture, which its private pool makes the pointers of every replay.
+template <bool BY_VALUE>
 __global__ __launch_bounds__(kBlock) void adam_kernel(const AdamTensor* tab, int n_tensors, const int32_t* chunk_tensor, float* step,
-                                                      double lr_d, double b1_d, double b2_d, float eps, float wd) {
+                                                      double lr_d, double b1_d, double b2_d, float eps, float wd, unsigned* ticket,
+                                                      const AdamGrads grads) {
   // torch.optim.Adam (no amsgrad, L2 weight decay folded into the gradient), step t = *step + 1 for every workgroup.
   // The scalars are formed in DOUBLE from double hyper-parameters and only then rounded to fp32, as torch does with its Python
   // floats: 1 - 0.999f is 1.3e-5 off 1e-3, which would put every second-moment update and bias correction off by that much.
@@ -118,26 +126,33 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(const AdamTensor* tab, int
   const float step_size = (float)(lr_d / (1.0 - pow(b1_d, t)));
   const float bc2s = (float)sqrt(1.0 - pow(b2_d, t));
   const float b2 = (float)b2_d, omb1 = (float)(1.0 - b1_d), omb2 = (float)(1.0 - b2_d);
-  const AdamTensor T = tab[chunk_tensor[blockIdx.x]];
+  const int ti = chunk_tensor[blockIdx.x];
+  const AdamTensor T = tab[ti];
+  const float* gp = BY_VALUE ? grads.g[ti] : T.g;
   const int64_t base = ((int64_t)blockIdx.x - T.chunk0) * kAdamChunk;
   const int64_t end = min(T.n, base + kAdamChunk);
   for (int64_t i = base + threadIdx.x; i < end; i += kBlock) {
     const float pv = T.p[i];
-    const float g = T.g[i] + wd * pv;                       // grad.add(param, alpha=weight_decay)
+    const float g = gp[i] + wd * pv;                        // grad.add(param, alpha=weight_decay)
     const float m = T.m[i] + omb1 * (g - T.m[i]);           // exp_avg.lerp_(grad, 1 - beta1)
     const float v = b2 * T.v[i] + omb2 * g * g;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     T.m[i] = m; T.v[i] = v;
     T.p[i] = pv - step_size * (m / (sqrtf(v) / bc2s + eps));   // param.addcdiv_(exp_avg, denom, value=-step_size)
   }
+  // the step counter moves when every workgroup has read it: each takes a ticket after its read, the last one ticks (the counter
+  // lives behind the table and is left at zero) - a second one-thread launch did this before
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1u) { *step = (float)t; *ticket = 0u; }
 }
-__global__ void adam_tick_kernel(float* step) { *step += 1.f; }
 
 // ---- K17: BatchNorm1d (training mode) + ReLU over the first n_valid rows of a padded batch, one launch each way ------------------
 // mma.py:121 `x = F.relu(batch_norm(conv(...)))` inside the graphed Net step (train_step.GraphedNetStep): the batch is padded to a
 // static shape, so the statistics run over the first *n_valid rows (a DEVICE scalar: the captured graph replays on batches of any
 // size) while every row is normalised.  As torch ops the masked form is ~30 small launches per layer and direction.
-// One workgroup owns 16 columns: 16 row lanes x 16 columns, fixed summation order (a strided partial sum per row lane, then a tree).
-constexpr int kBnCols = 16, kBnRows = kBlock / kBnCols;
+// One workgroup owns 4 columns: 64 row lanes x 4 columns, fixed summation order (a strided partial sum per row lane, then a tree); the
+// row loops fetch 8 rows per lane before they add (the batches of the graphed step are ~1 500 rows: with 16 columns per workgroup
+// and one load in flight per lane the two kernels took 48 / 77 us, a fifth of the whole Net step).
+constexpr int kBnCols = 4, kBnRows = kBlock / kBnCols, kBnAhead = 8;
 
 __device__ __forceinline__ float bn_block_sum(float v, float (*red)[kBnCols], int r, int c) {
   __syncthreads();
@@ -160,18 +175,38 @@ __global__ __launch_bounds__(kBlock) void masked_bn_relu_fwd_kernel(const float*
   const bool cv = col < C;
   const int64_t nv = min(max(*n_valid, (int64_t)1), N);
   const float cnt = (float)nv;
+  const int xc = cv ? col : 0;                                         // lanes past C read column 0 and add nothing
   float s = 0.f;
-  for (int64_t i = r; i < nv; i += kBnRows) s += cv ? x[i * ldx + col] : 0.f;
+  for (int64_t i = r; i < nv; i += kBnRows * kBnAhead) {
+    float v[kBnAhead];
+#pragma unroll
+    for (int u = 0; u < kBnAhead; ++u) { const int64_t j = i + u * kBnRows; v[u] = x[min(j, nv - 1) * ldx + xc]; }
+#pragma unroll
+    for (int u = 0; u < kBnAhead; ++u) s += (cv && i + u * kBnRows < nv) ? v[u] : 0.f;
+  }
   const float mean = bn_block_sum(s, red, r, c) / cnt;
   float q = 0.f;
-  for (int64_t i = r; i < nv; i += kBnRows) { const float d = cv ? x[i * ldx + col] - mean : 0.f; q += d * d; }
+  for (int64_t i = r; i < nv; i += kBnRows * kBnAhead) {
+    float v[kBnAhead];
+#pragma unroll
+    for (int u = 0; u < kBnAhead; ++u) { const int64_t j = i + u * kBnRows; v[u] = x[min(j, nv - 1) * ldx + xc]; }
+#pragma unroll
+    for (int u = 0; u < kBnAhead; ++u) { const float d = (cv && i + u * kBnRows < nv) ? v[u] - mean : 0.f; q += d * d; }
+  }
   const float var = bn_block_sum(q, red, r, c) / cnt;                  // biased: what normalises (torch BatchNorm training mode)
   const float rstd = rsqrtf(var + eps);
   if (cv) {
     const float g = gamma ? gamma[col] : 1.f, b = beta ? beta[col] : 0.f;
-    for (int64_t i = r; i < N; i += kBnRows) {
-      const float v = (x[i * ldx + col] - mean) * rstd * g + b;
-      y[i * ldy + col] = relu ? fmaxf(v, 0.f) : v;
+    for (int64_t i = r; i < N; i += kBnRows * kBnAhead) {
+      float v[kBnAhead];
+#pragma unroll
+      for (int u = 0; u < kBnAhead; ++u) { const int64_t j = i + u * kBnRows; v[u] = x[min(j, N - 1) * ldx + col]; }
+#pragma unroll
+      for (int u = 0; u < kBnAhead; ++u) {
+        const int64_t j = i + u * kBnRows;
+        const float w = (v[u] - mean) * rstd * g + b;
+        if (j < N) y[j * ldy + col] = relu ? fmaxf(w, 0.f) : w;
+      }
     }
     if (r == 0) {
       mean_out[col] = mean; rstd_out[col] = rstd;
@@ -197,22 +232,42 @@ __global__ __launch_bounds__(kBlock) void masked_bn_relu_bwd_kernel(const float*
   const int64_t nv = min(max(*n_valid, (int64_t)1), N);
   const float cnt = (float)nv;
   const float mean = cv ? mean_in[col] : 0.f, rstd = cv ? rstd_in[col] : 0.f;
+  const int xc = cv ? col : 0;
   float sg = 0.f, sgx = 0.f;
-  for (int64_t i = r; i < N; i += kBnRows) {
-    if (cv) {
-      const float g = (relu && !(y[i * ldy + col] > 0.f)) ? 0.f : gy[i * ldg + col];
-      sg += g; sgx += g * ((x[i * ldx + col] - mean) * rstd);
+  for (int64_t i = r; i < N; i += kBnRows * kBnAhead) {
+    float vy[kBnAhead], vg[kBnAhead], vx[kBnAhead];
+#pragma unroll
+    for (int u = 0; u < kBnAhead; ++u) {
+      const int64_t j = min(i + u * kBnRows, N - 1);
+      vy[u] = y[j * ldy + xc]; vg[u] = gy[j * ldg + xc]; vx[u] = x[j * ldx + xc];
+    }
+#pragma unroll
+    for (int u = 0; u < kBnAhead; ++u) {
+      if (cv && i + u * kBnRows < N) {
+        const float g = (relu && !(vy[u] > 0.f)) ? 0.f : vg[u];
+        sg += g; sgx += g * ((vx[u] - mean) * rstd);
+      }
     }
   }
   const float tg = bn_block_sum(sg, red, r, c);
   const float tgx = bn_block_sum(sgx, red, r, c);
   if (cv) {
     const float k = (gamma ? gamma[col] : 1.f) * rstd;
-    for (int64_t i = r; i < N; i += kBnRows) {
-      const float g = (relu && !(y[i * ldy + col] > 0.f)) ? 0.f : gy[i * ldg + col];
-      const float xh = (x[i * ldx + col] - mean) * rstd;
-      // the statistics depend on the first nv rows only: a padded row's x reaches nothing but its own y
-      gx[i * ldgx + col] = i < nv ? k * (g - tg / cnt - xh * (tgx / cnt)) : k * g;
+    for (int64_t i = r; i < N; i += kBnRows * kBnAhead) {
+      float vy[kBnAhead], vg[kBnAhead], vx[kBnAhead];
+#pragma unroll
+      for (int u = 0; u < kBnAhead; ++u) {
+        const int64_t j = min(i + u * kBnRows, N - 1);
+        vy[u] = y[j * ldy + col]; vg[u] = gy[j * ldg + col]; vx[u] = x[j * ldx + col];
+      }
+#pragma unroll
+      for (int u = 0; u < kBnAhead; ++u) {
+        const int64_t j = i + u * kBnRows;
+        const float g = (relu && !(vy[u] > 0.f)) ? 0.f : vg[u];
+        const float xh = (vx[u] - mean) * rstd;
+        // the statistics depend on the first nv rows only: a padded row's x reaches nothing but its own y
+        if (j < N) gx[j * ldgx + col] = j < nv ? k * (g - tg / cnt - xh * (tgx / cnt)) : k * g;
+      }
     }
     if (r == 0) { if (ggamma) ggamma[col] = tgx; if (gbeta) gbeta[col] = tg; }
   }
@@ -267,12 +322,12 @@ extern "C" int mma_logsoftmax_nll_bwd(const float* logp, int64_t ldo, const int6
 
 extern "C" int64_t mma_adam_table_bytes(int64_t n_tensors, int64_t total_chunks) {
   if (n_tensors < 0 || total_chunks < 0) return -1;
-  return n_tensors * (int64_t)sizeof(AdamTensor) + total_chunks * 4;
+  return n_tensors * (int64_t)sizeof(AdamTensor) + total_chunks * 4 + 4;       // records | chunk -> tensor ids | ticket counter (zero)
 }
 extern "C" int64_t mma_adam_chunks(int64_t n_elements) { return n_elements <= 0 ? 0 : (n_elements + kAdamChunk - 1) / kAdamChunk; }
 
-extern "C" int mma_adam_step(const void* table, int64_t n_tensors, int64_t total_chunks, float* step, double lr, double beta1, double beta2,
-                             float eps, float weight_decay, void* stream) {
+static int adam_launch(const void* table, int64_t n_tensors, int64_t total_chunks, float* step, double lr, double beta1, double beta2,
+                       float eps, float weight_decay, const uint8_t* grad_ptrs_host, void* stream) {
   MMA_REQUIRE(n_tensors >= 0 && total_chunks >= 0 && total_chunks < (1LL << 31), "bad table size");
   if (n_tensors == 0 || total_chunks == 0) return 0;
   MMA_REQUIRE(table && step, "NULL argument");
@@ -280,10 +335,36 @@ extern "C" int mma_adam_step(const void* table, int64_t n_tensors, int64_t total
   hipStream_t st = static_cast<hipStream_t>(stream);
   const AdamTensor* tab = static_cast<const AdamTensor*>(table);
   const int32_t* chunk_tensor = reinterpret_cast<const int32_t*>(tab + n_tensors);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)total_chunks), dim3(kBlock), 0, st, tab, (int)n_tensors, chunk_tensor, step, lr, beta1,
-                     beta2, eps, weight_decay);
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step);
+  unsigned* ticket = reinterpret_cast<unsigned*>(const_cast<int32_t*>(chunk_tensor) + total_chunks);
+  AdamGrads grads{};
+  if (grad_ptrs_host) {
+    MMA_REQUIRE(n_tensors <= kAdamByValue, "n_tensors=%lld: at most %d gradient pointers travel with the launch", (long long)n_tensors, kAdamByValue);
+    for (int64_t i = 0; i < n_tensors; ++i) {
+      uint64_t a = 0;
+      for (int b = 0; b < 8; ++b) a |= (uint64_t)grad_ptrs_host[i * 8 + b] << (8 * b);
+      MMA_REQUIRE(a != 0 && (a & 3u) == 0, "gradient %lld: NULL or misaligned pointer", (long long)i);
+      grads.g[i] = reinterpret_cast<const float*>(static_cast<uintptr_t>(a));
+    }
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)total_chunks), dim3(kBlock), 0, st, tab, (int)n_tensors, chunk_tensor, step, lr, beta1,
+                       beta2, eps, weight_decay, ticket, grads);
+  } else {
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)total_chunks), dim3(kBlock), 0, st, tab, (int)n_tensors, chunk_tensor, step, lr, beta1,
+                       beta2, eps, weight_decay, ticket, grads);
+  }
   return check_launch("adam_step");
+}
+
+extern "C" int mma_adam_step(const void* table, int64_t n_tensors, int64_t total_chunks, float* step, double lr, double beta1, double beta2,
+                             float eps, float weight_decay, void* stream) {
+  return adam_launch(table, n_tensors, total_chunks, step, lr, beta1, beta2, eps, weight_decay, nullptr, stream);
+}
+
+extern "C" int64_t mma_adam_max_grads_by_value(void) { return kAdamByValue; }
+
+extern "C" int mma_adam_step_grads(const void* table, int64_t n_tensors, int64_t total_chunks, float* step, double lr, double beta1,
+                                   double beta2, float eps, float weight_decay, const uint8_t* grad_ptrs_host, void* stream) {
+  MMA_REQUIRE(grad_ptrs_host, "NULL gradient pointer list");
+  return adam_launch(table, n_tensors, total_chunks, step, lr, beta1, beta2, eps, weight_decay, grad_ptrs_host, stream);
 }
 
 extern "C" int mma_l1_loss_fwd(const float* pred, const float* target, int64_t n, float* loss, void* stream) {

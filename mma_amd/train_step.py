@@ -122,10 +122,16 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=True))
         self._tables = None
+        self._max_by_value = _lib.query("mma_adam_max_grads_by_value")
 
     @staticmethod
     def _rec(p, st):
-        return (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr())
+        return (p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr())
+
+    def fresh_gradients_ok(self):
+        """True when every group's gradient pointers travel with the launch (<= 120 tensors per group): zero_grad(set_to_none=True)
+        is then honoured after the first step too, and a step costs neither a zero-fill nor an accumulating add per parameter."""
+        return all(len(g["params"]) <= self._max_by_value for g in self.param_groups)
 
     def _build(self):
         self._tables = []
@@ -152,29 +158,45 @@ class FusedAdam(torch.optim.Optimizer):
                         st[key] = st[key].to(device=p.device, dtype=torch.float32).contiguous()
                 st["step"] = step
                 n_chunks = _lib.query("mma_adam_chunks", p.numel())
-                recs += struct.pack("<QQQQqq", *self._rec(p, st), p.numel(), chunk0)
+                recs += struct.pack("<QQQQqq", p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                    p.numel(), chunk0)
                 chunk_ids += [t] * n_chunks
                 chunk0 += n_chunks
-            raw = recs + struct.pack("<%di" % len(chunk_ids), *chunk_ids)
+            raw = recs + struct.pack("<%di" % len(chunk_ids), *chunk_ids) + struct.pack("<i", 0)        # + the launch's ticket counter
             assert len(raw) == _lib.query("mma_adam_table_bytes", len(ps), chunk0)
             table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev) if ps else None
-            self._tables.append((gi, ps, table, chunk0, step, [self._rec(p, self.state[p]) for p in ps]))
+            by_value = len(ps) <= self._max_by_value
+            self._tables.append((gi, ps, table, chunk0, step, [self._rec(p, self.state[p]) for p in ps], by_value,
+                                 [p.grad.data_ptr() for p in ps]))
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         if self._tables is None:
             self._build()
-        for gi, ps, table, n_chunks, step, ptrs in self._tables:
+        for gi, ps, table, n_chunks, step, ptrs, by_value, gptrs in self._tables:
             if not ps:
                 continue
             group = self.param_groups[gi]        # looked up per step: load_state_dict() replaces the group dicts
             if any(self._rec(p, self.state[p]) != q for p, q in zip(ps, ptrs)):
-                raise RuntimeError("FusedAdam: a parameter, gradient or moment buffer moved; keep gradients allocated "
-                                   "(zero_grad(set_to_none=False)) and load checkpoints with load_state_dict()")
+                raise RuntimeError("FusedAdam: a parameter or moment buffer moved; load checkpoints with load_state_dict()")
             b1, b2 = group["betas"]
-            call("mma_adam_step", ptr(table), len(ps), n_chunks, ptr(step), group["lr"], b1, b2, group["eps"], group["weight_decay"],
-                 stream_ptr())
+            if by_value:            # this step's gradient tensors, wherever autograd put them
+                raw = bytearray()
+                for p in ps:
+                    g = p.grad
+                    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
+                        raise RuntimeError("FusedAdam: a parameter that had a gradient at the first step has none now (or a non-contiguous "
+                                           "/ non-fp32 one)")
+                    raw += struct.pack("<Q", g.data_ptr())
+                call("mma_adam_step_grads", ptr(table), len(ps), n_chunks, ptr(step), group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                     bytes(raw), stream_ptr())
+            else:
+                if any(p.grad is None or p.grad.data_ptr() != q for p, q in zip(ps, gptrs)):
+                    raise RuntimeError("FusedAdam: a gradient buffer moved; with more than %d tensors in a group keep gradients allocated "
+                                       "(zero_grad(set_to_none=False))" % self._max_by_value)
+                call("mma_adam_step", ptr(table), len(ps), n_chunks, ptr(step), group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                     stream_ptr())
         return loss
 
     @torch.no_grad()
@@ -187,7 +209,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         if live is None:
             return
-        for _gi, ps, _table, _n, step, _ptrs in self._tables:
+        for _gi, ps, _table, _n, step, *_rest in self._tables:
             steps = set()
             for p in ps:
                 new, old = self.state.get(p, {}), live[p]
@@ -204,7 +226,8 @@ class FusedAdam(torch.optim.Optimizer):
                 step.fill_(steps.pop())
 
     def zero_grad(self, set_to_none=False):
-        super().zero_grad(set_to_none=False if self._tables is not None else set_to_none)
+        keep = self._tables is not None and not all(t[6] for t in self._tables)      # a table that holds gradient addresses
+        super().zero_grad(set_to_none=False if keep else set_to_none)
 
 
 def _set_capturable(model, flag):
@@ -305,7 +328,9 @@ class GraphedNetStep:
     def forward_backward(self):
         """Loss and gradients of the loaded (padded) batch, no optimizer step."""
         self._fn._GR_GRAPHS.clear()            # the CSR of THIS batch is built inside the step (and inside the captured graph)
-        self.optimizer.zero_grad(set_to_none=False)
+        # fresh gradient tensors every step where the optimizer takes them (FusedAdam: pointers travel with the launch; torch's
+        # capturable Adam reads p.grad at capture time): no zero-fill and no accumulating add per parameter - 110 launches of the ~430
+        self.optimizer.zero_grad(set_to_none=getattr(self.optimizer, "fresh_gradients_ok", lambda: True)())
         out = self.net(self.x, self.ei, self.ea, self.batch, n_valid=self.n_valid, n_graphs=self.n_graphs)
         loss = fused_l1_loss(out[:self.n_graphs].squeeze(-1), self.y)
         loss.backward()

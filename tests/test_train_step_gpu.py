@@ -135,6 +135,48 @@ def test_fused_adam_matches_torch_adam():
         assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (a - b).abs().max()
 
 
+def test_fused_adam_takes_fresh_gradient_tensors_every_step():
+    """zero_grad(set_to_none=True) + NEW gradient tensors per step (what autograd hands over): the gradient pointers travel with
+    the K11 launch, so nothing has to stay allocated - same trajectory as torch.optim.Adam; more tensors than fit the launch
+    arguments fall back to the table (gradients must then stay in place, and a moved one raises)."""
+    from mma_amd.train_step import FusedAdam
+    g = torch.Generator().manual_seed(2)
+    shapes = [(129, 3), (4097,), (64, 16), (1,), (75, 225)]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    grads = [[torch.randn(*s, generator=g) for s in shapes] for _ in range(5)]
+    res = []
+    for fused in (False, True):
+        ps = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+        opt = (FusedAdam if fused else torch.optim.Adam)(ps, lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+        if fused:
+            assert opt.fresh_gradients_ok()
+        keep = []
+        for step_g in grads:
+            opt.zero_grad(set_to_none=True)
+            assert all(p.grad is None for p in ps)
+            for p, gg in zip(ps, step_g):
+                p.grad = gg.to(DEV).clone()
+                keep.append(p.grad)                       # old gradient tensors stay alive: the new ones cannot reuse their addresses
+            opt.step()
+        res.append([p.detach().clone() for p in ps])
+        if fused:
+            assert float(opt.state[ps[0]]["step"]) == len(grads)
+    for a, b in zip(*res):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (a - b).abs().max()
+    # beyond the by-value limit: the table form, which needs the gradients to stay where they were
+    many = [torch.nn.Parameter(torch.randn(5, device=DEV)) for _ in range(130)]
+    opt = FusedAdam(many, lr=0.01)
+    assert not opt.fresh_gradients_ok()
+    for p in many:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    opt.zero_grad(set_to_none=True)                       # kept allocated on purpose
+    assert all(p.grad is not None and float(p.grad.abs().sum()) == 0 for p in many)
+    many[3].grad = torch.ones_like(many[3])
+    with pytest.raises(RuntimeError, match="gradient buffer moved"):
+        opt.step()
+
+
 def test_fused_adam_checkpoint_round_trip_like_torch_adam():
     """FusedAdam checkpoints and resumes like the torch.optim.Adam it replaces.  Three steps, state_dict(), then
     (a) a FRESH FusedAdam loads it before its first step, (b) a LIVE FusedAdam (tables built, two unrelated steps taken) loads it
