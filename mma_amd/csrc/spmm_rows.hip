@@ -258,13 +258,41 @@ __global__ __launch_bounds__(kBlock) void col_sum_kernel(const ColSumParams p) {
   if (rl == 0 && c < p.C) p.out[(int64_t)blockIdx.y * p.C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
+// Short matrices (the bias gradients of a ~1 500-row molecule batch): ONE launch - a workgroup owns 4 columns with 64 row lanes, each
+// lane fetching 8 rows before it adds, then a tree over the lanes - instead of two passes of the 4-lane kernel above (the launch, not
+// the bytes, is the cost there).  Fixed order.
+constexpr int kColSumShortCols = 4, kColSumShortRows = kBlock / kColSumShortCols, kColSumShortMaxR = 8192;
+__global__ __launch_bounds__(kBlock) void col_sum_short_kernel(const ColSumParams p) {
+  __shared__ float red[kColSumShortRows][kColSumShortCols];
+  const int cl = threadIdx.x % kColSumShortCols, rl = threadIdx.x / kColSumShortCols;
+  const int c = (int)blockIdx.x * kColSumShortCols + cl;
+  const bool cv = c < p.C;
+  const float* q = p.g + (cv ? c : 0);
+  float a = 0.f;
+  for (int64_t r = rl; r < p.R; r += kColSumShortRows * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = q[min(r + u * kColSumShortRows, p.R - 1) * p.ldg];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += (r + u * kColSumShortRows < p.R) ? v[u] : 0.f;
+  }
+  red[rl][cl] = a;
+  __syncthreads();
+  for (int o = kColSumShortRows / 2; o > 0; o >>= 1) {
+    if (rl < o) red[rl][cl] += red[rl + o][cl];
+    __syncthreads();
+  }
+  if (rl == 0 && cv) p.out[c] = red[0][cl];
+}
+
 static int64_t col_sum_rows_per_block(int64_t R) {      // ~2*sqrt(R), a power of two in [64, 4096]: both passes stay short
   int64_t rpb = 64;
   while (rpb < 4096 && rpb * rpb < 4 * R) rpb *= 2;
   return rpb;
 }
-static int64_t col_sum_row_blocks(int64_t R) {
-  if (R <= 1024) return 1;
+static bool col_sum_short(int64_t R, int C) { return R > 256 && R <= kColSumShortMaxR && C <= 2048; }   // few columns: 16-byte row segments are fine
+static int64_t col_sum_row_blocks(int64_t R, int C) {
+  if (R <= 1024 || col_sum_short(R, C)) return 1;
   const int64_t rpb = col_sum_rows_per_block(R);
   return (R + rpb - 1) / rpb;
 }
@@ -393,7 +421,7 @@ extern "C" int mma_unpack_add_rows(const float* src, int64_t lds, const int32_t*
 }
 
 extern "C" int64_t mma_col_sum_workspace_floats(int64_t R, int32_t C) {
-  const int64_t nrb = col_sum_row_blocks(R);
+  const int64_t nrb = col_sum_row_blocks(R, C);
   return nrb > 1 ? nrb * (int64_t)C : 0;
 }
 
@@ -401,7 +429,7 @@ extern "C" int mma_col_sum(const float* g, int64_t ldg, int64_t R, int32_t C, fl
                            void* stream) {
   MMA_REQUIRE(R >= 0 && C >= 1 && ldg >= C, "R=%lld C=%d ldg=%lld unsupported", (long long)R, C, (long long)ldg);
   MMA_REQUIRE(out && (g || R == 0), "NULL argument");
-  const int64_t nrb = col_sum_row_blocks(R);
+  const int64_t nrb = col_sum_row_blocks(R, C);
   MMA_REQUIRE(nrb == 1 || (ws && ws_floats >= nrb * (int64_t)C), "workspace too small: %lld floats, need %lld",
               (long long)ws_floats, (long long)(nrb * (int64_t)C));
   MMA_REQUIRE(nrb < 65536, "R=%lld too large", (long long)R);
@@ -409,6 +437,10 @@ extern "C" int mma_col_sum(const float* g, int64_t ldg, int64_t R, int32_t C, fl
   const unsigned cb = (unsigned)((C + kWave - 1) / kWave);
   if (nrb == 1) {
     ColSumParams p{g, ldg, R, C, out, R > 0 ? R : 1};
+    if (col_sum_short(R, C)) {
+      hipLaunchKernelGGL(col_sum_short_kernel, dim3((unsigned)((C + kColSumShortCols - 1) / kColSumShortCols)), dim3(kBlock), 0, st, p);
+      return check_launch("col_sum_short_kernel");
+    }
     hipLaunchKernelGGL(col_sum_kernel, dim3(cb, 1), dim3(kBlock), 0, st, p);
     return check_launch("col_sum_kernel");
   }

@@ -55,7 +55,8 @@ def test_mm_autograd_uses_x3_and_matches():
 
 
 @pytest.mark.parametrize("R,C,pad", [(0, 7, 0), (1, 1, 0), (3, 75, 0), (1000, 375, 0), (1025, 64, 0), (204552, 375, 0),
-                                     (427376, 75, 0), (50000, 15, 5), (300001, 130, 2)])
+                                     (427376, 75, 0), (50000, 15, 5), (300001, 130, 2), (257, 3, 0), (1344, 760, 0), (8192, 75, 1), (8193, 75, 0),
+                                     (1411, 2049, 0), (2708, 7, 0)])
 def test_col_sum(R, C, pad):
     """K8 column sums: fixed-order (bitwise repeatable), fp32-accurate against an fp64 sum, strided rows, ragged sizes."""
     from mma_amd import dense
