@@ -17,6 +17,7 @@ import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -157,6 +158,9 @@ def main():
     print("default bench: %.2f ms/step, roofline %s frac %.3f, traffic %s" % (b["ms_per_step"], b["roofline"]["kernel"], b["roofline"]["frac"], b["roofline"]["traffic"]))
     b = bench_line("bench_c2l.log", os.path.join(P, "%s_bench_c2l.json" % rnd))
     print("c2l bench: %.2f ms/step, roofline %s frac %.3f / %.3f" % (b["ms_per_step"], b["roofline"]["kernel"], b["roofline"]["frac"], b["roofline_other"]["frac"]))
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out", "prof_small_round")):
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "small_summary.py"), os.path.join(ROOT, "gpurun_out", "prof_small_round"),
+                        os.path.join(P, "%s_small_graph_kernels.md" % rnd)], check=True)
     parity_report(os.path.join(P, "%s_parity_strict_report.md" % rnd))
     sq_clock(os.path.join(P, "%s_sq_clock.json" % rnd), rnd, ver, cmd4)
     gp = os.path.join(ROOT, "gpurun_out", "gemm_power.log")

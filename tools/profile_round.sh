@@ -8,6 +8,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 bash tools/prof_c4.sh round sq || exit 1
 bash tools/prof_c2l.sh round || exit 1
+bash tools/prof_small.sh round || exit 1
 timeout -k 10 600 python bench.py > gpurun_out/bench_default.log 2>&1 || exit 1
 timeout -k 10 300 python bench.py --workload c2l > gpurun_out/bench_c2l.log 2>&1 || exit 1
 timeout -k 10 200 python tools/gemm_power.py > gpurun_out/gemm_power.log 2>&1 || exit 1
