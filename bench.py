@@ -290,7 +290,45 @@ def nc_config(tag, fixture, H, names, C, p, dev, reps=50, replay=True):
         layer.graph_capturable = True
         gms = graph_replay_ms(step)
         r.update(ms_per_step_hipgraph=gms, edges_per_s_hipgraph=E / gms * 1e3)
+        r["fused_calls_in_graph_us"] = fused_calls_in_graph(layer, graph, x.detach(), names, p)
     return r
+
+
+def fused_calls_in_graph(layer, graph, x, names, p, reps=20):
+    """The two fused C-ABI calls (mma_nc_fused_fwd; mma_nc_fused_bwd with the node-level backward in its epilogue) on their own: `reps`
+    back-to-back calls of each captured into one hipGraph, replay time / reps = what ONE call costs inside a replayed step (kernel
+    start to next kernel start).  The eager HIP-event spans of the `kernels` table also hold the host's launch gaps."""
+    from mma_amd import functional as Fn
+    kinds, acts = layer._codes(names)
+    N, H = x.shape
+    KH = len(kinds) * H
+    masks = [getattr(layer, "mask_" + n).detach() for n in names]
+    PQ = x @ Fn.mask_weights(masks)
+    drop = Fn.DropoutSpec(p, seed=1234)
+    g = torch.randn(N, H, device=x.device)
+    gPQ = torch.empty((N, 2 * KH), device=x.device)
+    gx = torch.empty((N, H), device=x.device)
+    partial = torch.empty((graph.t_n_slots, (len(kinds) + 1) * H), device=x.device) if graph.t_n_slots else None
+    state = {}
+
+    def fwd():
+        state["out"] = Fn.nc_fwd_launch(x, PQ[:, :KH], PQ[:, KH:], graph, kinds, acts, drop, True, True)
+
+    def bwd():
+        _, T, _, crow = state["out"]
+        Fn.nc_bwd_edges_launch(x, PQ[:, :KH], PQ[:, KH:], None, g, crow, None, graph, kinds, acts, drop, gPQ[:, KH:], gx, partial, T=T,
+                               gP=gPQ[:, :KH])
+    fwd()
+    if state["out"][3] is None or not Fn.FUSE_NODE_BWD:
+        return None
+    res = {}
+    for name, fn in (("nc_fused_fwd", fwd), ("nc_fused_bwd", bwd)):
+        def many():
+            for _ in range(reps):
+                fn()
+        res[name] = graph_replay_ms(many, 20) / reps * 1e3
+    res["note"] = "%d back-to-back calls in one hipGraph, replay / %d" % (reps, reps)
+    return res
 
 
 def nc_model_config(tag, fixture, nfeat, density, hidden, names, nclass, p, n_train, dev, reps=30):

@@ -33,7 +33,7 @@ def auto_plan(E, H=None):
         # LONGEST serial chain of dependent gathers any wavefront walks, not bytes.  A wavefront gathers EPG = 64 / (H/4 lanes per row)
         # rows per step, a grouped item (one H/4-lane group) ONE row per step: the 256-edge chunks above leave Cora's 168-edge hub as one
         # wavefront's 42-step walk (K1 60 us for 11.6 MB), and Pubmed's 31-edge items as 31-step walks of a 4-lane group (K2b 110 us).
-        # So: chunks of 16 wavefront steps, grouped items below 4 edges.  Swept on the Cora / Pubmed structures (round 3, HIP-event spans
+        # So: chunks of 16 wavefront steps, grouped items below 4 edges (8 since the one-launch form: see the end of this comment).  Swept on the Cora / Pubmed structures (round 3, HIP-event spans
         # of the K1 / K2b calls in us, eager; (steps, group)):  Cora H=64: old plan 58.9 / 70.5, (4,4) 40.3 / 40.5, (8,4) 44.0 / 45.1,
         # (16,4) 44.1 / 47.8, (8,16) 47.6 / 51.9;  Pubmed H=16: old 68.7 / 76.4, (4,4) 62.1 / 43.4, (8,4) 67.8 / 43.3, (16,4) 51.0 / 37.7,
         # (16,16) 64.6 / 54.4.  Layer replay as one hipGraph: Cora 0.249 -> 0.197 ms, Pubmed 0.371 -> 0.319 ms.
@@ -41,12 +41,16 @@ def auto_plan(E, H=None):
         while lpr < min(-(-H // 4), 64):
             lpr *= 2
         epg = 64 // lpr
-        return max(16, SMALL_STEPS * epg), SMALL_GROUP_BELOW, SMALL_GROUP_BELOW
+        # One-launch form (late round 3; one call inside a replayed hipGraph, us, K1 / K2b; (forward, backward) thresholds): Cora (4,8) 12.0 /
+        # 17.4, (8,8) 12.2 / 17.8, (16,8) 13.3 / 17.4, (8,16) 11.9 / 19.8; Pubmed (4,8) 28.2 / 27.3, (8,8) 24.4 / 27.2, (16,8) 21.9 / 27.1,
+        # (32,8) 32.5 / 27.2, (8,32) 24.4 / 48.1: forward items shorter than one wavefront step (EPG rows) are better off grouped.
+        return max(16, SMALL_STEPS * epg), max(SMALL_GROUP_BELOW, epg), SMALL_T_GROUP_BELOW
     return 256, 32, 32
 
 
 SMALL_STEPS = int(__import__("os").environ.get("MMA_SMALL_STEPS", "16"))
 SMALL_GROUP_BELOW = int(__import__("os").environ.get("MMA_SMALL_GROUP", "8"))
+SMALL_T_GROUP_BELOW = int(__import__("os").environ.get("MMA_SMALL_T_GROUP", str(SMALL_GROUP_BELOW)))
 ONE_LAUNCH = __import__("os").environ.get("MMA_ONE_LAUNCH", "1") != "0"
 
 
