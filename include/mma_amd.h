@@ -349,6 +349,15 @@ int mma_masked_bn_relu_bwd(const float* gy, int64_t ldg, const float* y, int64_t
 int mma_pack_blocks(const int64_t* table, int64_t n_blocks, float* a_base, float* b0, float* b1, float* b2, float* b3, float* b4,
                     float* b5, float* b6, float* b7, int32_t unpack, void* stream);
 
+/* ---- K19: the edge encoder folded into the pre-NN's edge block (mma_conv.py:141-146: enc(e) We^T = e (We Wenc)^T + We benc) ----------
+ * fwd: wz (TF,ED) = We Wenc, bz (TF) = We benc.   We (TF,F) row pitch ldw; Wenc (F,ED) and the outputs contiguous; benc / bz both or
+ *      neither.  bwd: gWe (TF,F) = gwz Wenc^T + gbz (x) benc, gWenc (F,ED) = We^T gwz, gbenc (F) = We^T gbz (gbz / gbenc both or neither).
+ * Plain fp32 FMA chains in a fixed order; F, ED <= 512.  One launch each (seven torch launches at ZINC's 380 x 75 x 50). */
+int mma_edge_fold_fwd(const float* We, int64_t ldw, const float* Wenc, const float* benc, float* wz, float* bz, int64_t TF, int32_t F,
+                      int32_t ED, void* stream);
+int mma_edge_fold_bwd(const float* We, int64_t ldw, const float* Wenc, const float* benc, const float* gwz, const float* gbz, float* gWe,
+                      float* gWenc, float* gbenc, int64_t TF, int32_t F, int32_t ED, void* stream);
+
 /* ---- dropout seeds of a captured (hipGraph) step -------------------------------------------------------------------------------
  * seeds: DEVICE (2n,) uint64 - [0,n) the seeds the fused kernels read through their `seed_dev` argument (one per launch group of 8
  * masks), [n,2n) the splitmix64 states behind them (initialised by the caller from its own generator).  Each call advances every

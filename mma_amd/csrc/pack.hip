@@ -58,3 +58,110 @@ extern "C" int mma_pack_blocks(const int64_t* table, int64_t n_blocks, float* a_
   else hipLaunchKernelGGL(pack_blocks_kernel<false>, dim3((unsigned)n_blocks), dim3(kBlock), 0, st, p);
   return check_launch("pack_blocks_kernel");
 }
+
+// ---- K19: the edge encoder folded into the pre-NN's edge block, one launch each way ---------------------------------------------
+// MMAConv.message applies pre_nn([x_i | x_j | enc(e)]) with enc = Linear(edge_dim -> F) (mma_conv.py:141-146).  The fused path never
+// forms enc(e):  enc(e) We^T = e (We Wenc)^T + We benc,  so per layer call it needs  wz = We Wenc (T*Fw, edge_dim)  and
+// bz = We benc (T*Fw)  - 380 x 50 x 75 multiply-adds at ZINC's shape.  As torch ops that is a GEMM + a GEMV forward and a TN GEMM, a
+// GEMM, a GEMV, an outer product and an add backward: seven ~5 us launches for microseconds of arithmetic.  Plain fp32 FMA chains in a
+// fixed order (lengths F, edge_dim + 1, T*Fw).
+namespace mma {
+
+constexpr int kFoldRows = 8;      // rows of We (or gwz) a workgroup keeps in LDS
+constexpr int kFoldMaxWidth = 512;
+
+struct FoldParams {
+  const float* We; int64_t ldw; const float* Wenc; const float* benc;      // We (TF, F) pitch ldw; Wenc (F, ED) contiguous; benc (F) or NULL
+  float* wz; float* bz;                                                    // forward out: (TF, ED), (TF)
+  const float* gwz; const float* gbz; float* gWe; float* gWenc; float* gbenc;   // backward: in (TF, ED), (TF); out (TF, F), (F, ED), (F)
+  int TF, F, ED, row_blocks;
+};
+
+__global__ __launch_bounds__(kBlock) void edge_fold_fwd_kernel(const FoldParams p) {
+  __shared__ float rows[kFoldRows][kFoldMaxWidth];
+  const int r0 = (int)blockIdx.x * kFoldRows;
+  const int nr = min(kFoldRows, p.TF - r0);
+  for (int e = threadIdx.x; e < nr * p.F; e += kBlock) { const int r = e / p.F, f = e - r * p.F; rows[r][f] = p.We[(int64_t)(r0 + r) * p.ldw + f]; }
+  __syncthreads();
+  const int cols = p.ED + (p.bz ? 1 : 0);
+  for (int o = threadIdx.x; o < nr * cols; o += kBlock) {
+    const int r = o / cols, c = o - r * cols;
+    float a = 0.f;
+    if (c < p.ED) {
+#pragma unroll 5
+      for (int f = 0; f < p.F; ++f) a = fmaf(rows[r][f], p.Wenc[(int64_t)f * p.ED + c], a);
+      p.wz[(int64_t)(r0 + r) * p.ED + c] = a;
+    } else {
+#pragma unroll 5
+      for (int f = 0; f < p.F; ++f) a = fmaf(rows[r][f], p.benc[f], a);
+      p.bz[r0 + r] = a;
+    }
+  }
+}
+
+// blocks [0, row_blocks): gWe rows = gwz Wenc^T + gbz (x) benc; the rest: gWenc = We^T gwz and gbenc = We^T gbz, one output per wavefront
+__global__ __launch_bounds__(kBlock) void edge_fold_bwd_kernel(const FoldParams p) {
+  __shared__ float rows[kFoldRows][kFoldMaxWidth];
+  if ((int)blockIdx.x < p.row_blocks) {
+    const int r0 = (int)blockIdx.x * kFoldRows;
+    const int nr = min(kFoldRows, p.TF - r0);
+    for (int e = threadIdx.x; e < nr * p.ED; e += kBlock) { const int r = e / p.ED, c = e - r * p.ED; rows[r][c] = p.gwz[(int64_t)(r0 + r) * p.ED + c]; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < nr * p.F; o += kBlock) {
+      const int r = o / p.F, f = o - r * p.F;
+      const float* w = p.Wenc + (int64_t)f * p.ED;
+      float a = 0.f;
+#pragma unroll 5
+      for (int c = 0; c < p.ED; ++c) a = fmaf(rows[r][c], w[c], a);
+      if (p.gbz) a = fmaf(p.gbz[r0 + r], p.benc[f], a);
+      p.gWe[(int64_t)(r0 + r) * p.F + f] = a;
+    }
+    return;
+  }
+  // one WAVEFRONT per output: the lanes split the T*Fw rows of the reduction (a thread per output walked 380 dependent cache misses)
+  const int cols = p.ED + (p.gbenc ? 1 : 0);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int o = ((int)blockIdx.x - p.row_blocks) * (kBlock / kWave) + (int)(threadIdx.x >> 6);
+  if (o >= p.F * cols) return;                       // wave-uniform
+  const int f = o / cols, c = o - f * cols;
+  float a = 0.f;
+  if (c < p.ED) {
+    for (int r = lane; r < p.TF; r += kWave) a = fmaf(p.We[(int64_t)r * p.ldw + f], p.gwz[(int64_t)r * p.ED + c], a);
+  } else {
+    for (int r = lane; r < p.TF; r += kWave) a = fmaf(p.We[(int64_t)r * p.ldw + f], p.gbz[r], a);
+  }
+  for (int off = kWave / 2; off > 0; off >>= 1) a += __shfl_xor(a, off, kWave);
+  if (lane == 0) { if (c < p.ED) p.gWenc[(int64_t)f * p.ED + c] = a; else p.gbenc[f] = a; }
+}
+
+}  // namespace mma
+
+static int fold_check(int64_t TF, int32_t F, int32_t ED) {
+  MMA_REQUIRE(TF >= 1 && TF < (1 << 24) && F >= 1 && F <= kFoldMaxWidth && ED >= 1 && ED <= kFoldMaxWidth, "TF=%lld F=%d ED=%d unsupported (widths <= %d)",
+              (long long)TF, F, ED, kFoldMaxWidth);
+  return 0;
+}
+
+extern "C" int mma_edge_fold_fwd(const float* We, int64_t ldw, const float* Wenc, const float* benc, float* wz, float* bz, int64_t TF, int32_t F,
+                                 int32_t ED, void* stream) {
+  if (int rc = fold_check(TF, F, ED)) return rc;
+  MMA_REQUIRE(We && Wenc && wz && ldw >= F && ((benc == nullptr) == (bz == nullptr)), "NULL argument (benc and bz come together)");
+  FoldParams p{};
+  p.We = We; p.ldw = ldw; p.Wenc = Wenc; p.benc = benc; p.wz = wz; p.bz = bz; p.TF = (int)TF; p.F = F; p.ED = ED;
+  hipLaunchKernelGGL(edge_fold_fwd_kernel, dim3((unsigned)((TF + kFoldRows - 1) / kFoldRows)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch("edge_fold_fwd_kernel");
+}
+
+extern "C" int mma_edge_fold_bwd(const float* We, int64_t ldw, const float* Wenc, const float* benc, const float* gwz, const float* gbz, float* gWe,
+                                 float* gWenc, float* gbenc, int64_t TF, int32_t F, int32_t ED, void* stream) {
+  if (int rc = fold_check(TF, F, ED)) return rc;
+  MMA_REQUIRE(We && Wenc && gwz && gWe && gWenc && ldw >= F, "NULL argument");
+  MMA_REQUIRE((gbz == nullptr) == (gbenc == nullptr) && (gbz == nullptr || benc != nullptr), "gbz, gbenc and benc come together");
+  FoldParams p{};
+  p.We = We; p.ldw = ldw; p.Wenc = Wenc; p.benc = benc; p.gwz = gwz; p.gbz = gbz; p.gWe = gWe; p.gWenc = gWenc; p.gbenc = gbenc;
+  p.TF = (int)TF; p.F = F; p.ED = ED; p.row_blocks = (int)((TF + kFoldRows - 1) / kFoldRows);
+  const int64_t outs = (int64_t)F * (ED + (gbenc ? 1 : 0));
+  hipLaunchKernelGGL(edge_fold_bwd_kernel, dim3((unsigned)(p.row_blocks + (outs + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), p);
+  return check_launch("edge_fold_bwd_kernel");
+}

@@ -137,6 +137,40 @@ class _PackWeights(torch.autograd.Function):
                                              for i in range(n_acc, len(plan.shapes)))
 
 
+class _EdgeFold(torch.autograd.Function):
+    """K19: (wz, bz) = (We @ Wenc, We @ benc) - the edge encoder folded into the pre-NN's edge block - in one launch, and
+    (gWe, gWenc, gbenc) back in one (as torch ops: a GEMM + a GEMV forward, five launches backward, ~5 us each)."""
+
+    @staticmethod
+    def forward(ctx, We, Wenc, benc):
+        from ._lib import call, ptr, stream_ptr
+        We = We if We.stride(1) == 1 else We.contiguous()
+        Wenc, benc = Wenc.contiguous(), benc.contiguous()
+        TF, F_ = We.shape
+        ED = Wenc.shape[1]
+        wz = torch.empty((TF, ED), device=We.device, dtype=torch.float32)
+        bz = torch.empty((TF,), device=We.device, dtype=torch.float32)
+        call("mma_edge_fold_fwd", ptr(We), We.stride(0), ptr(Wenc), ptr(benc), ptr(wz), ptr(bz), TF, F_, ED, stream_ptr())
+        ctx.save_for_backward(We, Wenc, benc)
+        return wz, bz
+
+    @staticmethod
+    def backward(ctx, gwz, gbz):
+        from ._lib import call, ptr, stream_ptr
+        We, Wenc, benc = ctx.saved_tensors
+        TF, F_ = We.shape
+        ED = Wenc.shape[1]
+        gwz = torch.zeros((TF, ED), device=We.device) if gwz is None else gwz.contiguous()
+        gbz = torch.zeros((TF,), device=We.device) if gbz is None else gbz.contiguous()
+        gWe = torch.empty((TF, F_), device=We.device, dtype=torch.float32)
+        gWenc = torch.empty((F_, ED), device=We.device, dtype=torch.float32)
+        gbenc = torch.empty((F_,), device=We.device, dtype=torch.float32)
+        call("mma_edge_fold_bwd", ptr(We), We.stride(0), ptr(Wenc), ptr(benc), ptr(gwz), ptr(gbz), ptr(gWe), ptr(gWenc), ptr(gbenc), TF, F_, ED,
+             stream_ptr())
+        return gWe, gWenc, gbenc
+
+
+EDGE_FOLD = __import__("os").environ.get("MMA_EDGE_FOLD", "1") != "0"
 PACK_WEIGHTS = __import__("os").environ.get("MMA_PACK_WEIGHTS", "1") != "0"
 ACCUMULATE_UNREGISTERED = __import__("os").environ.get("MMA_ACC_UNREGISTERED", "1") != "0"
 
@@ -305,7 +339,11 @@ class MMAConv(torch.nn.Module):
                 # The (E, edge_dim) rows are put in target-sorted position order BEFORE the GEMM (50 floats per edge), so that Z
                 # - and in backward the (E, T*Fw) message gradients - stream contiguously through K3/K4.
                 We, enc = (packed[2] if packed else rows(2 * Fi, 3 * Fi)), self.edge_encoder
-                wz, bz = We @ enc.weight, (We @ enc.bias if enc.bias is not None else None)
+                if (EDGE_FOLD and enc.bias is not None and We.is_cuda and We.dtype == torch.float32 and max(We.shape[1], enc.weight.shape[1]) <= 512
+                        and enc.weight.dtype == torch.float32):
+                    wz, bz = _EdgeFold.apply(We, enc.weight, enc.bias)                   # K19: one launch each way
+                else:
+                    wz, bz = We @ enc.weight, (We @ enc.bias if enc.bias is not None else None)
                 if isinstance(edge_attr, CategoricalEdges):
                     # edge_attr = table[types] (an Embedding: mma.py:88,103): Z has only n_types distinct rows, so the kernels get
                     # the (n_types, T*Fw) table and one byte per edge instead of a (E, T*Fw) stream

@@ -383,3 +383,28 @@ def test_unregistered_mask_linears_accumulate_their_gradient_like_the_reference(
         for a, b in zip(s0, s1):
             assert torch.equal(a, b)
     assert not torch.equal(res[1][0][0], res[1][1][0]) and torch.equal(res[1][0][0], res[1][2][0])     # accumulated, then restarted
+
+
+@pytest.mark.parametrize("TF,F,ED,pad", [(380, 75, 50, 0), (7, 3, 1, 2), (129, 512, 40, 0), (1000, 76, 512, 1)])
+def test_edge_fold_matches_the_matmuls(TF, F, ED, pad):
+    """K19: wz = We Wenc, bz = We benc and their three gradients, one launch each way, against float64; strided We rows; repeatable."""
+    from mma_amd.mma_conv import _EdgeFold
+    rng = np.random.default_rng(TF + F + ED)
+    Wef = torch.from_numpy(rng.standard_normal((TF, F + pad)).astype(np.float32)).to(DEV)
+    We = Wef[:, :F].requires_grad_(True) if not pad else Wef[:, :F].detach().requires_grad_(True)
+    Wenc = torch.from_numpy(rng.standard_normal((F, ED)).astype(np.float32)).to(DEV).requires_grad_(True)
+    benc = torch.from_numpy(rng.standard_normal((F,)).astype(np.float32)).to(DEV).requires_grad_(True)
+    c1 = torch.from_numpy(rng.standard_normal((TF, ED)).astype(np.float32)).to(DEV)
+    c2 = torch.from_numpy(rng.standard_normal((TF,)).astype(np.float32)).to(DEV)
+    wz, bz = _EdgeFold.apply(We, Wenc, benc)
+    got = (wz.detach(), bz.detach()) + torch.autograd.grad((wz * c1).sum() + (bz * c2).sum(), [We, Wenc, benc])
+    W64, E64, b64 = (t.detach().double().requires_grad_(True) for t in (We, Wenc, benc))
+    wz64, bz64 = W64 @ E64, W64 @ b64
+    ref = (wz64.detach(), bz64.detach()) + torch.autograd.grad((wz64 * c1.double()).sum() + (bz64 * c2.double()).sum(), [W64, E64, b64])
+    absr = (We.detach().double().abs() @ Wenc.detach().double().abs(), We.detach().double().abs() @ benc.detach().double().abs(),
+            c1.double().abs() @ Wenc.detach().double().abs().t() + c2.double().abs()[:, None] * benc.detach().double().abs()[None],
+            We.detach().double().abs().t() @ c1.double().abs(), We.detach().double().abs().t() @ c2.double().abs())
+    for a, b, sc in zip(got, ref, absr):
+        assert a.shape == b.shape and bool(((a.double() - b).abs() <= 2e-6 * sc + 1e-30).all()), (a.double() - b).abs().max()
+    wz2, bz2 = _EdgeFold.apply(We, Wenc, benc)
+    assert torch.equal(wz2, wz) and torch.equal(bz2, bz)
