@@ -45,7 +45,7 @@ def main():
         files = glob.glob(os.path.join(src, cfg, "**", "*kernel_trace.csv"), recursive=True)
         if not files:
             continue
-        rows = list(csv.DictReader(open(files[0])))
+        rows = list(csv.DictReader(open(max(files, key=os.path.getmtime))))      # gpurun_out accumulates earlier rounds' files
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         rep = one_replay(rows, MARK[cfg])
         log = open(os.path.join(src, cfg + ".log")).read()
