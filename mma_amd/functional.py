@@ -264,6 +264,20 @@ class DeviceSeeds:
         return self.seeds
 
 
+class SeedSlot:
+    """Seed i of a DeviceSeeds shared by several modules (train_step.GraphedNetStep: the four MMAConv layers of the Net draw their
+    seeds from ONE advance launch per step): slot 0 advances the whole set, the others read theirs."""
+
+    def __init__(self, shared, i):
+        self.shared, self.i, self.n, self.device = shared, i, 1, shared.device
+        self.seeds = shared.seeds[i:i + 1]
+
+    def advance(self):
+        if self.i == 0:
+            self.shared.advance()
+        return self.seeds
+
+
 class _MaskWeights(torch.autograd.Function):
     """[W_1[:H] .. W_K[:H] | W_1[H:] .. W_K[H:]] (H, 2*K*H) from the K caller-owned (2H,H) mask weights in two launches, and their
     gradients back in one: as slices + torch.cat the forward is 3 launches and autograd's backward ~5 per mask (zero-fill + slice copy
@@ -583,9 +597,19 @@ class _TowerPost(torch.autograd.Function):
         Wb.view(T, S, 16, KFp + 16)[:, :, :O, :KF] = Wo.view(T, O, S, KF).permute(0, 2, 1, 3)
         Wa = Wb[:, :, :KFp].transpose(1, 2).contiguous()
         y = torch.empty((N, T * O), device=agg.device, dtype=torch.float32)
-        pre = torch.empty((N, 8), device=agg.device, dtype=torch.float32)       # the scaler products of every node, once: K13 / K14 / K15 read them
+        # the scaler products of every node, once: K13 / K14 / K15 read them - and once per GRAPH: the four layers of the reference's Net
+        # share edge_index, scalers and the degree statistics (mma.py:91-97), so the table rides on the plan's rowptr tensor
+        key = (N, tuple(scalers), float(avg_log), float(avg_lin))
+        cache = getattr(rowptr, "_mma_post_pre", None)
+        pre = cache[1] if cache is not None and cache[0] == key else None
         with _span("tower_post_fwd"):
-            call("mma_tower_post_pre", ptr(rowptr), ptr(pre), N, S, host_codes(scalers), float(avg_log), float(avg_lin), stream_ptr())
+            if pre is None:
+                pre = torch.empty((N, 8), device=agg.device, dtype=torch.float32)
+                call("mma_tower_post_pre", ptr(rowptr), ptr(pre), N, S, host_codes(scalers), float(avg_log), float(avg_lin), stream_ptr())
+                try:
+                    rowptr._mma_post_pre = (key, pre)
+                except AttributeError:
+                    pass
             call("mma_tower_post_fwd", ptr(agg), T * KF, ptr(pre), ptr(Wa), ptr(y), T * O, N, T, KF, S, O, host_codes(scalers),
                  float(avg_log), float(avg_lin), stream_ptr())
         ctx.save_for_backward(agg, Wb, pre)

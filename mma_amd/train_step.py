@@ -309,6 +309,14 @@ class GraphedNetStep:
         self.graph = None
         self._warmup = warmup
         _set_capturable(net, True)
+        # one dropout-seed launch per step for all MMAConv layers (they run in module order; slot 0 advances the shared set)
+        from .mma_conv import MMAConv
+        convs = [m for m in net.modules() if isinstance(m, MMAConv)]
+        if len(convs) > 1 and dev.type == "cuda":
+            shared = Fn.DeviceSeeds(len(convs), dev)
+            for i, m in enumerate(convs):
+                m._seeds = Fn.SeedSlot(shared, i)
+                m._seed_buf = m._seeds.seeds
 
     def load(self, x, edge_index, edge_attr, batch, y):
         """Copy a batch into the static buffers and pad it (device-side copies on the current stream, no sync)."""
