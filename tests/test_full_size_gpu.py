@@ -55,9 +55,11 @@ def test_full_size_properties_and_sample_parity(cfg):
     xg = x.to(DEV).requires_grad_(True)
     Wg = {n: Ws[n].to(DEV).requires_grad_(True) for n in names}
 
+    from mma_amd.dense import mm          # the layers' own product (layers.py::_aggregate): split-reduction weight gradient, not torch's
+
     def run(reduce_k):
-        P = xg @ torch.cat([Wg[n][:H] for n in names], 1)
-        Q = xg @ torch.cat([Wg[n][H:] for n in names], 1)
+        P = mm(xg, torch.cat([Wg[n][:H] for n in names], 1))
+        Q = mm(xg, torch.cat([Wg[n][H:] for n in names], 1))
         return Fn.nc_fused_aggregate(xg, P, Q, graph, kinds, acts, Fn.DropoutSpec(p, seed=seed), reduce_k=reduce_k)
 
     m = run(False)
