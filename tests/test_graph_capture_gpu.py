@@ -195,12 +195,13 @@ def test_graphed_net_step_refuses_a_batch_that_does_not_fit():
         st.load(b["x"], b["ei"], b["ea"], b["batch"], b["y"])
 
 
-def test_fused_masked_bn_relu_equals_the_torch_formulation():
+@pytest.mark.parametrize("N,nv,C", [(333, 301, 75), (5, 3, 2), (64, 64, 4), (1345, 1286, 75), (5000, 4999, 130), (513, 2, 7)])
+def test_fused_masked_bn_relu_equals_the_torch_formulation(N, nv, C):
     """K17 against net.masked_batch_norm + relu (torch ops) and, on the valid rows, against torch's own BatchNorm1d on the unpadded
-    rows: outputs, input / weight / bias gradients, running statistics."""
+    rows: outputs, input / weight / bias gradients, running statistics; fewer rows than row lanes, more than one 8-row batch per lane,
+    column counts that are no multiple of the 4 columns a workgroup owns."""
     from mma_amd import net as NN
     g = torch.Generator().manual_seed(3)
-    N, nv, C = 333, 301, 75
     x0 = (torch.randn(N, C, generator=g) * 2 + 0.5).to(DEV)
     cot = torch.randn(N, C, generator=g).to(DEV)
     cot[nv:] = 0                                      # rows of the dummy graph: the loss never reads them
