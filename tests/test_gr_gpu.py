@@ -319,8 +319,8 @@ def test_categorical_edges_equal_the_embedded_rows(n_graphs, p):
             assert (a - b).abs().max().item() <= (1e-3 if tall else 2e-5) * b.abs().max().item() + 1e-5, ((a - b).abs().max().item(), b.abs().max().item())
 
 
-@pytest.mark.parametrize("edge_dim,n_graphs", [(50, 64), (None, 20)])
-def test_packed_weights_equal_the_torch_plumbing(edge_dim, n_graphs, monkeypatch):
+@pytest.mark.parametrize("edge_dim,n_graphs,towers,F", [(50, 64, 5, 75), (None, 20, 5, 75), (5, 8, 2, 8), (3, 8, 1, 6)])
+def test_packed_weights_equal_the_torch_plumbing(edge_dim, n_graphs, towers, F, monkeypatch):
     """K18 (mma_pack_blocks): the padded [Wi;Wj], We, Wx, Wo and bias matrices built from the per-tower Linears in one launch - and all
     their gradients scattered back in one - are the matrices (and gradients) of the stack / slice / pad / cat formulation, bit for
     bit: layer output, dL/dx, every registered parameter and the unregistered pre-NN Linears."""
@@ -329,9 +329,9 @@ def test_packed_weights_equal_the_torch_plumbing(edge_dim, n_graphs, monkeypatch
     ei, N = molecule_batch(rng, n_graphs)
     E = ei.shape[1]
     monkeypatch.setattr(MC, "ACCUMULATE_UNREGISTERED", False)     # torch.autograd.grad below asks for the mask Linears' gradients
-    conv = make_conv(["min", "max"], ["identity", "amplification", "linear"], towers=5, F=75, edge_dim=edge_dim)
+    conv = make_conv(["min", "max"], ["identity", "amplification", "linear"], towers=towers, F=F, edge_dim=edge_dim)
     conv.drop_override = Fn.DropoutSpec(0.5, seed=0xABCDEF)
-    x = torch.from_numpy(rng.standard_normal((N, 75)).astype(np.float32)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((N, F)).astype(np.float32)).to(DEV)
     ea = torch.from_numpy(rng.standard_normal((E, edge_dim)).astype(np.float32)).to(DEV) if edge_dim else None
     cot = torch.from_numpy(rng.standard_normal((N, conv.out_channels)).astype(np.float32)).to(DEV)
     eig = torch.from_numpy(ei).to(DEV)
@@ -437,3 +437,43 @@ def test_segment_sum_is_the_sequential_sum_in_edge_order(n_rows, C, pad, hub):
     call("mma_csr_spmm", ptr(torch.from_numpy(rowptr).to(DEV)), ptr(torch.from_numpy(idx).to(DEV)), None, ptr(B), C + pad, E, 1, None,
          ptr(out), C, n_rows, C, stream_ptr())
     assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_pack_blocks_against_numpy():
+    """K18 on its own: zero padding on pack, the live region only on unpack, offsets from a base vs absolute addresses, the
+    accumulate flag."""
+    from mma_amd._lib import call, ptr, stream_ptr
+    rng = np.random.default_rng(0)
+    A = torch.from_numpy(rng.standard_normal((3, 7, 11)).astype(np.float32)).to(DEV)          # three sources (7,11), lda = 11
+    B0 = torch.full((40, 16), 7.0, device=DEV)
+    B1 = torch.full((64,), 7.0, device=DEV)
+    blocks = [  # a (absolute), lda, rows, cols, b index, b off, ldb, b_rows, b_cols, flags
+        [A[0].data_ptr() + 4 * 2, 11, 7, 5, 0, 0, 16, 8, 8, 0],                 # columns 2..6 of source 0 -> an (8,8) block, padded
+        [A[1].data_ptr(), 11, 7, 11, 0, 8 * 16 + 3, 16, 7, 11, 0],              # whole source 1 at row 8, column 3
+        [A[2].data_ptr() + 4 * 11, 11, 1, 11, 1, 5, 11, 1, 16, 0],              # row 1 of source 2 -> 16 floats of the vector, 5 of padding
+        [A[0].data_ptr(), 11, 0, 0, 1, 32, 8, 2, 8, 0],                         # zeros only
+    ]
+    table = torch.tensor(blocks, dtype=torch.int64).to(DEV)
+    call("mma_pack_blocks", ptr(table), len(blocks), None, ptr(B0), ptr(B1), None, None, None, None, None, None, 0, stream_ptr())
+    a = A.cpu().numpy()
+    w0 = np.full((40, 16), 7.0, np.float32); w1 = np.full(64, 7.0, np.float32)
+    w0[0:8, 0:8] = 0; w0[0:7, 0:5] = a[0][:, 2:7]
+    w0[8:15, 3:14] = a[1]
+    w1[5:21] = 0; w1[5:16] = a[2][1]
+    w1[32:48] = 0
+    assert np.array_equal(B0.cpu().numpy(), w0) and np.array_equal(B1.cpu().numpy(), w1)
+    # unpack: the same blocks addressed inside ONE flat buffer (offsets from a_base), the second one accumulating into an absolute address
+    flat = torch.full((3 * 77,), -1.0, device=DEV)
+    keep = torch.ones((7, 11), device=DEV)
+    ub = [[2, 11, 7, 5, 0, 0, 16, 8, 8, 0],
+          [keep.data_ptr(), 11, 7, 11, 0, 8 * 16 + 3, 16, 7, 11, 3],
+          [2 * 77 + 11, 11, 1, 11, 1, 5, 11, 1, 16, 0],
+          [0, 11, 0, 0, 1, 32, 8, 2, 8, 0]]
+    call("mma_pack_blocks", ptr(torch.tensor(ub, dtype=torch.int64).to(DEV)), len(ub), ptr(flat), ptr(B0), ptr(B1), None, None, None, None, None,
+         None, 1, stream_ptr())
+    f = flat.cpu().numpy().reshape(3, 7, 11)
+    want = np.full((3, 7, 11), -1.0, np.float32)
+    want[0][:, 2:7] = a[0][:, 2:7]
+    want[2][1] = a[2][1]
+    assert np.array_equal(f, want)
+    assert np.array_equal(keep.cpu().numpy(), 1.0 + a[1])
