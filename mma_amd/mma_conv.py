@@ -263,7 +263,7 @@ class MMAConv(torch.nn.Module):
         return Fn.DropoutSpec(self.dropout)
 
     # ---- weight plumbing (K18) ----------------------------------------------------------------------------
-    def _packed_weights(self, lins, has_edge, device):
+    def _packed_weights(self, lins, has_edge, device, plan_only=False):
         """(Wij (2*T*Fw, F), b2 (2*T*Fw,) | None, We (T*Fw, F) | None, Wx (T*F_out, F), Wo (T, F_out, K*S*Fw), bp (T*F_out,)) - the
         matrices forward() builds from the per-tower Linears, zero padding included - in one launch (and one for all their gradients)."""
         T, Fi, Fw, Fo = self.towers, self.F_in, self.fused_width(), self.F_out
@@ -293,6 +293,8 @@ class MMAConv(torch.nn.Module):
             if has_b:
                 blocks.append((0, 0, 0, 0, 1, TF, TF, 1, TF))                                        # V's half of the bias: zeros
             self._wplan = (key, _WeightPlan(params, blocks, outs, device, n_acc=ipw if ACCUMULATE_UNREGISTERED else 0))
+        if plan_only:
+            return self._wplan[1]
         Wij, b2, We, Wx, Wo, bp = _PackWeights.apply(self._wplan[1], *params)
         return Wij, (b2 if has_b else None), (We if has_edge else None), Wx, Wo, bp
 

@@ -115,3 +115,50 @@ def test_integration_md_stub_matches_binding():
     names = {"P": _lib._P, "I64": _lib._I64, "I32": _lib._I32, "U32": _lib._U32, "U64": _lib._U64}
     assert [names[t] for t in toks] == _lib.PROTOTYPES["mma_nc_fused_fwd"]
     assert "ABI version %d" % _lib.ABI_VERSION in src
+
+
+@pytest.mark.parametrize("towers,F,edge_dim", [(5, 75, 50), (2, 8, None), (1, 6, 3)])
+def test_weight_plan_table_reproduces_the_torch_plumbing(towers, F, edge_dim):
+    """K18's block table (mma_conv._WeightPlan) applied in numpy = the matrices MMAConv.forward builds with stack / slice / pad / cat:
+    [Wi;Wj], the bias pair, We, Wx, Wo, bp - zero padding included.  Host logic only: no kernel runs."""
+    import ctypes
+    import mma_amd
+    torch.manual_seed(1)
+    conv = mma_amd.MMAConv(F, F * towers, ["min", "max"], ["identity", "amplification", "linear"], torch.tensor([0, 10, 30, 50, 10]),
+                           edge_dim=edge_dim, towers=towers)
+    lins = [seq[0].active_linear() for seq in conv.pre_nns["max"]]
+    if lins[0].weight.is_cuda:
+        pytest.skip("the mask Linears sit on a GPU here (G2): the table check reads host memory")
+    plan = conv._packed_weights(lins, edge_dim is not None, torch.device("cpu"), plan_only=True)
+    outs = [np.full(shp, np.nan, np.float32) for shp in plan.outs]
+    for a, lda, rows, cols, oi, off, ldb, b_rows, b_cols, flags in plan.fwd.tolist():
+        flat = outs[oi].reshape(-1)
+        src = np.ctypeslib.as_array(ctypes.cast(a, ctypes.POINTER(ctypes.c_float)), shape=(max(rows, 1) * lda,)) if rows else None
+        for r in range(b_rows):
+            for c in range(b_cols):
+                flat[off + r * ldb + c] = src[r * lda + c] if (r < rows and c < cols) else 0.0
+    T, Fw, Fo = towers, conv.fused_width(), conv.F_out
+    KS = len(conv.aggregators) * len(conv.scalers)
+    TF = T * Fw
+    Wall = torch.stack([l.weight for l in lins]).detach()
+
+    def rows_(lo, hi):
+        return conv._pad_dim(Wall[:, :, lo:hi], 1, Fw).reshape(TF, hi - lo).numpy()
+    b = conv._pad_dim(torch.stack([l.bias for l in lins]).detach(), 1, Fw).reshape(TF).numpy()
+    Wp = torch.stack([seq[0].weight for seq in conv.post_nns]).detach()
+    want = [np.concatenate([rows_(0, F), rows_(F, 2 * F)]), np.concatenate([b, np.zeros_like(b)]),
+            rows_(2 * F, 3 * F) if edge_dim is not None else None, Wp[:, :, :F].reshape(T * Fo, F).numpy(),
+            conv._pad_dim(Wp[:, :, F:].reshape(T, Fo, KS, F), 3, Fw).reshape(T, Fo, KS * Fw).numpy(),
+            torch.cat([seq[0].bias for seq in conv.post_nns]).detach().numpy()]
+    for got, w in zip(outs, want):
+        if w is not None:
+            assert got.shape == w.shape and np.array_equal(got, w)
+    # the way back: every element of every Parameter's gradient is written exactly once
+    hits = np.zeros(plan.g_off[-1], np.int32)
+    n_acc_floats = plan.g_off[plan.n_acc]
+    base = plan.acc.data_ptr() if plan.n_acc else 0
+    for a, lda, rows, cols, oi, off, ldb, b_rows, b_cols, flags in plan.bwd.tolist():
+        start = (a - base) // 4 if flags & 1 else n_acc_floats + a
+        for r in range(rows):
+            hits[start + r * lda:start + r * lda + cols] += 1
+    assert hits.min() == 1 and hits.max() == 1
