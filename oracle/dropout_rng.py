@@ -46,3 +46,13 @@ def keep_mask(seed, thr, K, E, H, edge_ids=None):
     h = np.arange(H)
     byte = (r[:, :, h >> 2] >> (np.uint64(8) * (h & 3).astype(np.uint64))) & np.uint64(0xFF)
     return np.ascontiguousarray((byte >= np.uint64(thr)).astype(np.uint8))
+
+
+def splitmix64(state):
+    """One step of the seed stream behind a graph-capturable layer (mma_seed_advance, csrc/train_step.hip): (new state, seed)."""
+    mask = (1 << 64) - 1
+    state = (state + 0x9E3779B97F4A7C15) & mask
+    z = state
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+    return state, z ^ (z >> 31)

@@ -72,3 +72,20 @@ def test_words_are_a_function_of_the_global_edge_id_and_the_seed():
     assert not np.array_equal(mask_words(43, 4, 1000, 16), w)
     assert np.array_equal(mask_words(42, 1, 1000, 16)[0], w[0])
     assert len({w[k].tobytes() for k in range(4)}) == 4
+
+
+@pytest.mark.gpu
+def test_seed_advance_is_splitmix64():
+    """mma_seed_advance (the one captured launch that redraws a layer's dropout seeds per replay) against its restatement."""
+    import torch
+    from mma_amd import functional as Fn
+    from oracle.dropout_rng import splitmix64
+    ds = Fn.DeviceSeeds(5, torch.device("cuda:0"))
+    states = [int(v) & ((1 << 64) - 1) for v in ds.buf[5:].tolist()]
+    for _ in range(3):
+        got = [int(v) & ((1 << 64) - 1) for v in ds.advance().tolist()]
+        nxt = [splitmix64(s) for s in states]
+        states = [a for a, _ in nxt]
+        assert got == [b for _, b in nxt]
+        assert [int(v) & ((1 << 64) - 1) for v in ds.buf[5:].tolist()] == states
+    assert len(set(got)) == 5
