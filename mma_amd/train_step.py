@@ -240,8 +240,9 @@ class GraphedTrainStep:
     """Captures `optimizer.zero_grad(); loss = loss_fn(); loss.backward(); optimizer.step()` once and replays it.
 
     loss_fn: closure over STATIC device tensors (full-batch features / adjacency / labels / index sets).  The optimizer must
-    be graph-capturable (`torch.optim.Adam(..., capturable=True)`); gradients are kept allocated (`set_to_none=False`)
-    so their addresses stay valid across replays."""
+    be graph-capturable (`mma_amd.FusedAdam`, `torch.optim.Adam(..., capturable=True)`).  Gradients are fresh tensors every step
+    (`set_to_none=True`: no zero-fill and no accumulating add per parameter - the capture's private pool gives them the same addresses
+    on every replay) unless the optimizer needs them to stay in place (FusedAdam with more tensors than fit its launch arguments)."""
 
     def __init__(self, model, optimizer, loss_fn, warmup=3):
         params = [p for g in optimizer.param_groups for p in g["params"]]
@@ -262,7 +263,7 @@ class GraphedTrainStep:
             self.loss = self._eager()
 
     def _eager(self):
-        self.optimizer.zero_grad(set_to_none=False)
+        self.optimizer.zero_grad(set_to_none=getattr(self.optimizer, "fresh_gradients_ok", lambda: True)())
         loss = self.loss_fn()
         loss.backward()
         self.optimizer.step()
