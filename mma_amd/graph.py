@@ -304,6 +304,25 @@ class SpmmGraph:
         self.t_items, self.t_hubs = i32(it), i32(hb)
         self.t_n_wave_items = int(((it[:, 2] - it[:, 1]) >= SPMM_GROUP_BELOW).sum())
 
+    def scaled_by_source(self, f):
+        """A shallow copy of the plan with values A_ij * f_j (f: (n_cols,) / (n_cols,1) per source column, or one element for all):
+        the scaler stage of MMA.forward - a row factor on the support matrix (layers.py:856-860) - folded into the SpMM's edge values,
+        forward and transposed, instead of an element-wise launch each way."""
+        import copy
+        g = copy.copy(self)
+        f = f.detach().reshape(-1).to(torch.float32)
+        E = self.col.numel()
+        if f.numel() == 1:
+            v = tv = f.expand(E)
+        else:
+            assert f.numel() == self.n_cols
+            v = f.index_select(0, self.col.long())
+            counts = (self.t_rowptr[1:] - self.t_rowptr[:-1]).long()
+            tv = torch.repeat_interleave(f, counts, output_size=E)
+        g.val = (v if self.val is None else v * self.val).contiguous()
+        g.t_val = (tv if self.t_val is None else tv * self.t_val).contiguous()
+        return g
+
     @classmethod
     def from_torch_sparse(cls, adj, device=None):
         """`device`: where the plan lives (the layer passes its input's device: a CPU sparse adj next to GPU features must

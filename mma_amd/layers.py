@@ -22,6 +22,8 @@ from ._lib import require_gpu
 from .graph import DEFAULT_CHUNK, NCGraph, SpmmGraph
 from .scalers import SCALERS, scaler_row_factor, true_degree_row_factor
 
+FOLD_ROW_FACTOR = __import__("os").environ.get("MMA_FOLD_ROW_FACTOR", "1") != "0"
+
 # aggregator name -> (combine kind, raw logits under activation == "new_sigmoid")   layers.py:201-728
 _AGG = {
     "sum": ("sum", False), "sum2": ("sum", False), "sum3": ("sum", False), "sum4": ("sum", False),
@@ -144,6 +146,7 @@ class MMA(Module):
         # NCGraph may be passed as `add_all` (large graphs never materialise a Python list of arrays).
         self._graph = add_all if isinstance(add_all, NCGraph) else None
         self._sg = None         # (adj object, SpmmGraph) cache for the tail spmm
+        self._sg_scaled = None  # (SpmmGraph, factor tensor, its copy with the scaler row factor folded into the edge values)
         self.drop_override = None   # tests: a DropoutSpec (explicit keep mask / fixed seed) used instead of p
         # hipGraph capture (torch.cuda.graph) of the layer: the dropout seed then lives in a device buffer that is re-drawn
         # by one captured launch (Fn.DeviceSeeds) on every replay, instead of being baked into the kernel arguments at capture time
@@ -241,10 +244,17 @@ class MMA(Module):
         #     sum_k A (c * m_k W)  ==  A (c * (sum_k m_k) W):
         # the fused kernel emits sum_k m_k (N,H) directly - K x fewer bytes through the GEMM and the SpMM.
         msum = self._aggregate_all(self.aggregator_names, input, reduce_k=True)
-        support = mm(msum, self.weight) * self._scaler_factor(N, input.device)
         if self._sg is None or self._sg[0] is not adj:   # extension: a ready-made SpmmGraph is accepted as `adj`
             self._sg = (adj, adj if isinstance(adj, SpmmGraph) else SpmmGraph.from_torch_sparse(adj, input.device))
-        return Fn.csr_spmm(support, self.bias, self._sg[1], 1)                  # layers.py:861-867
+        if not FOLD_ROW_FACTOR:
+            support = mm(msum, self.weight) * self._scaler_factor(N, input.device)
+            return Fn.csr_spmm(support, self.bias, self._sg[1], 1)              # layers.py:861-867
+        # the row factor is a constant of the graph: it rides on the SpMM's edge values (A_ij * c_j), forward and transposed, instead of
+        # an element-wise launch each way
+        factor = self._scaler_factor(N, input.device)
+        if self._sg_scaled is None or self._sg_scaled[0] is not self._sg[1] or self._sg_scaled[1] is not factor:
+            self._sg_scaled = (self._sg[1], factor, self._sg[1].scaled_by_source(factor))
+        return Fn.csr_spmm(mm(msum, self.weight), self.bias, self._sg_scaled[2], 1)                  # layers.py:861-867
 
     def __repr__(self):
         return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
