@@ -112,7 +112,7 @@ def test_gemm_bf16x3_tn_accuracy(M, KA, NC, padx, padg):
 
 @pytest.mark.parametrize("M,KA,NC,padx,padg", [(70001, 128, 1024, 0, 0), (4097, 64, 96, 0, 32), (70001, 128, 512, 128, 0),
                                                (33, 32, 32, 0, 0), (262144 + 17, 96, 160, 0, 0), (66000, 256, 512, 0, 0),
-                                               (70001, 75, 76, 0, 0), (5001, 9, 33, 3, 1)])
+                                               (70001, 75, 76, 0, 0), (5001, 9, 33, 3, 1), (300007, 384, 160, 0, 4)])
 @pytest.mark.parametrize("maxima", ["given", "loose", "own"])
 def test_gemm_f16x2_tn_accuracy(M, KA, NC, padx, padg, maxima):
     """x^T g on the THREE-product TN kernel (fp16 x 2 pieces, row scales balanced between the operands): error at the level of an
@@ -144,13 +144,15 @@ def test_gemm_f16x2_tn_accuracy(M, KA, NC, padx, padg, maxima):
     assert torch.equal(dense.gemm_f16x2_tn(x, g, xm, gm), got)
 
 
+@pytest.mark.parametrize("KA", [128, 256])
 @pytest.mark.parametrize("case", ["spread", "inf", "nan", "subnormal", "zero"])
-def test_gemm_f16x2_tn_falls_back_on_the_device(case):
+def test_gemm_f16x2_tn_falls_back_on_the_device(case, KA):
     """Rows whose products lie more than 2^40 apart, or an inf / NaN / subnormal row maximum: the scale kernels flag the call and
-    the six-product kernel does it - the result is bit-for-bit gemm_bf16x3_tn's.  All-zero operands give exact zeros."""
+    the six-product kernel does it - the result is bit-for-bit gemm_bf16x3_tn's.  All-zero operands give exact zeros.  KA = 256: the
+    128-column blocks of x (hidden width 256, C5)."""
     from mma_amd import dense
     rng = np.random.default_rng(7)
-    M, KA, NC = 70001, 128, 256
+    M, NC = 70001, 256
     x = rng.standard_normal((M, KA)).astype(np.float32)
     g = rng.standard_normal((M, NC)).astype(np.float32)
     if case == "spread":
