@@ -158,7 +158,7 @@ def test_gemm_f16x2_tn_falls_back_on_the_device(case, KA):
     if case == "spread":
         x *= np.exp(rng.uniform(-25, 25, (M, 1))).astype(np.float32)
     elif case == "inf":
-        x[1234, 5] = np.inf
+        x[1234, 5::128] = np.inf                  # in every 128-column block of x: the blocks decide on their own
     elif case == "nan":
         g[4321, 7] = np.nan
     elif case == "subnormal":
