@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 28
+#define MMA_ABI_VERSION 29
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -45,6 +45,9 @@ enum { MMA_DROP_NONE = 0, MMA_DROP_HASH = 1, MMA_DROP_EXPLICIT = 2 };
 
 int mma_abi_version(void);
 const char* mma_last_error(void);
+/* SHA-256 (16 hex digits) over the kernel sources THIS library was built from (csrc/Makefile -> build_stamp.h; ABI 29): the identity a
+ * recorded measurement carries (tools/build_stamp.py), taken from the .so that ran, not from re-hashing the tree. */
+const char* mma_build_stamp(void);
 
 /* ---- K1: fused masked message + K-aggregator segmented reduce, node classification form ----------
  * Replaces, for all K selected aggregators at once, the per-node Python loop of
@@ -279,6 +282,10 @@ int mma_tower_linear_bwd(const float* gy, const float* a, const float* W, float*
  * KF = K*F <= 512, O <= 16, S <= 5; pre: the table of mma_tower_post_pre (from the CSR-by-target row pointers = degrees).  Neither `out` nor its
  * gradient is ever materialised. */
 int64_t mma_tower_post_kfp(int32_t KF);
+/* 1 when K13 / K14 (and their PLAIN form K16, with S = ceil(O / 16)) take this shape: 1 <= KF <= 512, 1 <= S <= 5 and the tower's staged
+ * weights plus the four wave tiles fit the 160 KB of LDS in BOTH layouts (forward KFp*S*16 floats, backward S*16*(KFp + 16)); 0 otherwise
+ * - the caller then keeps the unfactored / library path (ABI 29: the host-side gates ask the library instead of restating its limits). */
+int mma_tower_post_fits(int32_t KF, int32_t S);
 /* pre (N, 8): pre[n][q] = prod_{q' <= q} scaler_q'(clamp(rowptr[n+1] - rowptr[n], 1)), q < S - the table the three kernels below read */
 int mma_tower_post_pre(const int32_t* rowptr, float* pre, int64_t N, int32_t S, const uint8_t* scaler_host, float avg_log, float avg_lin,
                        void* stream);

@@ -478,6 +478,13 @@ using namespace mma;
 // padded weight shapes the caller prepares: forward Wa (T, KFp, S*16), backward Wb (T, S*16, KFp + 16), KFp = mma_tower_post_kfp(KF)
 extern "C" int64_t mma_tower_post_kfp(int32_t KF) { return KF < 1 ? -1 : ((int64_t)KF + kPostTile - 1) / kPostTile * kPostTile; }
 
+// the limits post_fill() and the launchers enforce, for the host-side gates (mma_conv.py's `factored`, dense._skinny_ok)
+extern "C" int mma_tower_post_fits(int32_t KF, int32_t S) {
+  if (KF < 1 || KF > 512 || S < 1 || S > kPostMaxS) return 0;
+  const int KFp = (KF + kPostTile - 1) / kPostTile * kPostTile;
+  return post_lds_bytes(KFp, S, false) <= 160 * 1024 && post_lds_bytes(KFp, S, true) <= 160 * 1024 ? 1 : 0;
+}
+
 extern "C" int mma_tower_post_pre(const int32_t* rowptr, float* pre, int64_t N, int32_t S, const uint8_t* scaler_host, float avg_log, float avg_lin,
                                   void* stream) {
   PostParams p{};

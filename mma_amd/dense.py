@@ -333,7 +333,15 @@ def _skinny_ok(x2, weight):
     them at ~0.11 ms per GEMM on 2e5 rows (61 MB in, 61 MB out); the fp32 matrix-core kernels stream them."""
     O, K = weight.shape
     return (USE_SKINNY and x2.is_cuda and x2.dtype == torch.float32 and weight.dtype == torch.float32 and x2.dim() == 2
-            and x2.shape[0] >= _SKINNY_MIN_ROWS and O <= 80 and K <= 512 and x2.stride(1) == 1)
+            and x2.shape[0] >= _SKINNY_MIN_ROWS and O <= 80 and K <= 512 and x2.stride(1) == 1
+            and tower_post_fits(K, -(-O // 16)))     # the kernels' own limits (weights + wave tiles inside 160 KB of LDS, both layouts)
+
+
+def tower_post_fits(KF, S):
+    """mma_tower_post_fits: do K13 / K14 (K16 with S = ceil(O/16)) take a (KF, S) product?  The library answers - the gates here do
+    not restate its limits (a shape inside a Python gate but outside the kernel's used to raise MMALibraryError instead of taking the
+    library GEMM)."""
+    return bool(_lib.query("mma_tower_post_fits", int(KF), int(S)))
 
 
 def _skinny_weights(weight):

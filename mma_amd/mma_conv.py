@@ -240,6 +240,18 @@ class MMAConv(torch.nn.Module):
             reset(stack)
         self.lin.reset_parameters()
 
+    def unregistered_parameters(self):
+        """The Parameters of the mask Linears, which live in plain dicts (G2): absent from parameters() / state_dict(), never stepped by
+        the optimizer, their .grad never zeroed by optimizer.zero_grad()."""
+        out = []
+        for stacks in self.pre_nns.values():
+            for seq in stacks:
+                for m in seq:
+                    for lin in getattr(m, "aggregation_layers", {}).values():
+                        if lin is not None:
+                            out.extend(lin.parameters())
+        return out
+
     # ---- graph plan ---------------------------------------------------------------------------------------
     def _graph(self, edge_index, N):
         return Fn.gr_graph(edge_index, N)        # shared by all layers that see this edge_index (mma.py:91-97: four of them)
@@ -357,7 +369,8 @@ class MMAConv(torch.nn.Module):
             # aggregates into it (Fn.tower_post): K3 then runs with the identity scaler only and leaves the K UNSCALED aggregates
             # (N,T,K*Fw), a third of `out` at S = 3; the (N,T,S*K*F) tensor of mma_conv.py:196 and its gradient never exist
             factored = FACTOR_SCALERS and self.post_layers == 1 and self.F_out <= 16 and len(self.scalers) <= 5 and \
-                all(s_ in Fn.GR_SCALER for s_ in self.scalers)
+                all(s_ in Fn.GR_SCALER for s_ in self.scalers) and \
+                dense.tower_post_fits(len(self.aggregators) * Fw, len(self.scalers))    # K*Fw <= 512 and the LDS fit: the kernels' own limits
             out = Fn.gr_fused_conv(UV, Z, graph, T, Fw, self.aggregators, ["identity"] if factored else self.scalers,
                                    self.avg_deg['log'], self.avg_deg['lin'], self._drop(x.device), z_by_pos=True, z_index=z_index)
         else:

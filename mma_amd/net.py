@@ -8,28 +8,37 @@ from torch.nn import BatchNorm1d, Embedding, Linear, ModuleList, ReLU, Sequentia
 from .mma_conv import CategoricalEdges, MMAConv
 
 
-def global_add_pool(x, batch, size=None):
+def global_add_pool(x, batch, size=None, assume_sorted=False):
+    """global_add_pool (mma.py:124) for ANY batch vector, in a fixed summation order.  assume_sorted: the caller guarantees a
+    non-decreasing batch vector (GraphedNetStep checks it when a batch is loaded) - the pooled row of a graph is then the sum of one
+    contiguous node range and no grouping pass is needed.  Otherwise the nodes are grouped by graph id with the stable K6 sort
+    (PyG's global_add_pool accepts an unsorted vector): same kernel, a few more launches, no host sync either way."""
     size = int(batch.max()) + 1 if size is None else size
     if x.is_cuda and x.dtype == torch.float32:
-        return _SegmentPool.apply(x, batch, size)
+        return _SegmentPool.apply(x, batch, size, bool(assume_sorted))
     return torch.zeros((size, x.shape[1]), device=x.device, dtype=x.dtype).index_add_(0, batch, x)
 
 
 class _SegmentPool(torch.autograd.Function):
-    """global_add_pool (mma.py:124) for a SORTED batch vector (PyG mini-batches number their nodes graph by graph): the pooled row
-    of a graph is the sum of one contiguous node range - the K5 segment-sum kernel in a fixed order instead of index_add_'s float
-    atomics, whose summation order changes from run to run (and between a hipGraph replay and the eager step it was captured from)."""
+    """Pooling as the K5 segment-sum kernel over the nodes grouped by graph: a fixed order instead of index_add_'s float atomics, whose
+    summation order changes from run to run (and between a hipGraph replay and the eager step it was captured from).  Sorted batch
+    vectors (PyG mini-batches number their nodes graph by graph) need no grouping: the row pointers are a searchsorted and the columns
+    the identity; unsorted ones are grouped by the stable device sort of mma_build_csr (functional.DeviceCSR)."""
 
     @staticmethod
-    def forward(ctx, x, batch, size):
+    def forward(ctx, x, batch, size, assume_sorted):
         from . import functional as Fn
         from ._lib import call, ptr, stream_ptr
         x = x.contiguous()
         N, C = x.shape
-        if N > 1 and not torch.cuda.is_current_stream_capturing():
-            torch._assert_async((batch[1:] >= batch[:-1]).all())       # the contiguous-range form needs the batch vector sorted
-        rowptr = torch.searchsorted(batch, torch.arange(size + 1, device=x.device, dtype=batch.dtype)).to(torch.int32)
-        col = torch.arange(N, device=x.device, dtype=torch.int32)
+        if assume_sorted:
+            rowptr = torch.searchsorted(batch, torch.arange(size + 1, device=x.device, dtype=batch.dtype)).to(torch.int32)
+            col = torch.arange(N, device=x.device, dtype=torch.int32)
+        else:
+            if N and not torch.cuda.is_current_stream_capturing():
+                torch._assert_async(((batch >= 0) & (batch < size)).all())      # index_add_ would raise for these (device-side, no sync)
+            csr = Fn.DeviceCSR(batch.to(torch.int64), None, size)
+            rowptr, col = csr.rowptr, csr.perm
         out = torch.empty((size, C), device=x.device, dtype=torch.float32)
         with Fn._span("pool_segsum"):
             call("mma_csr_spmm", ptr(rowptr), ptr(col), None, ptr(x), C, N, 1, None, ptr(out), C, size, C, stream_ptr())
@@ -39,7 +48,7 @@ class _SegmentPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         batch, = ctx.saved_tensors
-        return g.index_select(0, batch), None, None
+        return g.index_select(0, batch), None, None, None
 
 
 class _EmbedRows(torch.autograd.Function):
@@ -160,5 +169,6 @@ class Net(torch.nn.Module):
         for conv, batch_norm in zip(self.convs, self.batch_norms):
             h = conv(x, edge_index, edge_attr)
             x = F.relu(batch_norm(h)) if n_valid is None else masked_bn_relu(h, batch_norm, n_valid)
-        x = global_add_pool(x, batch, None if n_graphs is None else n_graphs + 1)
+        # the padded step (n_graphs given) has a sorted batch vector by construction (GraphedNetStep.load checks the caller's part)
+        x = global_add_pool(x, batch, None if n_graphs is None else n_graphs + 1, assume_sorted=n_graphs is not None)
         return self.mlp(x)

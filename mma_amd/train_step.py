@@ -236,6 +236,71 @@ def _set_capturable(model, flag):
             m.graph_capturable = flag
 
 
+class _WarmupState:
+    """Everything a warm-up step changes, saved before the warm-up and put back after it: the reference's loops take ONE optimizer step
+    per batch (train.py:72-80, mma.py:150-160), and capturing a hipGraph needs a few eager runs first.  Restored IN PLACE (the device
+    tables of FusedAdam and the captured graph hold the addresses): parameters, module buffers (BatchNorm's running statistics and
+    batch counter), optimizer state (moments and step counters; state created by the warm-up is zeroed = its initial value), the
+    dropout seed streams, and the never-zeroed `.grad` of MMAConv's unregistered mask Linears (quirk G2: it accumulates for the whole
+    run, so three warm-up backward passes would stay in it)."""
+
+    def __init__(self, model, optimizer):
+        self.optimizer = optimizer
+        self.params = [p for g in optimizer.param_groups for p in g["params"]]
+        self.param_vals = [p.detach().clone() for p in self.params]
+        self.buffers = [(b, b.detach().clone()) for b in model.buffers()]
+        self.opt_state = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in optimizer.state[p].items()}
+                          for p in self.params if p in optimizer.state and optimizer.state[p]}
+        self.seeds, seen = [], set()
+        for m in model.modules():
+            sd = getattr(m, "_seeds", None)
+            sd = getattr(sd, "shared", sd)                 # a SeedSlot shares one DeviceSeeds
+            if sd is not None and id(sd) not in seen:
+                seen.add(id(sd))
+                self.seeds.append((sd.buf, sd.buf.clone()))
+        self.model = model
+        self.loose = [(q, None if q.grad is None else q.grad.detach().clone()) for q in self._unregistered(model)]
+
+    @staticmethod
+    def _unregistered(model):
+        out = []
+        for m in model.modules():
+            f = getattr(m, "unregistered_parameters", None)
+            if f is not None:
+                out.extend(f())
+        return out
+
+    @torch.no_grad()
+    def restore(self):
+        for p, v in zip(self.params, self.param_vals):
+            p.copy_(v)
+        for b, v in self.buffers:
+            b.copy_(v)
+        for p in self.params:
+            st = self.optimizer.state.get(p)
+            if not st:
+                continue
+            was = self.opt_state.get(p, {})
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    if k in was:
+                        v.copy_(was[k])
+                    else:
+                        v.zero_()                          # created by the warm-up: back to its initial value
+        for buf, v in self.seeds:
+            buf.copy_(v)
+        # seed streams created DURING the warm-up (first call of a capturable layer) were drawn from torch's generator then: they
+        # simply continue - the reference has no notion of "the seed before the first step" either
+        had = {id(q): g for q, g in self.loose}
+        for q in self._unregistered(self.model):
+            if q.grad is not None:
+                g0 = had.get(id(q))
+                if g0 is None:
+                    q.grad.zero_()                         # None before: an all-zero running sum is the same starting point
+                else:
+                    q.grad.copy_(g0)
+
+
 class GraphedTrainStep:
     """Captures `optimizer.zero_grad(); loss = loss_fn(); loss.backward(); optimizer.step()` once and replays it.
 
@@ -244,7 +309,11 @@ class GraphedTrainStep:
     (`set_to_none=True`: no zero-fill and no accumulating add per parameter - the capture's private pool gives them the same addresses
     on every replay) unless the optimizer needs them to stay in place (FusedAdam with more tensors than fit its launch arguments)."""
 
-    def __init__(self, model, optimizer, loss_fn, warmup=3):
+    def __init__(self, model, optimizer, loss_fn, warmup=3, restore_after_warmup=True):
+        """warmup: eager runs of the step before the capture (allocator, lazily built plans, autotuned library kernels).  They are real
+        steps, so with restore_after_warmup (default) parameters, buffers, optimizer state and dropout seed streams are put back
+        afterwards (`_WarmupState`): construction leaves the model where it was and every later call is exactly one optimizer step,
+        like one epoch of train.py:72-80.  restore_after_warmup=False keeps the warm-up steps (round-3 behaviour)."""
         params = [p for g in optimizer.param_groups for p in g["params"]]
         require_gpu(*params)
         for g in optimizer.param_groups:
@@ -252,11 +321,14 @@ class GraphedTrainStep:
                 raise ValueError("GraphedTrainStep needs a capturable optimizer, e.g. torch.optim.Adam(..., capturable=True)")
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         _set_capturable(model, True)
+        saved = _WarmupState(model, optimizer) if restore_after_warmup and warmup > 0 else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up off the default stream, as capture requires
             for _ in range(warmup):
                 self._eager()
+            if saved is not None:
+                saved.restore()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -293,8 +365,13 @@ class GraphedNetStep:
             loss = step(data.x, data.edge_index, data.edge_attr, data.batch, data.y)     # 0-dim device tensor
     A batch that does not fit the bucket (or has another graph count) raises; use one step object per bucket."""
 
-    def __init__(self, net, optimizer, n_graphs, n_pad, e_pad, device="cuda:0", warmup=3):
+    def __init__(self, net, optimizer, n_graphs, n_pad, e_pad, device="cuda:0", warmup=3, restore_after_warmup=True):
+        """warmup: eager runs of the padded step on the FIRST batch before the capture.  With restore_after_warmup (default) their
+        effects are undone (`_WarmupState`: parameters, BatchNorm statistics, Adam moments / step, dropout seeds, the accumulating
+        gradients of the unregistered mask Linears), so the first call is ONE optimizer step on its batch - mma.py:150-160 takes one per
+        batch - and the trajectory equals `step_eager()` called once per batch, bit for bit at p = 0."""
         from . import functional as Fn
+        self._restore = bool(restore_after_warmup)
         self.net, self.optimizer, self.n_graphs, self.n_pad, self.e_pad = net, optimizer, int(n_graphs), int(n_pad), int(e_pad)
         dev = torch.device(device)
         for g in optimizer.param_groups:
@@ -325,6 +402,8 @@ class GraphedNetStep:
         if N + 1 > self.n_pad or E > self.e_pad or int(y.numel()) != self.n_graphs:
             raise ValueError("batch of %d nodes / %d edges / %d graphs does not fit the bucket (%d, %d, %d graphs); one dummy node is needed"
                              % (N, E, int(y.numel()), self.n_pad, self.e_pad, self.n_graphs))
+        if N > 1:      # the pooling of the padded step takes contiguous node ranges: the batch vector must be sorted (PyG loaders'
+            torch._assert_async((batch[1:] >= batch[:-1]).all())              # are).  load() is never captured: checked on EVERY batch
         self.x[:N].copy_(x.reshape(N, 1)); self.x[N:].zero_()
         self.batch[:N].copy_(batch); self.batch[N:].fill_(self.n_graphs)
         self.ei[:, :E].copy_(edge_index); self.ea[:E].copy_(edge_attr); self.ea[E:].zero_()
@@ -355,11 +434,14 @@ class GraphedNetStep:
         return self._step()
 
     def _capture(self):
+        saved = _WarmupState(self.net, self.optimizer) if self._restore and self._warmup > 0 else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(self._warmup):
                 self._step()
+            if saved is not None:
+                saved.restore()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -369,6 +451,6 @@ class GraphedNetStep:
         if x is not None:
             self.load(x, edge_index, edge_attr, batch, y)
         if self.graph is None:
-            self._capture()          # NOTE: the warm-up steps are real optimizer steps on the loaded batch (the capture itself runs nothing)
+            self._capture()          # warm-up steps on the loaded batch, undone again (restore_after_warmup); the capture itself runs nothing
         self.graph.replay()
         return self.loss

@@ -89,3 +89,27 @@ def test_seed_advance_is_splitmix64():
         assert got == [b for _, b in nxt]
         assert [int(v) & ((1 << 64) - 1) for v in ds.buf[5:].tolist()] == states
     assert len(set(got)) == 5
+
+
+def test_hash_dropout_says_which_probability_it_applies(monkeypatch):
+    """Round-3 VERDICT item 5: hash mode keeps one byte per element, so p is applied as round(256 p)/256.  The reference's F.dropout
+    takes any p (layers.py:219): the README's 0.5 / 0.75 are exact; a value further than 1e-3 from a multiple of 1/256 is announced
+    (once per value) with the applied probability, and refused under MMA_DROPOUT_STRICT=1."""
+    import warnings
+    from mma_amd import functional as Fn
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                       # none of these may warn
+        for p, thr in ((0.5, 128), (0.75, 192), (0.25, 64), (0.3, 77)):      # 77/256 is 7.8e-4 from 0.3
+            d = Fn.DropoutSpec(p, seed=1)
+            assert d.thr == thr and d.p_applied == thr / 256
+        assert Fn.DropoutSpec(0.0).p_applied == 0.0
+    Fn._WARNED_P.discard(0.33)
+    with pytest.warns(UserWarning, match=r"p=0.33 is applied as 84/256 = 0.328125"):
+        assert Fn.DropoutSpec(0.33, seed=1).p_applied == 84 / 256
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        Fn.DropoutSpec(0.33, seed=2)                         # once per value
+    monkeypatch.setenv("MMA_DROPOUT_STRICT", "1")
+    with pytest.raises(ValueError, match="MMA_DROPOUT_STRICT"):
+        Fn.DropoutSpec(0.1, seed=1)                          # 26/256 is 1.6e-3 from 0.1
+    Fn.DropoutSpec(0.75, seed=1)                             # exact values pass in strict mode

@@ -150,11 +150,14 @@ def test_graphed_net_step_equals_the_eager_padded_step_bit_for_bit():
     sg = mma_amd.GraphedNetStep(net_g, opt_g, 16, n_pad, e_pad, DEV, warmup=2)
     se = mma_amd.GraphedNetStep(net_e, opt_e, 16, n_pad, e_pad, DEV)
     b0 = batches[0]
-    lg = sg(b0["x"], b0["ei"], b0["ea"], b0["batch"], b0["y"])         # 2 warm-up steps + the captured one
-    se.load(b0["x"], b0["ei"], b0["ea"], b0["batch"], b0["y"])
-    for _ in range(3):
-        le = se.step_eager()
+    lg = sg(b0["x"], b0["ei"], b0["ea"], b0["batch"], b0["y"])         # 2 warm-up steps, UNDONE, + the replay: ONE optimizer
+    se.load(b0["x"], b0["ei"], b0["ea"], b0["batch"], b0["y"])         # step on the first batch, as mma.py:150-160 takes one per batch
+    le = se.step_eager()
     assert torch.equal(lg, le)
+    assert all(int(m.num_batches_tracked) == 1 for m in net_g.batch_norms)          # BatchNorm saw the first batch once
+    assert float(opt_g.state[next(iter(net_g.parameters()))]["step"]) == 1.0         # ... and Adam stepped once
+    for qg, qe in zip(net_g.convs[0].unregistered_parameters(), net_e.convs[0].unregistered_parameters()):
+        assert (qg.grad is None) == (qe.grad is None) and (qg.grad is None or torch.equal(qg.grad, qe.grad))   # G2: one backward's worth
     for b in batches[1:] + batches[:2]:
         lg = sg(b["x"], b["ei"], b["ea"], b["batch"], b["y"]).clone()
         se.load(b["x"], b["ei"], b["ea"], b["batch"], b["y"])
@@ -229,3 +232,24 @@ def test_fused_masked_bn_relu_equals_the_torch_formulation(N, nv, C):
     yr = torch.relu(bn(xr)); yr.backward(cot[:nv])
     assert torch.allclose(res[0][0][:nv], yr.detach(), rtol=2e-5, atol=2e-5) and torch.allclose(res[0][1][:nv], xr.grad, rtol=2e-5, atol=2e-5)
     assert torch.allclose(res[0][4], bn.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(res[0][5], bn.running_var, rtol=1e-5, atol=1e-6)
+
+
+def test_global_add_pool_takes_an_unsorted_batch_vector():
+    """PyG's global_add_pool (mma.py:124) accepts any batch vector; the segment kernel's contiguous-range form is only for
+    callers that guarantee a sorted one.  Unsorted (and sorted) vectors must give index_add_'s sums, in a fixed order, with gradients."""
+    from mma_amd.net import global_add_pool
+    g = torch.Generator().manual_seed(0)
+    N, C, G = 1000, 75, 17
+    x = torch.randn(N, C, generator=g).to(DEV).requires_grad_(True)
+    for batch in (torch.randint(0, G, (N,), generator=g), torch.sort(torch.randint(0, G, (N,), generator=g)).values,
+                  torch.full((N,), 3, dtype=torch.int64)):            # unsorted, sorted, one graph (others empty)
+        b = batch.to(DEV)
+        ref = torch.zeros(G, C, dtype=torch.float64, device=DEV).index_add_(0, b, x.detach().double())
+        out = global_add_pool(x, b, G)
+        assert (out.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+        assert torch.equal(out, global_add_pool(x, b, G))              # fixed order: bit-identical from call to call
+        cot = torch.randn(G, C, generator=g).to(DEV)
+        gx, = torch.autograd.grad((out * cot).sum(), [x])
+        assert torch.equal(gx, cot[b])
+    srt = torch.sort(torch.randint(0, G, (N,), generator=g)).values.to(DEV)
+    assert torch.equal(global_add_pool(x, srt, G, assume_sorted=True), global_add_pool(x, srt, G))

@@ -65,6 +65,29 @@ def test_argument_checks_run_on_host_without_gpu():
         _lib.call("mma_csr_spmm", None, None, None, None, 2, 5, 1, None, None, 2, 5, 4, None)
 
 
+def test_tower_post_fits_is_the_kernels_own_limit():
+    """the Python gates (mma_conv.py `factored`, dense._skinny_ok) ask the library which shapes K13 / K14 / K16 take instead
+    of restating its limits: KF <= 512, S <= 5 and weights + wave tiles inside 160 KB of LDS in both layouts."""
+    from mma_amd import dense
+    assert dense.tower_post_fits(152, 3)            # ZINC: 2 aggregators x 76 columns, 3 scalers
+    assert dense.tower_post_fits(75, 5)             # the 75 -> 75 Linear layers (S = ceil(75/16))
+    assert not dense.tower_post_fits(608, 3)        # 4 aggregators at F_in = 150: K*Fw > 512
+    assert not dense.tower_post_fits(512, 5)        # Linear(512 -> 80): 160 KB of weights alone
+    assert dense.tower_post_fits(512, 3) and not dense.tower_post_fits(0, 1) and not dense.tower_post_fits(8, 6)
+    KFp, tiles = 512, 4 * 64 * 34
+    for S in range(1, 6):                           # the answer IS the two LDS sums of tower_post.hip
+        fits = 4 * (KFp * S * 16 + tiles) <= 160 * 1024 and 4 * (S * 16 * (KFp + 16) + tiles) <= 160 * 1024
+        assert dense.tower_post_fits(512, S) == fits, S
+
+
+def test_host_code_lists_are_length_checked_by_the_torch_ops():
+    """a `*_host` list shorter than the count the call states used to feed uninitialised stack bytes to the C ABI."""
+    if _lib.binding() != "torch":
+        pytest.skip("torch-op binding not built")
+    with pytest.raises(_lib.MMALibraryError, match="scaler_host has 1 entries, the call says 3"):
+        _lib.call("mma_tower_post_pre", None, None, 10, 3, [0], 1.0, 1.0, None)
+
+
 def test_cpu_tensors_are_refused():
     import mma_amd
     from mma_amd import functional as Fn

@@ -81,6 +81,53 @@ def test_skinny_linear_against_float64(N, K, O, bias):
     assert (y2.double() - ref2).abs().max().item() <= 1e-5 * ref2.abs().max().item()
 
 
+def test_shapes_inside_the_old_gates_but_outside_the_kernels_take_the_library_path():
+    """Linear(512 -> 80) on >= 4096 rows passed `_skinny_ok` (O <= 80, K <= 512) but its 160 KB of staged weights do
+    not fit the LDS beside the wave tiles - MMA_REQUIRE raised where round 2 ran the library GEMM.  The gate now asks
+    mma_tower_post_fits; the layer works and matches float64."""
+    from mma_amd import dense
+    g = torch.Generator().manual_seed(5)
+    N, K, O = 4200, 512, 80
+    x, W, b = torch.randn(N, K, generator=g), torch.randn(O, K, generator=g) / np.sqrt(K), torch.randn(O, generator=g)
+    xd, wd, bd = x.to(DEV).requires_grad_(True), W.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    assert not dense._skinny_ok(xd, wd)
+    y = dense.linear(xd, wd, bd)
+    gx, gw, gb = torch.autograd.grad(y.square().sum(), [xd, wd, bd])
+    x64, w64, b64 = x.double().requires_grad_(True), W.double().requires_grad_(True), b.double().requires_grad_(True)
+    y64 = torch.nn.functional.linear(x64, w64, b64)
+    r = torch.autograd.grad(y64.square().sum(), [x64, w64, b64])
+    assert (y.cpu().double() - y64.detach()).abs().max().item() <= 2e-5 * y64.abs().max().item()
+    for got, ref in zip((gx, gw, gb), r):
+        assert (got.cpu().double() - ref).abs().max().item() <= 5e-5 * ref.abs().max().item()
+
+
+def test_mmaconv_with_wide_aggregate_blocks_takes_the_unfactored_post_nn():
+    """4 aggregators at F_in = 150 (K*Fw = 608 > 512) with F_out <= 16 and S <= 5: inside the `factored` gate of round 3, outside K13's
+    limits.  The layer must run (unfactored post-NN) and agree with the factored form's float64 restatement = the oracle."""
+    import mma_amd
+    from mma_amd import functional as Fn
+    from oracle import gr_oracle as G
+    from tools.synth import molecule_batch
+    rng = np.random.default_rng(3)
+    torch.manual_seed(0)
+    T, F = 1, 150
+    conv = mma_amd.MMAConv(F, 12, ["sum", "mean", "min", "max"], ["identity", "amplification"], torch.tensor([0, 10, 30, 50, 10]),
+                           edge_dim=None, towers=T).to(DEV)
+    assert conv.F_out == 12 and not __import__("mma_amd").dense.tower_post_fits(4 * conv.fused_width(), 2)
+    ei, N = molecule_batch(rng, 40)
+    x = rng.standard_normal((N, F)).astype(np.float32)
+    conv.drop_override = Fn.DropoutSpec(0.0)
+    xg = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    got = conv(xg, torch.from_numpy(ei).to(DEV))
+    gx, = torch.autograd.grad(got.square().sum(), [xg])
+    from test_gr_gpu import conv_params, to64
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    want = G.conv_forward(x64, torch.from_numpy(ei), None, to64(conv_params(conv)), conv.aggregators, conv.scalers, conv.avg_deg, T, False, None, 0.0)
+    g64, = torch.autograd.grad(want.square().sum(), [x64])
+    assert (got.cpu().double() - want.detach()).abs().max().item() <= 2e-5 * want.abs().max().item()
+    assert (gx.cpu().double() - g64).abs().max().item() <= 5e-5 * g64.abs().max().item()
+
+
 def test_batched_tn_product_against_float64():
     from mma_amd import dense
     g = torch.Generator().manual_seed(1)
