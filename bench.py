@@ -19,10 +19,17 @@ Workload `c2l` (BASELINE configs[1] at ZINC-split scale): the drop-in `mma_amd.M
 batches are independent, so the ranks are data-parallel REPLICAS (own batch each, parameters broadcast from rank 0, gradients
 averaged by one bucketed all-reduce per step; weak scaling).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant fused kernel, HIP-event timed inside the timed region,
-algorithmic bytes from DESIGN.md) and `cpu_baseline` (the CPU oracle on a bounded sample); at N=1 `extra` holds the
-other BASELINE configs that fit one GPU (C1, C3, C2, C2L: layer fwd+bwd, eager and one-hipGraph replay; C5 at its
-per-GPU shard shape).
+Prints ONE JSON line (rank 0) with `roofline` (dominant fused kernel, HIP-event timed inside the timed region) and
+`cpu_baseline` (the CPU oracle on a bounded sample); at N=1 `extra` holds the other BASELINE configs that fit one GPU
+(C1, C3, C2, C2L: layer fwd+bwd, eager and one-hipGraph replay; C5 at its per-GPU shard shape).
+
+Byte counts.  `roofline.achieved` = `algorithmic_bytes()` of THIS kernel / its HIP-event time: the bytes the kernel's design has to
+move with zero credit for cache reuse of gathered rows.  For K1 that is SURVEY 8d's B_fwd.  For the backward it is
+NOT 8d's B_bwd (which priced a re-gather + per-edge atomic scatter, 63.2 GB at C4): K2b walks the transposed CSR, writes every
+source row exactly once and carries the node-level backward in its epilogue - 41.35 GB at C4.  `roofline.frac_rocprof` prices the
+same bytes against the kernels' own durations in the committed rocprofv3 pass (no launch gaps; None when the recorded profile is of
+another build).  `kernels[name]` carries bytes / flops / bound / frac for EVERY timed call: the dense products state their work at
+the call site (mma_amd.functional._span).
 """
 import argparse
 import json
@@ -65,13 +72,15 @@ def self_launch(argv, gpus):
 
 
 class KernelTimer:
-    """HIP events around the C-ABI calls, on the stream the kernels are launched on (torch's current stream)."""
+    """HIP events around the C-ABI calls, on the stream the kernels are launched on (torch's current stream).  A call site may state
+    the bytes / flops its call has to do (mma_amd.functional._span): they are summed per name beside the times."""
 
     def __init__(self):
         self.spans = {}
+        self.work = {}          # name -> [bytes, flops, mfma kind]
         self.enabled = False
 
-    def span(self, name):
+    def span(self, name, nbytes=0, flops=0, mfma=None):
         timer = self
 
         class _Ctx:
@@ -84,6 +93,8 @@ class KernelTimer:
                 if timer.enabled:
                     self_.e1.record()
                     timer.spans.setdefault(name, []).append((self_.e0, self_.e1))
+                    w = timer.work.setdefault(name, [0, 0, None])
+                    w[0] += nbytes; w[1] += flops; w[2] = mfma or w[2]
         return _Ctx()
 
     def summary(self):
@@ -144,12 +155,13 @@ def pmc_traffic(name, workload):
             continue
         if d.get("build") != now:
             return None, "REFUSED %s: recorded on build %s, this tree is %s - re-run tools/profile_round.sh" % (
-                os.path.relpath(f, ROOT), json.dumps(d.get("build")), json.dumps(now))
+                os.path.relpath(f, ROOT), json.dumps(d.get("build")), json.dumps(now)), None
         # one C-ABI call = up to two launches of the kernel (items run one per wavefront / grouped) + the hub finalize
-        parts = [v["traffic_bytes"] for k, v in d["kernels"].items() if PMC_KERNEL.get(name, "?") in k]
-        if parts:
-            return sum(parts), os.path.relpath(f, ROOT)
-    return None, None
+        hit = [v for k, v in d["kernels"].items() if PMC_KERNEL.get(name, "?") in k]
+        if hit:
+            ns = [v.get("rocprof_avg_ns") for v in hit]
+            return sum(v["traffic_bytes"] for v in hit), os.path.relpath(f, ROOT), (sum(ns) / 1e6 if all(ns) else None)
+    return None, None, None
 
 
 def _traffic_source(traffic, src):
@@ -246,14 +258,38 @@ def wall_ms(fn, n):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-def _kernel_table(spans, steps, ab):
+# dense matrix-core peaks (MI355X_MICROARCH.md): fp16 / bf16 MFMA ~2.5 PFLOP/s; fp32-input MFMA = the fp32 vector rate, 157.3 TFLOP/s
+MFMA16_PEAK, MFMA32_PEAK = 2.5e15, 157.3e12
+PIECE_PRODUCTS = {"f16x3": 3, "bf16x6": 6}
+
+
+def _kernel_table(spans, steps, ab, work=None, step_ms=None):
+    """Per C-ABI call name: launches, ms per STEP, and - for every call whose work is known - its roofline (round-3 VERDICT item 1a):
+    `bytes` = algorithmic HBM bytes per step (the fused kernels: bench.py's formulas, `ab`; the dense ones: stated by their call
+    sites, mma_amd.functional._span), `flops` = fp32-equivalent flops per step, `bound` = the larger of the two floors - bytes at
+    8.0 TB/s ("hbm") or the matrix-core work at its dense peak ("mfma": a split-precision product runs 3 (fp16) or 6 (bf16) piece
+    products per fp32 product at 2.5 PFLOP/s; the exact-fp32 MFMA runs at 157 TFLOP/s) - `frac` = that floor / measured time (also
+    given per resource: hbm_frac, mfma_frac), `share` = its part of the step."""
     kernels = {}
     for name, (cnt, tot_ms) in spans.items():
         avg = tot_ms / steps            # per step (a sharded backward issues the call twice: halo / own sources)
         k = {"launches": cnt, "avg_ms": avg}
+        nbytes, flops, mfma = 0, 0, None
         if name in ab:
-            k["algorithmic_bytes"] = ab[name]
-            k["achieved_GBs"] = ab[name] / (avg * 1e-3) / 1e9
+            nbytes = ab[name]
+        elif work and name in work:
+            nbytes, flops, mfma = work[name][0] / steps, work[name][1] / steps, work[name][2]
+        if nbytes:
+            k["algorithmic_bytes"] = nbytes
+            k["achieved_GBs"] = nbytes / (avg * 1e-3) / 1e9
+            hbm_ms = nbytes / (HBM_PEAK_GBS * 1e9) * 1e3
+            mf_ms = 0.0
+            if flops and mfma:
+                mf_ms = (flops * PIECE_PRODUCTS[mfma] / MFMA16_PEAK if mfma in PIECE_PRODUCTS else flops / MFMA32_PEAK) * 1e3
+                k.update(flops=flops, mfma=mfma, mfma_frac=mf_ms / avg)
+            k.update(bytes=nbytes, hbm_frac=hbm_ms / avg, bound="mfma" if mf_ms > hbm_ms else "hbm", frac=max(hbm_ms, mf_ms) / avg)
+        if step_ms:
+            k["share"] = avg / step_ms
         kernels[name] = k
     return kernels
 
@@ -284,7 +320,7 @@ def nc_config(tag, fixture, H, names, C, p, dev, reps=50, replay=True):
     spans = t.summary(); Fn.TIMER = prev
     n_sel = sum(1 for a in names if a.rstrip("234") in ("max", "min", "softmax", "softmin")) if Fn.SHARED_GRAD_BWD else None
     r = {"config": tag, "nodes": N, "edges": E, "hidden": H, "K": K, "dropout": p, "ms_per_step_eager": ms, "edges_per_s_eager": E / ms * 1e3,
-         "kernels": _kernel_table(spans, reps, algorithmic_bytes(N, E, H, K, n_sel)),
+         "kernels": _kernel_table(spans, reps, algorithmic_bytes(N, E, H, K, n_sel), t.work, ms),
          "note": "launch-bound: the fused kernels move tens of MB (a few us at the HBM roofline)"}
     if replay:
         layer.graph_capturable = True
@@ -419,7 +455,7 @@ def gr_config(tag, n_graphs, dev, reps=20, replay=True, categorical=False):
     r = {"config": tag, "graphs": n_graphs, "nodes": N, "edges": E, "towers": 5, "F": 75, "ms_per_step_eager": ms,
          "edges_per_s_eager": E / ms * 1e3,
          "kernels": _kernel_table(spans, reps, gr_algorithmic_bytes(N, E, 5, 75, 2, 1 if __import__("mma_amd").mma_conv.FACTOR_SCALERS else 3,
-                                                                    "categorical" if categorical else True))}
+                                                                    "categorical" if categorical else True), t.work, ms)}
     if replay:
         conv.graph_capturable = True
         gms = graph_replay_ms(step, 20)
@@ -525,7 +561,7 @@ def c5_shard_config(dev, reps=3):
     n_sel = 4 if Fn.SHARED_GRAD_BWD else None
     return {"config": "C5 per-GPU shard shape: R-MAT 2^20 nodes / %d directed edges, feat=256, K=8 [%s], S=5 true-degree scalers, p=0.5" % (
                 E, ",".join(names)), "nodes": N, "edges": E, "hidden": H, "K": K, "ms_per_step": ms, "edges_per_s": E / ms * 1e3,
-            "kernels": _kernel_table(spans, reps, algorithmic_bytes(N, E, H, K, n_sel)),
+            "kernels": _kernel_table(spans, reps, algorithmic_bytes(N, E, H, K, n_sel), t.work, ms),
             "note": "one rank's share of configs[4] without the halo; the 8-GPU run itself is the driver's"}
 
 
@@ -574,6 +610,102 @@ def shared_graph(args, rank, world, barrier):
     return rowptr, col, tag
 
 
+def device_identity(dev):
+    """What tells two GPUs apart in the N > 1 line: index, name, and the uuid / PCI address where this torch exposes them."""
+    pr = torch.cuda.get_device_properties(dev)
+    d = {"index": dev.index, "name": pr.name}
+    for k in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        v = getattr(pr, k, None)
+        if v is not None:
+            d[k] = str(v)
+    d["key"] = d.get("uuid") or "%s:%s:%s" % (d.get("pci_domain_id"), d.get("pci_bus_id"), d.get("pci_device_id"))
+    return d
+
+
+def verify_sharded(rank, world, dev, backend, H, C, names, p, extra_kw):
+    """`--verify` (default for N > 1): the sharded layer against the unsharded one on a 2^14-node R-MAT, BEFORE anything is timed -
+    the first run on real multi-GPU hardware must say by itself whether its numbers mean anything.  Every rank runs its shard
+    (forward, backward, gradient all-reduce) with a fixed dropout seed (the hash is keyed by GLOBAL edge ids, so the shards draw the
+    bits of the whole graph); rank 0 also runs mma_amd.MMA on the whole graph with the same parameters and compares: output rows,
+    dL/dx rows, every parameter gradient.  Bars as tests/sharded_worker.py: 1e-5 + 1e-5 |ref| element-wise, long signed sums with
+    atol = max(1e-5, 1e-6 max|ref|).  Returns a dict for the JSON line; raises SystemExit(3) on every rank on mismatch."""
+    import torch.distributed as dist
+    import mma_amd
+    from mma_amd import functional as Fn
+    from mma_amd.sharded import ShardedMMA
+    from mma_amd import dense
+    rowptr, col = rmat_graph(14, 80_000, seed=7)
+    N, E = len(rowptr) - 1, int(rowptr[-1])
+    # The SAME work-item plan and the SAME GEMM kernels on both sides (tests/sharded_worker.py::check_gpu): a segment then takes the same
+    # summation order in the shard and in the whole graph and the logits are the same bits, so no max / min mask flips its selection on
+    # a near tie - a legitimate discontinuity of the reference's max(x_i, s), but one flip moves whole rows of dL/dx.  (A shard of a
+    # 2^14-node graph has fewer rows than the split-precision kernels' usual threshold.)
+    PLAN = dict(chunk=16, group_below=8, t_group_below=8)
+    min_rows, dense._MIN_ROWS_X3 = dense._MIN_ROWS_X3, 1
+    try:
+        sh = ShardedMMA.build(rowptr, col, rank, world, dev, H, C, names, p, seed=123, **PLAN, **extra_kw)
+        drop = Fn.DropoutSpec(p, seed=0xC0FFEE)
+        sh.drop_override = drop
+        x_all = feature_rows(0, N, H, 5)
+        cot_all = feature_rows(0, N, C, 6, relu=False)
+        x = torch.from_numpy(x_all[sh.lo:sh.hi]).to(dev).requires_grad_(True)
+        out = sh(x)
+        out.backward(torch.from_numpy(cot_all[sh.lo:sh.hi]).to(dev))
+        sh.allreduce_grads()
+        mine = {"lo": sh.lo, "hi": sh.hi, "out": out.detach().cpu(), "gx": (x.grad if x.grad is not None else torch.zeros_like(x)).cpu()}
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+        res = {"graph": "R-MAT 2^14 nodes / %d directed edges, %d ranks" % (E, world), "ok": True,
+               "bars": "rows: every element within 1e-5 + 1e-5|ref| + max(1e-5, 1e-6 max|ref|) - all rows of `out`, all but <= 0.1 % of the rows "
+                       "of dL/dx (a selection flip on a near tie is a discontinuity of the reference's own max(x_i, s)); parameter "
+                       "gradients: ||got - ref|| <= 1e-4 ||ref||"}
+        if rank == 0:
+            graph = mma_amd.NCGraph(rowptr, col, dev, H=H, **PLAN)
+            layer = make_layer(mma_amd, graph, H, C, names, p, dev, **extra_kw)
+            with torch.no_grad():
+                layer.weight.copy_(sh.weight); layer.bias.copy_(sh.bias)
+                for n in names:
+                    getattr(layer, "mask_" + n).copy_(sh.masks[n])
+            layer.drop_override = drop
+            dst = np.repeat(np.arange(N, dtype=np.int64), np.diff(rowptr))
+            adj = mma_amd.graph.SpmmGraph(dst, col, None, N, N, dev)
+            xf = torch.from_numpy(x_all).to(dev).requires_grad_(True)
+            ref = layer(xf, adj)
+            ref.backward(torch.from_numpy(cot_all).to(dev))
+            order = sorted(parts, key=lambda q: q["lo"])
+            worst = {}
+            for what, a, b, allowed in (("out", torch.cat([q["out"] for q in order]), ref.detach().cpu(), 0.0),
+                                        ("dL/dx", torch.cat([q["gx"] for q in order]), xf.grad.cpu(), 1e-3)):
+                a, b = a.double(), b.double()
+                err = (a - b).abs()
+                atol = max(1e-5, 1e-6 * b.abs().max().item())
+                rows_out = int((err > atol + 1e-5 * b.abs()).any(1).sum())
+                ok = a.shape == b.shape and rows_out <= int(allowed * b.shape[0])
+                worst[what] = {"max_err": err.max().item(), "max_ref": b.abs().max().item(), "rows_outside": rows_out, "rows": b.shape[0], "ok": ok}
+                res["ok"] = res["ok"] and ok
+            pg = [("dL/dweight", sh.weight.grad, layer.weight.grad), ("dL/dbias", sh.bias.grad, layer.bias.grad)]
+            pg += [("dL/dmask_" + n, sh.masks[n].grad, getattr(layer, "mask_" + n).grad) for n in names]
+            for what, a, b in pg:
+                a, b = a.double().cpu(), b.double().cpu()
+                rel = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+                worst[what] = {"rel_err": rel, "ok": rel <= 1e-4}
+                res["ok"] = res["ok"] and rel <= 1e-4
+            res["checks"] = worst
+    finally:
+        dense._MIN_ROWS_X3 = min_rows
+    flag = torch.tensor([1.0 if res["ok"] else 0.0])
+    if backend == "nccl":
+        flag = flag.to(dev)
+    dist.broadcast(flag, 0)
+    if flag.item() != 1.0:
+        if rank == 0:
+            print(json.dumps({"verify": res}), flush=True)
+            sys.stderr.write("bench.py --verify: the sharded layer does NOT match the unsharded one - nothing was timed\n")
+        dist.barrier()
+        sys.exit(3)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -592,6 +724,10 @@ def main():
                     "mma_conv.py:181-196 on the NC aggregates (strict_reference=False) instead of the reference's degenerate three")
     ap.add_argument("--molecules", type=int, default=10000, help="c2l: molecules in the batch")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded (RCCL) path even at world size 1")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=None, help="before timing, check the sharded layer against the "
+                    "unsharded one on a 2^14-node R-MAT (rank 0 computes both; forward, dL/dx, parameter gradients) and exit non-zero on "
+                    "mismatch: the default whenever the sharded path runs on more than one rank")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' (halo staged through the host) lets "
                     "several ranks share one GPU to rehearse the N>1 path on a 1-GPU box")
     ap.add_argument("--cpu-sample", type=int, default=150000, help="target nodes in the CPU-baseline sample (0 = skip)")
@@ -694,7 +830,10 @@ def main():
             out.backward(cot)
         local_edges, n_local = E, N
     else:
-        from mma_amd.sharded import ShardedMMA
+        from mma_amd.sharded import EXCHANGE_LOG, ShardedMMA
+        verify = None
+        if args.verify or (args.verify is None and world > 1):
+            verify = verify_sharded(rank, world, dev, args.backend, H, C, names, args.dropout, extra_kw)
         sh = ShardedMMA.build(rowptr, col, rank, world, dev, H, C, names, args.dropout, **extra_kw)
         x = torch.from_numpy(feature_rows(sh.lo, sh.hi, H, 42)).to(dev).requires_grad_(True)
         cot = torch.from_numpy(feature_rows(sh.lo, sh.hi, C, 43, relu=False)).to(dev)
@@ -716,29 +855,69 @@ def main():
         step()
     barrier()
     timer.enabled = True
+    if sharded:
+        EXCHANGE_LOG.reset()
+        EXCHANGE_LOG.timed = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank's own clock, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    ranks = None
     if sharded:
+        EXCHANGE_LOG.timed = False
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
     spans = timer.summary()
+    if sharded:
+        # one record per rank, gathered with ONE all_gather_object: who ran where, on what, what it exchanged and where its time went
+        # (round-3 VERDICT item 3: the first multi-GPU run must explain itself)
+        sp_ms = {k: v[1] / args.steps for k, v in spans.items()}
+        plan = sh.plan
+        n_send = int(plan.send_counts.sum())
+        me = {"rank": rank, "device": device_identity(dev), "own_rows": int(plan.n_own), "halo_rows": int(plan.n_halo), "rows_sent": n_send,
+              "local_edges": int(sh.local_edges), "peers_sent_to": int((plan.send_counts > 0).sum()), "peers_received_from": int((plan.recv_counts > 0).sum()),
+              "max_bytes_to_one_peer_fwd_x": int(plan.send_counts.max() if world > 1 else 0) * H * 4,
+              "bytes_sent": EXCHANGE_LOG.bytes_sent // max(args.steps, 1), "bytes_received": EXCHANGE_LOG.bytes_received // max(args.steps, 1),
+              "exchanges_per_step": EXCHANGE_LOG.calls // max(args.steps, 1),
+              "ms_per_step": dt_own / args.steps * 1e3, "exchange_ms": EXCHANGE_LOG.exchange_ms() / args.steps,
+              "halo_wait_ms": sp_ms.get("halo_wait", 0.0), "halo_pack_ms": sp_ms.get("halo_pack", 0.0), "halo_unpack_ms": sp_ms.get("halo_unpack", 0.0),
+              "nc_fused_fwd_ms": sp_ms.get("nc_fused_fwd", 0.0), "nc_fused_bwd_ms": sp_ms.get("nc_fused_bwd", 0.0),
+              "gemm_ms": sum(v for k, v in sp_ms.items() if k.startswith("gemm_x3") or k == "lib_mm"),
+              "note": "bytes per step over all four exchanges (x rows and tail rows forward, their gradients back); exchange_ms = sum over the "
+                      "step's exchanges of (collective enqueued -> last byte received) from events on a side stream; halo_wait_ms = HIP-event "
+                      "time of the compute stream's waits (what was NOT hidden behind compute)"}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        keys = {r["device"]["key"] for r in ranks}
+        if args.backend == "nccl" and world > 1 and len(keys) != world:
+            if rank == 0:
+                sys.stderr.write("bench.py: %d ranks but only %d distinct devices (%s): not a multi-GPU measurement\n" % (world, len(keys), sorted(keys)))
+            sys.exit(4)
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = E * args.steps / dt
         n_sel = sum(1 for a in names if a.rstrip("234") in ("max", "min", "softmax", "softmin")) if Fn.SHARED_GRAD_BWD else None
         ab = algorithmic_bytes(n_local, local_edges, H, K, n_sel)
-        kernels = _kernel_table(spans, args.steps, ab)
+        kernels = _kernel_table(spans, args.steps, ab, timer.work, ms_per_step)
         dom = max((n for n in kernels if n in ab), key=lambda n: kernels[n]["avg_ms"])
-        traffic, src = (None, None) if sharded else pmc_traffic(dom, {"nodes": N, "edges": E, "hidden": H, "K": K})
+        traffic, src, rocprof_ms = (None, None, None) if sharded else pmc_traffic(dom, {"nodes": N, "edges": E, "hidden": H, "K": K})
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": _traffic_source(traffic, src)}
+                "traffic_source": _traffic_source(traffic, src),
+                # WHICH byte count (round-3 VERDICT item 7): the bytes THIS kernel has to move with zero credit for cache reuse of gathered
+                # rows - bench.py::algorithmic_bytes, derived in DESIGN.md 3 (K1 = SURVEY 8d's B_fwd; K2b walks the transposed CSR and
+                # writes every source row once, so it is NOT 8d's B_bwd, which assumed a re-gather + per-edge scatter: that formula gives
+                # 63.2 GB at C4 against the 41.35 GB this kernel's design moves)
+                "algorithmic_bytes": ab[dom], "bytes_definition": "bench.py::algorithmic_bytes (DESIGN.md 3), not SURVEY 8d's B_bwd",
+                "duration": "HIP events around the C-ABI call (its 2-3 launches and the gaps between them), avg over the timed steps",
+                "frac_rocprof": (ab[dom] / (rocprof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rocprof_ms else None,
+                "frac_rocprof_note": "the same bytes / the kernels' own durations in the committed --kernel-trace --stats pass (no launch gaps)"}
         is_c4 = all(getattr(args, k) == v for k, v in C4_DEFAULTS.items()) and not args.true_degree_scalers
         is_c5 = all(getattr(args, k) == v for k, v in C5_PRESET.items())
         label = "C4" if is_c4 else ("C5" if is_c5 else "custom (not a BASELINE config)")
@@ -767,6 +946,14 @@ def main():
             "masked_edges_per_s": value * K,
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "plan_build": plan_build, "extra": extra,
         }
+        if sharded:
+            per = [r["ms_per_step"] for r in ranks]
+            line.update(ranks=ranks, ms_per_step_rank_max=max(per), ms_per_step_rank_mean=sum(per) / len(per), distinct_devices=len(keys),
+                        verify=verify, timing="ms_per_step = max over ranks of (barrier .. K steps .. barrier) / K (the contract); "
+                        "ms_per_step_rank_max / _mean: each rank's own clock over its K steps, before the closing barrier",
+                        multi_gpu_note=None if (args.backend == "nccl" and world > 1) else
+                        "NOT a multi-GPU measurement: %s" % ("gloo rehearsal, all ranks on one GPU, halo staged through the host"
+                                                             if args.backend == "gloo" else "one rank"))
         print(json.dumps(line), flush=True)
     if sharded:
         dist.destroy_process_group()
@@ -820,13 +1007,15 @@ def run_c2l(args, dev, rank=0, world=1, barrier=None):
     from mma_amd import mma_conv as _mc
     # with the degree scalers factored into the post-NN (round 3) the fused kernels move the K UNSCALED aggregates: S = 1 in their bytes
     ab = gr_algorithmic_bytes(N, E, T, F, K, 1 if _mc.FACTOR_SCALERS else S)
-    kernels = _kernel_table(timer.summary(), args.steps, ab)
+    kernels = _kernel_table(timer.summary(), args.steps, ab, timer.work, dt / args.steps * 1e3)
     roofs = {}
     for n in ("gr_fused_fwd", "gr_fused_bwd"):
-        traffic, src = pmc_traffic(n, {"workload": "c2l", "nodes": N, "edges": E}) if world == 1 else (None, None)
+        traffic, src, rocprof_ms = pmc_traffic(n, {"workload": "c2l", "nodes": N, "edges": E}) if world == 1 else (None, None, None)
         roofs[n] = {"bound": "hbm", "kernel": n, "achieved": kernels[n]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kernels[n]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": _traffic_source(traffic, src)}
+                    "traffic_source": _traffic_source(traffic, src), "algorithmic_bytes": ab[n],
+                    "bytes_definition": "bench.py::gr_algorithmic_bytes = SURVEY 8d's GR formulas on the UNSCALED aggregates (S = 1)",
+                    "frac_rocprof": (ab[n] / (rocprof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rocprof_ms else None}
     dom = max(roofs, key=lambda n: kernels[n]["avg_ms"])
     cpu = None
     if args.cpu_sample and world == 1:

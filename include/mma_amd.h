@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 29
+#define MMA_ABI_VERSION 30
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -190,9 +190,10 @@ int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, float* C, int6
 int mma_row_absmax(const float* A, int64_t lda, int64_t M, int32_t cols, float* out, void* stream);
 /* The B operand of the three-product kernels below from w (K,N) fp32 with element strides (stride_k, stride_n) - a transposed view
  * is fine: Bt2 = (2, N, K) fp16, piece 0 = hi and piece 1 = lo * 2^11 of w^T scaled per column by the power of two that puts the
- * column maximum into [2^14, 2^15); col_unscale (N,) = the reciprocal scales.  One launch. */
+ * column maximum into [2^14, 2^15); col_unscale (N,) = the reciprocal scales.  One launch.  plain_lo != 0 (ABI 30): piece 1 = lo itself,
+ * not pre-scaled - the operand of the one-accumulator kernels (mma_gemm_f16x2_nlp). */
 int mma_split_f16x2(const float* w, int64_t stride_k, int64_t stride_n, int32_t K, int32_t N, void* bt2, float* col_unscale,
-                    void* stream);
+                    int32_t plain_lo, void* stream);
 /* Three-product form for K = 128 (the forward [P|Q] = x [Wtop|Wbot] and every other tall product whose reduction fits one
  * 128-wide chunk): fp16 x 2 pieces, a = s_row (a_hi + 2^-11 a_lo), b = s_col (b_hi + 2^-11 b_lo), a b ~= hi hi + 2^-11 (hi lo +
  * lo hi) - half the MFMAs of the six-product bf16 form at the accuracy of an fp32 GEMM (measured 1.1e-7 sum|a||b|).  The
@@ -211,9 +212,17 @@ int mma_gemm_f16x2_k256(const float* A, int64_t lda, const float* row_max, const
 /* The same three-product form for N = 128 and a long reduction (dL/dx += [gP|gQ] [Wtop|Wbot]^T, K % 64 == 0): the row scales
  * cannot be formed in the kernel (a row is consumed in 64-wide chunks), so the caller passes row_max (M,) >= the maximum
  * |a| of every row (the backward kernels produce it: mma_nc_bwd_node / mma_nc_fused_bwd); 0 marks an all-zero row.
- * Bt2 = (2, 128, K) fp16 and col_unscale (128,) as for mma_gemm_f16x2.  accumulate != 0: C += A B (one L2 atomic per element). */
+ * Bt2 = (2, 128, K) fp16 and col_unscale (128,) as for mma_gemm_f16x2.  accumulate != 0: C += A B (a plain read - add - store of the tile;
+ * MMA_DX_ACC=atomic in the environment: one float atomic per element, round 3's form - same bits). */
 int mma_gemm_f16x2_n128(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale,
                         float* C, int64_t ldc, int64_t M, int32_t K, int32_t accumulate, void* stream);
+/* ABI 30: the same product, N = 128 or 256 (hidden width 256: all of dL/dx in ONE pass over [gP|gQ]), K % 128 == 0, K >= 256, with
+ * PLAIN lo pieces in both operands (a = s (a_hi + a_lo), Bt2 from mma_split_f16x2 with plain_lo = 1) accumulated into one fp32 tile -
+ * the TN kernel's numerics: 22 bits for every element within 2^16 of its row / column maximum, an absolute 2^-25 of the scaled maximum
+ * below - which frees the registers for a second chunk of A in flight (the two-accumulator form waits out one memory round trip per
+ * 64-deep chunk).  accumulate != 0: C += A B by a plain read - add - store (every element has exactly one writer). */
+int mma_gemm_f16x2_nlp(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale,
+                       float* C, int64_t ldc, int64_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
 /* TN form for the weight gradients (autograd's x^T g of layers.py:215-216's torch.mm): C (KA,NC) = X^T G with X (M,KA),
  * G (M,NC) fp32 row-major, C contiguous.  Any 1 <= KA <= 128 and NC >= 1 (ragged tiles are clamped on load and guarded on
  * store; KA % 32 == 0 with NC % 128 == 0 runs without the guards).  Both operands are split to bf16x3 on the

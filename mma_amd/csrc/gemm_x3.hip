@@ -28,7 +28,17 @@
 #include <cstdlib>
 #include "common.h"
 
+// Measurement builds only (tools/build_ablation.sh compiles this file with -DMMA_ABL=<bits> into scratch/ and the micro-benchmark loads
+// that library through MMA_LIB_OVERRIDE): bit 1 = no MFMAs, bit 2 = no C stores, bit 3 = no A loads, bit 4 = no split, bit 5 = no B slab
+// staging, in the forward column-group kernel and the pipelined dL/dx kernel.  A compile-time constant, 0 in the product library: the
+// ablated code does not exist there (run-time switches changed the register allocation of the kernels they were meant to measure).
+#ifndef MMA_ABL
+#define MMA_ABL 0
+#endif
+
 namespace mma {
+
+constexpr int kAbl = MMA_ABL;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -350,6 +360,7 @@ __device__ __forceinline__ HFrag hg_frag(const unsigned char* sb, int ks) {
 template <int G2>
 __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(const GemmParams p, const float* col_unscale, int64_t n_units,
                                                                            int n_groups, float* a_row_max) {
+  constexpr int dbg = kAbl;
   __shared__ __attribute__((aligned(16))) unsigned char lds[G2 * kHgLds];
   constexpr int NT = 4 * G2;                                           // 32-column tiles per workgroup
   const int tid = threadIdx.x;
@@ -367,7 +378,6 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
         *reinterpret_cast<const uint4*>(Bh + ((size_t)piece * p.N + (size_t)(g * 32 * NT + tile * 32 + col)) * 128 + kq * 8);
   }
   __syncthreads();
-  const uint32_t a_off = (uint32_t)r31 * (uint32_t)p.lda + 8u * h;
   const uint32_t c_off = 4u * h * (uint32_t)p.ldc + (uint32_t)r31;
   const unsigned char* sb0 = lds + r31 * kCgPitch + h * 16;
   HFrag cur = hg_frag(sb0, 0);
@@ -377,17 +387,38 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
   int cues[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) cues[t] = (int)((__float_as_uint(col_unscale[g * 32 * NT + 32 * t + r31]) >> 23) & 0xFF) - 127;
+  // the finished tile waiting to be stored (its stores ride between the next tile's MFMAs): values, descriptor, column offset.  Before the
+  // first tile the descriptor covers ZERO bytes: the hardware's range check drops those stores, so the loop needs no "is there one" branch
+  float prev[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) prev[r] = 0.f;
+  __amdgpu_buffer_rsrc_t crow_p = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000);
+  uint32_t pcol = 0;
+  // [r4] the rows of a unit are requested ONE UNIT AHEAD, before the stores of the unit in between: vmcnt is one in-order counter for
+  // loads and stores, so rows requested at the start of their own unit could only be waited for together with every store the wave had
+  // issued before them - up to 63 of them queued behind a saturated write path, ~5 us per unit with all eight waves of the CU waiting at
+  // once (measurement builds, C4: 1.04 ms with the loads, 0.81 without, 0.75 for the stores alone).  Requested a unit ahead they are
+  // older than the 128 stores that follow, and their wait leaves the youngest 63 of those in flight.
+  // [r4, measured and NOT kept] requesting a unit's rows one unit ahead (inline-asm loads, hand-placed vmcnt(63): hipcc otherwise merges
+  // the loop's entry and back edge into a vmcnt(14) .. vmcnt(0) ladder, a full drain of the wave's stores per unit) changed nothing:
+  // 1.04 -> 1.06-1.12 ms at C4.  Measurement builds (MMA_ABL): the stores alone 0.75 ms, everything but the A loads 0.81, with them
+  // 1.04 - the loads cost by BEING there, not by being waited for: a fragment-shaped load (32 rows x 32 bytes per instruction) is ~32 line
+  // requests to the texture addresser, time the store stream does not get.  The cure is a coalesced load + a transpose through LDS, for
+  // which there is no LDS left beside the resident B slab (136 KB).
   for (int64_t u = stream; u < n_units; u += n_streams) {
     const int64_t row0 = u * kCgRows + wave * 32;
     if (row0 >= p.M) continue;                                      // the last unit may be ragged: rows past M are re-read (the last
     const int64_t rows_here = min((int64_t)32, p.M - row0);          // row) and their stores dropped by the buffer range check
     float4 raw[16];
-    {
-      const float* ap = p.A + row0 * p.lda - (r31 >= rows_here ? (int64_t)(r31 - (rows_here - 1)) * p.lda : 0);
+    if (dbg & 8) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) raw[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+    } else {
+      const float* ap = p.A + min(row0 + r31, p.M - 1) * p.lda + 8 * h;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        raw[2 * ks] = *reinterpret_cast<const float4*>(ap + a_off + ks * 16);
-        raw[2 * ks + 1] = *reinterpret_cast<const float4*>(ap + a_off + ks * 16 + 4);
+        raw[2 * ks] = *reinterpret_cast<const float4*>(ap + ks * 16);
+        raw[2 * ks + 1] = *reinterpret_cast<const float4*>(ap + ks * 16 + 4);
       }
     }
     // row scale: a power of two that puts the row maximum into [2^14, 2^15)
@@ -428,22 +459,44 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
       const unsigned char* sbn = sb0 + ((ct + 1) & (NT - 1)) * kHgTile;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const HFrag nxt = ks < 7 ? hg_frag(sb, ks + 1) : hg_frag(sbn, 0);
+        if (!(dbg & 2)) {
+          const HFrag nxt = ks < 7 ? hg_frag(sb, ks + 1) : hg_frag(sbn, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b2, acl, 0, 0, 0);
+          acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], cur.b1, acl, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b1, acc, 0, 0, 0);
+          cur = nxt;
+        } else {
+          asm volatile("" :: "v"(af[ks][0]), "v"(af[ks][1]));      // keep the split alive
+        }
+        // [r4] two stores of the PREVIOUS tile behind every k-step of this one (in program order: a wave issues in order).  With the 16
+        // stores of a tile issued in one burst after its MFMAs, all eight waves of the CU multiplied together and then all sat in front
+        // of the full store queue together: stores alone 0.74 ms, everything but the stores 0.64 ms, both 1.05 ms (measurement
+        // builds, C4) - nothing overlapped.  Spread out, a wave that waits for a store slot has its MFMAs in between.
+        if (!(dbg & 4)) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int r = 2 * ks + j;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[r]), crow_p, c_off * 4u,
+                                                  (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc) * 4u + pcol, kCgStoreAux);
+          }
+        } else {
+          asm volatile("" :: "v"(prev[2 * ks]), "v"(prev[2 * ks + 1]));
+        }
         __builtin_amdgcn_sched_barrier(0);
-        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b2, acl, 0, 0, 0);
-        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], cur.b1, acl, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b1, acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
       }
       // row r of the tile belongs to lane-row (r&3)+8*(r>>2)+4h: its scale lives in the lane with that r31
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ldexpf(acc[r] + acl[r] * (1.f / 2048.f), cue - rse[r])), crow, c_off * 4u,
-                                              (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + g * 32 * NT + ct * 32) * 4u, kCgStoreAux);
-      }
+      for (int r = 0; r < 16; ++r) prev[r] = ldexpf(acc[r] + acl[r] * (1.f / 2048.f), cue - rse[r]);
+      crow_p = crow;
+      pcol = (uint32_t)(g * 32 * NT + ct * 32) * 4u;
     }
   }
+  // the last tile of the last unit
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[r]), crow_p, c_off * 4u, (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc) * 4u + pcol,
+                                          kCgStoreAux);
 }
 
 // ---- K == 256, three products (round 2, late): the forward [P|Q] = x [Wtop|Wbot] of hidden width 256 (C5) -----------------------------
@@ -472,12 +525,16 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_k256_kernel
         *reinterpret_cast<const uint4*>(Bh + ((size_t)piece * p.N + (size_t)(g * 128 + tile * 32 + col)) * 256 + kq * 8);
   }
   __syncthreads();
-  const uint32_t a_off = (uint32_t)r31 * (uint32_t)p.lda + 8u * h;
   const uint32_t c_off = 4u * h * (uint32_t)p.ldc + (uint32_t)r31;
   const unsigned char* sb0 = lds + r31 * kH2Pitch + h * 16;
   int cues[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) cues[t] = (int)((__float_as_uint(col_unscale[g * 128 + 32 * t + r31]) >> 23) & 0xFF) - 127;
+  float prev[16];                                  // the finished tile whose stores ride between the next tile's MFMAs (zero-byte descriptor at first)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) prev[r] = 0.f;
+  __amdgpu_buffer_rsrc_t crow_p = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000);
+  uint32_t pcol = 0;
   for (int64_t u = stream; u < n_units; u += n_streams) {
     const int64_t row0 = u * kCgRows + wave * 32;
     if (row0 >= p.M) break;                                          // units ascend: every later one starts past M as well
@@ -537,16 +594,23 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_k256_kernel
         acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b2, acl, 0, 0, 0);
         acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], cur.b1, acl, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b1, acc, 0, 0, 0);
+        // [r4] one store of the PREVIOUS tile behind every k-step (see gemm_f16x2_colgroup_kernel): the 17 GB this product writes at
+        // hidden width 256 leave in a steady stream beside the MFMAs instead of in bursts between them
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[ks]), crow_p, c_off * 4u,
+                                              (uint32_t)(((ks & 3) + 8 * (ks >> 2)) * (int)p.ldc) * 4u + pcol, kCgStoreAux);
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ldexpf(acc[r] + acl[r] * (1.f / 2048.f), cue - rse[r])), crow, c_off * 4u,
-                                              (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + g * 128 + ct * 32) * 4u, kCgStoreAux);
-      }
+      for (int r = 0; r < 16; ++r) prev[r] = ldexpf(acc[r] + acl[r] * (1.f / 2048.f), cue - rse[r]);
+      crow_p = crow;
+      pcol = (uint32_t)(g * 128 + ct * 32) * 4u;
     }
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[r]), crow_p, c_off * 4u, (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc) * 4u + pcol,
+                                          kCgStoreAux);
 }
 
 // ---- N == 128, long K: the dL/dx products g [Wtop|Wbot]^T (round 2) ---------------------------------------------------
@@ -683,7 +747,13 @@ __global__ __launch_bounds__(kNlThreads, 1) void gemm_x3_n128_kernel(const GemmP
 // dropped by the buffer range check).
 constexpr int kHnSlab = 2 * kNlPiece;                    // 36 864 B per K chunk (two fp16 pieces of all 128 columns)
 
-template <bool ACC>
+// ACC: 0 = C = A B, 1 = C += A B by one float atomic per element, 2 = C += A B by a plain read - add - store of the tile (every element has
+// exactly one writer either way, so both accumulate forms give the same bits: old + product, one rounding).  Round 4: the atomic form
+// issues 64 atomics per wave at the end of every 256-row unit, all eight waves of the one workgroup a CU holds at once, and float
+// atomics execute at the memory side at ~1.3 TB/s chip-wide, one 256-byte wave-instruction per ~50 ns per CU
+// (MI355X_MICROARCH.md "Global float atomics"): 512 of them are ~25 us of a 75 us unit with nothing else running on the CU.  Form 2
+// fetches the 64 old values in one batch when the last chunk's MFMAs are done (the A / slab prefetch registers are dead by then).
+template <int ACC>
 __global__ __launch_bounds__(kNlThreads, 1) void gemm_f16x2_n128_kernel(const GemmParams p, const float* row_max, const float* col_unscale,
                                                                         int64_t n_units) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kHnSlab];
@@ -782,6 +852,26 @@ __global__ __launch_bounds__(kNlThreads, 1) void gemm_f16x2_n128_kernel(const Ge
     if (rows_here <= 0) continue;                         // (after the barriers)
     const __amdgpu_buffer_rsrc_t crow =
         __builtin_amdgcn_make_buffer_rsrc(p.C + row0 * p.ldc, 0, (int)min((int64_t)0x7fffffff, rows_here * p.ldc * 4), 0x00020000);
+    if (ACC == 2) {
+      float oldv[4][16];                                  // all 64 loads in flight before the first use
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          oldv[t][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crow, c_off, (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + t * 32) * 4u, 0));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int cue = (int)((__float_as_uint(col_unscale[t * 32 + r31]) >> 23) & 0xFF) - 127;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rse = __shfl(sce, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+          const float val = ldexpf(acc[t][r] + acl[t][r] * (1.f / 2048.f), cue - rse);
+          const uint32_t so = (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + t * 32) * 4u;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oldv[t][r] + val), crow, c_off, so, 0);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int cue = (int)((__float_as_uint(col_unscale[t * 32 + r31]) >> 23) & 0xFF) - 127;
@@ -790,8 +880,273 @@ __global__ __launch_bounds__(kNlThreads, 1) void gemm_f16x2_n128_kernel(const Ge
         const int rse = __shfl(sce, (r & 3) + 8 * (r >> 2) + 4 * h, 64);          // once per 256 x 128 block: not worth 16 registers
         const float val = ldexpf(acc[t][r] + acl[t][r] * (1.f / 2048.f), cue - rse);
         const uint32_t so = (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + t * 32) * 4u;
-        if (ACC) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(val, crow, c_off, so, 0);
+        if (ACC == 1) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(val, crow, c_off, so, 0);
         else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), crow, c_off, so, 0);
+      }
+    }
+  }
+}
+
+// ---- N = 32 NT (128 or 256), long K, three products, ONE accumulator set, two raw A chunks in flight (round 4) ---------------------------
+// What held gemm_f16x2_n128_kernel at 0.56 of the HBM peak (round-4 measurements: the atomic epilogue was 3 % of it, not more): a wave
+// had ONE 64-deep chunk of A in flight, issued after the split of the previous one and drained by the __syncthreads() at the end of every
+// chunk - per chunk ~4 000 cycles of MFMA + split and ~5 800 of waiting, i.e. one exposed memory round trip per chunk, with 8 KB per
+// wave in flight for about half of the time (Little: 23 GB/s per CU x 2.5 us needs ~60 KB per CU continuously).  This form:
+//   * pieces hi = fp16(a s), lo = fp16(a s - hi), PLAIN (not pre-scaled by 2^11), for both operands: hi hi + hi lo + lo hi accumulate into
+//     ONE fp32 tile (the TN kernel's numerics: 22 bits for every element within 2^16 of its row / column maximum, an absolute 2^-25 of the
+//     scaled maximum below that) - 64 accumulator registers less than the two-set form;
+//   * those registers hold a SECOND raw chunk: chunk c+1 is split during the first half of step c - in program order BETWEEN the MFMA
+//     groups (a wave issues in order: VALU work hides in an MFMA's shadow only if it sits there) - and its registers are re-requested
+//     with chunk c+3 at mid-step, so a chunk has a step and a half to arrive and the memory pipe never runs dry at a chunk boundary;
+//   * raw barriers (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() also waits for vmcnt(0), i.e. for the prefetches just issued;
+//     the slab registers are requested BEFORE the A chunk, so their wait (vmcnt(8)) leaves the A loads in flight;
+//   * NT = 8: all 256 output columns of hidden width 256 (C5) in one pass over A - the two-set form needed two launches, each reading
+//     the whole 17 GB of [gP|gQ].
+// Bt2 = (2, 32 NT, K) fp16 with PLAIN lo pieces (mma_split_f16x2 with plain_lo = 1).  K % 128 == 0, K >= 256.
+typedef float nlp_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int nlp_u4 __attribute__((ext_vector_type(4)));
+
+template <int NT, int ACC>
+__global__ __launch_bounds__(kNlThreads, 1) void gemm_f16x2_nlp_kernel(const GemmParams p, const float* row_max, const float* col_unscale,
+                                                                       int64_t n_units) {
+  constexpr int dbg = kAbl;
+  constexpr bool PIPE = NT == 4;                           // two raw chunks in flight + the split under the MFMAs (NT = 8: registers for one)
+  constexpr int kPieceB = 32 * NT * kNlPitch;              // one fp16 piece of all 32 NT columns, one K chunk
+  constexpr int kSlabB = 2 * kPieceB;                      // 36 864 B (NT = 4) / 73 728 B (NT = 8) per K chunk
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kSlabB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, h = lane >> 5;
+  const int n_kc = p.K / kNlKC;                            // even, >= 4 (checked by the launcher)
+  const uint32_t c_off = (4u * h * (uint32_t)p.ldc + (uint32_t)r31) * 4u;
+  const unsigned char* fb = lds + r31 * kNlPitch + h * 16;
+  // slab staging: 64 NT rows (piece, column) x 8 chunks of 16 B = 512 NT chunks, NT per thread; row = (tid >> 3) + 64 i is also the row of Bt2.
+  // Every global address is a wave-uniform base (SGPRs) + ONE 32-bit lane offset: 64-bit pointers per load cost the kernel ~20 VGPRs.
+  const int s_row = tid >> 3, s_kq = tid & 7;
+  const uint32_t s_voff = ((uint32_t)s_row * (uint32_t)p.K + (uint32_t)s_kq * 8u) * 2u;                  // bytes into Bt2
+  const _Float16* Bh = reinterpret_cast<const _Float16*>(p.Bt);
+  unsigned char* s_dst = lds + s_row * kNlPitch + s_kq * 16;
+
+  for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+    const int64_t row0 = u * kNlRows + wave * 32;
+    const int64_t rows_here = min((int64_t)32, p.M - row0);          // <= 0: this wave has no row, but it still stages and syncs
+    const int64_t base_row = min(row0, p.M - 1);                     // wave-uniform; rows past M re-read the last row, never stored
+    const int drow = (int)(min(row0 + min((int64_t)r31, max(rows_here, (int64_t)1) - 1), p.M - 1) - base_row);       // 0 .. 31
+    const uint32_t a_voff = ((uint32_t)drow * (uint32_t)p.lda + 8u * h) * 4u;                             // bytes from the wave's base row
+    const float* abase = p.A + base_row * p.lda;                     // + chunk * 64 floats
+    const float rmax = row_max[base_row + drow];
+    const int ex = (int)((__float_as_uint(rmax) >> 23) & 0xFF);
+    const int sce = min(max(14 - (ex - 127), -126), 127);
+    const float sc = __uint_as_float((uint32_t)(sce + 127) << 23);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    nlp_u4 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7;           // named scalars: an indexed array of staging registers ends up in scratch
+    nlp_f4 rawA[8], rawB[8];
+    f16x8 afP[4][2], afQ[4][2];
+    if (dbg || NT <= 4) { sr4 = sr5 = sr6 = sr7 = nlp_u4{0, 0, 0, 0}; }
+    if (dbg || !PIPE) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rawB[i] = nlp_f4{1.f, 1.f, 1.f, 1.f};
+    }
+    if (dbg) {                                                // measurement builds skip loads / splits: defined values everywhere
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rawA[i] = nlp_f4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { afP[ks][q][i] = (_Float16)1.f; afQ[ks][q][i] = (_Float16)1.f; }
+      sr0 = sr1 = sr2 = sr3 = nlp_u4{0, 0, 0, 0};
+    }
+
+// All global loads are INLINE ASM and every wait is written by hand (cdna_hip_programming.md 5.7).  hipcc's own bookkeeping could not
+// express this pipeline: it merged the loop's entry and back edge into a full vmcnt(4) .. vmcnt(0) drain at the loop head, and at 256
+// registers it spilled a register it had just loaded - a vmcnt(0) in the middle of a step (both seen in the ISA; 1.55 ms).  vmcnt is one
+// in-order counter: a wait for an operation is a wait for everything older.  Order inside a step: slab (NT loads) | at mid-step: A chunk
+// (8 loads) | at the end vmcnt(8): the slab has landed, and with it every OLDER load - the raw set requested in the middle of the
+// previous step, which the next step splits.  Each wait statement names the registers it releases ("+v"), so the compiler can neither
+// read them earlier nor reuse them while a load is in flight; tools/check_asm_waits.py audits the ISA for copies in between.
+// One asm statement per load group.  `s_nop 4` opens it: the base is an SGPR pair the compiler may have just restored from a spill lane
+// with v_readlane - a VALU write of an SGPR needs 5 wait states before a vector-memory instruction reads it, and hipcc pads nothing
+// inside an asm string (5.7 item 2; without the pad the first build of this kernel read a stale base: a memory access fault).  Outputs are
+// early-clobber: the statement writes its first destination before it has read the offset register for the last time.
+#define MMA_NLP_LOADA(R_, C_)                                                                      \
+    if (!(dbg & 8)) {                                                                              \
+      const float* ab_ = abase + (int64_t)(C_) * kNlKC;                                            \
+      asm volatile("s_nop 4\n\t"                                                                   \
+                   "global_load_dwordx4 %0, %8, %9 offset:0\n\t"   "global_load_dwordx4 %1, %8, %9 offset:16\n\t"   \
+                   "global_load_dwordx4 %2, %8, %9 offset:64\n\t"  "global_load_dwordx4 %3, %8, %9 offset:80\n\t"   \
+                   "global_load_dwordx4 %4, %8, %9 offset:128\n\t" "global_load_dwordx4 %5, %8, %9 offset:144\n\t"  \
+                   "global_load_dwordx4 %6, %8, %9 offset:192\n\t" "global_load_dwordx4 %7, %8, %9 offset:208"      \
+                   : "=&v"(R_[0]), "=&v"(R_[1]), "=&v"(R_[2]), "=&v"(R_[3]), "=&v"(R_[4]), "=&v"(R_[5]), "=&v"(R_[6]), "=&v"(R_[7])  \
+                   : "v"(a_voff), "s"(ab_) : "memory");                                            \
+    }
+#define MMA_NLP_SLABLOAD(C_)                                                                       \
+    if (!(dbg & 32)) {                                                                             \
+      const _Float16* sb_ = Bh + (int64_t)(C_) * kNlKC;                                            \
+      const int64_t sk_ = (int64_t)64 * p.K;                                                       \
+      const _Float16 *q0_ = sb_, *q1_ = sb_ + sk_, *q2_ = sb_ + 2 * sk_, *q3_ = sb_ + 3 * sk_;     \
+      asm volatile("s_nop 4\n\t"                                                                   \
+                   "global_load_dwordx4 %0, %4, %5\n\t" "global_load_dwordx4 %1, %4, %6\n\t"       \
+                   "global_load_dwordx4 %2, %4, %7\n\t" "global_load_dwordx4 %3, %4, %8"           \
+                   : "=&v"(sr0), "=&v"(sr1), "=&v"(sr2), "=&v"(sr3) : "v"(s_voff), "s"(q0_), "s"(q1_), "s"(q2_), "s"(q3_) : "memory");  \
+      if (NT > 4) {                                                                                \
+        const _Float16 *q4_ = sb_ + 4 * sk_, *q5_ = sb_ + 5 * sk_, *q6_ = sb_ + 6 * sk_, *q7_ = sb_ + 7 * sk_;      \
+        asm volatile("s_nop 4\n\t"                                                                 \
+                     "global_load_dwordx4 %0, %4, %5\n\t" "global_load_dwordx4 %1, %4, %6\n\t"     \
+                     "global_load_dwordx4 %2, %4, %7\n\t" "global_load_dwordx4 %3, %4, %8"         \
+                     : "=&v"(sr4), "=&v"(sr5), "=&v"(sr6), "=&v"(sr7) : "v"(s_voff), "s"(q4_), "s"(q5_), "s"(q6_), "s"(q7_) : "memory"); \
+      }                                                                                            \
+    }
+// wait until at most N_ younger loads are in flight; releases the slab registers and the raw set R_
+#define MMA_NLP_WAIT(N_, R_)                                                                       \
+    if (!(dbg & 8) || !(dbg & 32)) {                                                               \
+      if (NT > 4)                                                                                  \
+        asm volatile("s_waitcnt vmcnt(" #N_ ")" : "+v"(sr0), "+v"(sr1), "+v"(sr2), "+v"(sr3), "+v"(sr4), "+v"(sr5), "+v"(sr6), "+v"(sr7),  \
+                     "+v"(R_[0]), "+v"(R_[1]), "+v"(R_[2]), "+v"(R_[3]), "+v"(R_[4]), "+v"(R_[5]), "+v"(R_[6]), "+v"(R_[7]) :: "memory"); \
+      else                                                                                         \
+        asm volatile("s_waitcnt vmcnt(" #N_ ")" : "+v"(sr0), "+v"(sr1), "+v"(sr2), "+v"(sr3),      \
+                     "+v"(R_[0]), "+v"(R_[1]), "+v"(R_[2]), "+v"(R_[3]), "+v"(R_[4]), "+v"(R_[5]), "+v"(R_[6]), "+v"(R_[7]) :: "memory"); \
+    }
+#define MMA_NLP_SS1(I_, B_) *reinterpret_cast<nlp_u4*>(s_dst + (B_) * kSlabB + 64 * (I_) * kNlPitch)
+#define MMA_NLP_SLABSTORE(B_)                                                                      \
+    MMA_NLP_SS1(0, B_) = sr0; MMA_NLP_SS1(1, B_) = sr1; MMA_NLP_SS1(2, B_) = sr2; MMA_NLP_SS1(3, B_) = sr3;   \
+    if (NT > 4) { MMA_NLP_SS1(4, B_) = sr4; MMA_NLP_SS1(5, B_) = sr5; MMA_NLP_SS1(6, B_) = sr6; MMA_NLP_SS1(7, B_) = sr7; }
+// value V_ (0..31) of raw chunk R_ -> pieces of AF_: k-step V_ / 8, element V_ % 8 (vector V_ / 4, component V_ % 4)
+#define MMA_NLP_SPLIT1(R_, AF_, V_)                                                                \
+    if (!(dbg & 16)) {                                                                             \
+      const float xv = R_[(V_) >> 2][(V_) & 3] * sc;                                               \
+      const _Float16 hi = (_Float16)xv;                                                            \
+      AF_[(V_) >> 3][0][(V_) & 7] = hi;                                                            \
+      AF_[(V_) >> 3][1][(V_) & 7] = (_Float16)(xv - (float)hi);                                    \
+    }
+// One K chunk: 4 NT groups of three MFMAs (column tile x k-step); fragments of group g+1 are read while group g multiplies.
+//   SLAB_ : stage the NEXT chunk's B slab - requested first, stored last (behind WAITN_), then the raw barrier;
+//   PIPE  : the raw set RS_ (chunk C_+1, released by the previous step's wait) is split into AFN_ during the FIRST half of the step, in
+//           program order BETWEEN the MFMA groups (a wave issues in order: VALU work hides in an MFMA's shadow only if it sits there),
+//           and re-requested (LOADA_: chunk C_+3) at mid-step: a chunk has a step and a half to arrive.  A CU's fair share of the HBM
+//           rate moves the 64 KB its eight waves ask for per step in about a step's time - one step of slack was not enough (measured:
+//           with the loads issued but never waited for the kernel takes 0.69 ms, waiting for them a step later added 0.67);
+//   !PIPE : LOADA_ requests chunk C_+1 before the MFMAs, the caller splits it after the barrier;
+//   WAITN_: 8 when this step requested an A chunk (those 8 loads stay in flight), else 0;  RW_: the raw set the wait releases.
+#define MMA_NLP_STEP(C_, B_, AFC_, AFN_, RS_, RW_, SLAB_, LOADA_, SPLIT_, WAITN_)                  \
+    {                                                                                              \
+      if (SLAB_) { MMA_NLP_SLABLOAD((C_) + 1) }                                                    \
+      if (LOADA_ && !PIPE) { MMA_NLP_LOADA(RS_, (C_) + 1) }                                        \
+      const unsigned char* sb = fb + (B_) * kSlabB;                                                \
+      HFrag cur;                                                                                   \
+      cur.b1 = *reinterpret_cast<const f16x8*>(sb);                                                \
+      cur.b2 = *reinterpret_cast<const f16x8*>(sb + kPieceB);                                      \
+      _Pragma("unroll") for (int g = 0; g < 4 * NT; ++g) {                                         \
+        const int ct = g >> 2, ks = g & 3;                                                         \
+        HFrag nxt = cur;                                                                           \
+        if (g + 1 < 4 * NT) {                                                                      \
+          const unsigned char* q = sb + ((g + 1) >> 2) * 32 * kNlPitch + ((g + 1) & 3) * 32;       \
+          nxt.b1 = *reinterpret_cast<const f16x8*>(q);                                             \
+          nxt.b2 = *reinterpret_cast<const f16x8*>(q + kPieceB);                                   \
+        }                                                                                          \
+        if (PIPE && LOADA_ && g == 2 * NT) { MMA_NLP_LOADA(RS_, (C_) + 3) }                        \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (!(dbg & 2)) {                                                                          \
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AFC_[ks][1], cur.b1, acc[ct], 0, 0, 0);   \
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AFC_[ks][0], cur.b2, acc[ct], 0, 0, 0);   \
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AFC_[ks][0], cur.b1, acc[ct], 0, 0, 0);   \
+        } else { asm volatile("" :: "v"(AFC_[ks][0]), "v"(AFC_[ks][1]), "v"(cur.b1), "v"(cur.b2)); } \
+        if (PIPE && SPLIT_ && g < 2 * NT) {                                                        \
+          constexpr int per = 32 / (2 * NT);                /* 4 values per group (NT = 4) */      \
+          _Pragma("unroll") for (int j = 0; j < per; ++j) MMA_NLP_SPLIT1(RS_, AFN_, g * per + j)   \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        cur = nxt;                                                                                 \
+      }                                                                                            \
+      if (SLAB_) {                                                                                 \
+        MMA_NLP_WAIT(WAITN_, RW_)                                                                  \
+        MMA_NLP_SLABSTORE(1 - (B_))                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        __builtin_amdgcn_s_barrier();                                                              \
+        asm volatile("" ::: "memory");                                                             \
+      }                                                                                            \
+    }
+
+    MMA_NLP_SLABLOAD(0)
+    MMA_NLP_LOADA(rawA, 0)
+    if (PIPE) {
+      MMA_NLP_LOADA(rawB, 1)
+      MMA_NLP_WAIT(8, rawA)                                   // slab 0 and chunk 0 have landed, chunk 1 may still fly
+    } else {
+      MMA_NLP_WAIT(0, rawA)
+    }
+    // every wave has left the previous unit's last chunk (buffer 1) behind the barrier below; buffer 0 was last read one step earlier
+    MMA_NLP_SLABSTORE(0)
+#pragma unroll
+    for (int v = 0; v < 32; ++v) MMA_NLP_SPLIT1(rawA, afP, v)
+    if (PIPE) {
+      MMA_NLP_LOADA(rawA, 2)                                  // chunk 2 into the set chunk 0 has just left
+      MMA_NLP_WAIT(8, rawB)                                   // chunk 1 (split by step 0) has landed; chunk 2 flies
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    if (PIPE) {
+      // step c: multiply chunk c (afP / afQ in turn); split chunk c+1 out of one raw set in the first half and re-request that set with
+      // chunk c+3 at mid-step; the OTHER set holds chunk c+2, under way since the middle of the previous step and released by this
+      // step's closing wait
+      for (int kc = 0; kc < n_kc - 4; kc += 2) {
+        MMA_NLP_STEP(kc, 0, afP, afQ, rawB, rawA, true, true, true, 8)
+        MMA_NLP_STEP(kc + 1, 1, afQ, afP, rawA, rawB, true, true, true, 8)
+      }
+      MMA_NLP_STEP(n_kc - 4, 0, afP, afQ, rawB, rawA, true, true, true, 8)
+      MMA_NLP_STEP(n_kc - 3, 1, afQ, afP, rawA, rawB, true, false, true, 0)
+      MMA_NLP_STEP(n_kc - 2, 0, afP, afQ, rawB, rawA, true, false, true, 0)
+      MMA_NLP_STEP(n_kc - 1, 1, afQ, afP, rawA, rawB, false, false, false, 0)
+    } else {
+      // NT = 8: 128 accumulator registers leave room for ONE raw chunk - requested before the step's MFMAs, split after its barrier
+      for (int kc = 0; kc < n_kc - 1; ++kc) {
+        MMA_NLP_STEP(kc, kc & 1, afP, afP, rawA, rawA, true, true, false, 0)
+#pragma unroll
+        for (int v = 0; v < 32; ++v) MMA_NLP_SPLIT1(rawA, afP, v)
+      }
+      MMA_NLP_STEP(n_kc - 1, (n_kc - 1) & 1, afP, afP, rawA, rawA, false, false, false, 0)
+    }
+#undef MMA_NLP_STEP
+#undef MMA_NLP_SPLIT1
+#undef MMA_NLP_SLABSTORE
+#undef MMA_NLP_SS1
+#undef MMA_NLP_WAIT
+#undef MMA_NLP_SLABLOAD
+#undef MMA_NLP_LOADA
+    // the last chunk was read from buffer 1; the next unit's prologue writes buffer 0 (last read before the previous barrier) and
+    // then meets everybody at its own barrier before buffer 1 is written again
+
+    if (rows_here <= 0) continue;
+    const __amdgpu_buffer_rsrc_t crow =
+        __builtin_amdgcn_make_buffer_rsrc(p.C + row0 * p.ldc, 0, (int)min((int64_t)0x7fffffff, rows_here * p.ldc * 4), 0x00020000);
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += 4) {                  // four tiles at a time: 64 old values in flight (the raw / fragment registers are dead)
+      float oldv[4][16];
+      if (ACC == 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            oldv[t][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crow, c_off, (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + (t0 + t) * 32) * 4u, 0));
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int cue = (int)((__float_as_uint(col_unscale[(t0 + t) * 32 + r31]) >> 23) & 0xFF) - 127;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rse = __shfl(sce, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+          const float val = ldexpf(acc[t0 + t][r], cue - rse);
+          const uint32_t so = (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc + (t0 + t) * 32) * 4u;
+          if (ACC == 1) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(val, crow, c_off, so, 0);
+          else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ACC == 2 ? oldv[t][r] + val : val), crow, c_off, so, 0);
+        }
       }
     }
   }
@@ -802,7 +1157,7 @@ __global__ __launch_bounds__(kNlThreads, 1) void gemm_f16x2_n128_kernel(const Ge
 // [2^14, 2^15), pieces hi = fp16(w s), lo = fp16((w s - hi) 2^11) at [piece][n][k] (k contiguous), col_unscale[n] = 1/s.
 // (The torch expression of the same thing was twelve small launches per GEMM call.)  One workgroup per column, any strides.
 __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* w, int64_t stride_k, int64_t stride_n, int K, int N, _Float16* bt2,
-                                                          float* col_unscale) {
+                                                          float* col_unscale, int plain_lo) {
   __shared__ uint32_t red[4];
   const int n = blockIdx.x;
   uint32_t m = 0;
@@ -819,7 +1174,7 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* w, int64_
     const float x = w[k * stride_k + n * stride_n] * sc;
     const _Float16 hi = (_Float16)x;
     bt2[(size_t)n * K + k] = hi;
-    bt2[((size_t)N + n) * K + k] = (_Float16)((x - (float)hi) * 2048.f);
+    bt2[((size_t)N + n) * K + k] = (_Float16)(plain_lo ? x - (float)hi : (x - (float)hi) * 2048.f);
   }
   if (threadIdx.x == 0) col_unscale[n] = __uint_as_float((uint32_t)(e - 14 + 127) << 23);
 }
@@ -1390,12 +1745,12 @@ extern "C" int mma_gemm_bf16x3(const float* A, int64_t lda, const void* Bt3, flo
 }
 
 extern "C" int mma_split_f16x2(const float* w, int64_t stride_k, int64_t stride_n, int32_t K, int32_t N, void* bt2, float* col_unscale,
-                               void* stream) {
+                               int32_t plain_lo, void* stream) {
   MMA_REQUIRE(K >= 1 && N >= 1 && K <= (1 << 20) && N <= (1 << 20) && (int64_t)K * N < (1LL << 31), "K=%d N=%d out of range", K, N);
   MMA_REQUIRE(w && bt2 && col_unscale, "NULL argument");
   MMA_REQUIRE(stride_k >= 0 && stride_n >= 0 && (int64_t)(K - 1) * stride_k + (int64_t)(N - 1) * stride_n < (1LL << 31), "strides out of range");
   hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)N), dim3(256), 0, static_cast<hipStream_t>(stream), w, stride_k, stride_n, K, N,
-                     static_cast<_Float16*>(bt2), col_unscale);
+                     static_cast<_Float16*>(bt2), col_unscale, plain_lo ? 1 : 0);
   return check_launch("split_f16x2_kernel");
 }
 
@@ -1443,9 +1798,34 @@ extern "C" int mma_gemm_f16x2_n128(const float* A, int64_t lda, const float* row
   const int64_t n_units = (M + kNlRows - 1) / kNlRows;
   const dim3 g((unsigned)(n_units < 256 ? n_units : 256));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (accumulate) hipLaunchKernelGGL(gemm_f16x2_n128_kernel<true>, g, dim3(kNlThreads), 0, st, p, row_max, col_unscale, n_units);
-  else hipLaunchKernelGGL(gemm_f16x2_n128_kernel<false>, g, dim3(kNlThreads), 0, st, p, row_max, col_unscale, n_units);
+  static const bool acc_atomic = getenv("MMA_DX_ACC") && getenv("MMA_DX_ACC")[0] == 'a';     // MMA_DX_ACC=atomic: round 3's epilogue (A/B switch)
+  if (accumulate && acc_atomic) hipLaunchKernelGGL(gemm_f16x2_n128_kernel<1>, g, dim3(kNlThreads), 0, st, p, row_max, col_unscale, n_units);
+  else if (accumulate) hipLaunchKernelGGL(gemm_f16x2_n128_kernel<2>, g, dim3(kNlThreads), 0, st, p, row_max, col_unscale, n_units);
+  else hipLaunchKernelGGL(gemm_f16x2_n128_kernel<0>, g, dim3(kNlThreads), 0, st, p, row_max, col_unscale, n_units);
   return check_launch("gemm_f16x2_n128_kernel");
+}
+
+extern "C" int mma_gemm_f16x2_nlp(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale, float* C,
+                                  int64_t ldc, int64_t M, int32_t N, int32_t K, int32_t accumulate, void* stream) {
+  MMA_REQUIRE(M >= 0 && (N == 128 || N == 256) && K >= 4 * kNlKC && K % (2 * kNlKC) == 0 && K <= (1 << 20),
+              "M=%lld N=%d K=%d: need N in {128, 256}, K %% 128 == 0, K >= 256", (long long)M, N, K);
+  MMA_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && lda < (1 << 24) && ldc < (1 << 24), "row pitch too small, unaligned or >= 2^24");
+  if (M == 0) return 0;
+  MMA_REQUIRE(A && row_max && Bt2 && col_unscale && C && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt2) & 15) == 0,
+              "NULL or misaligned argument");
+  GemmParams p{A, lda, static_cast<const __bf16*>(Bt2), C, ldc, M, N, K, accumulate ? 1 : 0};
+  const int64_t n_units = (M + kNlRows - 1) / kNlRows;
+  const dim3 g((unsigned)(n_units < 256 ? n_units : 256));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static const bool acc_atomic = getenv("MMA_DX_ACC") && getenv("MMA_DX_ACC")[0] == 'a';
+  const int mode = accumulate ? (acc_atomic ? 1 : 2) : 0;
+#define MMA_NLP_LAUNCH(NT_)                                                                                                        \
+  if (mode == 0) hipLaunchKernelGGL((gemm_f16x2_nlp_kernel<NT_, 0>), g, dim3(kNlThreads), 0, st, p, row_max, col_unscale, n_units);      \
+  else if (mode == 1) hipLaunchKernelGGL((gemm_f16x2_nlp_kernel<NT_, 1>), g, dim3(kNlThreads), 0, st, p, row_max, col_unscale, n_units); \
+  else hipLaunchKernelGGL((gemm_f16x2_nlp_kernel<NT_, 2>), g, dim3(kNlThreads), 0, st, p, row_max, col_unscale, n_units);
+  if (N == 128) { MMA_NLP_LAUNCH(4) } else { MMA_NLP_LAUNCH(8) }
+#undef MMA_NLP_LAUNCH
+  return check_launch("gemm_f16x2_nlp_kernel");
 }
 
 extern "C" int64_t mma_gemm_bf16x3_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC) {

@@ -9,6 +9,7 @@
 // 64 at a time (one coalesced load) and handed to the sub-rows with ds_bpermute.  Two edge steps are
 // kept in flight per lane.  Sub-row partial sums meet in a butterfly at the end of the segment; there
 // are no atomics anywhere, so results are bitwise reproducible.
+#include <cstdlib>
 #include "common.h"
 
 #ifndef NC_FWD_UNROLL
@@ -1023,6 +1024,10 @@ extern "C" int mma_nc_fused_fwd(
                   (!save || (aligned16(T) && (!sel || aligned16(sel)))) && (partial == nullptr || aligned16(partial));
   const Geometry g = geometry(H, v4);
   p.x = x; p.ldx = ldx; p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.rowptr = rowptr; p.col = col;
+  // MEASUREMENT ONLY (round-3 VERDICT item 6, "P inside K1": what would K1 gain if it did not have to read P?): MMA_NC_ABLATE_P=1 makes
+  // every target read P's row 0 (a cache hit) - the results are WRONG, only the kernel's time means anything.  DESIGN.md 9 has the number.
+  static const bool ablate_p = getenv("MMA_NC_ABLATE_P") && atoi(getenv("MMA_NC_ABLATE_P")) != 0;
+  if (ablate_p) p.ldp = 0;
   p.items = reinterpret_cast<const int4*>(items); p.n_items = n_items;
   p.partial = partial; p.pstride = 2LL * K * H;
   p.m = m; p.m_kstride = N * (int64_t)H; p.msum = m_sum; p.ldms = ldms; p.T = T; p.sel = sel; p.ldt = ldt;

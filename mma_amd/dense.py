@@ -11,9 +11,9 @@ from . import _lib
 from ._lib import call, ptr, stream_ptr
 
 
-def _span(name):
+def _span(name, nbytes=0, flops=0, mfma=None):
     from . import functional as Fn      # late: functional imports this module
-    return Fn._span(name)
+    return Fn._span(name, nbytes, flops, mfma)
 
 _ROWS_PER_BATCH = 8192
 USE_BF16X3 = True     # fp32-accurate GEMM on the bf16 matrix cores (csrc/gemm_x3.hip) where the shape allows
@@ -42,18 +42,19 @@ def gemm_f16x2(a, w, out=None, row_max_out=None):
     bt2, cu = _split_f16x2(w)
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
-    with _span("gemm_x3_k128"):
+    with _span("gemm_x3_k128", nbytes=4 * M * (K + N), flops=2 * M * K * N, mfma="f16x3"):        # A in, C out (B is 0.5 MB)
         call("mma_gemm_f16x2", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(out), out.stride(0), ptr(row_max_out), M, N, stream_ptr())
     return out
 
 
-def _split_f16x2(w):
+def _split_f16x2(w, plain_lo=False):
     """w (K,N) fp32, any strides -> ((2,N,K) fp16 pieces of B^T scaled per column by a power of two that puts the column maximum
-    into [2^14, 2^15), (N,) fp32 reciprocal scales): one launch (mma_split_f16x2)."""
+    into [2^14, 2^15), (N,) fp32 reciprocal scales): one launch (mma_split_f16x2).  plain_lo: the lo piece as it is, not times 2^11
+    (the one-accumulator kernels)."""
     K, N = w.shape
     bt2 = torch.empty((2, N, K), device=w.device, dtype=torch.float16)
     cu = torch.empty((N,), device=w.device, dtype=torch.float32)
-    call("mma_split_f16x2", ptr(w), w.stride(0), w.stride(1), K, N, ptr(bt2), ptr(cu), stream_ptr())
+    call("mma_split_f16x2", ptr(w), w.stride(0), w.stride(1), K, N, ptr(bt2), ptr(cu), 1 if plain_lo else 0, stream_ptr())
     return bt2, cu
 
 
@@ -75,13 +76,24 @@ def row_absmax(a):
     return out
 
 
+USE_NLP = __import__("os").environ.get("MMA_DX_NLP", "1") != "0"      # round 4: the pipelined one-accumulator form (0: round 3's kernel)
+
+
 def gemm_f16x2_n128(a, row_max, w, out, accumulate=False):
-    """out (M,N) (+)= a (M,K) @ w (K,N), N a multiple of 128, on the three-product kernel, one launch per 128-column block of the
-    output (hidden width 256: C5); row_max (M,) >= max |a[i,:]| (0 for an all-zero row)."""
+    """out (M,N) (+)= a (M,K) @ w (K,N), N a multiple of 128, on the three-product kernels; row_max (M,) >= max |a[i,:]| (0 for an
+    all-zero row).  N in {128, 256} with K % 128 == 0 takes the pipelined one-accumulator kernel (mma_gemm_f16x2_nlp: ONE pass over
+    `a`, also for N = 256 - hidden width 256, C5); other shapes one launch of the two-accumulator kernel per 128-column block."""
     M, K = a.shape
     N = w.shape[1]
+    if USE_NLP and N in (128, 256) and K % 128 == 0 and K >= 256 and out.stride(1) == 1:
+        bt2, cu = _split_f16x2(w, plain_lo=True)
+        with _span("gemm_x3_acc" if accumulate else "gemm_x3_persist", nbytes=4 * M * (K + (2 if accumulate else 1) * N), flops=2 * M * K * N, mfma="f16x3"):
+            call("mma_gemm_f16x2_nlp", ptr(a), a.stride(0), ptr(row_max), ptr(bt2), ptr(cu), ptr(out), out.stride(0), M, N, K,
+                 1 if accumulate else 0, stream_ptr())
+        return out
     bt2, cu = _split_f16x2(w)                                            # (2, N, K), (N,)
-    with _span("gemm_x3_acc" if accumulate else "gemm_x3_persist"):
+    # A in once (algorithmic: the column blocks of a wider output re-read it), C out - and in, when accumulating
+    with _span("gemm_x3_acc" if accumulate else "gemm_x3_persist", nbytes=4 * M * (K + (2 if accumulate else 1) * N), flops=2 * M * K * N, mfma="f16x3"):
         # (walking A in row slabs that stay in the Infinity Cache between the column blocks was measured at C5's forward shape -
         # 32 blocks over a 1 GB A: 11.3 -> 11.2 ms, i.e. the kernel, not the re-reads of A, is what the product costs)
         for b in range(N // 128):
@@ -127,7 +139,7 @@ def gemm_bf16x3(a, w, out=None, accumulate=False, row_max_box=None):
             # column-group form with the whole 256-deep B slab resident: A is read once per column group through L2 instead of once per
             # 128-column launch from HBM (C5 forward, N = 4096: 32 launches of the chunked kernel)
             bt2, cu = _split_f16x2(w)
-            with _span("gemm_x3_persist"):
+            with _span("gemm_x3_persist", nbytes=4 * M * (K + N), flops=2 * M * K * N, mfma="f16x3"):
                 call("mma_gemm_f16x2_k256", ptr(a), a.stride(0), ptr(rm), ptr(bt2), ptr(cu), ptr(out), out.stride(0), M, N, stream_ptr())
             return out
         return gemm_f16x2_n128(a, rm, w, out)
@@ -139,7 +151,8 @@ def gemm_bf16x3(a, w, out=None, accumulate=False, row_max_box=None):
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
     acc = 1 if accumulate else 0
-    with _span("gemm_x3_acc" if accumulate else ("gemm_x3_k128" if K == 128 else "gemm_x3_persist")):
+    with _span("gemm_x3_acc" if accumulate else ("gemm_x3_k128" if K == 128 else "gemm_x3_persist"),
+               nbytes=4 * M * (K + (2 if accumulate else 1) * N), flops=2 * M * K * N, mfma="bf16x6"):
         if K == 128 or N <= 128:
             call("mma_gemm_bf16x3", ptr(a), a.stride(0), ptr(bt3), ptr(out), out.stride(0), M, N, K, acc, stream_ptr())
         else:                                                # K > 128 and N > 128: one launch per 128-column block of the output
@@ -182,15 +195,16 @@ def _rows_mm(a, w):
         return gemm_bf16x3(a, w)
     N = a.shape[0]
     B = N // _ROWS_PER_BATCH
-    if B < 4:
-        return torch.mm(a, w)
-    a = a.contiguous()
-    n = B * _ROWS_PER_BATCH
-    out = torch.empty((N, w.shape[1]), device=a.device, dtype=a.dtype)
-    torch.bmm(a[:n].view(B, _ROWS_PER_BATCH, -1), w.unsqueeze(0).expand(B, -1, -1), out=out[:n].view(B, _ROWS_PER_BATCH, -1))
-    if n < N:
-        torch.mm(a[n:], w, out=out[n:])
-    return out
+    with _span("lib_mm", nbytes=4 * N * (a.shape[1] + w.shape[1]), flops=2 * N * a.shape[1] * w.shape[1], mfma="f32"):      # rocBLAS fp32
+        if B < 4:
+            return torch.mm(a, w)
+        a = a.contiguous()
+        n = B * _ROWS_PER_BATCH
+        out = torch.empty((N, w.shape[1]), device=a.device, dtype=a.dtype)
+        torch.bmm(a[:n].view(B, _ROWS_PER_BATCH, -1), w.unsqueeze(0).expand(B, -1, -1), out=out[:n].view(B, _ROWS_PER_BATCH, -1))
+        if n < N:
+            torch.mm(a[n:], w, out=out[n:])
+        return out
 
 
 class _MM(torch.autograd.Function):
@@ -234,7 +248,7 @@ def gemm_bf16x3_tn(x, g):
     kb = KA if KA <= 128 else 128
     n_ws = int(_lib.lib().mma_gemm_bf16x3_tn_workspace_floats(N, kb, NC))
     ws = torch.empty((n_ws,), device=x.device, dtype=torch.float32) if n_ws else None
-    with _span("gemm_x3_tn"):
+    with _span("gemm_x3_tn", nbytes=4 * N * (KA + NC), flops=2 * N * KA * NC, mfma="bf16x6"):
         for j in range(0, KA, kb):                           # one launch per 128-column block of x (= row block of the result)
             call("mma_gemm_bf16x3_tn", ptr(x[:, j:j + kb]), x.stride(0), ptr(g), g.stride(0), ptr(out[j:j + kb]), ptr(ws), n_ws, N, kb,
                  NC, stream_ptr())
@@ -255,7 +269,7 @@ def gemm_f16x2_tn(x, g, x_row_max=None, g_row_max=None):
     kb = KA if KA <= 128 else 128
     n_ws = int(_lib.lib().mma_gemm_f16x2_tn_workspace_floats(N, kb, NC))
     ws = torch.empty((n_ws,), device=x.device, dtype=torch.float32)
-    with _span("gemm_x3_tn"):
+    with _span("gemm_x3_tn", nbytes=4 * N * (KA + NC), flops=2 * N * KA * NC, mfma="f16x3"):
         for j in range(0, KA, kb):          # wider x (C5): 128-column blocks; the maxima of the whole row bound every block's
             call("mma_gemm_f16x2_tn", ptr(x[:, j:j + kb]), x.stride(0), ptr(g), g.stride(0),
                  ptr(x_row_max), ptr(g_row_max), ptr(out[j:j + kb]), ptr(ws), n_ws, N, kb,
@@ -298,7 +312,7 @@ def xt_g_batched(x, ka, g, nc, B):
         return torch.stack([xt_g(x[:, b * ka:(b + 1) * ka], g[:, b * nc:(b + 1) * nc]) for b in range(B)])
     out = torch.empty((B, ka, nc), device=x.device, dtype=torch.float32)
     ws = torch.empty((n_ws,), device=x.device, dtype=torch.float32) if n_ws else None
-    with _span("gemm_x3_tn"):
+    with _span("gemm_x3_tn", nbytes=4 * M * B * (ka + nc), flops=2 * M * B * ka * nc, mfma="bf16x6"):
         call("mma_gemm_bf16x3_tn_batched", ptr(x), x.stride(0), ka, ptr(g), g.stride(0), nc, ptr(out), ptr(ws), n_ws, M, ka, nc, B,
              stream_ptr())
     return out
@@ -369,7 +383,7 @@ class _Linear(torch.autograd.Function):
             O, K = weight.shape
             Wa, Wb = _skinny_weights(weight)
             y = torch.empty((x2.shape[0], O), device=x.device, dtype=torch.float32)
-            with _span("skinny_linear_fwd"):
+            with _span("skinny_linear_fwd", nbytes=4 * x2.shape[0] * (K + O), flops=2 * x2.shape[0] * Wa.shape[0] * Wa.shape[1], mfma="f32"):
                 call("mma_skinny_linear_fwd", ptr(x2), x2.stride(0), ptr(Wa), ptr(bias.contiguous() if bias is not None else None), ptr(y), O,
                      x2.shape[0], K, O, stream_ptr())
             ctx.save_for_backward(x, weight, Wb)
@@ -387,7 +401,8 @@ class _Linear(torch.autograd.Function):
                 O, K = weight.shape
                 g2 = g2 if g2.stride(1) == 1 else g2.contiguous()
                 gx2 = torch.empty((g2.shape[0], K), device=g.device, dtype=torch.float32)
-                with _span("skinny_linear_bwd"):
+                Wb_ = ctx.saved_tensors[2]
+                with _span("skinny_linear_bwd", nbytes=4 * g2.shape[0] * (K + O), flops=2 * g2.shape[0] * Wb_.shape[0] * (Wb_.shape[1] - 16), mfma="f32"):
                     call("mma_skinny_linear_bwd_dx", ptr(g2), g2.stride(0), ptr(ctx.saved_tensors[2]), ptr(gx2), K, g2.shape[0], K, O, stream_ptr())
                 gx = gx2.view(x.shape)
             else:

@@ -28,8 +28,13 @@ class _NoSpan:
         return False
 
 
-def _span(name):
-    return TIMER.span(name) if TIMER is not None else _NoSpan()
+def _span(name, nbytes=0, flops=0, mfma=None):
+    """A timed region around one C-ABI call (bench.py installs TIMER).  The call site states what the call HAS to do - nbytes: the HBM
+    bytes it must move with no credit for cache reuse (DESIGN.md 3 "algorithmic bytes"), flops: its fp32-equivalent multiply-adds x 2,
+    mfma: how those run on the matrix cores ("f16x3": three fp16 piece products per fp32 product, "bf16x6": six bf16 ones, "f32":
+    v_mfma_f32_16x16x4_f32 at the vector rate, None: no matrix work) - so that bench.py can put every kernel, not only the fused ones,
+    against its roofline (round-3 VERDICT item 1a).  The fused NC / GR kernels are priced by bench.py's own formulas."""
+    return TIMER.span(name, nbytes, flops, mfma) if TIMER is not None else _NoSpan()
 
 
 KIND = {"sum": 0, "mean": 1, "max": 2, "min": 3, "softmax": 4, "softmin": 5}
@@ -351,7 +356,8 @@ class _CsrSpmm(torch.autograd.Function):
         assert B.shape[0] == K * rows_per_block and rows_per_block == sg.n_cols
         C = B.shape[1]
         out = torch.empty((sg.n_rows, C), device=B.device, dtype=torch.float32)
-        with _span("csr_spmm_fwd"):
+        # per stored element: column id + value + the gathered row; per output row: row pointer / item + the row written
+        with _span("csr_spmm_fwd", nbytes=K * sg.col.numel() * (8 + 4 * C) + sg.n_rows * (16 + 4 * C), flops=2 * K * sg.col.numel() * C):
             _spmm_call(sg.rowptr, sg.col, sg.val, sg.items, sg.hubs, sg.n_slots, B, rows_per_block, K, bias, out, sg.n_rows, C,
                        sg.n_wave_items)
         ctx.sg, ctx.K, ctx.has_bias = sg, K, bias is not None
@@ -363,7 +369,7 @@ class _CsrSpmm(torch.autograd.Function):
         g = g.contiguous()
         C = g.shape[1]
         gB1 = torch.empty((sg.n_cols, C), device=g.device, dtype=torch.float32)
-        with _span("csr_spmm_bwd"):
+        with _span("csr_spmm_bwd", nbytes=sg.t_col.numel() * (8 + 4 * C) + sg.n_cols * (16 + 4 * C), flops=2 * sg.t_col.numel() * C):
             _spmm_call(sg.t_rowptr, sg.t_col, sg.t_val, sg.t_items, sg.t_hubs, sg.t_n_slots, g, sg.n_rows, 1, None, gB1, sg.n_cols, C,
                        sg.t_n_wave_items)
         gB = gB1 if K == 1 else gB1.unsqueeze(0).expand(K, -1, -1).reshape(K * sg.n_cols, C)  # every k-block sees the same A^T g
@@ -585,7 +591,7 @@ class _GRAggregate(torch.autograd.Function):
             return (gmsg.view(E, T, F),) + (None,) * 12
         cs = graph.by_source
         rows = graph.by_source_pos if by_pos else cs.perm      # gmsg rows: positions (by_pos) or original edge ids
-        with _span("gr_segsum"):
+        with _span("gr_segsum", nbytes=E * (4 + 4 * D) + N * (4 + 4 * D), flops=E * D):
             call("mma_csr_spmm", ptr(cs.rowptr), ptr(rows), None, ptr(gmsg), gmsg.stride(0), E, 1, None, ptr(gUV[:, D:]), gUV.stride(0), N, D,
                  stream_ptr())
         gz = gmsg if has_z else None
@@ -621,7 +627,8 @@ class _TowerPost(torch.autograd.Function):
         key = (N, tuple(scalers), float(avg_log), float(avg_lin))
         cache = getattr(rowptr, "_mma_post_pre", None)
         pre = cache[1] if cache is not None and cache[0] == key else None
-        with _span("tower_post_fwd"):
+        # agg rows in, y rows out, the scaler table; S x 16 padded outputs per (node, tower, kf) on the fp32 matrix cores
+        with _span("tower_post_fwd", nbytes=4 * N * (T * KF + T * O + 8), flops=2 * N * T * KFp * S * 16, mfma="f32"):
             if pre is None:
                 pre = torch.empty((N, 8), device=agg.device, dtype=torch.float32)
                 call("mma_tower_post_pre", ptr(rowptr), ptr(pre), N, S, host_codes(scalers), float(avg_log), float(avg_lin), stream_ptr())
@@ -645,7 +652,8 @@ class _TowerPost(torch.autograd.Function):
         gy = gy.contiguous()
         gagg = torch.empty_like(agg)
         need_w = ctx.needs_input_grad[1]
-        with _span("tower_post_bwd"):
+        KFp = Wb.shape[2] - 16
+        with _span("tower_post_bwd", nbytes=4 * N * (T * KF + T * O + 8), flops=2 * N * T * KFp * S * 16, mfma="f32"):
             call("mma_tower_post_bwd", ptr(gy), T * O, ptr(pre), ptr(Wb), ptr(gagg), T * KF, None, 0, N, T, KF, S, O,
                  host_codes(scalers), float(avg_log), float(avg_lin), stream_ptr())
         gWo = None
@@ -655,7 +663,7 @@ class _TowerPost(torch.autograd.Function):
             kfp16 = -(-KF // 16) * 16
             n_chunks = int(_lib.lib().mma_tower_post_gw_chunks(N, T))
             part = torch.empty((n_chunks, T * S * 16 * kfp16), device=agg.device, dtype=torch.float32)
-            with _span("tower_post_gw"):
+            with _span("tower_post_gw", nbytes=4 * N * (T * KF + T * O + 8) + 4 * part.numel(), flops=2 * N * T * kfp16 * S * 16, mfma="f32"):
                 call("mma_tower_post_gw", ptr(gy), T * O, ptr(agg), T * KF, ptr(pre), ptr(part), n_chunks, N, T, KF, S, O,
                      host_codes(scalers), float(avg_log), float(avg_lin), stream_ptr())
                 gWq = dense.col_sum(part).view(T, S, 16, kfp16)

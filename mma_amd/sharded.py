@@ -74,15 +74,50 @@ def all_to_all_rows(send, send_counts, recv_counts, group=None):
     return recv
 
 
+class ExchangeLog:
+    """What the halo exchanges of this rank moved and how long they took (bench.py's per-rank diagnosis, round-3 VERDICT item 3).
+    bytes: payload rows x row bytes, by direction, counted at every all_to_all_rows_start().  With `timed` set (bench.py, during the
+    timed steps) every exchange also gets two events: e0 on the compute stream where the collective is enqueued (its send buffer
+    is packed by then), e1 on a SIDE stream that waits for nothing but the collective - so e0 -> e1 is the exchange itself
+    (launch to last byte received, waiting for slower peers included), whatever compute the layer queues meanwhile."""
+
+    def __init__(self):
+        self.reset()
+        self.timed = False
+        self._side = {}
+
+    def reset(self):
+        self.calls = 0
+        self.bytes_sent = 0
+        self.bytes_received = 0
+        self.events = []
+
+    def side_stream(self, device):
+        key = str(device)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=device)
+        return self._side[key]
+
+    def exchange_ms(self):
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.events)
+
+
+EXCHANGE_LOG = ExchangeLog()
+
+
 class _A2AHandle:
     """An all-to-all-v in flight.  NCCL/RCCL: runs on the communicator's own stream beside the compute stream;
     wait() makes the compute stream wait for it (no host sync).  gloo (tests): already done when returned."""
 
-    def __init__(self, work, recv, keep):
-        self.work, self.recv, self.keep = work, recv, keep
+    def __init__(self, work, recv, keep, done=None):
+        self.work, self.recv, self.keep, self.done = work, recv, keep, done
 
     def wait(self):
-        if self.work is not None:
+        if self.done is not None:                # timed form: the side stream already waits for the collective; wait for ITS event
+            torch.cuda.current_stream().wait_event(self.done)
+            self.done = self.work = None
+        elif self.work is not None:
             self.work.wait()
             self.work = None
         self.keep = None
@@ -92,17 +127,40 @@ class _A2AHandle:
 def all_to_all_rows_start(send, send_counts, recv_counts, group=None, out=None):
     """Start an all-to-all-v of row blocks; `out` (n_recv, W) may be a row slice of a larger buffer."""
     n_recv = int(sum(recv_counts))
+    log = EXCHANGE_LOG
+    row_bytes = send.element_size() * int(np.prod(send.shape[1:])) if send.dim() > 1 else send.element_size()
+    log.calls += 1
+    log.bytes_sent += int(sum(send_counts)) * row_bytes
+    log.bytes_received += n_recv * row_bytes
+    timed = log.timed and send.is_cuda
+    if timed:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     if _backend(group) == "gloo" and send.is_cuda:      # test path: synchronous, staged through the host
         r = all_to_all_rows(send, send_counts, recv_counts, group)
         if out is not None:
             out.copy_(r)
             r = out
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            log.events.append((e0, e1))
         return _A2AHandle(None, r, None)
     recv = out if out is not None else torch.empty((n_recv,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
     send = send.contiguous()
     work = dist.all_to_all_single(recv, send, [int(c) for c in recv_counts], [int(c) for c in send_counts], group=group,
                                   async_op=True)
-    return _A2AHandle(work, recv, send)
+    if not timed:
+        return _A2AHandle(work, recv, send)
+    # e1 on a side stream that waits for the collective only (Work.wait() blocks the CURRENT stream, here the side stream); the
+    # compute stream later waits for e1 - the same dependency as work.wait() on it, one event further
+    side = log.side_stream(send.device)
+    e1 = torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(side):
+        work.wait()
+        e1.record()
+    log.events.append((e0, e1))
+    return _A2AHandle(work, recv, send, done=e1)
 
 
 def all_reduce_sum(t, group=None):

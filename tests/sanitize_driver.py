@@ -131,7 +131,10 @@ def recipe(lib, name, rng, keep):
         return dict(lda=C + rng.choice([0, 5]), M=M, cols=C)
     if name == "mma_split_f16x2":
         K, Nc = rng.choice([(128, 1024), (1024, 128), (256, 4096), (1, 1), (1 << 20, 4096)])
-        return dict(stride_k=rng.choice([Nc, 1]), stride_n=rng.choice([1, K]), K=K, N=Nc)
+        return dict(stride_k=rng.choice([Nc, 1]), stride_n=rng.choice([1, K]), K=K, N=Nc, plain_lo=rng.choice([0, 1]))
+    if name == "mma_gemm_f16x2_nlp":
+        M, Nc, K = rng.choice([(0, 128, 256), (1, 128, 1024), (1 << 20, 256, 4096), (70001, 128, 1024), (1000, 256, 256), (5, 128, 192), (5, 64, 256)])
+        return dict(lda=K + rng.choice([0, 64]), ldc=Nc + rng.choice([0, 4]), M=M, N=Nc, K=K, accumulate=rng.choice([0, 1]))
     if name == "mma_col_sum":
         R, C = rng.choice([(0, 7), (1, 1), (1000, 375), (204552, 375), (427376, 75), (300001, 130), (1 << 31, 16)])
         lib.mma_col_sum_workspace_floats.restype = ctypes.c_int64

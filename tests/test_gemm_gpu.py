@@ -192,6 +192,8 @@ def test_split_f16x2_one_launch_matches_the_torch_expression(K, N, transposed):
     x = (w * s).t().contiguous()
     hi = x.half()
     assert torch.equal(cu, 1.0 / s) and torch.equal(bt2[0], hi) and torch.equal(bt2[1], ((x - hi.float()) * 2048.0).half())
+    bt2p, cup = dense._split_f16x2(w, plain_lo=True)                     # the one-accumulator kernels' operand: lo as it is
+    assert torch.equal(cup, cu) and torch.equal(bt2p[0], hi) and torch.equal(bt2p[1], (x - hi.float()).half())
 
 
 @pytest.mark.parametrize("M,C,pad", [(1, 1, 0), (7, 33, 3), (70001, 256, 0), (5000, 75, 5), (1025, 4096, 0)])
@@ -350,6 +352,44 @@ def test_gemm_f16x2_edge_rows():
     assert (got[3] == 0).all()
     assert err[scale > 0].max().item() < 5e-7, err[scale > 0].max().item()
     assert torch.equal(got, dense.gemm_f16x2(av, w))
+
+
+@pytest.mark.parametrize("M,K,N,acc", [(70001, 1024, 256, True), (66000, 4096, 256, False), (65536 + 255, 256, 128, True), (300, 512, 256, True)])
+def test_gemm_f16x2_nlp_one_accumulator_form(M, K, N, acc, monkeypatch):
+    """Round 4: the pipelined dL/dx kernel (mma_gemm_f16x2_nlp) - PLAIN lo pieces in both operands, one fp32 accumulator tile, two raw
+    chunks of A in flight, N = 128 or 256 in ONE pass - against float64 under the bound of the two-accumulator form (5e-7 sum|a||b| and
+    the one fp32 addition onto C), with rows of very different sizes, a wide range INSIDE rows (elements 2^-20 of their row maximum keep
+    their relative precision in the bound's terms), all-zero rows, loose row bounds, ragged M (also fewer rows than one 256-row unit),
+    bit-repeatable; and against the two-accumulator kernel it replaces."""
+    from mma_amd import dense
+    rng = np.random.default_rng(M + K + N)
+    a = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-12, 12, (M, 1)))).astype(np.float32)
+    a[7] *= np.exp(rng.uniform(-14, 0, K)).astype(np.float32)            # a wide range inside one row
+    a[5] = 0.0
+    a[M - 1] = 0.0
+    at = torch.from_numpy(a).to(DEV)
+    w = torch.from_numpy(((rng.random((K, N)) * 2 - 1) / np.sqrt(K) * np.exp(rng.uniform(-2, 2, (1, N)))).astype(np.float32)).to(DEV)
+    c0 = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV) if acc else torch.zeros((M, N), device=DEV)
+    rm = at.abs().amax(1)
+    rm[::3] *= 8.0                                               # a bound, not the exact maximum
+    assert dense.USE_NLP
+    out = c0.clone()
+    dense.gemm_f16x2_n128(at, rm, w, out, accumulate=acc)
+    prod = at.double() @ w.double()
+    scale = at.double().abs() @ w.double().abs()
+    got_prod = out.double() - (c0.double() if acc else 0)
+    nz = scale > 0
+    tol = 5e-7 * scale + (1.2e-7 * c0.double().abs() if acc else 0)      # + the one fp32 addition onto c0
+    assert ((got_prod - prod).abs()[nz] <= tol[nz]).all(), ((got_prod - prod).abs() / scale.clamp_min(1e-300))[nz].max().item()
+    assert torch.equal(out[5], c0[5]) and torch.equal(out[M - 1], c0[M - 1])
+    again = c0.clone()
+    dense.gemm_f16x2_n128(at, rm, w, again, accumulate=acc)
+    assert torch.equal(again, out)
+    if M >= (1 << 16):                                           # the two-accumulator kernel it replaces (its own launcher wants tall inputs)
+        monkeypatch.setattr(dense, "USE_NLP", False)
+        old = c0.clone()
+        dense.gemm_f16x2_n128(at, rm, w, old, accumulate=acc)
+        assert ((old.double() - out.double()).abs()[nz] <= 2 * tol[nz]).all()
 
 
 @pytest.mark.parametrize("M,K,acc", [(70001, 1024, True), (66000, 512, False), (65536 + 255, 192, True)])

@@ -60,6 +60,13 @@ def traffic(base, out, workload, note):
     stamp_file = os.path.join(ROOT, base + "_stamp.json")
     from tools.build_stamp import build_stamp
     stamp = json.load(open(stamp_file)) if os.path.exists(stamp_file) and os.path.getsize(stamp_file) else build_stamp()
+    # the average duration of every kernel in the --kernel-trace --stats pass of the same command: bench.py's roofline.frac_rocprof
+    avg_ns = {}
+    try:
+        for r in csv.DictReader(open(find(base + "_stats/**/*kernel_stats.csv"))):
+            avg_ns[r["Name"]] = float(r["AverageNs"])
+    except SystemExit:
+        pass
     res = {"note": note, "workload": workload, "build": stamp,
            "correction": "traffic_bytes = 2*FETCH_SIZE_KiB*1024 + WRITE_SIZE_KiB*1024 (gfx950: FETCH_SIZE halves wide reads; MI355X_MICROARCH.md HBM)",
            "kernels": {}}
@@ -67,7 +74,8 @@ def traffic(base, out, workload, note):
         if "mma::" in k:
             n, f = F[k]
             w = W.get(k, (0, 0.0))[1]
-            res["kernels"][k] = {"launches_sampled": n, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes": 2 * f * 1024 + w * 1024}
+            res["kernels"][k] = {"launches_sampled": n, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes": 2 * f * 1024 + w * 1024,
+                                 "rocprof_avg_ns": avg_ns.get(k)}
     json.dump(res, open(out, "w"), indent=1)
     return res
 
@@ -81,8 +89,10 @@ def bench_line(log, out):
         if r:
             wl = {"workload": "c2l", "nodes": c["nodes"], "edges": c["edges"]} if "towers" in c else \
                 {"nodes": c["nodes"], "edges": c["edges"], "hidden": c["hidden"], "K": c["K"]}
-            t, src = bench.pmc_traffic(r["kernel"], wl)
+            t, src, rms = bench.pmc_traffic(r["kernel"], wl)
             r["traffic"], r["traffic_source"] = t, bench._traffic_source(t, src)
+            if rms and r.get("algorithmic_bytes"):
+                r["frac_rocprof"] = r["algorithmic_bytes"] / (rms * 1e-3) / 1e9 / r["peak"]
     json.dump(b, open(out, "w"))
     return b
 
