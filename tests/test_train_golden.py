@@ -171,3 +171,108 @@ def test_hip_model_walks_the_reference_training_trajectory(fx, sparse_first_laye
         losses.append(loss.item())
     assert np.allclose(losses, z["losses"], rtol=1e-5, atol=1e-5), (losses, z["losses"])
     _check_final(fx, {n: getattr(model, n).detach() for n in ("weight0", "bias0", "weight1", "bias1", "weight_mean", "weight_mean2")}, out[idx])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sparse_first_layer,fused_step", [(True, False), (False, False), (True, True)])
+def test_trajectory_noise_is_single_step_rounding_amplified_by_adam(fx, capsys, sparse_first_layer, fused_step):
+    """Round-3 VERDICT item 4: the final log-probabilities of the 3-epoch trajectory needed 4.32 (of the 8 then allowed) times the
+    reference's own fp32 noise.  WHICH operation moves them?  Three trajectories on the fixture's inputs - the oracle in float64 (exact
+    arithmetic of the reference's formulas), the oracle in float32 (the reference's numerics: pinned to it within the strict bar by
+    test_oracle_walks_the_reference_training_trajectory), the HIP model - compared epoch by epoch, free-running and TEACHER-FORCED
+    (the HIP model restarted every epoch from the float32 oracle's parameters and Adam state, so that it takes exactly one step from
+    the same point).  Finding (printed below, quoted in DESIGN.md 6): from the same point the HIP step is as close to the float32
+    oracle as that is to exact arithmetic (multiple <= ~1.5 in every epoch, every kernel involved: sparse first layer, fused
+    aggregate, SpMM tail, log-softmax, Adam); free-running, the differences of epoch 1 - rounding-level differences in gradient
+    elements whose magnitude is near Adam's eps, where the update lr g / (sqrt(v) + eps) turns a relative change of g into an absolute
+    change of the weight - are carried and amplified by the next steps like the reference's own noise is.  It is accumulation order
+    through an ill-conditioned optimiser step, not a kernel."""
+    import mma_amd
+    from mma_amd import functional as Fn
+    from mma_amd.models import MMAConv
+    from oracle import nc_oracle as O
+    z = fx.z
+    labels_c, idx_c = torch.from_numpy(fx.labels), torch.from_numpy(fx.idx_train)
+    used = ["weight0", "bias0", "weight1", "bias1"] + ["weight_" + a for a in fx.aggs]
+
+    def oracle_run(dtype):
+        x = torch.from_numpy(fx.features).to(dtype)
+        prm = {n: torch.from_numpy(v.copy()).to(dtype).requires_grad_(n in used) for n, v in fx.prm.items()}
+        opt = torch.optim.Adam([prm[n] for n in fx.prm], lr=fx.lr, weight_decay=fx.wd)
+        snaps, logps = [], []
+        for ep in range(fx.epochs):
+            snaps.append(({n: prm[n].detach().clone() for n in used},
+                          {n: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state[prm[n]].items()} for n in used if prm[n] in opt.state}))
+            opt.zero_grad()
+            out = O.model_forward(x, prm, fx.aggs, fx.rowptr, fx.col, z["adj_row"], z["adj_col"], z["adj_val"], "new_sigmoid", fx.p,
+                                  fx.hidden_keep(ep), {a: fx.mask_keep(ep, a) for a in fx.aggs})
+            torch.nn.functional.nll_loss(out[idx_c], labels_c[idx_c]).backward()
+            opt.step()
+            logps.append(out[idx_c].detach().double().numpy())
+        return snaps, logps
+
+    snaps32, logp32 = oracle_run(torch.float32)
+    _, logp64 = oracle_run(torch.float64)
+
+    x = torch.from_numpy(fx.features).to(DEV)
+    idxa = torch.from_numpy(np.stack([z["adj_row"], z["adj_col"]]).astype(np.int64))
+    adj = torch.sparse_coo_tensor(idxa, torch.from_numpy(z["adj_val"]), (fx.N, fx.N)).to(DEV)
+    labels, idx = labels_c.to(DEV), idx_c.to(DEV)
+
+    from mma_amd.train_step import FusedAdam
+    Opt = FusedAdam if fused_step else torch.optim.Adam
+
+    def hip_model():
+        m = MMAConv(fx.add_all, "new_sigmoid", 2, fx.nfeat, fx.H, fx.nclass, fx.p, fx.aggs, DEV)
+        if not sparse_first_layer:
+            m.gc1.SPARSE_BELOW = 0.0                                   # dense (library) GEMM for the first layer
+        with torch.no_grad():
+            for n, v in fx.prm.items():
+                getattr(m, n).copy_(torch.from_numpy(v))
+        m.train()
+        return m
+
+    def hip_epoch(m, opt, ep):
+        m.hidden_keep = torch.from_numpy(fx.hidden_keep(ep)).to(DEV)
+        keep = torch.from_numpy(np.stack([fx.mask_keep(ep, a) for a in fx.aggs]).astype(np.uint8)).to(DEV)
+        m.gc2.drop_override = Fn.DropoutSpec(fx.p, keep=keep)
+        opt.zero_grad()
+        if fused_step:
+            loss, out = m.nll_loss(x, adj, idx, labels)
+        else:
+            out = m(x, adj)
+            loss = torch.nn.functional.nll_loss(out[idx], labels[idx])
+        loss.backward()
+        opt.step()
+        return out[idx].detach().double().cpu().numpy()
+
+    def need(got, ep):
+        ref, truth = logp32[ep], logp64[ep]
+        noise = np.abs(ref - truth).max(1, keepdims=True)
+        err = np.abs(got - ref)
+        over = np.maximum(err - (1e-5 + 1e-5 * np.abs(ref)), 0.0) / np.maximum(noise, 1e-30)
+        return float(over[np.broadcast_to(noise, err.shape) > 0].max()), float(np.abs(ref - truth).max()), float(err.max())
+
+    m = hip_model()
+    opt = Opt([getattr(m, n) for n in fx.prm], lr=fx.lr, weight_decay=fx.wd)
+    free = [need(hip_epoch(m, opt, ep), ep) for ep in range(fx.epochs)]
+    forced = []
+    for ep in range(fx.epochs):
+        m = hip_model()
+        opt = Opt([getattr(m, n) for n in fx.prm], lr=fx.lr, weight_decay=fx.wd)
+        prm32, st32 = snaps32[ep]
+        with torch.no_grad():
+            for n in used:
+                getattr(m, n).copy_(prm32[n])
+        for n, st in st32.items():                                   # Adam's moments and step of the float32 oracle at this point
+            opt.state[getattr(m, n)] = {k: (v.to(DEV).float() if torch.is_tensor(v) else v) for k, v in st.items()}
+        forced.append(need(hip_epoch(m, opt, ep), ep))
+    with capsys.disabled():
+        print("\n[trajectory noise] variant: %s first layer, %s loss + optimiser" % ("sparse (K5)" if sparse_first_layer else "dense (library GEMM)",
+                                                                                      "fused K10 + K11" if fused_step else "torch"))
+        print("[trajectory noise] epoch | max |fp32 oracle - fp64| of the train log-probabilities | free-running HIP: max |HIP - fp32|, multiple of "
+              "the row's reference noise needed | teacher-forced HIP: the same")
+        for ep in range(fx.epochs):
+            print("[trajectory noise]   %d   | %.3g | %.3g, %.2f | %.3g, %.2f" % (ep + 1, free[ep][1], free[ep][2], free[ep][0], forced[ep][2], forced[ep][0]))
+    assert max(f[0] for f in forced) <= 2.0, forced            # ONE step from the same point: within twice the reference's own noise
+    assert max(f[0] for f in free) <= 6.0, free
