@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 30
+#define MMA_ABI_VERSION 31
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -223,6 +223,15 @@ int mma_gemm_f16x2_n128(const float* A, int64_t lda, const float* row_max, const
  * 64-deep chunk).  accumulate != 0: C += A B by a plain read - add - store (every element has exactly one writer). */
 int mma_gemm_f16x2_nlp(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale,
                        float* C, int64_t ldc, int64_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
+/* ABI 31: the forward product C (M, N) = A (M, K) B for K = 128 or 256 and N a multiple of 256 with N / 256 dividing 32, on the
+ * W-STATIONARY kernel: a wave keeps its 32 columns of B in registers for the whole launch, the eight waves of a workgroup load each
+ * 64-row (K = 256: 32-row) slice of A together, row-major (whole lines), form the row maxima and power-of-two row scales and split
+ * once, and share the fp16 pieces through LDS.  Same products in the same order as mma_gemm_f16x2: bit-identical results.  Bt2 = (2, N, K)
+ * and col_unscale (N,) from mma_split_f16x2 (plain_lo = 0).  a_row_max (M,) or NULL: receives max |A[i,:]| (K = 256 callers no longer
+ * need the mma_row_absmax pass).  MMA_FWD_WS=1 in the environment makes mma_gemm_f16x2 take this kernel when the shape fits (default: the
+ * column-group kernel, which is faster as measured in round 4: 1.06 vs 1.37 ms at M = 2^20, N = 1024). */
+int mma_gemm_f16x2_ws(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,
+                      float* a_row_max, int64_t M, int32_t N, int32_t K, void* stream);
 /* TN form for the weight gradients (autograd's x^T g of layers.py:215-216's torch.mm): C (KA,NC) = X^T G with X (M,KA),
  * G (M,NC) fp32 row-major, C contiguous.  Any 1 <= KA <= 128 and NC >= 1 (ragged tiles are clamped on load and guarded on
  * store; KA % 32 == 0 with NC % 128 == 0 runs without the guards).  Both operands are split to bf16x3 on the

@@ -499,6 +499,186 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
                                           kCgStoreAux);
 }
 
+// ---- forward, W-STATIONARY (round 4): C (M, N) = x (M, K) W (K, N), K = 128 or 256, N % 256 == 0 ------------------------------------------
+// The column-group kernels above keep W in LDS and stream x through registers in the MFMA's fragment shape: 32 rows x 32 bytes per load
+// instruction - ~32 line requests to the texture addresser for 1 KB, and every 256-column (K = 256: 128-column) group of the same
+// rows loads them again.  Measurement builds at C4: the stores alone 0.75 ms, everything but the x loads 0.81, with them 1.04 - the
+// loads cost by being there, whether waited for or not (an asm-prefetched form changed nothing).  Here the roles are swapped:
+//   * a WAVE keeps its own 32 columns of W in registers for the whole launch (both fp16 pieces of all K/16 k-steps: 64 VGPRs at
+//     K = 128, 128 at K = 256) - there is no B slab in LDS, no fragment read of B, and LDS is free for x;
+//   * the eight waves of a workgroup (256 columns) load each 64-row (K = 256: 32-row) slice of x TOGETHER, row-major: one load
+//     instruction covers two whole rows (K = 256: one), 8 lines instead of 32; a row's maximum is a butterfly over the lanes that hold
+//     it, the power-of-two row scale and the split are done ONCE per row (not once per wave that multiplies it), and the fp16 pieces go to
+//     LDS in the MFMA's A-fragment order, [block][piece][k-step][lane][8 halves], which every wave then reads with lane-linear
+//     ds_read_b128 (conflict-free);
+//   * two LDS slots: iteration i multiplies slot i % 2 while the slice for iteration i+1 - requested at the top of iteration i, so that
+//     it is in flight behind the multiplications and is both issued and waited for inside ONE iteration (no load crosses the loop's
+//     back edge: hipcc merges entry and back edge into a full vmcnt drain otherwise) - is split and written to the other slot at the
+//     bottom; one barrier per iteration;
+//   * the stores of a finished 32 x 32 tile ride between the MFMAs of the next one (as in the column-group kernels, [r4]).
+// Same products in the same order as gemm_f16x2_colgroup_kernel (hi lo, lo hi into one accumulator, hi hi into the other, lo pieces
+// pre-scaled by 2^11): the results are bit-identical to it.  Bt2 = (2, N, K) as for mma_gemm_f16x2.
+template <int KS, int RBI>
+__global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_ws_kernel(const GemmParams p, const float* col_unscale, int64_t n_rgroups,
+                                                                     int n_cgroups, float* a_row_max) {
+  constexpr int K = 16 * KS;
+  constexpr int RI = 32 * RBI;                             // rows per iteration (a "row group")
+  constexpr int kKsP = 1024 + 32;                          // bytes per (piece, k-step) block of A fragments; the pad spreads the k-steps over the banks
+  constexpr int kPieceP = KS * kKsP, kBlkP = 2 * kPieceP;  // piece / 32-row block pitch
+  constexpr int kSlot = RBI * kBlkP + RI * 4;              // + the rows' scale exponents
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kSlot];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, h = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+  const int streams_per_xcd = kCgSlotsPerXcd / n_cgroups;
+  if (slot_id >= streams_per_xcd * n_cgroups) return;      // (before any barrier)
+  const int cg = slot_id % n_cgroups;
+  const int64_t stream = xcd * streams_per_xcd + slot_id / n_cgroups, n_streams = 8 * streams_per_xcd;
+  const int col0 = cg * 256 + wave * 32;                   // this wave's 32 columns
+
+  // W: this wave's columns, both pieces, every k-step - B[k][n]: lane (n = r31, h) holds k = 16 ks + 8 h + 0..7 of column col0 + r31
+  f16x8 wh[KS], wl[KS];
+  {
+    const _Float16* Bh = reinterpret_cast<const _Float16*>(p.Bt);
+    const _Float16* wp = Bh + (size_t)(col0 + r31) * K + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      wh[ks] = *reinterpret_cast<const f16x8*>(wp + ks * 16);
+      wl[ks] = *reinterpret_cast<const f16x8*>(wp + (size_t)p.N * K + ks * 16);
+    }
+  }
+  const int cue = (int)((__float_as_uint(col_unscale[col0 + r31]) >> 23) & 0xFF) - 127;     // log2 of this lane's column un-scale
+  const uint32_t c_off = (4u * h * (uint32_t)p.ldc + (uint32_t)r31) * 4u;
+  const uint32_t pcol = (uint32_t)col0 * 4u;
+
+  // producer role: this wave prepares rows [wave * 4 RBI, +4 RBI) of every row group; 4 float4 per lane, row-major
+  constexpr int C4 = K / 4;                                // float4 per row: 32 or 64
+  int p_row[4], p_k0[4];                                   // row inside the group and first k of the lane's float4 number i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = lane + 64 * i;
+    p_row[i] = wave * (4 * RBI) + f / C4;
+    p_k0[i] = 4 * (f % C4);
+  }
+  float4 raw[4];
+#define MMA_WS_LOAD(G_)                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+    const int64_t row = min((G_) * RI + p_row[i], p.M - 1);          /* rows past M re-read the last row; never stored */ \
+    raw[i] = *reinterpret_cast<const float4*>(p.A + row * p.lda + p_k0[i]);                        \
+  }
+// raw (rows of group G_) -> row maxima, scale exponents and fragment-ordered fp16 pieces in LDS slot S_
+#define MMA_WS_PRODUCE1(G_, S_, I_)                                                               \
+  {                                                                                                \
+    unsigned char* sl_ = lds + (S_) * kSlot;                                                       \
+    /* pins the part HERE: arithmetic on the loaded values is free to move up to the loads otherwise (IR-level code motion does not */ \
+    /* see sched_barrier) - and with it the wait for them, in front of the iteration's stores (seen in the K = 256 ISA: vmcnt(3)) */  \
+    asm volatile("" : "+v"(raw[I_].x), "+v"(raw[I_].y), "+v"(raw[I_].z), "+v"(raw[I_].w));          \
+    float rmax = fmaxf(0.f, fmaxf(fmaxf(fabsf(raw[I_].x), fabsf(raw[I_].y)), fmaxf(fabsf(raw[I_].z), fabsf(raw[I_].w))));   \
+    _Pragma("unroll") for (int o = 1; o < C4; o <<= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o, 64));            \
+    const int ex = (int)((__float_as_uint(rmax) >> 23) & 0xFF);                                    \
+    const int sce = min(max(14 - (ex - 127), -126), 127);            /* the row maximum lands in [2^14, 2^15) */ \
+    const float sc = __uint_as_float((uint32_t)(sce + 127) << 23);                                 \
+    if ((lane & (C4 - 1)) == 0) {                                    /* one lane per row */        \
+      reinterpret_cast<int*>(sl_ + RBI * kBlkP)[p_row[I_]] = sce;                                  \
+      const int64_t grow = (G_) * RI + p_row[I_];                                                  \
+      if (a_row_max && cg == 0 && grow < p.M) a_row_max[grow] = rmax;        /* for the weight-gradient product (TN form) */ \
+    }                                                                                              \
+    const float v[4] = {raw[I_].x * sc, raw[I_].y * sc, raw[I_].z * sc, raw[I_].w * sc};           \
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));                                       \
+    h4 hi, lo;                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+      hi[j] = (_Float16)v[j];                                                                      \
+      lo[j] = (_Float16)((v[j] - (float)hi[j]) * 2048.f);                                          \
+    }                                                                                              \
+    const int blk_ = p_row[I_] >> 5, m_ = p_row[I_] & 31, k0 = p_k0[I_];                           \
+    unsigned char* d = sl_ + blk_ * kBlkP + (k0 >> 4) * kKsP + (m_ + 32 * ((k0 >> 3) & 1)) * 16 + (k0 & 7) * 2;  \
+    *reinterpret_cast<h4*>(d) = hi;                                                                \
+    *reinterpret_cast<h4*>(d + kPieceP) = lo;                                                      \
+  }
+#define MMA_WS_PRODUCE(G_, S_) { MMA_WS_PRODUCE1(G_, S_, 0) MMA_WS_PRODUCE1(G_, S_, 1) MMA_WS_PRODUCE1(G_, S_, 2) MMA_WS_PRODUCE1(G_, S_, 3) }
+
+  // the finished tile waiting to be stored: values, descriptor (ZERO bytes before the first tile: the range check drops those stores)
+  float prev[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) prev[r] = 0.f;
+  __amdgpu_buffer_rsrc_t crow_p = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000);
+
+  if (stream < n_rgroups) {
+    MMA_WS_LOAD(stream)
+    MMA_WS_PRODUCE(stream, 0)
+  }
+  __syncthreads();
+  int it = 0;
+  for (int64_t gI = stream; gI < n_rgroups; gI += n_streams, ++it) {
+    const int64_t gN = gI + n_streams < n_rgroups ? gI + n_streams : gI;        // the last group requests its own rows again (4 loads, unused)
+    MMA_WS_LOAD(gN)
+    const unsigned char* sl = lds + (it & 1) * kSlot;
+#pragma unroll
+    for (int blk = 0; blk < RBI; ++blk) {
+      const int64_t row0 = gI * RI + blk * 32;
+      const int64_t rows_here = min((int64_t)32, p.M - row0);
+      const __amdgpu_buffer_rsrc_t crow = __builtin_amdgcn_make_buffer_rsrc(
+          p.C + min(row0, p.M - 1) * p.ldc, 0, rows_here > 0 ? (int)min((int64_t)0x7fffffff, rows_here * p.ldc * 4) : 0, 0x00020000);
+      f32x16 acc, acl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acl[r] = 0.f; }
+      const unsigned char* fa = sl + blk * kBlkP + lane * 16;
+      f16x8 ah = *reinterpret_cast<const f16x8*>(fa), al = *reinterpret_cast<const f16x8*>(fa + kPieceP);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        f16x8 nh = ah, nl = al;
+        if (ks + 1 < KS) {
+          nh = *reinterpret_cast<const f16x8*>(fa + (ks + 1) * kKsP);
+          nl = *reinterpret_cast<const f16x8*>(fa + kPieceP + (ks + 1) * kKsP);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[ks], acl, 0, 0, 0);
+        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[ks], acl, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 16 / KS; ++j) {                          // 2 stores of the previous tile per k-step (K = 128), 1 (K = 256)
+          const int r = (16 / KS) * ks + j;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[r]), crow_p, c_off,
+                                                (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc) * 4u + pcol, kCgStoreAux);
+        }
+        // the NEXT group's rows, one load's worth (a row or two) every KS/4 k-steps of the group's last block: row maximum, scale, split
+        // and the LDS writes sit in the MFMAs' shadow like the stores do - at the bottom of the iteration all eight waves did them
+        // at once, with the matrix pipe and the store queue idle (1.36 ms at C4 against the column-group kernel's 1.10)
+        if (blk == RBI - 1 && (ks % (KS / 4)) == KS / 4 - 1) {
+          constexpr int dummy_ = 0; (void)dummy_;
+          switch (ks / (KS / 4)) {
+            case 0: MMA_WS_PRODUCE1(gN, (it + 1) & 1, 0) break;
+            case 1: MMA_WS_PRODUCE1(gN, (it + 1) & 1, 1) break;
+            case 2: MMA_WS_PRODUCE1(gN, (it + 1) & 1, 2) break;
+            default: MMA_WS_PRODUCE1(gN, (it + 1) & 1, 3) break;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ah = nh; al = nl;
+      }
+      // the scale exponents of the 16 rows this lane's accumulator registers hold, rows (r&3) + 8 (r>>2) + 4h - fetched now, not before
+      // the k-steps: at K = 256 (128 registers of W) sixteen more live registers through the loop meant spills
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int4 e4 = *reinterpret_cast<const int4*>(sl + RBI * kBlkP + (blk * 32 + 8 * q + 4 * h) * 4);
+        const int rse[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) prev[4 * q + j] = ldexpf(acc[4 * q + j] + acl[4 * q + j] * (1.f / 2048.f), cue - rse[j]);
+      }
+      crow_p = crow;
+    }
+    __syncthreads();
+  }
+#undef MMA_WS_LOAD
+#undef MMA_WS_PRODUCE
+#undef MMA_WS_PRODUCE1
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[r]), crow_p, c_off, (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc) * 4u + pcol,
+                                          kCgStoreAux);
+}
+
 // ---- K == 256, three products (round 2, late): the forward [P|Q] = x [Wtop|Wbot] of hidden width 256 (C5) -----------------------------
 // The column-group form with a 256-deep reduction: a workgroup owns 128 columns, their B slab (2 pieces x 128 columns x 256 k fp16 = 135 KB
 // with the row padding) stays in LDS for the whole launch, a wave's 32 rows (256 floats each) are loaded once, scaled by the power of
@@ -1416,6 +1596,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 constexpr int kTn2Slab = 2 * kTnPiece;           // 20 KB
 constexpr int kTnMaxSpread = 40;
 
+__global__ void tn_state_init_kernel(int* state) {
+  if (threadIdx.x < 4) state[threadIdx.x] = 0;
+}
+
 __global__ __launch_bounds__(256) void tn_scale_range_kernel(const float* xmax, const float* gmax, int64_t M, int* state) {
   // a FEW workgroups, grid-stride, one atomic each: 16 000 wavefronts updating the same three words took 0.37 ms at M = 2^20
   __shared__ int red[3][4];
@@ -1762,6 +1946,16 @@ extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, cons
   MMA_REQUIRE(A && Bt2 && col_unscale && C && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt2) & 15) == 0,
               "NULL or misaligned argument");
   GemmParams p{A, lda, static_cast<const __bf16*>(Bt2), C, ldc, M, N, 128, 0};
+  // MMA_FWD_WS=1: the W-stationary kernel (A/B switch, read per call).  Measured SLOWER than the column-group kernel (C4 1.37 vs 1.06 ms,
+  // C5 8.4 vs 7.8 ms): its waves meet at a barrier every 64 rows, and a wave's wait for the next rows is a wait for every store it issued
+  // before them (one in-order vmcnt) - see DESIGN.md "forward GEMM, round 4"; kept for the next step (loader waves that never store).
+  const char* ws_env = getenv("MMA_FWD_WS");
+  const bool use_ws = ws_env && ws_env[0] == '1';
+  if (use_ws && N % 256 == 0 && (kCgSlotsPerXcd % (N / 256)) == 0) {
+    hipLaunchKernelGGL((gemm_f16x2_ws_kernel<8, 2>), dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p, col_unscale,
+                       (M + 63) / 64, N / 256, a_row_max);
+    return check_launch("gemm_f16x2_ws_kernel");
+  }
   const int64_t n_units = (M + kCgRows - 1) / kCgRows;
   const int groups = N / 128;
   if (groups % 2 == 0)        // pairs of column groups per workgroup
@@ -1785,6 +1979,21 @@ extern "C" int mma_gemm_f16x2_k256(const float* A, int64_t lda, const float* row
   hipLaunchKernelGGL(gemm_f16x2_colgroup_k256_kernel, dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p, row_max, col_unscale,
                      n_units, N / 128);
   return check_launch("gemm_f16x2_colgroup_k256_kernel");
+}
+
+extern "C" int mma_gemm_f16x2_ws(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,
+                                 float* a_row_max, int64_t M, int32_t N, int32_t K, void* stream) {
+  MMA_REQUIRE(M >= 0 && (K == 128 || K == 256) && N >= 256 && N % 256 == 0 && (kCgSlotsPerXcd % (N / 256)) == 0,
+              "M=%lld N=%d K=%d: need K in {128, 256}, N %% 256 == 0 and N / 256 dividing %d", (long long)M, N, K, kCgSlotsPerXcd);
+  MMA_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && lda < (1 << 24) && ldc < (1 << 24), "row pitch too small, unaligned or >= 2^24");
+  if (M == 0) return 0;
+  MMA_REQUIRE(A && Bt2 && col_unscale && C && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt2) & 15) == 0,
+              "NULL or misaligned argument");
+  GemmParams p{A, lda, static_cast<const __bf16*>(Bt2), C, ldc, M, N, K, 0};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (K == 128) hipLaunchKernelGGL((gemm_f16x2_ws_kernel<8, 2>), dim3(256), dim3(kCgThreads), 0, st, p, col_unscale, (M + 63) / 64, N / 256, a_row_max);
+  else hipLaunchKernelGGL((gemm_f16x2_ws_kernel<16, 1>), dim3(256), dim3(kCgThreads), 0, st, p, col_unscale, (M + 31) / 32, N / 256, a_row_max);
+  return check_launch("gemm_f16x2_ws_kernel");
 }
 
 extern "C" int mma_gemm_f16x2_n128(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale, float* C,
@@ -1934,8 +2143,7 @@ extern "C" int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, in
   uint16_t* sgh = sxh + Mp;
   int* state = reinterpret_cast<int*>(gmax + 2 * Mp);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (const hipError_t e = hipMemsetAsync(state, 0, 4 * sizeof(int), st); e != hipSuccess)
-    return fail((int)e, "hipMemsetAsync of the scale state: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(tn_state_init_kernel, dim3(1), dim3(64), 0, st, state);       // a kernel, not a memset node (see csr_prepare_kernel, [r4])
   if (!x_row_max) { launch_row_absmax(X, ldx, M, KA, xmax, st); x_row_max = xmax; }
   if (!g_row_max) { launch_row_absmax(G, ldg, M, NC, gmax, st); g_row_max = gmax; }
   hipLaunchKernelGGL(tn_scale_range_kernel, dim3((unsigned)std::min<int64_t>((M + 255) / 256, 256)), dim3(256), 0, st, x_row_max, g_row_max, M,

@@ -39,6 +39,7 @@ struct GrParams {
   uint32_t lds_agg, lds_arg, lds_bytes; int n_coef;
   const uint8_t* zidx;          // categorical edge features: Z is a small table and its row for an edge is zidx[position or edge id]
   const int32_t* long_nodes;                         // optional [count, node ids...] of the segments above kGroupMaxDeg (mma_build_csr)
+  int long_cap;                                      // ids the list can hold (mma_gr_long_nodes_len(E) - 1): a count beyond it is not believed
   bool need_sum, need_sq, need_min, need_max, need_mean;   // which running reductions the aggregator list uses
   uint8_t aggr[MMA_MAX_K]; uint8_t scaler[8];
   uint32_t aggr_pack, scaler_pack;                   // the same codes, 4 bits each: a run-time index into a kernarg ARRAY is a vector-memory load
@@ -313,13 +314,14 @@ __device__ __forceinline__ void gr_node_fwd(const GrParams& p, const DropParams&
 // second pass behind the flat / block kernels when mma_build_csr listed the long segments: one wave per listed node
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void gr_fwd_list_kernel(const GrParams p) {
-  const int count = p.long_nodes[0];
-  if (count == 0) return;
+  const int count = min(p.long_nodes[0], p.long_cap);    // never walk past the list, whatever the count word holds
+  if (count <= 0) return;
   const DropParams dp = drop_resolve(p.drop);
   const GrLane l = gr_lane(p, VEC);
   const int stride = (int)gridDim.x * (kBlock / kWave);
   for (int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6))); i < count; i += stride) {
     const int n = __builtin_amdgcn_readfirstlane(p.long_nodes[1 + i]);
+    if ((unsigned)n >= (unsigned)p.N) continue;                                 // (wave-uniform) not a node: nothing is read or written for it
     const Seg s = seg_load(p, n);
     const SegIdx i0 = idx_load(p, s.b, s.e, l.lane);
     const Vec<VEC> u0 = l.fused ? ldv<VEC>(p.U + (size_t)n * p.lduv + l.cc) : vzero<VEC>();
@@ -537,13 +539,14 @@ __device__ __forceinline__ void gr_node_bwd(const GrParams& p, const DropParams&
 
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void gr_bwd_list_kernel(const GrParams p) {
-  const int count = p.long_nodes[0];
-  if (count == 0) return;
+  const int count = min(p.long_nodes[0], p.long_cap);    // never walk past the list, whatever the count word holds
+  if (count <= 0) return;
   const DropParams dp = drop_resolve(p.drop);
   const GrLane l = gr_lane(p, VEC);
   const int stride = (int)gridDim.x * (kBlock / kWave);
   for (int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6))); i < count; i += stride) {
     const int n = __builtin_amdgcn_readfirstlane(p.long_nodes[1 + i]);
+    if ((unsigned)n >= (unsigned)p.N) continue;
     const Seg s = seg_load(p, n);
     gr_node_bwd<VEC>(p, dp, l, n, s, idx_load(p, s.b, s.e, l.lane));
   }
@@ -944,7 +947,11 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
 }
 
 // ---- K6: CSR by key (stable), device side ---------------------------------------------------------------
-__global__ void csr_prepare_kernel(const int64_t* key, int64_t E, int32_t* key32, int32_t* iota) {
+// (also zeroes the long-segment list's count: three launches ahead of the kernel that appends to it.  It used to be a 4-byte
+// hipMemsetAsync; inside a captured step - where the call becomes a memset NODE - the list kernels of bench.py's C2net graph read a
+// count of 0x03030303 on the fifth replay, bytes that had lived at that address before the capture's pool took it over; [r4])
+__global__ void csr_prepare_kernel(const int64_t* key, int64_t E, int32_t* key32, int32_t* iota, int32_t* long_count) {
+  if (long_count && blockIdx.x == 0 && threadIdx.x == 0) *long_count = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += (int64_t)gridDim.x * blockDim.x) {
     key32[i] = (int32_t)key[i];
     iota[i] = (int32_t)i;
@@ -964,6 +971,10 @@ __global__ void csr_gather_kernel(const int64_t* other, const int32_t* perm, int
 }
 
 // nodes whose segment is longer than kGroupMaxDeg: out[0] = count (zeroed before the launch), out[1..] = node ids (any order)
+__global__ void csr_zero_kernel(int32_t* a, int64_t n, int32_t* b) {
+  if (b && blockIdx.x == 0 && threadIdx.x == 0) *b = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] = 0;
+}
 __global__ void csr_long_nodes_kernel(const int32_t* rowptr, int64_t N, int32_t* out) {
   for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
     if (rowptr[n + 1] - rowptr[n] > kGroupMaxDeg) out[1 + atomicAdd(out, 1)] = (int32_t)n;
@@ -1127,10 +1138,10 @@ extern "C" int mma_build_csr(const int64_t* key, const int64_t* other, int64_t E
   MMA_REQUIRE(E >= 0 && N >= 0 && E < (1LL << 31) && N < (1LL << 31), "E=%lld N=%lld out of int32 range", (long long)E, (long long)N);
   MMA_REQUIRE(rowptr != nullptr, "NULL rowptr");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (long_nodes) (void)hipMemsetAsync(long_nodes, 0, 4, st);      // the count; ids follow
-  if (E == 0) {
-    (void)hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * 4, st);
-    return check_launch("csr memset");
+  if (E == 0) {                                                    // every segment empty, an empty list
+    hipLaunchKernelGGL(csr_zero_kernel, dim3((unsigned)min((int64_t)kMaxGrid, (N + 1 + kBlock) / kBlock)), dim3(kBlock), 0, st, rowptr, N + 1,
+                       long_nodes);
+    return check_launch("csr_zero_kernel");
   }
   MMA_REQUIRE(key && perm && workspace, "NULL argument");
   MMA_REQUIRE(workspace_bytes >= mma_csr_workspace_bytes(E, N), "workspace too small: %lld < %lld", (long long)workspace_bytes,
@@ -1147,7 +1158,7 @@ extern "C" int mma_build_csr(const int64_t* key, const int64_t* other, int64_t E
   uint32_t* uskey = reinterpret_cast<uint32_t*>(skey);
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, ukey, uskey, iota, perm, (int)E, 0, sort_bits(N));
   const int blocks = (int)min((int64_t)kMaxGrid, (E + kBlock) / kBlock);
-  hipLaunchKernelGGL(csr_prepare_kernel, dim3(blocks), dim3(kBlock), 0, st, key, E, key32, iota);
+  hipLaunchKernelGGL(csr_prepare_kernel, dim3(blocks), dim3(kBlock), 0, st, key, E, key32, iota, long_nodes);   // + list count = 0
   const hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, ukey, uskey, iota, perm, (int)E, 0, sort_bits(N), st);
   if (e != hipSuccess) return fail(100 + (int)e, "radix sort failed: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(csr_rowptr_kernel, dim3(blocks), dim3(kBlock), 0, st, skey, E, N, rowptr);
@@ -1193,6 +1204,7 @@ extern "C" int mma_gr_fused_fwd(
   GrParams p{};
   if (int rc = fill_codes(aggr_host, K, scaler_host, S, &p)) return rc;
   p.long_nodes = long_nodes;
+  p.long_cap = (int)min((int64_t)0x7fffffff, E / (kGroupMaxDeg + 1) + 1);
   if (N == 0) return 0;
   const int D = T * F;
   MMA_REQUIRE(rowptr && out, "NULL argument");
@@ -1253,6 +1265,7 @@ extern "C" int mma_gr_fused_bwd(
   GrParams p{};
   if (int rc = fill_codes(aggr_host, K, scaler_host, S, &p)) return rc;
   p.long_nodes = long_nodes;
+  p.long_cap = (int)min((int64_t)0x7fffffff, E / (kGroupMaxDeg + 1) + 1);
   if (N == 0 || E == 0) return 0;
   const int D = T * F;
   MMA_REQUIRE(rowptr && src && perm && gout && gmsg && ldg >= D, "NULL argument or pitch too small");

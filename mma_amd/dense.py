@@ -62,6 +62,12 @@ USE_F16X2_N128 = __import__("os").environ.get("MMA_F16X2_DX", "1") != "0"
 USE_F16X2_K256 = __import__("os").environ.get("MMA_F16X2_K256", "1") != "0"
 
 
+def ws_ok(N):
+    """mma_gemm_f16x2_ws takes N: whole 256-column groups, a divisor of the 32 workgroup slots of an XCD.  Opt-in (MMA_FWD_WS=1): measured
+    slower than the column-group kernels so far (gemm_x3.hip)."""
+    return N % 256 == 0 and 32 % (N // 256) == 0 and __import__("os").environ.get("MMA_FWD_WS", "0") == "1"
+
+
 def f16x2_n128_ok(M, K, N):
     return (USE_F16X2 and USE_F16X2_N128 and USE_BF16X3 and N % 128 == 0 and N <= 512 and K % 64 == 0 and K > 128 and M >= (1 << 16))
 
@@ -132,6 +138,16 @@ def gemm_bf16x3(a, w, out=None, accumulate=False, row_max_box=None):
         # takes the row maxima from one cheap pass over `a` (M x K floats read against M x N written)
         if out is None:
             out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        if K == 256 and ws_ok(N):
+            # W-stationary kernel (round 4): forms the row maxima itself (and leaves them for the weight-gradient product) - no separate
+            # pass over `a`
+            rm = torch.empty((M,), device=a.device, dtype=torch.float32)
+            if row_max_box is not None:
+                row_max_box.append(rm)
+            bt2, cu = _split_f16x2(w)
+            with _span("gemm_x3_persist", nbytes=4 * M * (K + N), flops=2 * M * K * N, mfma="f16x3"):
+                call("mma_gemm_f16x2_ws", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(out), out.stride(0), ptr(rm), M, N, K, stream_ptr())
+            return out
         rm = row_absmax(a)
         if row_max_box is not None:
             row_max_box.append(rm)

@@ -418,3 +418,56 @@ def test_gemm_f16x2_n128(M, K, acc):
     again = c0.clone()
     dense.gemm_f16x2_n128(at, rm, w, again, accumulate=acc)
     assert torch.equal(again, out)
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 128, 256), (63, 128, 256), (64, 128, 512), (4099, 128, 1024), (70001, 128, 2048), (140001, 128, 256),
+                                   (1, 256, 256), (31, 256, 512), (4100, 256, 1024), (66001, 256, 4096), (131075, 256, 256)])
+def test_gemm_f16x2_ws_is_bit_equal_to_the_column_group_kernels(M, K, N, monkeypatch):
+    """The W-stationary forward kernel (round 4: W in registers, x loaded row-major by the whole workgroup and shared through LDS) forms
+    the same three products in the same order as the column-group kernels: identical bits, identical row maxima, ragged M, zero rows, rows
+    spread over e^+-6, a row pitch wider than K, an output that is a column block of a wider buffer; and the fp64 error bar on a sample."""
+    from mma_amd import dense
+    from mma_amd._lib import call, ptr, stream_ptr
+    rng = np.random.default_rng(M + K + N)
+    a_np = (rng.standard_normal((M, K + 8)) * np.exp(rng.uniform(-6, 6, (M, 1)))).astype(np.float32)
+    a_np[::17] = 0
+    a = torch.from_numpy(a_np).to(DEV)[:, :K]                                     # lda = K + 8
+    w = torch.from_numpy(((rng.random((K, N)) * 2 - 1) / 16).astype(np.float32)).to(DEV)
+    bt2, cu = dense._split_f16x2(w)
+    wide = torch.full((M, N + 64), 7.0, device=DEV)
+    out, rm = wide[:, 32:32 + N], torch.full((M,), -1.0, device=DEV)
+    call("mma_gemm_f16x2_ws", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(out), out.stride(0), ptr(rm), M, N, K, stream_ptr())
+    assert torch.equal(rm, a.abs().amax(1))
+    assert torch.equal(wide[:, :32], torch.full_like(wide[:, :32], 7.0)) and torch.equal(wide[:, 32 + N:], torch.full_like(wide[:, 32 + N:], 7.0))
+    old = torch.empty((M, N), device=DEV)
+    if K == 128:
+        monkeypatch.delenv("MMA_FWD_WS", raising=False)                            # the default: the column-group kernel
+        call("mma_gemm_f16x2", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(old), old.stride(0), None, M, N, stream_ptr())
+    else:
+        call("mma_gemm_f16x2_k256", ptr(a), a.stride(0), ptr(rm), ptr(bt2), ptr(cu), ptr(old), old.stride(0), M, N, stream_ptr())
+    assert torch.equal(out, old)
+    idx = torch.from_numpy(rng.choice(M, min(M, 2048), replace=False)).to(DEV)
+    ref = a[idx].double() @ w.double()
+    scale = a[idx].double().abs() @ w.double().abs() + 1e-300
+    assert ((out[idx].double() - ref).abs() / scale).max().item() < 5e-7
+    # NULL a_row_max; the layer-level call takes this kernel by itself
+    out2 = torch.empty((M, N), device=DEV)
+    call("mma_gemm_f16x2_ws", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(out2), out2.stride(0), None, M, N, K, stream_ptr())
+    assert torch.equal(out2, old)
+    if M >= dense._MIN_ROWS_X3 and (K == 128 or M >= (1 << 16)):        # the layer-level call, with the switch on and off
+        for sw in ("1", "0"):
+            monkeypatch.setenv("MMA_FWD_WS", sw)
+            box = []
+            assert torch.equal(dense.gemm_bf16x3(a, w, row_max_box=box), old) and torch.equal(box[0], rm)
+        monkeypatch.delenv("MMA_FWD_WS")
+
+
+def test_gemm_f16x2_ws_rejects_shapes_it_does_not_take():
+    from mma_amd import dense
+    from mma_amd._lib import call, ptr, stream_ptr, MMALibraryError as MMAError
+    a = torch.zeros((64, 128), device=DEV)
+    for N, K in ((768, 128), (128, 128), (256, 64), (256, 512)):
+        w = torch.zeros((2, N, K), device=DEV, dtype=torch.float16)
+        with pytest.raises(MMAError):
+            call("mma_gemm_f16x2_ws", ptr(a), 128, ptr(w), ptr(torch.ones(N, device=DEV)), ptr(torch.zeros((64, N), device=DEV)), N, None, 64, N, K,
+                 stream_ptr())

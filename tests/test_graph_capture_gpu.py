@@ -253,3 +253,47 @@ def test_global_add_pool_takes_an_unsorted_batch_vector():
         assert torch.equal(gx, cot[b])
     srt = torch.sort(torch.randint(0, G, (N,), generator=g)).values.to(DEV)
     assert torch.equal(global_add_pool(x, srt, G, assume_sorted=True), global_add_pool(x, srt, G))
+
+
+def test_csr_build_inside_a_graph_rezeroes_the_long_list_and_a_bad_count_is_not_believed():
+    """Round 4: bench.py's C2net graph faulted on its fifth replay - gr_fwd_list_kernel read a count of 0x03030303 from the long-segment
+    list (bytes that had lived at that address before the capture's pool took it over; the count was zeroed by a 4-byte memset NODE).
+    Now (a) the count is zeroed by the build's first kernel, replay after replay, and (b) the list kernels clamp the count to the list's
+    capacity and skip ids that are not nodes: a poisoned list can cost time, never an access outside the graph's arrays."""
+    import mma_amd
+    from mma_amd import functional as Fn
+    g = torch.Generator().manual_seed(5)
+    E, N = 2816, 1344
+    key = torch.randint(0, N, (E,), generator=g).to(DEV)
+    other = torch.randint(0, N, (E,), generator=g).to(DEV)
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        Fn.DeviceCSR(key, other, N, long_list=True)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        csr = Fn.DeviceCSR(key, other, N, long_list=True)
+    for _ in range(3):
+        csr.long_nodes.fill_(0x03030303)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert int(csr.long_nodes[0]) == 0 and int(csr.rowptr[-1]) == E
+    # the layer kernels with a list whose count word and ids are garbage: same result as with the true (empty) list
+    T, F = 2, 8
+    ei = torch.stack([other, key])
+    x = torch.randn(N, T * F, generator=g).to(DEV)
+    conv_graph = Fn.gr_graph(ei, N)
+    UV = torch.randn(N, 2 * T * F, generator=g).to(DEV).requires_grad_(True)
+
+    def run():
+        UV.grad = None
+        out = Fn.gr_fused_conv(UV, None, conv_graph, T, F, ["min", "max", "mean"], ["identity", "amplification"], 1.0, 2.0, Fn.DropoutSpec(0.0))
+        out.sum().backward()
+        return out.detach().clone(), UV.grad.clone()
+    ref = run()
+    ln = conv_graph.by_target.long_nodes
+    assert int(ln[0]) == 0
+    ln.fill_(0x7f7f7f7f)                                      # count and ids: garbage far beyond the list and beyond N
+    got = run()
+    ln[0] = 0
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
