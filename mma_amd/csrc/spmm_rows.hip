@@ -65,18 +65,19 @@ struct SpmmItemParams {
   const int4* items; int64_t n_items; float* partial; int C, lpr_log;
 };
 
+// items [0, n): one per wavefront; (bx, gx) = this workgroup's index and count among the workgroups that run this body, by = column chunk
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void spmm_items_kernel(const SpmmItemParams p) {
+__device__ __forceinline__ void spmm_wave_items(const SpmmItemParams& p, const int4* items, int64_t n, int bx, int gx, int by) {
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log;
   const int epg = kWave >> p.lpr_log;
   const int sub = lane >> p.lpr_log;
-  const int c = ((int)blockIdx.y * lpr + (lane & (lpr - 1))) * VEC;
+  const int c = (by * lpr + (lane & (lpr - 1))) * VEC;
   const bool fvalid = c < p.C;
   const int cc = fvalid ? c : 0;
-  const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave);
-  for (int64_t it0 = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); it0 < p.n_items; it0 += stride) {
-    const int4 item = p.items[__builtin_amdgcn_readfirstlane((int)it0)];
+  const int64_t stride = (int64_t)gx * (kBlock / kWave);
+  for (int64_t it0 = (int64_t)bx * (kBlock / kWave) + (threadIdx.x >> 6); it0 < n; it0 += stride) {
+    const int4 item = items[__builtin_amdgcn_readfirstlane((int)it0)];
     const int row = __builtin_amdgcn_readfirstlane(item.x);
     const int ebeg = __builtin_amdgcn_readfirstlane(item.y);
     const int eend = __builtin_amdgcn_readfirstlane(item.z);
@@ -120,12 +121,17 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(const SpmmItemParams
   }
 }
 
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void spmm_items_kernel(const SpmmItemParams p) {
+  spmm_wave_items<VEC>(p, p.items, p.n_items, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+}
+
 // Short items, one per group of LPR lanes (64/LPR items per wavefront), each group walking its own segment with four gathers
 // in flight and no cross-lane traffic at all (a lane owns its VEC columns of the output row).  At C = 16 an item-per-wave
 // launch issues ONE 640-byte gather per ~10-edge row and then waits out the memory latency; here a wave keeps 64 rows in
 // flight.
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void spmm_items_group_kernel(const SpmmItemParams p) {
+__device__ __forceinline__ void spmm_group_items(const SpmmItemParams& p, const int4* items, int64_t n, int bx, int gx) {
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log;
   const int gpw = kWave >> p.lpr_log;
@@ -133,12 +139,12 @@ __global__ __launch_bounds__(kBlock) void spmm_items_group_kernel(const SpmmItem
   const int c = (lane & (lpr - 1)) * VEC;               // lpr lanes cover the whole row on this path (host: chunks == 1)
   const bool fvalid = c < p.C;
   const int cc = fvalid ? c : 0;
-  const int64_t n_w = (p.n_items + gpw - 1) / gpw;
-  const int64_t stride = (int64_t)gridDim.x * (kBlock / kWave);
-  for (int64_t w = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); w < n_w; w += stride) {
+  const int64_t n_w = (n + gpw - 1) / gpw;
+  const int64_t stride = (int64_t)gx * (kBlock / kWave);
+  for (int64_t w = (int64_t)bx * (kBlock / kWave) + (threadIdx.x >> 6); w < n_w; w += stride) {
     const int64_t it = w * gpw + grp;
-    if (it >= p.n_items) continue;
-    const int4 item = p.items[it];
+    if (it >= n) continue;
+    const int4 item = items[it];
     Vec<VEC> acc = vzero<VEC>();
     int e = item.y;
     for (; e + 4 <= item.z; e += 4) {
@@ -171,6 +177,20 @@ __global__ __launch_bounds__(kBlock) void spmm_items_group_kernel(const SpmmItem
       }
     }
   }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void spmm_items_group_kernel(const SpmmItemParams p) {
+  spmm_group_items<VEC>(p, p.items, p.n_items, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// [r4] both passes in ONE launch (column chunks == 1): workgroups [0, blocks_wave) take the long items, one per wavefront, the rest the
+// short ones, one per lane group - the same items, walked the same way, as the two launches were (bit-identical); on the Cora / Pubmed
+// structures every launch of the layer is 5-6 us of a 0.13-0.18 ms replay.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void spmm_items_both_kernel(const SpmmItemParams p, int64_t n_wave, int blocks_wave) {
+  if ((int)blockIdx.x < blocks_wave) spmm_wave_items<VEC>(p, p.items, n_wave, (int)blockIdx.x, blocks_wave, 0);
+  else spmm_group_items<VEC>(p, p.items + n_wave, p.n_items - n_wave, (int)blockIdx.x - blocks_wave, (int)gridDim.x - blocks_wave);
 }
 
 __global__ __launch_bounds__(kBlock) void spmm_items_finalize_kernel(const SpmmItemParams p, const int4* hubs, int64_t n_hubs) {
@@ -344,6 +364,16 @@ extern "C" int mma_csr_spmm_items(const int32_t* col, const float* val, const fl
   // items [0, n_wave_items): one per wavefront; the rest (short rows) one per lpr-lane group when a wave holds several groups
   const int gpw = kWave >> p.lpr_log;
   if (gpw == 1 || chunks != 1 || n_wave_items > n_items) n_wave_items = n_items;
+  const char* one_env = getenv("MMA_SPMM_ONE_LAUNCH");                   // 0: the two launches of round 3 (A/B and the equality test)
+  if (n_wave_items > 0 && n_items > n_wave_items && chunks == 1 && !(one_env && one_env[0] == '0')) {       // both kinds of item: one launch
+    int64_t ba = (n_wave_items + 3) / 4, bb = (n_items - n_wave_items + 4 * gpw - 1) / (4 * gpw);
+    if (ba > kMaxGrid) ba = kMaxGrid;
+    if (bb > 4 * kMaxGrid) bb = 4 * kMaxGrid;
+    if (v4) hipLaunchKernelGGL((spmm_items_both_kernel<4>), dim3((unsigned)(ba + bb)), dim3(kBlock), 0, st, p, n_wave_items, (int)ba);
+    else hipLaunchKernelGGL((spmm_items_both_kernel<1>), dim3((unsigned)(ba + bb)), dim3(kBlock), 0, st, p, n_wave_items, (int)ba);
+    if (int rc = check_launch("spmm_items_both_kernel")) return rc;
+    n_wave_items = n_items = 0;                                         // nothing left for the two single-kind launches below
+  }
   if (n_wave_items > 0) {
     p.n_items = n_wave_items;
     int64_t blocks = (n_wave_items + 3) / 4;

@@ -200,6 +200,9 @@ def rows_mm_add_(acc, a, w):
         return acc
     if _x3_ok(a, w) and acc.stride(1) == 1:
         return gemm_bf16x3(a, w, acc, accumulate=True)
+    if a.shape[0] // _ROWS_PER_BATCH < 4:                  # small: the library GEMM adds in its epilogue (beta = 1) - one launch, not two
+        with _span("lib_mm", nbytes=4 * a.shape[0] * (a.shape[1] + 2 * w.shape[1]), flops=2 * a.shape[0] * a.shape[1] * w.shape[1], mfma="f32"):
+            return acc.addmm_(a, w)
     return acc.add_(_rows_mm(a, w))
 
 

@@ -303,7 +303,7 @@ class SeedSlot:
 
 
 class _MaskWeights(torch.autograd.Function):
-    """[W_1[:H] .. W_K[:H] | W_1[H:] .. W_K[H:]] (H, 2*K*H) from the K caller-owned (2H,H) mask weights in two launches, and their
+    """[W_1[:H] .. W_K[:H] | W_1[H:] .. W_K[H:]] (H, 2*K*H) from the K caller-owned (2H,H) mask weights in one launch, and their
     gradients back in one: as slices + torch.cat the forward is 3 launches and autograd's backward ~5 per mask (zero-fill + slice copy
     per half, an add, the accumulation) - on Cora, where every kernel of the layer is a few microseconds, a fifth of the replay."""
 
@@ -312,7 +312,9 @@ class _MaskWeights(torch.autograd.Function):
         K = len(masks)
         H = masks[0].shape[1]
         ctx.shape = (K, H)
-        return torch.stack(masks).view(K, 2, H, H).permute(2, 1, 0, 3).reshape(H, 2 * K * H)
+        # ONE concatenation kernel (the K top halves, then the K bottom halves, are contiguous row blocks of their masks); as
+        # stack + permuted copy it was two launches
+        return torch.cat([w[:H] for w in masks] + [w[H:] for w in masks], 1)
 
     @staticmethod
     def backward(ctx, g):

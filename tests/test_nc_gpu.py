@@ -406,3 +406,32 @@ def test_one_launch_form_equals_the_separate_launches(N, H, names, p, chunk, hub
         for a, b in zip(got, ref):
             assert torch.equal(a, b)
         assert int(graph._sync.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("C", [3, 7, 16, 64])
+def test_spmm_one_launch_equals_the_two_launches(C, monkeypatch):
+    """Round 4: long items (one per wavefront) and short items (one per lane group) of the K = 1 SpMM run in ONE launch; the same items
+    walked the same way - bit-identical to the two launches (MMA_SPMM_ONE_LAUNCH=0), forward and transposed, with hub chunks."""
+    from mma_amd import functional as Fn
+    from mma_amd.graph import SpmmGraph
+    rng = np.random.default_rng(C)
+    N = 3000
+    deg = np.minimum(rng.zipf(1.7, N), 1500)                     # most rows short, a few hubs beyond the 512-edge chunk
+    row = np.repeat(np.arange(N), deg)
+    col = rng.integers(0, N, row.size)
+    adj = torch.sparse_coo_tensor(torch.tensor(np.stack([row, col])), torch.ones(row.size), (N, N)).coalesce()
+    sg = SpmmGraph.from_torch_sparse(adj.to(DEV))
+    assert 0 < sg.n_wave_items < sg.items.shape[0]
+    B = torch.from_numpy(rng.standard_normal((N, C)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).to(DEV)
+    cot = torch.from_numpy(rng.standard_normal((N, C)).astype(np.float32)).to(DEV)
+    res = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("MMA_SPMM_ONE_LAUNCH", sw)
+        Bg = B.clone().requires_grad_(True)
+        out = Fn.csr_spmm(Bg, bias, sg, 1)
+        out.backward(cot)
+        res.append((out.detach().clone(), Bg.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    ref = torch.sparse.mm(adj.to(DEV), B) + bias
+    assert (res[0][0] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
