@@ -252,7 +252,9 @@ int mma_gemm_bf16x3_tn_batched(const float* X, int64_t ldx, int64_t xb, const fl
  * G (0 marks an all-zero row), either may be NULL (then one extra pass over that operand forms them; the backward kernels
  * produce G's: mma_nc_bwd_node / mma_nc_fused_bwd).  |error| <= 2^-22 sum|x||g| + M 2^-39 max_i(max|x_i| max|g_i|).  If some row's
  * products lie more than 2^40 below the largest row's, or a row maximum is inf / NaN / subnormal, the six-product kernel
- * (mma_gemm_bf16x3_tn) does the call instead - decided on the device, no synchronisation.  Shapes as mma_gemm_bf16x3_tn, M < 2^30.
+ * (mma_gemm_bf16x3_tn) does the call instead - decided on the device, no synchronisation.  Shapes as mma_gemm_bf16x3_tn, M < 2^30,
+ * and KA up to 256 (round 4: eight waves share one staged tile of G, which is then read once for hidden width 256 - same bits as
+ * one call per 128-column block of X).
  * ws: mma_gemm_f16x2_tn_workspace_floats(M, KA, NC) floats, 16-byte aligned (never NULL). */
 int64_t mma_gemm_f16x2_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC);
 int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, const float* x_row_max, const float* g_row_max,

@@ -1687,8 +1687,13 @@ __device__ __forceinline__ float scale_of(const u32x4& q, const int i) {
   return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
 }
 
-template <bool FULLCT>
-__global__ __launch_bounds__(kBlock, 2) void gemm_f16x2_tn_kernel(const TnParams p) {
+// NW = 4: 256 threads, X up to 128 columns wide (a wave per 32 of them), two workgroups per CU.  NW = 8 [r4]: 512 threads for X up to 256
+// columns wide (hidden width 256, C5) - the eight waves share ONE staged G tile, so G is read once instead of once per 128-column block
+// of X (two launches, each reading all 17 GB of [gP|gQ] at the C5 shard shape), and a thread splits 8 of its values per chunk, not 16.
+template <bool FULLCT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_f16x2_tn_kernel(const TnParams p) {
+  constexpr int KG = 8 / NW;                     // 8-row k-groups of the 32-row chunk a thread stages: 2 (groups skg, skg + 2) or 1
+  constexpr int GV = 8 * KG;                     // its G values per chunk
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kTn2Slab];
   if (p.state[2] != 0) return;                    // the six-product kernel does this call
   const int tid = threadIdx.x;
@@ -1734,8 +1739,8 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_f16x2_tn_kernel(const TnParams
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  float graw0[16], xraw0[16], graw1[16], xraw1[16];
-  u32x4 gs0[2], xs0[2], gs1[2], xs1[2];                       // row scales of the raw sets
+  float graw0[GV], xraw0[16], graw1[GV], xraw1[16];
+  u32x4 gs0[KG], xs0[2], gs1[KG], xs1[2];                     // row scales of the raw sets
   f16x8 af[2][2];
 
 #define MMA_TN2_LOAD(C_, GR_, XR_, GS_, XS_)                                                   \
@@ -1743,11 +1748,11 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_f16x2_tn_kernel(const TnParams
     int gv = g_voff + (C_) * (kTnKC * ldg_b);                                                  \
     int xv = x_voff + (C_) * (kTnKC * ldx_b);                                                  \
     asm volatile("" : "+v"(gv), "+v"(xv));                                                     \
-    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                            \
+    _Pragma("unroll") for (int g = 0; g < KG; ++g)                                             \
       GS_[g] = __builtin_amdgcn_raw_buffer_load_b128(sg_rsrc, sg_voff + (C_) * (kTnKC * 2) + g * 32, 0, 0); \
-      XS_[g] = __builtin_amdgcn_raw_buffer_load_b128(sx_rsrc, sx_voff + (C_) * (kTnKC * 2) + g * 32, 0, 0); \
-    }                                                                                          \
     _Pragma("unroll") for (int g = 0; g < 2; ++g)                                              \
+      XS_[g] = __builtin_amdgcn_raw_buffer_load_b128(sx_rsrc, sx_voff + (C_) * (kTnKC * 2) + g * 32, 0, 0); \
+    _Pragma("unroll") for (int g = 0; g < KG; ++g)                                             \
       _Pragma("unroll") for (int i = 0; i < 8; ++i)                                            \
         GR_[g * 8 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rsrc, gv, (g * 16 + i) * ldg_b, 2 /* nt: G streams through once, X is what the column blocks share in L2 */)); \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
@@ -1764,7 +1769,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_f16x2_tn_kernel(const TnParams
 #define MMA_TN2_PUBLISH(B_, GR_, XR_, GS_, XS_)                                                \
   {                                                                                            \
     unsigned char* d = lds + (B_) * kTn2Slab + sn * kTnPitch;                                  \
-    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                            \
+    _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                           \
       f16x8 a, b;                                                                              \
       _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                          \
         _Float16 u, v;                                                                         \
@@ -1801,14 +1806,14 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_f16x2_tn_kernel(const TnParams
       if (t1) acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], bq[pa][1][1], acc[c1], 0, 0, 0); \
       if (t0) acc[c0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], bq[pa][0][0], acc[c0], 0, 0, 0); \
       if (t1) acc[c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], bq[pa][1][0], acc[c1], 0, 0, 0); \
-      _Pragma("unroll") for (int j = 4 * m; j < 4 * m + 4; ++j) { /* values 4m..4m+3 of the next chunk's G set */ \
+      _Pragma("unroll") for (int j = (GV / 4) * m; j < (GV / 4) * (m + 1); ++j) { /* a quarter of the next chunk's G values */ \
         _Float16 u, v;                                                                         \
         split2s(GR_[j], scale_of(GS_[j >> 3], j & 7), u, v);                                   \
         ga[j & 7] = u; gb[j & 7] = v;                                                          \
       }                                                                                        \
-      if (m & 1) {                                                                             \
-        *reinterpret_cast<f16x8*>(pd + 0 * kTnPiece + (m >> 1) * 32) = ga;                     \
-        *reinterpret_cast<f16x8*>(pd + 1 * kTnPiece + (m >> 1) * 32) = gb;                     \
+      if (((GV / 4) * (m + 1)) % 8 == 0) {         /* a k-group of 8 rows is complete */       \
+        *reinterpret_cast<f16x8*>(pd + 0 * kTnPiece + (((GV / 4) * (m + 1)) / 8 - 1) * 32) = ga; \
+        *reinterpret_cast<f16x8*>(pd + 1 * kTnPiece + (((GV / 4) * (m + 1)) / 8 - 1) * 32) = gb; \
       }                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                       \
     }                                                                                          \
@@ -2125,8 +2130,8 @@ extern "C" int64_t mma_gemm_f16x2_tn_workspace_floats(int64_t M, int32_t KA, int
 
 extern "C" int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, const float* x_row_max, const float* g_row_max,
                                  float* C, float* ws, int64_t ws_floats, int64_t M, int32_t KA, int32_t NC, void* stream) {
-  MMA_REQUIRE(M >= 1 && M < (1LL << 30) && KA >= 1 && KA <= 128 && NC >= 1 && (int64_t)KA * NC < (1LL << 31),
-              "M=%lld KA=%d NC=%d: need M < 2^30, 1 <= KA <= 128, NC >= 1", (long long)M, KA, NC);
+  MMA_REQUIRE(M >= 1 && M < (1LL << 30) && KA >= 1 && KA <= 256 && NC >= 1 && (int64_t)KA * NC < (1LL << 31),
+              "M=%lld KA=%d NC=%d: need M < 2^30, 1 <= KA <= 256, NC >= 1", (long long)M, KA, NC);
   MMA_REQUIRE(X && G && C && ws && ldx >= KA && ldg >= NC && ldx < (1 << 24) && ldg < (1 << 24), "NULL argument or row pitch out of range");
   MMA_REQUIRE((reinterpret_cast<uintptr_t>(X) & 3) == 0 && (reinterpret_cast<uintptr_t>(G) & 3) == 0 &&
               (reinterpret_cast<uintptr_t>(ws) & 15) == 0, "misaligned argument");
@@ -2153,11 +2158,22 @@ extern "C" int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, in
   TnParams p{X, ldx, G, ldg, s == 1 ? C : ws, M, rps, KA, NC, s, sxh, sgh, state, 0};
   const dim3 grid((unsigned)(((NC + 127) / 128) * s));
   const bool full = NC % 128 == 0 && KA % 32 == 0;
-  if (full) hipLaunchKernelGGL(gemm_f16x2_tn_kernel<true>, grid, dim3(kBlock), 0, st, p);
-  else hipLaunchKernelGGL(gemm_f16x2_tn_kernel<false>, grid, dim3(kBlock), 0, st, p);
+  if (KA > 128) {                                                    // [r4] X up to 256 columns wide: eight waves on one staged G tile
+    if (full) hipLaunchKernelGGL((gemm_f16x2_tn_kernel<true, 8>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gemm_f16x2_tn_kernel<false, 8>), grid, dim3(512), 0, st, p);
+  } else {
+    if (full) hipLaunchKernelGGL((gemm_f16x2_tn_kernel<true, 4>), grid, dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((gemm_f16x2_tn_kernel<false, 4>), grid, dim3(kBlock), 0, st, p);
+  }
   p.want_bad = 1;                                                    // the six-product form takes over when the scale kernels said so
-  if (full) hipLaunchKernelGGL(gemm_x3_tn_kernel<true>, grid, dim3(kBlock), 0, st, p);
-  else hipLaunchKernelGGL(gemm_x3_tn_kernel<false>, grid, dim3(kBlock), 0, st, p);
+  for (int j = 0; j < KA; j += 128) {                                // (it holds 128 columns of X per launch: the same partial tiles)
+    TnParams q = p;
+    q.X = X + j; q.KA = KA - j < 128 ? KA - j : 128;
+    q.part = p.part + (size_t)j * NC; q.part_ss = (int64_t)KA * NC;
+    const bool fq = NC % 128 == 0 && q.KA % 32 == 0;
+    if (fq) hipLaunchKernelGGL(gemm_x3_tn_kernel<true>, grid, dim3(kBlock), 0, st, q);
+    else hipLaunchKernelGGL(gemm_x3_tn_kernel<false>, grid, dim3(kBlock), 0, st, q);
+  }
   if (int rc = check_launch("gemm_f16x2_tn_kernel")) return rc;
   if (s == 1) return 0;
   return mma_col_sum(ws, (int64_t)KA * NC, s, KA * NC, C, nullptr, 0, stream);

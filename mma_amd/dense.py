@@ -278,6 +278,9 @@ USE_F16X2_TN = __import__("os").environ.get("MMA_F16X2_TN", "1") != "0"
 _MIN_ROWS_F16X2_TN = 1 << 16
 
 
+TN_KA256 = __import__("os").environ.get("MMA_TN_KA256", "1") != "0"       # 0: 128-column blocks of x, one launch each (round 3)
+
+
 def gemm_f16x2_tn(x, g, x_row_max=None, g_row_max=None):
     """x^T @ g like gemm_bf16x3_tn on the three-product fp16 x 2 kernel: row scales balanced between the operands, derived on
     the device from the row maxima ((N,) upper bounds of max |x[i,:]| / max |g[i,:]|; None = one extra pass over that operand);
@@ -285,7 +288,8 @@ def gemm_f16x2_tn(x, g, x_row_max=None, g_row_max=None):
     N, KA = x.shape
     NC = g.shape[1]
     out = torch.empty((KA, NC), device=x.device, dtype=torch.float32)
-    kb = KA if KA <= 128 else 128
+    # [r4] x up to 256 columns wide in ONE launch (hidden width 256: G is read once, not once per 128-column block of x)
+    kb = KA if KA <= 128 else (256 if TN_KA256 and KA % 256 == 0 else 128)
     n_ws = int(_lib.lib().mma_gemm_f16x2_tn_workspace_floats(N, kb, NC))
     ws = torch.empty((n_ws,), device=x.device, dtype=torch.float32)
     with _span("gemm_x3_tn", nbytes=4 * N * (KA + NC), flops=2 * N * KA * NC, mfma="f16x3"):

@@ -471,3 +471,27 @@ def test_gemm_f16x2_ws_rejects_shapes_it_does_not_take():
         with pytest.raises(MMAError):
             call("mma_gemm_f16x2_ws", ptr(a), 128, ptr(w), ptr(torch.ones(N, device=DEV)), ptr(torch.zeros((64, N), device=DEV)), N, None, 64, N, K,
                  stream_ptr())
+
+
+@pytest.mark.parametrize("M,NC", [(70001, 512), (131072, 4096), (66000, 96)])
+def test_gemm_f16x2_tn_256_columns_of_x_in_one_launch(M, NC):
+    """Round 4: x up to 256 columns wide (hidden width 256) is one launch of the eight-wave TN kernel - the staged G tile is shared, G
+    is read once - with the bits of one launch per 128-column block of x; the on-device fall-back (a row 2^50 below the rest) too."""
+    from mma_amd import dense
+    rng = np.random.default_rng(M + NC)
+    x = torch.from_numpy(rng.standard_normal((M, 256)).astype(np.float32)).to(DEV)
+    g = torch.from_numpy((rng.standard_normal((M, NC)) * np.exp(rng.uniform(-3, 3, (M, 1)))).astype(np.float32)).to(DEV)
+    for bad in (False, True):
+        if bad:
+            x = x.clone(); x[5] *= 2.0 ** -60                      # sends the call to the six-product kernel (decided on the device)
+        xm, gm = x.abs().amax(1), g.abs().amax(1)
+        dense.TN_KA256 = False
+        try:
+            ref = dense.gemm_f16x2_tn(x, g, xm, gm)
+        finally:
+            dense.TN_KA256 = True
+        got = dense.gemm_f16x2_tn(x, g, xm, gm)
+        assert torch.equal(got, ref)
+        truth = x.double().t() @ g.double()
+        scale = x.double().abs().t() @ g.double().abs() + 1e-300
+        assert ((got.double() - truth).abs() / scale).max().item() < 5e-7
