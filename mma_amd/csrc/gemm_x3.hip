@@ -679,6 +679,224 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_ws_kernel(const Gemm
                                           kCgStoreAux);
 }
 
+// ---- forward, LOADER WAVES (round 4): the W-stationary kernel above with its two jobs given to different waves ---------------------------
+// What the W-stationary kernel taught: vmcnt is ONE in-order counter for loads and stores, so a wave that
+// stores tiles and also waits for rows of x waits for its own stores first.  Here waves 0-7 MULTIPLY (W in registers, A fragments from
+// LDS, tile stores between the MFMAs) and never issue a global load after their prologue - nothing they wait for stands behind a store;
+// waves 8-11 LOAD: each brings 16 of the row group's 64 rows in, row-major (whole lines), forms the row maxima, splits and writes the
+// fp16 pieces to the other LDS slot - their vmcnt queue holds loads only (plus one 4-byte row-maximum store per row).  One raw barrier per iteration (lgkmcnt only: a
+// __syncthreads() would also drain the multipliers' stores).  K = 128, N % 256 == 0; same products in the same order: the bits of
+// mma_gemm_f16x2.
+constexpr int kLwThreads = 768;          // 8 multiplier waves + 4 loader waves
+typedef float lw_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kLwThreads, 1) void gemm_f16x2_lw_kernel(const GemmParams p, const float* col_unscale, int64_t n_rgroups,
+                                                                     int n_cgroups, float* a_row_max) {
+  constexpr int KS = 8, K = 128, RBI = 2, RI = 64;
+  constexpr int kKsP = 1024 + 32;
+  constexpr int kPieceP = KS * kKsP, kBlkP = 2 * kPieceP;
+  constexpr int kSlot = RBI * kBlkP + RI * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kSlot];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, h = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+  const int streams_per_xcd = kCgSlotsPerXcd / n_cgroups;
+  if (slot_id >= streams_per_xcd * n_cgroups) return;      // (before any barrier)
+  const int cg = slot_id % n_cgroups;
+  const int64_t stream = xcd * streams_per_xcd + slot_id / n_cgroups, n_streams = 8 * streams_per_xcd;
+  const int64_t n_it = stream < n_rgroups ? (n_rgroups - stream + n_streams - 1) / n_streams : 0;     // row groups of this workgroup
+#define MMA_LW_BARRIER() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+
+  if (wave >= 8) {
+    // ---------------- loader: rows [32 lw, 32 lw + 32) of every row group; load i covers rows 2i, 2i+1 (lane >> 5), 16 bytes per lane
+    const int lw = wave - 8;                                  // 0..3: rows [16 lw, 16 lw + 16) of the group, load i = rows 2i, 2i+1
+    const int row_in = 16 * lw + h, k0 = 4 * r31;             // + 2 i
+    const uint32_t lda_b = (uint32_t)p.lda * 4u;
+    const uint32_t a_voff = (uint32_t)h * lda_b + (uint32_t)k0 * 4u, a_voff_c = (uint32_t)k0 * 4u;
+    lw_f4 rawA[8], rawB[8];
+// The loader's loads cross the loop's back edge (requested one iteration before they are split): hipcc then drains vmcnt at the loop head
+// (seen in the ISA: vmcnt(0) once per pair of iterations - the prefetch waited for on the spot), so they are inline asm with hand-placed
+// counted waits, as in gemm_f16x2_nlp_kernel: a wave-uniform SGPR base per row pair + one 32-bit lane offset, `s_nop 4` in front (the
+// base may come straight from a v_readlane: 5 wait states before a vector-memory instruction reads it), early-clobber outputs; the
+// wait names the registers it releases.  Rows past M: the base row is clamped to M-1 and the lane offset of the pair's second row to
+// the first (they are never stored).
+#define MMA_LW_LOAD(R_, IT_)                                                                       \
+    {                                                                                              \
+      const int64_t g_ = stream + min((int64_t)(IT_), n_it - 1) * n_streams;      /* past the end: the last group again (unused) */ \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                              \
+        const int64_t r_ = g_ * RI + 16 * lw + 2 * i;                                              \
+        const float* b_ = p.A + min(r_, p.M - 1) * p.lda;                                          \
+        const uint32_t vo_ = (r_ + 1 < p.M) ? a_voff : a_voff_c;                                   \
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(R_[i]) : "v"(vo_), "s"(b_) : "memory");          \
+      }                                                                                            \
+    }
+// at most 8 younger operations in flight: releases the raw set R_ (and everything older)
+#define MMA_LW_WAIT8(R_)                                                                           \
+    asm volatile("s_waitcnt vmcnt(8)" : "+v"(R_[0]), "+v"(R_[1]), "+v"(R_[2]), "+v"(R_[3]), "+v"(R_[4]), "+v"(R_[5]), "+v"(R_[6]), "+v"(R_[7]) :: "memory");
+// three passes over the 8 row pairs, so that their dependency chains interleave: with the one-lane store of the row maximum inside the
+// per-pair loop every pair was its own basic block and the wave walked eight ~40-instruction chains one after the other
+#define MMA_LW_PRODUCE(R_, IT_, S_)                                                                \
+    {                                                                                              \
+      unsigned char* sl_ = lds + (S_) * kSlot;                                                     \
+      const int64_t g_ = stream + (int64_t)(IT_) * n_streams;                                      \
+      const bool real_ = (IT_) < n_it;                                                             \
+      float rmax_[8]; int sce_[8];                                                                 \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                              \
+        float rmax = fmaxf(0.f, fmaxf(fmaxf(fabsf(R_[i][0]), fabsf(R_[i][1])), fmaxf(fabsf(R_[i][2]), fabsf(R_[i][3]))));   \
+        /* maximum over the 32 lanes that hold the row: four DPP steps inside the 16-lane rows (quad xor 1, xor 2, half-row mirror, row */ \
+        /* mirror) and one swizzle across the two rows - as five ds_bpermute round trips per row the LOADERS set the kernel's pace */       \
+        rmax = fmaxf(rmax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rmax), 0xB1, 0xF, 0xF, true)));   \
+        rmax = fmaxf(rmax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rmax), 0x4E, 0xF, 0xF, true)));   \
+        rmax = fmaxf(rmax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rmax), 0x141, 0xF, 0xF, true)));  \
+        rmax = fmaxf(rmax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rmax), 0x140, 0xF, 0xF, true)));  \
+        rmax = fmaxf(rmax, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(rmax), 0x401F)));              \
+        const int ex = (int)((__float_as_uint(rmax) >> 23) & 0xFF);                                \
+        rmax_[i] = rmax;                                                                           \
+        sce_[i] = min(max(14 - (ex - 127), -126), 127);                                            \
+      }                                                                                            \
+      if (r31 == 0) {                                                /* one lane per row */        \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                            \
+          const int pr = row_in + 2 * i;                             /* row inside the group */    \
+          reinterpret_cast<int*>(sl_ + RBI * kBlkP)[pr] = sce_[i];                                 \
+          const int64_t grow = g_ * RI + pr;                                                       \
+          if (a_row_max && cg == 0 && real_ && grow < p.M) a_row_max[grow] = rmax_[i];             \
+        }                                                                                          \
+      }                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                              \
+        const float sc = __uint_as_float((uint32_t)(sce_[i] + 127) << 23);                         \
+        const float v[4] = {R_[i][0] * sc, R_[i][1] * sc, R_[i][2] * sc, R_[i][3] * sc};           \
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));                                   \
+        h4 hi, lo;                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+          hi[j] = (_Float16)v[j];                                                                  \
+          lo[j] = (_Float16)((v[j] - (float)hi[j]) * 2048.f);                                      \
+        }                                                                                          \
+        const int pr = row_in + 2 * i, m_ = pr & 31;                                               \
+        unsigned char* d = sl_ + (pr >> 5) * kBlkP + (k0 >> 4) * kKsP + (m_ + 32 * ((k0 >> 3) & 1)) * 16 + (k0 & 7) * 2;   \
+        *reinterpret_cast<h4*>(d) = hi;                                                            \
+        *reinterpret_cast<h4*>(d + kPieceP) = lo;                                                  \
+      }                                                                                            \
+    }
+    // two raw sets: the rows of group it+2 are requested before the rows of group it+1 are split (a full iteration ahead).  Four loader
+    // waves: with two, and the rows requested just before the barrier, the LOADERS set the pace (6.2 us per 64 rows against the ~3 us
+    // the multipliers' stores need: 1.59 ms at C4)
+    if (n_it > 0 && !(kAbl & 8)) {
+      MMA_LW_LOAD(rawA, 0)
+      MMA_LW_LOAD(rawB, 1)
+      MMA_LW_WAIT8(rawA)
+      MMA_LW_PRODUCE(rawA, 0, 0)
+    }
+    MMA_LW_BARRIER()
+    // whole pairs of iterations, then the odd one: no path on which a raw set is requested twice without a wait in between (the wait
+    // audit, tools/check_asm_waits.py, walks every path of the control-flow graph)
+    int64_t it = 0;
+    for (; it + 1 < n_it; it += 2) {
+      // multipliers are on group `it` (slot 0): group it+1 goes to slot 1, the rows of group it+2 are requested
+      if (!(kAbl & 8)) {
+        MMA_LW_LOAD(rawA, it + 2)
+        MMA_LW_WAIT8(rawB)
+        MMA_LW_PRODUCE(rawB, it + 1, 1)
+      }
+      MMA_LW_BARRIER()
+      if (!(kAbl & 8)) {
+        MMA_LW_LOAD(rawB, it + 3)
+        MMA_LW_WAIT8(rawA)
+        MMA_LW_PRODUCE(rawA, it + 2, 0)
+      }
+      MMA_LW_BARRIER()
+    }
+    if (it < n_it) MMA_LW_BARRIER()                         // the multipliers' last (odd) iteration: nothing left to bring in
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawA[0]), "+v"(rawA[1]), "+v"(rawA[2]), "+v"(rawA[3]), "+v"(rawA[4]), "+v"(rawA[5]), "+v"(rawA[6]), "+v"(rawA[7]),
+                 "+v"(rawB[0]), "+v"(rawB[1]), "+v"(rawB[2]), "+v"(rawB[3]), "+v"(rawB[4]), "+v"(rawB[5]), "+v"(rawB[6]), "+v"(rawB[7]) :: "memory");   // nothing in flight into dead registers at the end
+#undef MMA_LW_LOAD
+#undef MMA_LW_WAIT8
+#undef MMA_LW_PRODUCE
+    return;
+  }
+
+  // ---------------- multipliers
+  const int col0 = cg * 256 + wave * 32;
+  f16x8 wh[KS], wl[KS];
+  {
+    const _Float16* Bh = reinterpret_cast<const _Float16*>(p.Bt);
+    const _Float16* wp = Bh + (size_t)(col0 + r31) * K + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      wh[ks] = *reinterpret_cast<const f16x8*>(wp + ks * 16);
+      wl[ks] = *reinterpret_cast<const f16x8*>(wp + (size_t)p.N * K + ks * 16);
+    }
+  }
+  const int cue = (int)((__float_as_uint(col_unscale[col0 + r31]) >> 23) & 0xFF) - 127;
+  const uint32_t c_off = (4u * h * (uint32_t)p.ldc + (uint32_t)r31) * 4u;
+  const uint32_t pcol = (uint32_t)col0 * 4u;
+  float prev[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) prev[r] = 0.f;
+  __amdgpu_buffer_rsrc_t crow_p = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // W and the column un-scale have landed: no load is waited for below
+#define MMA_LW_CONSUME(IT_, S_)                                                                    \
+  {                                                                                                \
+    const unsigned char* sl = lds + (S_) * kSlot;                                                  \
+    const int64_t gI = stream + (int64_t)(IT_) * n_streams;                                        \
+    _Pragma("unroll") for (int blk = 0; blk < RBI; ++blk) {                                        \
+      const int64_t row0 = gI * RI + blk * 32;                                                     \
+      const int64_t rows_here = min((int64_t)32, p.M - row0);                                      \
+      const __amdgpu_buffer_rsrc_t crow = __builtin_amdgcn_make_buffer_rsrc(                       \
+          p.C + min(row0, p.M - 1) * p.ldc, 0, rows_here > 0 ? (int)min((int64_t)0x7fffffff, rows_here * p.ldc * 4) : 0, 0x00020000); \
+      f32x16 acc, acl;                                                                             \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acl[r] = 0.f; }               \
+      const unsigned char* fa = sl + blk * kBlkP + lane * 16;                                      \
+      f16x8 ah = *reinterpret_cast<const f16x8*>(fa), al = *reinterpret_cast<const f16x8*>(fa + kPieceP); \
+      _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                          \
+        f16x8 nh = ah, nl = al;                                                                    \
+        if (ks + 1 < KS) {                                                                         \
+          nh = *reinterpret_cast<const f16x8*>(fa + (ks + 1) * kKsP);                              \
+          nl = *reinterpret_cast<const f16x8*>(fa + kPieceP + (ks + 1) * kKsP);                    \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (!(kAbl & 2)) {                                                                         \
+        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[ks], acl, 0, 0, 0);                    \
+        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[ks], acl, 0, 0, 0);                    \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[ks], acc, 0, 0, 0);                    \
+        } else { asm volatile("" :: "v"(ah), "v"(al), "v"(wh[ks]), "v"(wl[ks])); }                 \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
+          const int r = 2 * ks + j;                                                                \
+          if (!(kAbl & 4)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[r]), crow_p, c_off, \
+                                                (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc) * 4u + pcol, kCgStoreAux); \
+          else asm volatile("" :: "v"(prev[r]));                                                   \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        ah = nh; al = nl;                                                                          \
+      }                                                                                            \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                              \
+        const int4 e4 = *reinterpret_cast<const int4*>(sl + RBI * kBlkP + (blk * 32 + 8 * q + 4 * h) * 4); \
+        const int rse[4] = {e4.x, e4.y, e4.z, e4.w};                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+          prev[4 * q + j] = ldexpf(acc[4 * q + j] + acl[4 * q + j] * (1.f / 2048.f), cue - rse[j]); \
+      }                                                                                            \
+      crow_p = crow;                                                                               \
+    }                                                                                              \
+  }
+  MMA_LW_BARRIER()                                                                                 // slot 0 holds the first group
+  int64_t it = 0;
+  for (; it + 1 < n_it; it += 2) {
+    MMA_LW_CONSUME(it, 0)
+    MMA_LW_BARRIER()
+    MMA_LW_CONSUME(it + 1, 1)
+    MMA_LW_BARRIER()
+  }
+  if (it < n_it) {
+    MMA_LW_CONSUME(it, 0)
+    MMA_LW_BARRIER()
+  }
+#undef MMA_LW_CONSUME
+#undef MMA_LW_BARRIER
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[r]), crow_p, c_off, (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc) * 4u + pcol,
+                                          kCgStoreAux);
+}
+
 // ---- K == 256, three products (round 2, late): the forward [P|Q] = x [Wtop|Wbot] of hidden width 256 (C5) -----------------------------
 // The column-group form with a 256-deep reduction: a workgroup owns 128 columns, their B slab (2 pieces x 128 columns x 256 k fp16 = 135 KB
 // with the row padding) stays in LDS for the whole launch, a wave's 32 rows (256 floats each) are loaded once, scaled by the power of
@@ -1956,6 +2174,11 @@ extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, cons
   // before them (one in-order vmcnt) - see DESIGN.md "forward GEMM, round 4"; kept for the next step (loader waves that never store).
   const char* ws_env = getenv("MMA_FWD_WS");
   const bool use_ws = ws_env && ws_env[0] == '1';
+  if (ws_env && ws_env[0] == '2' && N % 256 == 0 && (kCgSlotsPerXcd % (N / 256)) == 0) {         // MMA_FWD_WS=2: loader waves
+    hipLaunchKernelGGL(gemm_f16x2_lw_kernel, dim3(256), dim3(kLwThreads), 0, static_cast<hipStream_t>(stream), p, col_unscale, (M + 63) / 64,
+                       N / 256, a_row_max);
+    return check_launch("gemm_f16x2_lw_kernel");
+  }
   if (use_ws && N % 256 == 0 && (kCgSlotsPerXcd % (N / 256)) == 0) {
     hipLaunchKernelGGL((gemm_f16x2_ws_kernel<8, 2>), dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p, col_unscale,
                        (M + 63) / 64, N / 256, a_row_max);

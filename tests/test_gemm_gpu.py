@@ -443,6 +443,12 @@ def test_gemm_f16x2_ws_is_bit_equal_to_the_column_group_kernels(M, K, N, monkeyp
     if K == 128:
         monkeypatch.delenv("MMA_FWD_WS", raising=False)                            # the default: the column-group kernel
         call("mma_gemm_f16x2", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(old), old.stride(0), None, M, N, stream_ptr())
+        # the loader-wave kernel (MMA_FWD_WS=2): eight multiplier waves + two loader waves, same bits and row maxima
+        monkeypatch.setenv("MMA_FWD_WS", "2")
+        lw, rm2 = torch.full((M, N), 3.0, device=DEV), torch.full((M,), -1.0, device=DEV)
+        call("mma_gemm_f16x2", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(lw), lw.stride(0), ptr(rm2), M, N, stream_ptr())
+        monkeypatch.delenv("MMA_FWD_WS")
+        assert torch.equal(lw, old) and torch.equal(rm2, a.abs().amax(1))
     else:
         call("mma_gemm_f16x2_k256", ptr(a), a.stride(0), ptr(rm), ptr(bt2), ptr(cu), ptr(old), old.stride(0), M, N, stream_ptr())
     assert torch.equal(out, old)
