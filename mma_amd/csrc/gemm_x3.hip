@@ -473,7 +473,15 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
         // stores of a tile issued in one burst after its MFMAs, all eight waves of the CU multiplied together and then all sat in front
         // of the full store queue together: stores alone 0.74 ms, everything but the stores 0.64 ms, both 1.05 ms (measurement
         // builds, C4) - nothing overlapped.  Spread out, a wave that waits for a store slot has its MFMAs in between.
-        if (!(dbg & 4)) {
+        if (dbg & 64) {                          // measurement: the tile as FOUR 16-byte stores (8 whole 128-byte rows each), wrong data
+          if (ks & 1) {
+            const int q4 = ks >> 1;
+            typedef unsigned int su4 __attribute__((ext_vector_type(4)));
+            const su4 v = {__float_as_uint(prev[4 * q4]), __float_as_uint(prev[4 * q4 + 1]), __float_as_uint(prev[4 * q4 + 2]), __float_as_uint(prev[4 * q4 + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, crow_p, ((uint32_t)(lane >> 3) * (uint32_t)p.ldc + (uint32_t)(lane & 7) * 4u) * 4u,
+                                                   (uint32_t)(8 * q4 * (int)p.ldc) * 4u + pcol, kCgStoreAux);
+          }
+        } else if (!(dbg & 4)) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int r = 2 * ks + j;
