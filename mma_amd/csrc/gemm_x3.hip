@@ -1339,6 +1339,7 @@ __global__ __launch_bounds__(kNlThreads, 1) void gemm_f16x2_nlp_kernel(const Gem
     const int64_t base_row = min(row0, p.M - 1);                     // wave-uniform; rows past M re-read the last row, never stored
     const int drow = (int)(min(row0 + min((int64_t)r31, max(rows_here, (int64_t)1) - 1), p.M - 1) - base_row);       // 0 .. 31
     const uint32_t a_voff = ((uint32_t)drow * (uint32_t)p.lda + 8u * h) * 4u;                             // bytes from the wave's base row
+    const uint32_t a_voff_rm = ((uint32_t)(lane >> 4) * (uint32_t)p.lda + 4u * (lane & 15)) * 4u;         // (measurement build 128)
     const float* abase = p.A + base_row * p.lda;                     // + chunk * 64 floats
     const float rmax = row_max[base_row + drow];
     const int ex = (int)((__float_as_uint(rmax) >> 23) & 0xFF);
@@ -1381,7 +1382,18 @@ __global__ __launch_bounds__(kNlThreads, 1) void gemm_f16x2_nlp_kernel(const Gem
 // inside an asm string (5.7 item 2; without the pad the first build of this kernel read a stale base: a memory access fault).  Outputs are
 // early-clobber: the statement writes its first destination before it has read the offset register for the last time.
 #define MMA_NLP_LOADA(R_, C_)                                                                      \
-    if (!(dbg & 8)) {                                                                              \
+    if (dbg & 128) {   /* measurement: the chunk as 8 ROW-MAJOR loads (4 whole 256-byte row segments each), wrong lane layout */      \
+      const float* ab_ = abase + (int64_t)(C_) * kNlKC;                                            \
+      const float *b0_ = ab_, *b1_ = ab_ + 4 * p.lda, *b2_ = ab_ + 8 * p.lda, *b3_ = ab_ + 12 * p.lda,                          \
+                  *b4_ = ab_ + 16 * p.lda, *b5_ = ab_ + 20 * p.lda, *b6_ = ab_ + 24 * p.lda, *b7_ = ab_ + 28 * p.lda;          \
+      asm volatile("s_nop 4\n\t"                                                                   \
+                   "global_load_dwordx4 %0, %8, %9\n\t"  "global_load_dwordx4 %1, %8, %10\n\t"     \
+                   "global_load_dwordx4 %2, %8, %11\n\t" "global_load_dwordx4 %3, %8, %12\n\t"     \
+                   "global_load_dwordx4 %4, %8, %13\n\t" "global_load_dwordx4 %5, %8, %14\n\t"     \
+                   "global_load_dwordx4 %6, %8, %15\n\t" "global_load_dwordx4 %7, %8, %16"          \
+                   : "=&v"(R_[0]), "=&v"(R_[1]), "=&v"(R_[2]), "=&v"(R_[3]), "=&v"(R_[4]), "=&v"(R_[5]), "=&v"(R_[6]), "=&v"(R_[7])  \
+                   : "v"(a_voff_rm), "s"(b0_), "s"(b1_), "s"(b2_), "s"(b3_), "s"(b4_), "s"(b5_), "s"(b6_), "s"(b7_) : "memory");    \
+    } else if (!(dbg & 8)) {                                                                       \
       const float* ab_ = abase + (int64_t)(C_) * kNlKC;                                            \
       asm volatile("s_nop 4\n\t"                                                                   \
                    "global_load_dwordx4 %0, %8, %9 offset:0\n\t"   "global_load_dwordx4 %1, %8, %9 offset:16\n\t"   \
