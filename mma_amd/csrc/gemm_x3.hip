@@ -718,6 +718,8 @@ __global__ __launch_bounds__(kLwThreads, 1) void gemm_f16x2_lw_kernel(const Gemm
   if (wave >= 8) {
     // ---------------- loader: rows [32 lw, 32 lw + 32) of every row group; load i covers rows 2i, 2i+1 (lane >> 5), 16 bytes per lane
     const int lw = wave - 8;                                  // 0..3: rows [16 lw, 16 lw + 16) of the group, load i = rows 2i, 2i+1
+    __builtin_amdgcn_s_setprio(3);                            // the loaders' short instruction stream goes ahead of the multipliers' MFMAs:
+                                                              // loaders + multipliers without stores 0.79 -> 0.71 ms, everything 1.27 -> 1.19
     const int row_in = 16 * lw + h, k0 = 4 * r31;             // + 2 i
     const uint32_t lda_b = (uint32_t)p.lda * 4u;
     const uint32_t a_voff = (uint32_t)h * lda_b + (uint32_t)k0 * 4u, a_voff_c = (uint32_t)k0 * 4u;
