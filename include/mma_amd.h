@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 31
+#define MMA_ABI_VERSION 32
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -302,6 +302,12 @@ int mma_tower_linear_bwd(const float* gy, const float* a, const float* W, float*
  * KF = K*F <= 512, O <= 16, S <= 5; pre: the table of mma_tower_post_pre (from the CSR-by-target row pointers = degrees).  Neither `out` nor its
  * gradient is ever materialised. */
 int64_t mma_tower_post_kfp(int32_t KF);
+/* ABI 32: both padded layouts from the contiguous weight columns Wo (T, O, S*KF) in one launch: Wa (T, KFp, S*16), Wb (T, S*16, KFp + 16),
+ * zero padding included (the caller need not clear them). */
+int mma_tower_post_weights(const float* Wo, int32_t T, int32_t O, int32_t S, int32_t KF, float* Wa, float* Wb, void* stream);
+/* ABI 32: mma_tower_post_gw's partial tiles (n_chunks <= 1024 rows of T*S*16*kfp16 floats, kfp16 = KF rounded up to 16) summed in
+ * mma_col_sum's order and written in the weight layout gWo (T, O, S*KF) - one launch instead of the reduction + a permuting copy. */
+int mma_tower_post_gw_reduce(const float* part, int64_t n_chunks, int32_t T, int32_t S, int32_t O, int32_t KF, float* gWo, void* stream);
 /* 1 when K13 / K14 (and their PLAIN form K16, with S = ceil(O / 16)) take this shape: 1 <= KF <= 512, 1 <= S <= 5 and the tower's staged
  * weights plus the four wave tiles fit the 160 KB of LDS in BOTH layouts (forward KFp*S*16 floats, backward S*16*(KFp + 16)); 0 otherwise
  * - the caller then keeps the unfactored / library path (ABI 29: the host-side gates ask the library instead of restating its limits). */

@@ -478,6 +478,32 @@ using namespace mma;
 // padded weight shapes the caller prepares: forward Wa (T, KFp, S*16), backward Wb (T, S*16, KFp + 16), KFp = mma_tower_post_kfp(KF)
 extern "C" int64_t mma_tower_post_kfp(int32_t KF) { return KF < 1 ? -1 : ((int64_t)KF + kPostTile - 1) / kPostTile * kPostTile; }
 
+// [r4] both padded layouts of the post-NN weight columns in ONE launch (as torch ops: a zero-fill, a strided copy and a transposing copy per
+// MMAConv call - three of the ~39 kernels of a ZINC-batch layer step, where every launch is 5 us of 300): Wo (T, O, S*KF) contiguous ->
+// Wb[t][q*16+o][c] = Wo[t][o][q*KF + c] for o < O, c < KF (else 0), Wa[t][c][q*16+o] = the same for c < KFp.
+__global__ __launch_bounds__(kBlock) void post_weights_kernel(const float* Wo, int T, int O, int S, int KF, int KFp, float* Wa, float* Wb) {
+  const int ldb = KFp + 16, R = S * 16;
+  const int64_t total = (int64_t)T * R * ldb;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ldb);
+    const int r = (int)((i / ldb) % R);
+    const int t = (int)(i / ((int64_t)ldb * R));
+    const int q = r >> 4, o = r & 15;
+    const float v = (o < O && c < KF) ? Wo[((size_t)t * O + o) * ((size_t)S * KF) + (size_t)q * KF + c] : 0.f;
+    Wb[i] = v;
+    if (c < KFp) Wa[((size_t)t * KFp + c) * R + r] = v;
+  }
+}
+extern "C" int mma_tower_post_weights(const float* Wo, int32_t T, int32_t O, int32_t S, int32_t KF, float* Wa, float* Wb, void* stream) {
+  MMA_REQUIRE(T >= 1 && O >= 1 && O <= 16 && S >= 1 && S <= kPostMaxS && KF >= 1 && KF <= 512, "T=%d O=%d S=%d KF=%d unsupported", T, O, S, KF);
+  MMA_REQUIRE(Wo && Wa && Wb, "NULL argument");
+  const int KFp = (KF + kPostTile - 1) / kPostTile * kPostTile;
+  const int64_t total = (int64_t)T * S * 16 * (KFp + 16);
+  hipLaunchKernelGGL(post_weights_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, kMaxGrid)), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), Wo, (int)T, (int)O, (int)S, (int)KF, KFp, Wa, Wb);
+  return check_launch("post_weights_kernel");
+}
+
 // the limits post_fill() and the launchers enforce, for the host-side gates (mma_conv.py's `factored`, dense._skinny_ok)
 extern "C" int mma_tower_post_fits(int32_t KF, int32_t S) {
   if (KF < 1 || KF > 512 || S < 1 || S > kPostMaxS) return 0;
@@ -540,6 +566,43 @@ extern "C" int mma_tower_post_gw(const float* gy, int64_t ldg, const float* agg,
   const dim3 grid((unsigned)(n_chunks / (kBlock / kWave)), (unsigned)T);
   MMA_POST_LAUNCH(tower_post_gw_kernel, 0, gy, agg, pre, part, npw, kfp16)
   return check_launch("tower_post_gw_kernel");
+}
+
+// [r4] K15's per-wave partial tiles (n_chunks, T, S, 16, kfp16) summed in mma_col_sum's order (col_sum_kernel, one row block: four row
+// lanes of four accumulators - the same bits as the K8 launch it replaces) and written straight into the weight layout
+// gWo (T, O, S*KF): the permuting copy behind the K8 launch was one more launch per layer step.
+__global__ __launch_bounds__(kBlock) void post_gw_reduce_kernel(const float* part, int R, int T, int S, int O, int KF, int kfp16, float* gWo) {
+  const int64_t total = (int64_t)T * O * S * KF;
+  const size_t ld = (size_t)T * S * 16 * kfp16;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kf = (int)(i % KF);
+    const int q = (int)((i / KF) % S);
+    const int o = (int)((i / ((int64_t)KF * S)) % O);
+    const int t = (int)(i / ((int64_t)KF * S * O));
+    const float* qp = part + (((size_t)t * S + q) * 16 + o) * kfp16 + kf;
+    float red[4];
+#pragma unroll
+    for (int rl = 0; rl < 4; ++rl) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int r = rl;
+      for (; r + 12 < R; r += 16) { a0 += qp[(size_t)r * ld]; a1 += qp[(size_t)(r + 4) * ld]; a2 += qp[(size_t)(r + 8) * ld]; a3 += qp[(size_t)(r + 12) * ld]; }
+      for (; r < R; r += 4) a0 += qp[(size_t)r * ld];
+      red[rl] = (a0 + a1) + (a2 + a3);
+    }
+    gWo[i] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+extern "C" int mma_tower_post_gw_reduce(const float* part, int64_t n_chunks, int32_t T, int32_t S, int32_t O, int32_t KF, float* gWo, void* stream) {
+  MMA_REQUIRE(n_chunks >= 1 && n_chunks <= 1024 && T >= 1 && S >= 1 && S <= kPostMaxS && O >= 1 && O <= 16 && KF >= 1 && KF <= 512,
+              "n_chunks=%lld T=%d S=%d O=%d KF=%d unsupported (n_chunks <= 1024: mma_col_sum's single-pass order)", (long long)n_chunks, T, S, O, KF);
+  MMA_REQUIRE(part && gWo, "NULL argument");
+  MMA_REQUIRE(n_chunks <= 256 || (int64_t)T * S * 16 * ((KF + 15) / 16 * 16) > 2048,
+              "n_chunks=%lld with %lld columns: mma_col_sum sums this shape in its short-matrix order", (long long)n_chunks,
+              (long long)T * S * 16 * ((KF + 15) / 16 * 16));
+  const int64_t total = (int64_t)T * O * S * KF;
+  hipLaunchKernelGGL(post_gw_reduce_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, kMaxGrid)), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), part, (int)n_chunks, (int)T, (int)S, (int)O, (int)KF, (KF + 15) / 16 * 16, gWo);
+  return check_launch("post_gw_reduce_kernel");
 }
 
 extern "C" int mma_tower_post_bwd(const float* gy, int64_t ldg, const float* pre, const float* Wb, float* gagg, int64_t lda,

@@ -435,6 +435,13 @@ class GRGraph:
         return self.by_target.perm[:self.E]
 
     @property
+    def perm_long(self):
+        """perm as int64 (an index_select index), converted once per graph - not once per layer call."""
+        if self.__dict__.get("_perm_long") is None:
+            self._perm_long = self.perm.long()
+        return self._perm_long
+
+    @property
     def inv_perm(self):
         """(E,) int64: target-sorted position of each original edge."""
         if self._inv_perm is None:
@@ -498,7 +505,7 @@ def rows_by_position(x, graph):
     """x (E, ...) by original edge id -> rows in target-sorted position order (so that a GEMM on it yields Z by position)."""
     if graph.E == 0:
         return x
-    return _PermuteRows.apply(x, graph.perm.long(), graph.inv_perm)
+    return _PermuteRows.apply(x, graph.perm_long, graph.inv_perm)
 
 
 def _gr_call(fn, csr, U, V, Z, by_pos, inputs, extra, N, E, T, F, aggr, scalers, avg_log, avg_lin, drop, z_index=None):
@@ -620,9 +627,9 @@ class _TowerPost(torch.autograd.Function):
         KFp = int(_lib.lib().mma_tower_post_kfp(KF))
         # the weight columns twice, zero-padded: Wa (T, KFp, S*16) [kf][q*16+o] for the forward, Wb (T, S*16, KFp+16) [q*16+o][kf]
         # for the backward (the tower's weights are staged in LDS in exactly these layouts)
-        Wb = torch.zeros((T, S * 16, KFp + 16), device=agg.device, dtype=torch.float32)
-        Wb.view(T, S, 16, KFp + 16)[:, :, :O, :KF] = Wo.view(T, O, S, KF).permute(0, 2, 1, 3)
-        Wa = Wb[:, :, :KFp].transpose(1, 2).contiguous()
+        Wb = torch.empty((T, S * 16, KFp + 16), device=agg.device, dtype=torch.float32)
+        Wa = torch.empty((T, KFp, S * 16), device=agg.device, dtype=torch.float32)
+        call("mma_tower_post_weights", ptr(Wo.contiguous()), T, O, S, KF, ptr(Wa), ptr(Wb), stream_ptr())      # one launch (a fill + two copies before)
         y = torch.empty((N, T * O), device=agg.device, dtype=torch.float32)
         # the scaler products of every node, once: K13 / K14 / K15 read them - and once per GRAPH: the four layers of the reference's Net
         # share edge_index, scalers and the degree statistics (mma.py:91-97), so the table rides on the plan's rowptr tensor
@@ -668,8 +675,13 @@ class _TowerPost(torch.autograd.Function):
             with _span("tower_post_gw", nbytes=4 * N * (T * KF + T * O + 8) + 4 * part.numel(), flops=2 * N * T * kfp16 * S * 16, mfma="f32"):
                 call("mma_tower_post_gw", ptr(gy), T * O, ptr(agg), T * KF, ptr(pre), ptr(part), n_chunks, N, T, KF, S, O,
                      host_codes(scalers), float(avg_log), float(avg_lin), stream_ptr())
-                gWq = dense.col_sum(part).view(T, S, 16, kfp16)
-            gWo = gWq[:, :, :O, :KF].permute(0, 2, 1, 3).reshape(T, O, S * KF)
+                if n_chunks <= 256 or (n_chunks <= 1024 and part.shape[1] > 2048):      # (where K8 takes its single-block order) the
+                    # partial tiles summed straight into the weight layout: one launch, not two
+                    gWo = torch.empty((T, O, S * KF), device=agg.device, dtype=torch.float32)
+                    call("mma_tower_post_gw_reduce", ptr(part), n_chunks, T, S, O, KF, ptr(gWo), stream_ptr())
+                else:
+                    gWq = dense.col_sum(part).view(T, S, 16, kfp16)
+                    gWo = gWq[:, :, :O, :KF].permute(0, 2, 1, 3).reshape(T, O, S * KF)
         return gagg, gWo, None, None, None, None
 
 

@@ -56,7 +56,7 @@ class CategoricalEdges:
                 # hipGraph capture, whose eager warm-up has just run it on the same buffers)
                 torch._assert_async(((self.types >= 0) & (self.types < self.table.shape[0])).all())
             t = self.types.to(torch.uint8)
-            self._by_pos = (key, t if graph.E == 0 else t.index_select(0, graph.perm.long()).contiguous())
+            self._by_pos = (key, t if graph.E == 0 else t.index_select(0, graph.perm_long).contiguous())
         return self._by_pos[1]
 
 

@@ -141,3 +141,36 @@ def test_batched_tn_product_against_float64():
         assert ((out[b].double() - ref).abs() <= 5e-7 * mag).all(), b          # the six-product kernel's bound (tests/test_gemm_gpu.py)
     one = torch.stack([dense.xt_g(x[:, b * ka:(b + 1) * ka], y[:, b * nc:(b + 1) * nc]) for b in range(B)])
     assert (out - one).abs().max().item() <= 5e-7 * mag.max().item()
+
+
+@pytest.mark.parametrize("T,O,S,KF", [(5, 15, 3, 152), (1, 1, 1, 4), (3, 16, 5, 100), (2, 7, 2, 512)])
+def test_tower_post_weight_layouts_in_one_launch(T, O, S, KF):
+    """mma_tower_post_weights (round 4): both zero-padded layouts of the post-NN weight columns from one launch equal the three torch
+    operations they replace (fill, strided copy, transposing copy), padding included (the buffers start as garbage)."""
+    from mma_amd import _lib
+    from mma_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator().manual_seed(T + O + S + KF)
+    Wo = torch.randn(T, O, S * KF, generator=g).to(DEV)
+    KFp = int(_lib.lib().mma_tower_post_kfp(KF))
+    Wb_ref = torch.zeros((T, S * 16, KFp + 16), device=DEV)
+    Wb_ref.view(T, S, 16, KFp + 16)[:, :, :O, :KF] = Wo.view(T, O, S, KF).permute(0, 2, 1, 3)
+    Wa_ref = Wb_ref[:, :, :KFp].transpose(1, 2).contiguous()
+    Wb = torch.full((T, S * 16, KFp + 16), float("nan"), device=DEV)
+    Wa = torch.full((T, KFp, S * 16), float("nan"), device=DEV)
+    call("mma_tower_post_weights", ptr(Wo), T, O, S, KF, ptr(Wa), ptr(Wb), stream_ptr())
+    assert torch.equal(Wb, Wb_ref) and torch.equal(Wa, Wa_ref)
+
+
+@pytest.mark.parametrize("R,T,S,O,KF", [(4, 5, 3, 15, 152), (1, 1, 1, 1, 4), (300, 2, 5, 16, 100), (1024, 4, 2, 7, 36), (256, 1, 1, 3, 8)])
+def test_tower_post_gw_reduce_equals_col_sum_and_permute(R, T, S, O, KF):
+    """mma_tower_post_gw_reduce (round 4): the partial tiles summed in mma_col_sum's order, written in the weight layout - the bits of
+    the K8 launch + the permuting copy it replaces."""
+    from mma_amd import dense
+    from mma_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator().manual_seed(R + T + KF)
+    kfp16 = -(-KF // 16) * 16
+    part = torch.randn(R, T * S * 16 * kfp16, generator=g).to(DEV)
+    ref = dense.col_sum(part).view(T, S, 16, kfp16)[:, :, :O, :KF].permute(0, 2, 1, 3).reshape(T, O, S * KF)
+    got = torch.full((T, O, S * KF), float("nan"), device=DEV)
+    call("mma_tower_post_gw_reduce", ptr(part), R, T, S, O, KF, ptr(got), stream_ptr())
+    assert torch.equal(got, ref)
