@@ -307,6 +307,9 @@ int64_t mma_tower_post_kfp(int32_t KF);
 int mma_tower_post_weights(const float* Wo, int32_t T, int32_t O, int32_t S, int32_t KF, float* Wa, float* Wb, void* stream);
 /* ABI 32: mma_tower_post_gw's partial tiles (n_chunks <= 1024 rows of T*S*16*kfp16 floats, kfp16 = KF rounded up to 16) summed in
  * mma_col_sum's order and written in the weight layout gWo (T, O, S*KF) - one launch instead of the reduction + a permuting copy. */
+/* ABI 32: the two padded layouts of a Linear weight W (O, K) contiguous for mma_skinny_linear_fwd / _bwd_dx in one launch:
+ * Wa (KFp, S*16), Wb (S*16, KFp + 16), S = ceil(O / 16), KFp = mma_tower_post_kfp(K); zero padding included. */
+int mma_skinny_linear_weights(const float* W, int32_t O, int32_t K, float* Wa, float* Wb, void* stream);
 int mma_tower_post_gw_reduce(const float* part, int64_t n_chunks, int32_t T, int32_t S, int32_t O, int32_t KF, float* gWo, void* stream);
 /* 1 when K13 / K14 (and their PLAIN form K16, with S = ceil(O / 16)) take this shape: 1 <= KF <= 512, 1 <= S <= 5 and the tower's staged
  * weights plus the four wave tiles fit the 160 KB of LDS in BOTH layouts (forward KFp*S*16 floats, backward S*16*(KFp + 16)); 0 otherwise

@@ -494,6 +494,27 @@ __global__ __launch_bounds__(kBlock) void post_weights_kernel(const float* Wo, i
     if (c < KFp) Wa[((size_t)t * KFp + c) * R + r] = v;
   }
 }
+// the PLAIN (K16) layouts of a Linear weight W (O, K): Wb (S*16, KFp + 16)[r][c] = W[r][c], Wa (KFp, S*16) its transpose, S = ceil(O / 16)
+__global__ __launch_bounds__(kBlock) void skinny_weights_kernel(const float* W, int O, int K, int KFp, int R, float* Wa, float* Wb) {
+  const int ldb = KFp + 16;
+  const int64_t total = (int64_t)R * ldb;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ldb), r = (int)(i / ldb);
+    const float v = (r < O && c < K) ? W[(size_t)r * K + c] : 0.f;
+    Wb[i] = v;
+    if (c < KFp) Wa[(size_t)c * R + r] = v;
+  }
+}
+extern "C" int mma_skinny_linear_weights(const float* W, int32_t O, int32_t K, float* Wa, float* Wb, void* stream) {
+  MMA_REQUIRE(O >= 1 && O <= kPostMaxS * kPostO && K >= 1 && K <= 512, "O=%d K=%d unsupported", O, K);
+  MMA_REQUIRE(W && Wa && Wb, "NULL argument");
+  const int KFp = (K + kPostTile - 1) / kPostTile * kPostTile, R = (O + kPostO - 1) / kPostO * 16;
+  const int64_t total = (int64_t)R * (KFp + 16);
+  hipLaunchKernelGGL(skinny_weights_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, kMaxGrid)), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), W, (int)O, (int)K, KFp, R, Wa, Wb);
+  return check_launch("skinny_weights_kernel");
+}
+
 extern "C" int mma_tower_post_weights(const float* Wo, int32_t T, int32_t O, int32_t S, int32_t KF, float* Wa, float* Wb, void* stream) {
   MMA_REQUIRE(T >= 1 && O >= 1 && O <= 16 && S >= 1 && S <= kPostMaxS && KF >= 1 && KF <= 512, "T=%d O=%d S=%d KF=%d unsupported", T, O, S, KF);
   MMA_REQUIRE(Wo && Wa && Wb, "NULL argument");

@@ -386,9 +386,10 @@ def _skinny_weights(weight):
     O, K = weight.shape
     S = -(-O // 16)
     kfp = int(_lib.lib().mma_tower_post_kfp(K))
-    Wb = torch.zeros((S * 16, kfp + 16), device=weight.device, dtype=torch.float32)
-    Wb[:O, :K] = weight
-    return Wb[:, :kfp].t().contiguous(), Wb
+    Wb = torch.empty((S * 16, kfp + 16), device=weight.device, dtype=torch.float32)
+    Wa = torch.empty((kfp, S * 16), device=weight.device, dtype=torch.float32)
+    call("mma_skinny_linear_weights", ptr(weight.contiguous()), O, K, ptr(Wa), ptr(Wb), stream_ptr())      # one launch (a fill + two copies before)
+    return Wa, Wb
 
 
 class _Linear(torch.autograd.Function):

@@ -174,3 +174,17 @@ def test_tower_post_gw_reduce_equals_col_sum_and_permute(R, T, S, O, KF):
     got = torch.full((T, O, S * KF), float("nan"), device=DEV)
     call("mma_tower_post_gw_reduce", ptr(part), R, T, S, O, KF, ptr(got), stream_ptr())
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("O,K", [(75, 75), (1, 1), (80, 512), (16, 50), (33, 130)])
+def test_skinny_linear_weight_layouts_in_one_launch(O, K):
+    """mma_skinny_linear_weights (round 4) equals the fill + copy + transposing copy it replaces."""
+    from mma_amd import _lib
+    from mma_amd._lib import call, ptr, stream_ptr
+    W = torch.randn(O, K, generator=torch.Generator().manual_seed(O * K)).to(DEV)
+    S, kfp = -(-O // 16), int(_lib.lib().mma_tower_post_kfp(K))
+    Wb_ref = torch.zeros((S * 16, kfp + 16), device=DEV)
+    Wb_ref[:O, :K] = W
+    Wb = torch.full_like(Wb_ref, float("nan")); Wa = torch.full((kfp, S * 16), float("nan"), device=DEV)
+    call("mma_skinny_linear_weights", ptr(W), O, K, ptr(Wa), ptr(Wb), stream_ptr())
+    assert torch.equal(Wb, Wb_ref) and torch.equal(Wa, Wb_ref[:, :kfp].t().contiguous())
