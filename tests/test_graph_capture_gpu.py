@@ -297,3 +297,19 @@ def test_csr_build_inside_a_graph_rezeroes_the_long_list_and_a_bad_count_is_not_
     got = run()
     ln[0] = 0
     assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+
+
+def test_bench_c2net_flow_eager_phase_then_graphed_step_replays_without_a_fault():
+    """The exact process history in which bench.py's default run faulted in round 4: an eager training phase
+    of the Net on rotating batches, THEN a second Net captured as one hipGraph and replayed past the fifth replay.  A fault would take the
+    test process down; the replayed losses must also be finite and the long-segment list of the captured CSR empty after every replay."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mma_amd import functional as Fn
+    r = bench.gr_model_config("C2net (test)", 64, torch.device(DEV), reps=8, graphed=True)
+    torch.cuda.synchronize()
+    assert np.isfinite(r["loss_after_hipgraph"]) and all(np.isfinite(v) for v in r["loss_first_steps_hipgraph"])
+    assert r["ms_per_step_hipgraph"] < r["ms_per_step_eager"]
+    for g in Fn._GR_GRAPHS.values():
+        assert int(g.by_target.long_nodes[0]) == 0
