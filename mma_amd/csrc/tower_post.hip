@@ -18,6 +18,8 @@
 // The tower's weights sit in LDS for the whole workgroup (30 KB at ZINC's shape), aggregate rows enter / leave as whole 128-byte row
 // segments through a wave-private LDS tile.  (A first version kept lane = node on the VALU with the 16 weights of a (q, kf) as SGPR
 // operands from s_load_dwordx16: 0.41 / 1.02 ms at C2L - the 29 KB weight sweep of every wave thrashes the 16 KB scalar cache.)
+#include <algorithm>
+#include <cstdlib>
 #include "common.h"
 
 namespace mma {
@@ -28,6 +30,12 @@ constexpr int kPostTile = 32;     // kf columns per LDS tile round
 constexpr int kPostPrePitch = 8;   // floats per node in the table of scaler products K14 leaves for K15
 constexpr int kPostPitch = 34;    // tile pitch: (j*34 + k) mod 32 is distinct over the 16 x 2 lanes one ds_read_b32 group covers
 typedef float post_f32x4 __attribute__((ext_vector_type(4)));
+// Measurement builds only (scratch/build_post_abl.sh: -DMMA_POST_ABL=<bits>, loaded through MMA_LIB_OVERRIDE): 1 = no MFMAs, 2 = no B loads
+// after the prologue, 4 = no split (the raw bits as pieces), 8 = no stores in K14, 16 = no MFMAs in the fp32 forward.  0 in the product library.
+#ifndef MMA_POST_ABL
+#define MMA_POST_ABL 0
+#endif
+constexpr int kPostAbl = MMA_POST_ABL;
 
 __device__ __forceinline__ float post_scaler(int code, float deg, float avg_log, float avg_lin) {
   switch (code) {       // mma_conv.py:183-192
@@ -46,7 +54,18 @@ struct PostParams {
   int tiles_per_wave;       // 64-node tiles a wavefront walks with the tower's weights staged once
   int vec4;                 // rows of agg / gagg are 16-byte aligned (pitch % 4 == 0, KF % 4 == 0): float4 row segments; else dwords
   const float* bias;        // PLAIN forward only, may be NULL
+  int tower_major;          // 1: the round-3 launch order (all node blocks of tower 0, then tower 1, ...) - the A/B of post_block()
 };
+
+// [r4] Workgroup -> (tower, node block), TOWER FASTEST: the workgroups that run at the same time then read (K13, K15) or write (K14) whole
+// rows of agg - T x 608 bytes at C2L - instead of every fifth 608-byte run of them.  With the tower on blockIdx.y the chip walked ONE
+// tower's column block of all rows at a time: 20 % of every DRAM page it opened, and no kernel of the family - fp32 or bf16 pieces, with or
+// without its MFMAs, one k-step or three in flight - moved more than 3.7 TB/s.
+__device__ __forceinline__ void post_block(const PostParams& p, int& t, int64_t& bx) {
+  const unsigned lin = blockIdx.x, T = (unsigned)p.T;
+  if (p.tower_major) { const unsigned nbx = gridDim.x / T; t = (int)(lin / nbx); bx = lin % nbx; }
+  else { t = (int)(lin % T); bx = lin / T; }
+}
 
 // running products of the scalers for one node, in the reference's multiplication order ((v f0) f1) ...
 template <int S>
@@ -142,12 +161,13 @@ __global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* Wl = post_smem;                                       // (KFp, R)
   float* tile = post_smem + (size_t)p.KFp * R + wave * (kWave * kPostPitch);
-  const int t = (int)blockIdx.y;
+  int t; int64_t bx;
+  post_block(p, t, bx);
   post_stage_weights(Wl, Wa + (size_t)t * p.KFp * R, p.KFp * R);
   __syncthreads();                                             // weights staged: the only workgroup barrier
   const int j = lane & 15, kq = lane >> 4;                     // MFMA 16x16x4 operand lane: row/column j, k index kq
   for (int rt = 0; rt < p.tiles_per_wave; ++rt) {
-  const int64_t nblk = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * p.tiles_per_wave + rt;
+  const int64_t nblk = (bx * (kBlock / kWave) + wave) * p.tiles_per_wave + rt;
   const bool tvalid = nblk * kWave < p.N;                      // wave-uniform
   if (!tvalid) break;
   const int64_t n0 = nblk * kWave;
@@ -174,7 +194,10 @@ __global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int q = 0; q < S; ++q) acc[nt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[nt], acc[nt][q], 0, 0, 0);
+        for (int q = 0; q < S; ++q) {
+          if (kPostAbl & 16) { asm volatile("" : "+v"(acc[nt][q]) : "v"(a[q]), "v"(b[nt])); }
+          else acc[nt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[nt], acc[nt][q], 0, 0, 0);
+        }
     }
     post_wave_sync();
   }
@@ -225,12 +248,13 @@ __global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* Wl = post_smem;                                       // (R, wb_pitch): pitch = KFp + 16, so that k and k+1 fall on different banks
   float* tile = post_smem + (size_t)R * wb_pitch + wave * (kWave * kPostPitch);
-  const int t = (int)blockIdx.y;
+  int t; int64_t bx;
+  post_block(p, t, bx);
   post_stage_weights(Wl, Wb + (size_t)t * R * wb_pitch, R * wb_pitch);
   __syncthreads();               // weights staged: the only workgroup barrier
   const int j = lane & 15, kq = lane >> 4;
   for (int rt = 0; rt < p.tiles_per_wave; ++rt) {
-  const int64_t nblk = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * p.tiles_per_wave + rt;
+  const int64_t nblk = (bx * (kBlock / kWave) + wave) * p.tiles_per_wave + rt;
   const bool tvalid = nblk * kWave < p.N;
   if (!tvalid) break;
   const int64_t n0 = nblk * kWave;
@@ -322,8 +346,9 @@ __global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams 
   constexpr int G = S <= 2 ? 10 : 5;                           // kf tiles per pass: S*G accumulator tiles + two operand groups in flight
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int t = (int)blockIdx.y;
-  const int64_t chunk = (int64_t)blockIdx.x * (kBlock / kWave) + wave;
+  int t; int64_t bx;
+  post_block(p, t, bx);
+  const int64_t chunk = bx * (kBlock / kWave) + wave;
   const int64_t nb = chunk * npw, ne = min(p.N, nb + npw);
   const int j = lane & 15, kq = lane >> 4;
   const int n_kft = kfp16 / 16;
@@ -392,6 +417,191 @@ __global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams 
   }
 }
 
+// ---- [r4] K13 on the bf16 matrix cores: every fp32 operand split exactly into three bf16 pieces, six piece products per k-step
+// (gemm_x3.hip's scheme: as accurate as the fp32 product - the forward's largest error against float64 drops from 2.5e-7 to 1.4e-7 of
+// sum|a||w| with the small products summed apart - and v_mfma_f32_16x16x32_bf16 runs at 16x the fp32 MFMA's rate, so six products cost
+// 6/16 of it).  The k index of an MFMA is a summation index: ANY bijection between the (lane group, element) slots of the two operand
+// fragments and the 32 k values of a step is allowed as long as both operands use the same one.  post_kmap gives lane group kg the k
+// values {4kg..4kg+3} and {16+4kg..16+4kg+3}: the B fragment is then two float4 loads straight from the lane's own node row - no LDS tile,
+// no wave barriers - and the weights, split once per workgroup while they are staged, sit in LDS in fragment order (one conflict-free
+// ds_read_b128 per piece).  C2L (tools/post_micro.py): 0.240 -> 0.200 ms.
+// What the measurement builds say about the rest: no kernel of this family is bound by its matrix-core time.  This
+// kernel without its MFMAs 0.208 ms, without the split 0.21, without MFMAs AND split (loads + skeleton) 0.198, without its loads 0.123,
+// without all three 0.075 (weight staging, A-fragment reads, epilogue); the fp32 kernel above without its MFMAs 0.185.  A ring of THREE
+// k-steps in flight per wave (inline-asm loads, hand-counted waits, audited by tools/check_asm_waits.py --asm-only) 0.211-0.216: depth
+// is not what is missing either; nor is the layout (one tower with contiguous 608-byte rows: 0.199).  The same forms of K14 and K15 were
+// written, tested and measured - K14 0.30-0.34 ms against 0.27-0.28 for the fp32 kernel (its 64-byte store runs), K15 0.245 against
+// 0.255 - and not kept.  The fp32 kernel stays for shapes whose split weights do not fit the LDS, for K16, and behind MMA_POST_EXACT=1
+// (the A/B switch, read per call).
+typedef __attribute__((ext_vector_type(8))) __bf16 post_bf16x8;
+struct PostBf3 { __bf16 a, b, c; };
+__device__ __forceinline__ PostBf3 post_split3(const float v) {
+  PostBf3 r;
+  r.a = (__bf16)v;
+  const float r1 = v - (float)r.a;
+  r.b = (__bf16)r1;
+  r.c = (__bf16)(r1 - (float)r.b);
+  return r;
+}
+struct PostFrag { post_bf16x8 p1, p2, p3; };
+__device__ __forceinline__ void post_frag_set(PostFrag& f, int e, float v) {
+  if (kPostAbl & 4) {
+    const __bf16 h = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(v) >> 16));
+    f.p1[e] = h; f.p2[e] = h; f.p3[e] = h;
+    return;
+  }
+  const PostBf3 t = post_split3(v);
+  f.p1[e] = t.a; f.p2[e] = t.b; f.p3[e] = t.c;
+}
+__device__ __forceinline__ constexpr int post_kmap(int kg, int e) { return e < 4 ? 4 * kg + e : 16 + 4 * kg + (e - 4); }
+// acc += a b from the six piece products that matter, smallest first
+#define MMA_POST_X3(ACC, A, B, PROD)                                                                                     \
+  if (kPostAbl & 1) { asm volatile("" : "+v"(ACC) : "v"(A.p1), "v"(A.p2), "v"(A.p3), "v"(B.p1), "v"(B.p2), "v"(B.p3)); } else                      \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PROD == 0 ? A.p1 : PROD == 1 ? A.p2 : PROD == 2 ? A.p3 : PROD == 3 ? A.p1 : PROD == 4 ? A.p2 : A.p1, \
+                                                PROD == 0 ? B.p3 : PROD == 1 ? B.p2 : PROD == 2 ? B.p1 : PROD == 3 ? B.p2 : PROD == 4 ? B.p1 : B.p1, ACC, 0, 0, 0)
+
+// forward weights of one tower, Wa (KFp, R) fp32 -> LDS [ks][q][piece][lane] fragments: lane (i = lane & 15, kg = lane >> 4), element e holds
+// Wa[32 ks + kmap(kg, e)][16 q + i]
+template <int S>
+__device__ __forceinline__ void post_stage_x3_fwd(post_bf16x8* Wl, const float* __restrict__ Wa_t, int KFp) {
+  constexpr int R = S * kPostO;
+  const int units = (KFp / 32) * S * kWave;
+  for (int u = threadIdx.x; u < units; u += kBlock) {
+    const int lane = u & (kWave - 1), q = (u >> 6) % S, ks = (u >> 6) / S;
+    const int i = lane & 15, kg = lane >> 4;
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = Wa_t[(size_t)(32 * ks + post_kmap(kg, e)) * R + q * kPostO + i];
+    PostFrag f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) post_frag_set(f, e, w[e]);
+    post_bf16x8* d = Wl + (size_t)((ks * S + q) * 3) * kWave + lane;
+    d[0] = f.p1; d[kWave] = f.p2; d[2 * kWave] = f.p3;
+  }
+}
+
+// One k-step of B rows (8 KB per wave) is requested ahead of the step being multiplied; the A fragments of a scaler are read once per
+// step and used for the four node tiles.
+template <int S, bool PLAIN, bool VEC4>
+__global__ __launch_bounds__(kBlock) void tower_post_fwd_x3_kernel(const PostParams p, const float* __restrict__ agg, const float* __restrict__ pre_tab,
+                                                                   const float* __restrict__ Wa, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float post_smem[];
+  constexpr int R = S * kPostO;
+  post_bf16x8* Wl = reinterpret_cast<post_bf16x8*>(post_smem);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int t; int64_t bx;
+  post_block(p, t, bx);
+  const int j = lane & 15, kg = lane >> 4;
+  const int nks = p.KFp / 32;
+  const int64_t tiles = (p.N + kWave - 1) / kWave;
+  const int64_t tile0 = (bx * (kBlock / kWave) + wave) * p.tiles_per_wave;
+  const int my_tiles = (int)max((int64_t)0, min((int64_t)p.tiles_per_wave, tiles - tile0));
+  const int steps = my_tiles * nks;
+  float4 raw[4][2];
+  auto fetch = [&](int64_t n0, int ks) {
+    const int c0 = 32 * ks + 4 * kg, c1 = c0 + 16;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int64_t row = min(n0 + nt * 16 + j, p.N - 1);
+      const float* base = agg + (size_t)row * p.lda + (size_t)t * p.KF;
+      if (VEC4) {                                              // KF % 4 == 0: a quad is inside or outside
+        raw[nt][0] = *reinterpret_cast<const float4*>(base + min(c0, p.KF - 4));
+        raw[nt][1] = *reinterpret_cast<const float4*>(base + min(c1, p.KF - 4));
+      } else {
+        raw[nt][0] = make_float4(base[min(c0, p.KF - 1)], base[min(c0 + 1, p.KF - 1)], base[min(c0 + 2, p.KF - 1)], base[min(c0 + 3, p.KF - 1)]);
+        raw[nt][1] = make_float4(base[min(c1, p.KF - 1)], base[min(c1 + 1, p.KF - 1)], base[min(c1 + 2, p.KF - 1)], base[min(c1 + 3, p.KF - 1)]);
+      }
+    }
+  };
+  int ks = 0;
+  int64_t n0 = tile0 * kWave;
+  if (steps > 0) fetch(n0, 0);                                 // the first tile's rows travel while the weights are staged
+  post_stage_x3_fwd<S>(Wl, Wa + (size_t)t * p.KFp * R, p.KFp);
+  __syncthreads();                                             // weights staged: the only workgroup barrier
+  post_f32x4 acc[4][S];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int q = 0; q < S; ++q) acc[nt][q] = post_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int step = 0; step < steps; ++step) {
+    // this step's B fragments: columns past KF are zeroed (their weights are zero, but 0 x inf is not); rows past N feed only columns
+    // of D nobody stores
+    PostFrag b[4];
+    {
+      const int c0 = 32 * ks + 4 * kg, c1 = c0 + 16;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float4 lo = raw[nt][0], hi = raw[nt][1];
+        post_frag_set(b[nt], 0, c0 < p.KF ? lo.x : 0.f); post_frag_set(b[nt], 1, c0 + 1 < p.KF ? lo.y : 0.f);
+        post_frag_set(b[nt], 2, c0 + 2 < p.KF ? lo.z : 0.f); post_frag_set(b[nt], 3, c0 + 3 < p.KF ? lo.w : 0.f);
+        post_frag_set(b[nt], 4, c1 < p.KF ? hi.x : 0.f); post_frag_set(b[nt], 5, c1 + 1 < p.KF ? hi.y : 0.f);
+        post_frag_set(b[nt], 6, c1 + 2 < p.KF ? hi.z : 0.f); post_frag_set(b[nt], 7, c1 + 3 < p.KF ? hi.w : 0.f);
+      }
+    }
+    const bool last = ks == nks - 1;
+    const int ksn = last ? 0 : ks + 1;
+    const int64_t n0n = last ? n0 + kWave : n0;
+    if (step + 1 < steps && !(kPostAbl & 2)) fetch(n0n, ksn);                     // in flight behind this step's MFMAs
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      PostFrag a;
+      const post_bf16x8* wl = Wl + (size_t)((ks * S + q) * 3) * kWave + lane;
+      a.p1 = wl[0]; a.p2 = wl[kWave]; a.p3 = wl[2 * kWave];
+      // the five small piece products (<= 2^-8 of the sixth) are summed on their own and added once: six roundings of the running sum per
+      // k-step put the tail of the forward's error at 3.6e-7 sum|a||w| (one element in 3e5 over the 3e-7 bound the fp32 kernels keep)
+      post_f32x4 small[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) small[nt] = post_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < 5; ++pr)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { MMA_POST_X3(small[nt], a, b[nt], pr); }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) { MMA_POST_X3(acc[nt][q], a, b[nt], 5); }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt][q] += small[nt];
+    }
+    if (last) {
+      // C/D map of 16x16: column = lane & 15 (the node), row = 4 * (lane >> 4) + reg (the output o): y[o] = sum_q pre_q D_q[o]
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int64_t node = n0 + nt * 16 + j;
+        const bool valid = node < p.N;
+        if (PLAIN) {
+          if (valid) {
+#pragma unroll
+            for (int q = 0; q < S; ++q)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int col = q * kPostO + 4 * kg + r;
+                if (col < p.O) y[(size_t)node * p.ldy + col] = acc[nt][q][r] + (p.bias ? p.bias[col] : 0.f);
+              }
+          }
+        } else {
+          float pre[S];
+#pragma unroll
+          for (int q = 0; q < S; ++q) pre[q] = pre_tab[(size_t)min(node, p.N - 1) * kPostPrePitch + q];
+          float yv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < S; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[r] = fmaf(pre[q], acc[nt][q][r], yv[r]);
+          if (valid) {
+            float* yr = y + (size_t)node * p.ldy + (size_t)t * p.O + 4 * kg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (4 * kg + r < p.O) yr[r] = yv[r];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < S; ++q) acc[nt][q] = post_f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    ks = ksn; n0 = n0n;
+  }
+}
+
 static int64_t post_gw_npw(int64_t N, int T) {
   // about two waves per SIMD over the whole grid (1024 SIMDs), node ranges in multiples of 64
   int64_t waves = 2048 / (T < 1 ? 1 : T);
@@ -412,6 +622,8 @@ static int post_fill(PostParams* p, int64_t N, int T, int KF, int S, int O, cons
   }
   p->N = N; p->T = T; p->KF = KF; p->KFp = (KF + kPostTile - 1) / kPostTile * kPostTile; p->S = S; p->O = O; p->avg_log = avg_log; p->avg_lin = avg_lin;
   p->tiles_per_wave = 1;
+  { const char* e = getenv("MMA_POST_TOWER_MAJOR"); p->tower_major = (e && e[0] == '1') ? 1 : 0; }       // read per call (A/B)
+  MMA_REQUIRE(((N + kWave - 1) / kWave + 3) / 4 * (int64_t)T < (1LL << 31), "N=%lld x T=%d workgroups exceed the grid", (long long)N, T);
   return 0;
 }
 
@@ -434,13 +646,16 @@ static int post_tiles_per_wave(int64_t N, int T) {
   }
   return best;
 }
-static dim3 post_grid(const PostParams& p, int T) {
+static dim3 post_grid(const PostParams& p, int T) {       // one-dimensional: post_block() takes it apart
   const int64_t tiles = (p.N + kWave - 1) / kWave;
   const int64_t per_block = (int64_t)(kBlock / kWave) * p.tiles_per_wave;
-  return dim3((unsigned)((tiles + per_block - 1) / per_block), (unsigned)T);
+  return dim3((unsigned)((tiles + per_block - 1) / per_block * T));
 }
 
 static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+// LDS of the bf16-piece forward: the split weights in fragment order, nothing else ((KFp/32) x S fragments of 3 x 1 KB)
+static unsigned post_x3_lds_bytes(int KFp, int S) { return (unsigned)((KFp / 32) * S * 3 * 1024); }
+static bool post_exact() { const char* e = getenv("MMA_POST_EXACT"); return e && e[0] == '1'; }     // the fp32-MFMA kernels (A/B), read per call
 static unsigned post_lds_bytes(int KFp, int S, bool bwd) {
   const int R = S * kPostO;
   return (unsigned)(((size_t)(bwd ? R * (KFp + 16) : KFp * R) + (size_t)(kBlock / kWave) * kWave * kPostPitch) * sizeof(float));
@@ -556,11 +771,15 @@ extern "C" int mma_tower_post_fwd(const float* agg, int64_t lda, const float* pr
               "NULL / misaligned argument or row pitch too small");
   p.lda = lda; p.ldy = ldy; p.vec4 = (KF % 4 == 0 && lda % 4 == 0 && al16(agg)) ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned lds = post_lds_bytes(p.KFp, S, false);
-  MMA_REQUIRE(lds <= 160 * 1024, "the tower's weights (%u bytes with the tiles) do not fit the LDS", lds);
-  // tower = blockIdx.y; 256 * tiles_per_wave nodes (four waves x 64 x tiles) per workgroup
+  // 256 * tiles_per_wave nodes (four waves x 64 x tiles) of one tower per workgroup, tower fastest (post_block)
   p.tiles_per_wave = post_tiles_per_wave(N, T);
   const dim3 grid = post_grid(p, T);
+  if (const unsigned lx = post_x3_lds_bytes(p.KFp, S); lx <= 160 * 1024 && !post_exact()) {
+    if (p.vec4) { MMA_POST_LAUNCH3(tower_post_fwd_x3_kernel, false, true, lx, agg, pre, Wa, y) } else { MMA_POST_LAUNCH3(tower_post_fwd_x3_kernel, false, false, lx, agg, pre, Wa, y) }
+    return check_launch("tower_post_fwd_x3_kernel");
+  }
+  const unsigned lds = post_lds_bytes(p.KFp, S, false);
+  MMA_REQUIRE(lds <= 160 * 1024, "the tower's weights (%u bytes with the tiles) do not fit the LDS", lds);
   if (p.vec4) { MMA_POST_LAUNCH3(tower_post_fwd_kernel, false, true, lds, agg, pre, Wa, y) } else { MMA_POST_LAUNCH3(tower_post_fwd_kernel, false, false, lds, agg, pre, Wa, y) }
   return check_launch("tower_post_fwd_kernel");
 }
@@ -584,7 +803,7 @@ extern "C" int mma_tower_post_gw(const float* gy, int64_t ldg, const float* agg,
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int kfp16 = (KF + 15) / 16 * 16;
   const int64_t npw = post_gw_npw(N, T);
-  const dim3 grid((unsigned)(n_chunks / (kBlock / kWave)), (unsigned)T);
+  const dim3 grid((unsigned)(n_chunks / (kBlock / kWave) * T));
   MMA_POST_LAUNCH(tower_post_gw_kernel, 0, gy, agg, pre, part, npw, kfp16)
   return check_launch("tower_post_gw_kernel");
 }
@@ -638,11 +857,11 @@ extern "C" int mma_tower_post_bwd(const float* gy, int64_t ldg, const float* pre
   MMA_REQUIRE(!gys || ldgs >= (int64_t)T * S * kPostO, "gys needs a pitch >= T*S*16 floats");
   p.lda = lda; p.ldg = ldg; p.ldgs = ldgs; p.vec4 = (KF % 4 == 0 && lda % 4 == 0 && al16(gagg)) ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned lds = post_lds_bytes(p.KFp, S, true);
-  MMA_REQUIRE(lds <= 160 * 1024, "the tower's weights (%u bytes with the tiles) do not fit the LDS", lds);
   const int wb_pitch = p.KFp + 16;
   p.tiles_per_wave = post_tiles_per_wave(N, T);
   const dim3 grid = post_grid(p, T);
+  const unsigned lds = post_lds_bytes(p.KFp, S, true);
+  MMA_REQUIRE(lds <= 160 * 1024, "the tower's weights (%u bytes with the tiles) do not fit the LDS", lds);
   MMA_POST_LAUNCH2(tower_post_bwd_kernel, false, lds, gy, pre, Wb, wb_pitch, gagg, gys)
   return check_launch("tower_post_bwd_kernel");
 }
@@ -661,11 +880,11 @@ extern "C" int mma_skinny_linear_fwd(const float* x, int64_t ldx, const float* W
   MMA_REQUIRE(x && Wa && y && al16(Wa) && ldx >= K && ldy >= O && (reinterpret_cast<uintptr_t>(x) & 3) == 0, "NULL / misaligned argument or row pitch too small");
   p.lda = ldx; p.ldy = ldy; p.bias = bias; p.vec4 = (K % 4 == 0 && ldx % 4 == 0 && al16(x)) ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned lds = post_lds_bytes(p.KFp, S, false);
-  MMA_REQUIRE(lds <= 160 * 1024, "the weights (%u bytes with the tiles) do not fit the LDS", lds);
   p.tiles_per_wave = post_tiles_per_wave(N, 1);
   const dim3 grid = post_grid(p, 1);
   const float* pre = nullptr;
+  const unsigned lds = post_lds_bytes(p.KFp, S, false);
+  MMA_REQUIRE(lds <= 160 * 1024, "the weights (%u bytes with the tiles) do not fit the LDS", lds);
   if (p.vec4) { MMA_POST_LAUNCH3(tower_post_fwd_kernel, true, true, lds, x, pre, Wa, y) } else { MMA_POST_LAUNCH3(tower_post_fwd_kernel, true, false, lds, x, pre, Wa, y) }
   return check_launch("tower_post_fwd_kernel (plain)");
 }
@@ -680,13 +899,13 @@ extern "C" int mma_skinny_linear_bwd_dx(const float* gy, int64_t ldg, const floa
   MMA_REQUIRE(gy && Wb && gx && al16(Wb) && ldx >= K && ldg >= O && (reinterpret_cast<uintptr_t>(gx) & 3) == 0, "NULL / misaligned argument or row pitch too small");
   p.lda = ldx; p.ldg = ldg; p.vec4 = (K % 4 == 0 && ldx % 4 == 0 && al16(gx)) ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned lds = post_lds_bytes(p.KFp, S, true);
-  MMA_REQUIRE(lds <= 160 * 1024, "the weights (%u bytes with the tiles) do not fit the LDS", lds);
   const int wb_pitch = p.KFp + 16;
   p.tiles_per_wave = post_tiles_per_wave(N, 1);
   const dim3 grid = post_grid(p, 1);
   const float* pre = nullptr;
   float* gys = nullptr;
+  const unsigned lds = post_lds_bytes(p.KFp, S, true);
+  MMA_REQUIRE(lds <= 160 * 1024, "the weights (%u bytes with the tiles) do not fit the LDS", lds);
   MMA_POST_LAUNCH2(tower_post_bwd_kernel, true, lds, gy, pre, Wb, wb_pitch, gx, gys)
   return check_launch("tower_post_bwd_kernel (plain)");
 }

@@ -637,7 +637,9 @@ class _TowerPost(torch.autograd.Function):
         cache = getattr(rowptr, "_mma_post_pre", None)
         pre = cache[1] if cache is not None and cache[0] == key else None
         # agg rows in, y rows out, the scaler table; S x 16 padded outputs per (node, tower, kf) on the fp32 matrix cores
-        with _span("tower_post_fwd", nbytes=4 * N * (T * KF + T * O + 8), flops=2 * N * T * KFp * S * 16, mfma="f32"):
+        # (K13 runs on three bf16 pieces per operand, six piece products, where its split weights fit the LDS and MMA_POST_EXACT is unset)
+        x3 = os.environ.get("MMA_POST_EXACT") != "1" and (KFp // 32) * S * 3 * 1024 <= 160 * 1024
+        with _span("tower_post_fwd", nbytes=4 * N * (T * KF + T * O + 8), flops=2 * N * T * KFp * S * 16, mfma="bf16x6" if x3 else "f32"):
             if pre is None:
                 pre = torch.empty((N, 8), device=agg.device, dtype=torch.float32)
                 call("mma_tower_post_pre", ptr(rowptr), ptr(pre), N, S, host_codes(scalers), float(avg_log), float(avg_lin), stream_ptr())

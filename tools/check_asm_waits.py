@@ -9,7 +9,12 @@ N youngest).  An instruction that mentions a VGPR which is the destination of a 
 a spill, an early use - is a violation.  States are (pc, in-flight queue) pairs, each visited once, so loops converge.
 
     hipcc ... -save-temps=obj -c gemm_x3.hip -o /tmp/x/gemm_x3.o ; python tools/check_asm_waits.py /tmp/x/gemm_x3-hip-amdgcn-amd-amdhsa-gfx950.s [kernel-substring]
-Exit status 1 when any kernel has a violation."""
+Exit status 1 when any kernel has a violation.
+
+--asm-only keeps ONLY the inline-asm loads in the modelled queue (compiler-issued loads and stores are left out).  That model is
+conservative - an asm load has at least as many younger operations in the real queue as in the model, so whatever a wait retires in the
+model it retires on the machine - and it is what makes kernels with many conditional stores tractable: the number of stores on a path no
+longer multiplies the states."""
 import re
 import sys
 
@@ -37,6 +42,9 @@ def kernels(path):
             if "s_endpgm" in line:
                 yield name, body
                 name = None
+
+
+ASM_ONLY = False
 
 
 def check(name, body):
@@ -88,7 +96,10 @@ def check(name, body):
                     for d in q:
                         if d and lo <= d[1] and hi >= d[0]:
                             viol.append((pc, t, d))
-                q = (q + (dst,))[-MAXQ:]
+                if dst is not None and not a:
+                    dst = None                                  # a compiler-issued load: the compiler waits for it itself
+                if not (ASM_ONLY and not a):
+                    q = (q + (dst,))[-MAXQ:]
             else:
                 for lo, hi in regs(t):
                     for d in q:
@@ -111,8 +122,11 @@ def check(name, body):
 
 
 def main():
-    path = sys.argv[1]
-    want = sys.argv[2] if len(sys.argv) > 2 else ""
+    global ASM_ONLY
+    args = [a for a in sys.argv[1:] if a != "--asm-only"]
+    ASM_ONLY = "--asm-only" in sys.argv[1:]
+    path = args[0]
+    want = args[1] if len(args) > 1 else ""
     bad = 0
     for name, body in kernels(path):
         if want and want not in name:
