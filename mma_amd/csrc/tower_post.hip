@@ -30,8 +30,8 @@ constexpr int kPostTile = 32;     // kf columns per LDS tile round
 constexpr int kPostPrePitch = 8;   // floats per node in the table of scaler products K14 leaves for K15
 constexpr int kPostPitch = 34;    // tile pitch: (j*34 + k) mod 32 is distinct over the 16 x 2 lanes one ds_read_b32 group covers
 typedef float post_f32x4 __attribute__((ext_vector_type(4)));
-// Measurement builds only (scratch/build_post_abl.sh: -DMMA_POST_ABL=<bits>, loaded through MMA_LIB_OVERRIDE): 1 = no MFMAs, 2 = no B loads
-// after the prologue, 4 = no split (the raw bits as pieces), 8 = no stores in K14, 16 = no MFMAs in the fp32 forward.  0 in the product library.
+// Measurement builds only (tools/build_ablation.sh post <bits>: -DMMA_POST_ABL, loaded through MMA_LIB_OVERRIDE): 1 = no MFMAs, 2 = no B loads
+// after the first step, 4 = no split (the raw bits as pieces), 16 = no MFMAs in the fp32 forward.  0 in the product library.
 #ifndef MMA_POST_ABL
 #define MMA_POST_ABL 0
 #endif
