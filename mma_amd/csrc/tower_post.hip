@@ -465,25 +465,37 @@ __device__ __forceinline__ constexpr int post_kmap(int kg, int e) { return e < 4
 template <int S>
 __device__ __forceinline__ void post_stage_x3_fwd(post_bf16x8* Wl, const float* __restrict__ Wa_t, int KFp) {
   constexpr int R = S * kPostO;
+  constexpr int MU = 4;                                        // units per thread and pass: their 32 loads are ONE round trip, not four
   const int units = (KFp / 32) * S * kWave;
-  for (int u = threadIdx.x; u < units; u += kBlock) {
-    const int lane = u & (kWave - 1), q = (u >> 6) % S, ks = (u >> 6) / S;
-    const int i = lane & 15, kg = lane >> 4;
-    float w[8];
+  for (int u0 = threadIdx.x; u0 < units; u0 += kBlock * MU) {
+    float w[MU][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) w[e] = Wa_t[(size_t)(32 * ks + post_kmap(kg, e)) * R + q * kPostO + i];
-    PostFrag f;
+    for (int m = 0; m < MU; ++m) {
+      const int u = min(u0 + m * kBlock, units - 1);           // past the end: the last unit again (not stored)
+      const int lane = u & (kWave - 1), q = (u >> 6) % S, ks = (u >> 6) / S;
+      const int i = lane & 15, kg = lane >> 4;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) post_frag_set(f, e, w[e]);
-    post_bf16x8* d = Wl + (size_t)((ks * S + q) * 3) * kWave + lane;
-    d[0] = f.p1; d[kWave] = f.p2; d[2 * kWave] = f.p3;
+      for (int e = 0; e < 8; ++e) w[m][e] = Wa_t[(size_t)(32 * ks + post_kmap(kg, e)) * R + q * kPostO + i];
+    }
+#pragma unroll
+    for (int m = 0; m < MU; ++m) {
+      const int u = u0 + m * kBlock;
+      if (u < units) {
+        const int lane = u & (kWave - 1), q = (u >> 6) % S, ks = (u >> 6) / S;
+        PostFrag f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) post_frag_set(f, e, w[m][e]);
+        post_bf16x8* d = Wl + (size_t)((ks * S + q) * 3) * kWave + lane;
+        d[0] = f.p1; d[kWave] = f.p2; d[2 * kWave] = f.p3;
+      }
+    }
   }
 }
 
 // One k-step of B rows (8 KB per wave) is requested ahead of the step being multiplied; the A fragments of a scaler are read once per
 // step and used for the four node tiles.
 template <int S, bool PLAIN, bool VEC4>
-__global__ __launch_bounds__(kBlock) void tower_post_fwd_x3_kernel(const PostParams p, const float* __restrict__ agg, const float* __restrict__ pre_tab,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void tower_post_fwd_x3_kernel(const PostParams p, const float* __restrict__ agg, const float* __restrict__ pre_tab,
                                                                    const float* __restrict__ Wa, float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float post_smem[];
   constexpr int R = S * kPostO;
@@ -524,7 +536,18 @@ __global__ __launch_bounds__(kBlock) void tower_post_fwd_x3_kernel(const PostPar
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int q = 0; q < S; ++q) acc[nt][q] = post_f32x4{0.f, 0.f, 0.f, 0.f};
+  float pre[4][S];                                             // the tile's scaler products, requested at its FIRST k-step: no round trip in its epilogue
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int q = 0; q < S; ++q) pre[nt][q] = 0.f;
   for (int step = 0; step < steps; ++step) {
+    if (!PLAIN && ks == 0) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int q = 0; q < S; ++q) pre[nt][q] = pre_tab[(size_t)min(n0 + nt * 16 + j, p.N - 1) * kPostPrePitch + q];
+    }
     // this step's B fragments: columns past KF are zeroed (their weights are zero, but 0 x inf is not); rows past N feed only columns
     // of D nobody stores
     PostFrag b[4];
@@ -579,14 +602,11 @@ __global__ __launch_bounds__(kBlock) void tower_post_fwd_x3_kernel(const PostPar
               }
           }
         } else {
-          float pre[S];
-#pragma unroll
-          for (int q = 0; q < S; ++q) pre[q] = pre_tab[(size_t)min(node, p.N - 1) * kPostPrePitch + q];
           float yv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int q = 0; q < S; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) yv[r] = fmaf(pre[q], acc[nt][q][r], yv[r]);
+            for (int r = 0; r < 4; ++r) yv[r] = fmaf(pre[nt][q], acc[nt][q][r], yv[r]);
           if (valid) {
             float* yr = y + (size_t)node * p.ldy + (size_t)t * p.O + 4 * kg;
 #pragma unroll
@@ -773,6 +793,7 @@ extern "C" int mma_tower_post_fwd(const float* agg, int64_t lda, const float* pr
   hipStream_t st = static_cast<hipStream_t>(stream);
   // 256 * tiles_per_wave nodes (four waves x 64 x tiles) of one tower per workgroup, tower fastest (post_block)
   p.tiles_per_wave = post_tiles_per_wave(N, T);
+  if (const char* e = getenv("MMA_POST_TPW")) { if (atoi(e) > 0) p.tiles_per_wave = atoi(e); }      // plan sweep (tools/post_micro.py)
   const dim3 grid = post_grid(p, T);
   if (const unsigned lx = post_x3_lds_bytes(p.KFp, S); lx <= 160 * 1024 && !post_exact()) {
     if (p.vec4) { MMA_POST_LAUNCH3(tower_post_fwd_x3_kernel, false, true, lx, agg, pre, Wa, y) } else { MMA_POST_LAUNCH3(tower_post_fwd_x3_kernel, false, false, lx, agg, pre, Wa, y) }
