@@ -494,7 +494,7 @@ __device__ __forceinline__ void post_stage_x3_fwd(post_bf16x8* Wl, const float* 
 
 // One k-step of B rows (8 KB per wave) is requested ahead of the step being multiplied; the A fragments of a scaler are read once per
 // step and used for the four node tiles.
-template <int S, bool PLAIN, bool VEC4>
+template <int S, bool VEC4>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void tower_post_fwd_x3_kernel(const PostParams p, const float* __restrict__ agg, const float* __restrict__ pre_tab,
                                                                    const float* __restrict__ Wa, float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float post_smem[];
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int q = 0; q < S; ++q) pre[nt][q] = 0.f;
   for (int step = 0; step < steps; ++step) {
-    if (!PLAIN && ks == 0) {
+    if (ks == 0) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -591,28 +591,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       for (int nt = 0; nt < 4; ++nt) {
         const int64_t node = n0 + nt * 16 + j;
         const bool valid = node < p.N;
-        if (PLAIN) {
-          if (valid) {
+        float yv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < S; ++q)
+        for (int q = 0; q < S; ++q)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int col = q * kPostO + 4 * kg + r;
-                if (col < p.O) y[(size_t)node * p.ldy + col] = acc[nt][q][r] + (p.bias ? p.bias[col] : 0.f);
-              }
-          }
-        } else {
-          float yv[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int r = 0; r < 4; ++r) yv[r] = fmaf(pre[nt][q], acc[nt][q][r], yv[r]);
+        if (valid) {
+          float* yr = y + (size_t)node * p.ldy + (size_t)t * p.O + 4 * kg;
 #pragma unroll
-          for (int q = 0; q < S; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) yv[r] = fmaf(pre[nt][q], acc[nt][q][r], yv[r]);
-          if (valid) {
-            float* yr = y + (size_t)node * p.ldy + (size_t)t * p.O + 4 * kg;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (4 * kg + r < p.O) yr[r] = yv[r];
-          }
+          for (int r = 0; r < 4; ++r)
+            if (4 * kg + r < p.O) yr[r] = yv[r];
         }
 #pragma unroll
         for (int q = 0; q < S; ++q) acc[nt][q] = post_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -796,7 +784,7 @@ extern "C" int mma_tower_post_fwd(const float* agg, int64_t lda, const float* pr
   if (const char* e = getenv("MMA_POST_TPW")) { if (atoi(e) > 0) p.tiles_per_wave = atoi(e); }      // plan sweep (tools/post_micro.py)
   const dim3 grid = post_grid(p, T);
   if (const unsigned lx = post_x3_lds_bytes(p.KFp, S); lx <= 160 * 1024 && !post_exact()) {
-    if (p.vec4) { MMA_POST_LAUNCH3(tower_post_fwd_x3_kernel, false, true, lx, agg, pre, Wa, y) } else { MMA_POST_LAUNCH3(tower_post_fwd_x3_kernel, false, false, lx, agg, pre, Wa, y) }
+    if (p.vec4) { MMA_POST_LAUNCH2(tower_post_fwd_x3_kernel, true, lx, agg, pre, Wa, y) } else { MMA_POST_LAUNCH2(tower_post_fwd_x3_kernel, false, lx, agg, pre, Wa, y) }
     return check_launch("tower_post_fwd_x3_kernel");
   }
   const unsigned lds = post_lds_bytes(p.KFp, S, false);
