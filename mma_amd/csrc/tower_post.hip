@@ -338,7 +338,8 @@ __global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams
 // whole range; both operands come straight from memory in the MFMA's own lane order - A[i = o][k = node] = pre_q gy (16 lanes read 64
 // consecutive bytes of a gy row, the scalers are re-evaluated per node), B[k = node][j = kf] = agg (64-byte runs of four rows) - no
 // LDS, no scaled copy of gy (round 3's first form wrote gys (N, T*S*16) and ran five TN launches of the bf16x3 kernel: 0.4-0.5 ms).
-// The per-wave partial tiles are summed in a fixed order by mma_col_sum.
+// The four waves' tiles of a workgroup are added through LDS, the per-workgroup partial tiles are summed in a fixed order by
+// mma_tower_post_gw_reduce / mma_col_sum.
 template <int S>
 __global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams p, const float* __restrict__ gy, const float* __restrict__ agg,
                                                                const float* __restrict__ pre_tab, float* __restrict__ part, int64_t npw,
@@ -352,7 +353,10 @@ __global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams 
   const int64_t nb = chunk * npw, ne = min(p.N, nb + npw);
   const int j = lane & 15, kq = lane >> 4;
   const int n_kft = kfp16 / 16;
-  float* out = part + ((size_t)chunk * p.T + t) * (size_t)(S * kPostO) * kfp16;
+  // [r4] the four waves of a workgroup add their tiles through LDS (fixed order (w0 + w1) + (w2 + w3)) and the workgroup writes ONE
+  // partial tile: a quarter of the partials to write and to sum (C2L: 63 MB -> 16 MB; the reduction launch 0.052 -> 0.02 ms)
+  extern __shared__ __attribute__((aligned(16))) float post_smem[];
+  float* out = part + ((size_t)bx * p.T + t) * (size_t)(S * kPostO) * kfp16;
   const int jo = j < p.O ? j : 0;                              // clamped column of gy (the value is zeroed by a select)
   const int64_t nlast = p.N - 1;
   for (int kt0 = 0; kt0 < n_kft; kt0 += G) {
@@ -404,16 +408,22 @@ __global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams 
       multiply(r1);                                            // past the range: valid is false, the operands are zeros
       __builtin_amdgcn_sched_barrier(0);
     }
-    // D: row = 4 * kq + reg = o, column = lane & 15 = kf inside the tile
+    // D: row = 4 * kq + reg = o, column = lane & 15 = kf inside the tile.  red[wave][(q, c, r)][lane]
 #pragma unroll
     for (int q = 0; q < S; ++q)
 #pragma unroll
-      for (int c = 0; c < G; ++c) {
-        if (kt0 + c < n_kft) {
+      for (int c = 0; c < G; ++c)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) out[(size_t)(q * kPostO + 4 * kq + r) * kfp16 + (kt0 + c) * 16 + j] = acc[q][c][r];
-        }
-      }
+        for (int r = 0; r < 4; ++r) post_smem[((wave * S + q) * G + c) * 4 * kWave + r * kWave + lane] = acc[q][c][r];
+    __syncthreads();
+    constexpr int kItems = S * G * 4, kWaveStride = S * G * 4 * kWave;
+    for (int it = wave; it < kItems; it += kBlock / kWave) {
+      const int q = it / (G * 4), c = (it >> 2) % G, r = it & 3;
+      const float* rp = post_smem + it * kWave + lane;
+      const float v = (rp[0] + rp[kWaveStride]) + (rp[2 * kWaveStride] + rp[3 * kWaveStride]);
+      if (kt0 + c < n_kft) out[(size_t)(q * kPostO + 4 * kq + r) * kfp16 + (kt0 + c) * 16 + j] = v;
+    }
+    __syncthreads();                                           // the next pass writes the same LDS
   }
 }
 
@@ -796,7 +806,7 @@ extern "C" int mma_tower_post_fwd(const float* agg, int64_t lda, const float* pr
 extern "C" int64_t mma_tower_post_gw_chunks(int64_t N, int32_t T) {
   if (N <= 0 || T <= 0) return 0;
   const int64_t npw = post_gw_npw(N, T);
-  return ((N + npw - 1) / npw + kBlock / kWave - 1) / (kBlock / kWave) * (kBlock / kWave);        // whole workgroups of four waves
+  return ((N + npw - 1) / npw + kBlock / kWave - 1) / (kBlock / kWave);        // ONE partial tile per workgroup of four waves
 }
 
 extern "C" int mma_tower_post_gw(const float* gy, int64_t ldg, const float* agg, int64_t lda, const float* pre, float* part,
@@ -812,12 +822,14 @@ extern "C" int mma_tower_post_gw(const float* gy, int64_t ldg, const float* agg,
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int kfp16 = (KF + 15) / 16 * 16;
   const int64_t npw = post_gw_npw(N, T);
-  const dim3 grid((unsigned)(n_chunks / (kBlock / kWave) * T));
-  MMA_POST_LAUNCH(tower_post_gw_kernel, 0, gy, agg, pre, part, npw, kfp16)
+  const dim3 grid((unsigned)(n_chunks * T));
+  const int G = S <= 2 ? 10 : 5;
+  const unsigned lds = (unsigned)((kBlock / kWave) * S * G * 4 * kWave * sizeof(float));
+  MMA_POST_LAUNCH(tower_post_gw_kernel, lds, gy, agg, pre, part, npw, kfp16)
   return check_launch("tower_post_gw_kernel");
 }
 
-// [r4] K15's per-wave partial tiles (n_chunks, T, S, 16, kfp16) summed in mma_col_sum's order (col_sum_kernel, one row block: four row
+// [r4] K15's per-workgroup partial tiles (n_chunks, T, S, 16, kfp16) summed in mma_col_sum's order (col_sum_kernel, one row block: four row
 // lanes of four accumulators - the same bits as the K8 launch it replaces) and written straight into the weight layout
 // gWo (T, O, S*KF): the permuting copy behind the K8 launch was one more launch per layer step.
 __global__ __launch_bounds__(kBlock) void post_gw_reduce_kernel(const float* part, int R, int T, int S, int O, int KF, int kfp16, float* gWo) {
