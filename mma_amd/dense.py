@@ -454,6 +454,7 @@ def linear(x, weight, bias=None):
 # K = 128 and N % 128 == 0 they are ordinary inputs of the bf16x3 kernels.  The ones column that carries the bias sits in the
 # K padding, so forward folds the bias in and the TN weight-gradient GEMM returns the bias gradient as one more row.
 X3_LINEAR = True
+FUSED_PAD = __import__("os").environ.get("MMA_PAD_ONES", "1") != "0"        # 0: torch's pad + a strided fill (round 3)
 X3_LINEAR_MIN_ROWS = 32768
 _PADDED = {}          # data_ptr -> weakref to a (rows, pitch) fp32 buffer whose columns beyond the payload are ZERO
 
@@ -492,8 +493,12 @@ class _LinearX3(torch.autograd.Function):
         N, fin = x.shape
         fout = weight.shape[0]
         OP = _round_up(fout, 128)
-        xp = torch.nn.functional.pad(x, (0, 128 - fin))             # (N, 128): [x | 1 | 0 ...]
-        xp[:, fin] = 1.0
+        if FUSED_PAD and x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1:
+            xp = torch.empty((N, 128), device=x.device, dtype=torch.float32)      # (N, 128): [x | 1 | 0 ...] in ONE launch [r4]
+            call("mma_pad_ones_rows", ptr(x), x.stride(0), N, fin, ptr(xp), 128, 128, stream_ptr())
+        else:
+            xp = torch.nn.functional.pad(x, (0, 128 - fin))
+            xp[:, fin] = 1.0
         wt = weight.new_zeros((128, OP))                             # [W^T ; b ; 0 ...], pad columns zero
         wt[:fin, :fout] = weight.t()
         if bias is not None:

@@ -243,3 +243,36 @@ def test_tower_post_results_do_not_depend_on_the_workgroup_order(monkeypatch):
         b = _post_run(agg, Wo, rowptr, scalers, cot)
         for x, y, what in zip(a, b, ("y", "gagg", "gWo")):
             assert torch.equal(x, y), (what, exact)
+
+
+@pytest.mark.parametrize("N,fin,pitch", [(5000, 75, 75), (4099, 50, 64), (33000, 127, 127), (1, 3, 3), (2000, 76, 380)])
+def test_pad_ones_rows_equals_pad_and_fill(N, fin, pitch):
+    """[r4] mma_pad_ones_rows: [x | 1 | 0 ...] of the zero-padded tall Linear in one launch = torch's pad + a strided fill, bit for bit
+    (row-strided x included: a column block of a wider buffer)."""
+    from mma_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator().manual_seed(N + fin)
+    wide = torch.randn(N, pitch, generator=g).to(DEV)
+    x = wide[:, :fin]
+    want = torch.nn.functional.pad(x, (0, 128 - fin))
+    want[:, fin] = 1.0
+    got = torch.full((N, 128), float("nan"), device=DEV)
+    call("mma_pad_ones_rows", ptr(x), x.stride(0), N, fin, ptr(got), 128, 128, stream_ptr())
+    assert torch.equal(got, want)
+
+
+def test_linear_tall_with_and_without_the_fused_pad(monkeypatch):
+    from mma_amd import dense
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(40000, 75, generator=g).to(DEV)
+    W = (torch.randn(760, 75, generator=g) / 9).to(DEV)
+    b = torch.randn(760, generator=g).to(DEV)
+    assert dense.linear_x3_ok(x, W)
+    outs = []
+    for flag in (True, False):
+        monkeypatch.setattr(dense, "FUSED_PAD", flag)
+        xr, wr, br = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = dense.linear_tall(xr, wr, br)
+        gr = torch.autograd.grad((y * y).sum(), [xr, wr, br])
+        outs.append((y.detach(),) + gr)
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
