@@ -382,11 +382,13 @@ int mma_masked_bn_relu_bwd(const float* gy, int64_t ldg, const float* y, int64_t
  * unpack != 0:  A[r*lda + c] (+)= B[r*ldb + c]                              for r < rows,   c < cols
  * One workgroup per block, no overlap checks: blocks of one call must not write the same element.  The table is trusted (addresses
  * are the caller's): a wrong entry is an out-of-bounds access, as with any pointer argument. */
-/* ABI 33: out (M, width) = [x | 1 | 0 ...] from x (M, fin) with row pitches ldx / ldo, fin < width, width % 4 == 0, out 16-byte aligned:
- * the A operand of the zero-padded tall Linear layers (graph regression: the pre-NN on [x_i | x_j | e], mma_conv.py:81-84,170-176, as ONE
- * GEMM per operand with the bias riding on a ones column) in one launch - was torch's pad (a zero fill of the whole buffer + a strided
- * copy) and a strided fill. */
-int mma_pad_ones_rows(const float* x, int64_t ldx, int64_t M, int32_t fin, float* out, int64_t ldo, int32_t width, void* stream);
+/* ABI 33: out (M_out, width) = [x | col | 0 ...] from x (M, fin) with row pitches ldx / ldo, fin < width, width % 4 == 0, out 16-byte
+ * aligned; col (M,) or NULL = a column of ones; rows M .. M_out - 1 are zero.  The operands of the zero-padded tall Linear layers (graph
+ * regression: the pre-NN on [x_i | x_j | e], mma_conv.py:81-84,170-176, as ONE GEMM per operand with the bias riding on a ones column):
+ * A = [x | 1 | 0], and [W | b | 0] - the weight operand of the forward (as its transposed view) and of dL/dx (its leading columns) - one
+ * launch each; was torch's pad (a zero fill of the whole buffer + a strided copy) and a strided fill per operand. */
+int mma_pad_rows(const float* x, int64_t ldx, int64_t M, int32_t fin, const float* col /* (M,) or NULL */, float* out, int64_t ldo,
+                 int32_t width, int64_t M_out, void* stream);
 int mma_pack_blocks(const int64_t* table, int64_t n_blocks, float* a_base, float* b0, float* b1, float* b2, float* b3, float* b4,
                     float* b5, float* b6, float* b7, int32_t unpack, void* stream);
 

@@ -142,37 +142,44 @@ static int fold_check(int64_t TF, int32_t F, int32_t ED) {
   return 0;
 }
 
-// [r4] The A operand of the zero-padded tall Linear (dense._LinearX3: 75 -> 760 on 2e5 rows, 50 -> 380 on 4e5): out (M, width) =
-// [x | 1 | 0 ...] from x (M, fin), fin < width, width % 4 == 0 - the ones column carries the bias through the GEMM.  As torch ops this
-// was a zero fill of the whole (M, 128) buffer, a strided copy and a strided fill (three launches, the buffer written twice).
-__global__ __launch_bounds__(256) void pad_ones_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int fin, float* __restrict__ out,
-                                                            int64_t ldo, int width) {
+// [r4] The operands of the zero-padded tall Linear (dense._LinearX3: 75 -> 760 on 2e5 rows, 50 -> 380 on 4e5): out (M_out, width) =
+// [x | col | 0 ...] from x (M, fin), fin < width, width % 4 == 0; col (M,) or NULL = a column of ones; rows M .. M_out - 1 are zero.
+// A = [x | 1 | 0] carries the bias through the GEMM, [W | b | 0] (fout rows padded to a multiple of 128) is the weight operand of the
+// forward (as its transposed view) AND of dL/dx (as its leading columns).  As torch ops: a zero fill of the whole buffer, a strided copy
+// and a strided fill per operand, and a second zero-padded copy of W in backward.
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int fin, const float* __restrict__ col,
+                                                       float* __restrict__ out, int64_t ldo, int width, int64_t M_out) {
   const int q4 = width / 4;
-  const int64_t total = M * q4;
+  const int64_t total = M_out * q4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / q4;
     const int c = (int)(i % q4) * 4;
-    const float* xr = x + r * ldx;
-    float4 v;
-    v.x = c < fin ? xr[c] : (c == fin ? 1.f : 0.f);
-    v.y = c + 1 < fin ? xr[c + 1] : (c + 1 == fin ? 1.f : 0.f);
-    v.z = c + 2 < fin ? xr[c + 2] : (c + 2 == fin ? 1.f : 0.f);
-    v.w = c + 3 < fin ? xr[c + 3] : (c + 3 == fin ? 1.f : 0.f);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < M) {
+      const float* xr = x + r * ldx;
+      const float one = col ? col[r] : 1.f;
+      v.x = c < fin ? xr[c] : (c == fin ? one : 0.f);
+      v.y = c + 1 < fin ? xr[c + 1] : (c + 1 == fin ? one : 0.f);
+      v.z = c + 2 < fin ? xr[c + 2] : (c + 2 == fin ? one : 0.f);
+      v.w = c + 3 < fin ? xr[c + 3] : (c + 3 == fin ? one : 0.f);
+    }
     *reinterpret_cast<float4*>(out + r * ldo + c) = v;
   }
 }
 
-extern "C" int mma_pad_ones_rows(const float* x, int64_t ldx, int64_t M, int32_t fin, float* out, int64_t ldo, int32_t width, void* stream) {
-  MMA_REQUIRE(M >= 0 && fin >= 1 && width > fin && width % 4 == 0 && ldx >= fin && ldo >= width && ldo % 4 == 0,
-              "M=%lld fin=%d width=%d ldx=%lld ldo=%lld unsupported (fin < width, width and ldo multiples of 4)", (long long)M, fin, width,
-              (long long)ldx, (long long)ldo);
-  if (M == 0) return 0;
-  MMA_REQUIRE(x && out && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "NULL or misaligned argument");
-  const int64_t total = M * (width / 4);
+extern "C" int mma_pad_rows(const float* x, int64_t ldx, int64_t M, int32_t fin, const float* col, float* out, int64_t ldo, int32_t width,
+                            int64_t M_out, void* stream) {
+  MMA_REQUIRE(M >= 0 && M_out >= M && fin >= 1 && width > fin && width % 4 == 0 && ldx >= fin && ldo >= width && ldo % 4 == 0,
+              "M=%lld M_out=%lld fin=%d width=%d ldx=%lld ldo=%lld unsupported (fin < width, width and ldo multiples of 4)", (long long)M,
+              (long long)M_out, fin, width, (long long)ldx, (long long)ldo);
+  if (M_out == 0) return 0;
+  MMA_REQUIRE((x || M == 0) && out && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "NULL or misaligned argument");
+  const int64_t total = M_out * (width / 4);
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8 * kMaxGrid) blocks = 8 * kMaxGrid;
-  hipLaunchKernelGGL(pad_ones_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, M, (int)fin, out, ldo, (int)width);
-  return check_launch("pad_ones_rows_kernel");
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, M, (int)fin, col, out, ldo,
+                     (int)width, M_out);
+  return check_launch("pad_rows_kernel");
 }
 
 extern "C" int mma_edge_fold_fwd(const float* We, int64_t ldw, const float* Wenc, const float* benc, float* wz, float* bz, int64_t TF, int32_t F,

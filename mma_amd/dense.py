@@ -493,24 +493,39 @@ class _LinearX3(torch.autograd.Function):
         N, fin = x.shape
         fout = weight.shape[0]
         OP = _round_up(fout, 128)
-        if FUSED_PAD and x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1:
-            xp = torch.empty((N, 128), device=x.device, dtype=torch.float32)      # (N, 128): [x | 1 | 0 ...] in ONE launch [r4]
-            call("mma_pad_ones_rows", ptr(x), x.stride(0), N, fin, ptr(xp), 128, 128, stream_ptr())
+        fused = FUSED_PAD and x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and weight.dtype == torch.float32
+        if fused:
+            # [r4] both padded operands in ONE launch each (mma_pad_rows): A = [x | 1 | 0] (N, 128), and wpad = [W | b | 0] (OP, 128), whose
+            # transposed VIEW is the forward's B and whose leading columns are dL/dx's B - no second padded copy of W in backward
+            xp = torch.empty((N, 128), device=x.device, dtype=torch.float32)
+            call("mma_pad_rows", ptr(x), x.stride(0), N, fin, None, ptr(xp), 128, 128, N, stream_ptr())
+            w2 = weight if weight.stride(1) == 1 else weight.contiguous()
+            wpad = torch.empty((OP, 128), device=x.device, dtype=torch.float32)
+            if bias is not None:
+                call("mma_pad_rows", ptr(w2), w2.stride(0), fout, fin, ptr(bias.contiguous()), ptr(wpad), 128, 128, OP, stream_ptr())
+            else:
+                call("mma_pad_rows", ptr(w2), w2.stride(0), fout, fin + 0, ptr(torch.zeros((fout,), device=x.device)), ptr(wpad), 128, 128, OP, stream_ptr())
+            wt = wpad.t()
         else:
-            xp = torch.nn.functional.pad(x, (0, 128 - fin))
+            xp = torch.nn.functional.pad(x, (0, 128 - fin))         # (N, 128): [x | 1 | 0 ...]
             xp[:, fin] = 1.0
-        wt = weight.new_zeros((128, OP))                             # [W^T ; b ; 0 ...], pad columns zero
-        wt[:fin, :fout] = weight.t()
-        if bias is not None:
-            wt[fin, :fout] = bias
+            wt = weight.new_zeros((128, OP))                         # [W^T ; b ; 0 ...], pad columns zero
+            wt[:fin, :fout] = weight.t()
+            if bias is not None:
+                wt[fin, :fout] = bias
+            wpad = None
         y = gemm_bf16x3(xp, wt)                                      # (N, OP); columns beyond fout are exact zeros
-        ctx.save_for_backward(xp, weight)
+        if wpad is not None:
+            ctx.save_for_backward(xp, weight, wpad)
+        else:
+            ctx.save_for_backward(xp, weight)
         ctx.dims = (fin, fout, OP, bias is not None)
         return y[:, :fout]
 
     @staticmethod
     def backward(ctx, g):
-        xp, weight = ctx.saved_tensors
+        xp, weight = ctx.saved_tensors[:2]
+        wpad = ctx.saved_tensors[2] if len(ctx.saved_tensors) > 2 else None
         fin, fout, OP, has_bias = ctx.dims
         gp = _padded_parent(g, OP)                                   # the producer's own zero-padded buffer: no copy
         if gp is None:
@@ -523,8 +538,11 @@ class _LinearX3(torch.autograd.Function):
             gb = gwb[fin, :fout].contiguous() if has_bias else None
         if ctx.needs_input_grad[0]:
             NP = _round_up(fin, 32)
-            wp = weight.new_zeros((OP, NP))
-            wp[:fout, :fin] = weight
+            if wpad is not None:
+                wp = wpad[:, :NP]           # column fin (the bias) lands in a pad column of gx that the slice below drops
+            else:
+                wp = weight.new_zeros((OP, NP))
+                wp[:fout, :fin] = weight
             gx = gemm_bf16x3(gp, wp)[:, :fin]
         return gx, gw, gb
 

@@ -246,9 +246,9 @@ def test_tower_post_results_do_not_depend_on_the_workgroup_order(monkeypatch):
 
 
 @pytest.mark.parametrize("N,fin,pitch", [(5000, 75, 75), (4099, 50, 64), (33000, 127, 127), (1, 3, 3), (2000, 76, 380)])
-def test_pad_ones_rows_equals_pad_and_fill(N, fin, pitch):
-    """[r4] mma_pad_ones_rows: [x | 1 | 0 ...] of the zero-padded tall Linear in one launch = torch's pad + a strided fill, bit for bit
-    (row-strided x included: a column block of a wider buffer)."""
+def test_pad_rows_equals_pad_and_fill(N, fin, pitch):
+    """[r4] mma_pad_rows: [x | 1 | 0 ...] (and [W | b | 0 ...] with zero rows below) of the zero-padded tall Linear in one launch = torch's
+    pad + a strided fill, bit for bit (row-strided x included: a column block of a wider buffer)."""
     from mma_amd._lib import call, ptr, stream_ptr
     g = torch.Generator().manual_seed(N + fin)
     wide = torch.randn(N, pitch, generator=g).to(DEV)
@@ -256,8 +256,17 @@ def test_pad_ones_rows_equals_pad_and_fill(N, fin, pitch):
     want = torch.nn.functional.pad(x, (0, 128 - fin))
     want[:, fin] = 1.0
     got = torch.full((N, 128), float("nan"), device=DEV)
-    call("mma_pad_ones_rows", ptr(x), x.stride(0), N, fin, ptr(got), 128, 128, stream_ptr())
+    call("mma_pad_rows", ptr(x), x.stride(0), N, fin, None, ptr(got), 128, 128, N, stream_ptr())
     assert torch.equal(got, want)
+    # a given column and zero rows below (the weight operand)
+    col = torch.randn(N, generator=g).to(DEV)
+    rows_out = -(-N // 128) * 128 + 128
+    want2 = torch.zeros((rows_out, 128), device=DEV)
+    want2[:N, :fin] = x
+    want2[:N, fin] = col
+    got2 = torch.full((rows_out, 128), float("nan"), device=DEV)
+    call("mma_pad_rows", ptr(x), x.stride(0), N, fin, ptr(col), ptr(got2), 128, 128, rows_out, stream_ptr())
+    assert torch.equal(got2, want2)
 
 
 def test_linear_tall_with_and_without_the_fused_pad(monkeypatch):
@@ -267,12 +276,14 @@ def test_linear_tall_with_and_without_the_fused_pad(monkeypatch):
     W = (torch.randn(760, 75, generator=g) / 9).to(DEV)
     b = torch.randn(760, generator=g).to(DEV)
     assert dense.linear_x3_ok(x, W)
-    outs = []
-    for flag in (True, False):
-        monkeypatch.setattr(dense, "FUSED_PAD", flag)
-        xr, wr, br = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
-        y = dense.linear_tall(xr, wr, br)
-        gr = torch.autograd.grad((y * y).sum(), [xr, wr, br])
-        outs.append((y.detach(),) + gr)
-    for a, c in zip(*outs):
-        assert torch.equal(a, c)
+    for bias in (True, False):
+        outs = []
+        for flag in (True, False):
+            monkeypatch.setattr(dense, "FUSED_PAD", flag)
+            xr, wr = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+            br = b.clone().requires_grad_(True) if bias else None
+            y = dense.linear_tall(xr, wr, br)
+            gr = torch.autograd.grad((y * y).sum(), [xr, wr] + ([br] if bias else []))
+            outs.append((y.detach(),) + gr)
+        for a, c in zip(*outs):
+            assert torch.equal(a, c), bias
