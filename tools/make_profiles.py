@@ -82,7 +82,11 @@ def traffic(base, out, workload, note):
 
 def bench_line(log, out):
     import bench
-    b = json.loads([l for l in open(os.path.join(ROOT, "gpurun_out", log)) if l.startswith("{")][-1])
+    # the log holds stdout + stderr: the verbose {"detail": ...} record (stderr) and the compact metric line (stdout, last)
+    lines = [l for l in open(os.path.join(ROOT, "gpurun_out", log)) if l.startswith("{")]
+    det = [l for l in lines if l.startswith('{"detail"')]
+    b = json.loads(det[-1])["detail"] if det else json.loads(lines[-1])
+    b["compact_line"] = json.loads(lines[-1]) if det else None
     c = b["config"]
     for key in ("roofline", "roofline_other"):
         r = b.get(key)
