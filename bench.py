@@ -832,6 +832,9 @@ def main():
     ap.add_argument("--rendezvous-only", action="store_true", help="(tests) ranks meet, all-reduce their rank and leave: "
                     "checks the launch path without a GPU")
     args = ap.parse_args()
+    if os.environ.get("MMA_LIB_OVERRIDE"):
+        sys.exit("bench.py: MMA_LIB_OVERRIDE is set (%s): a measurement / ablation library is not the product - nothing is timed on it" %
+                 os.environ["MMA_LIB_OVERRIDE"])
     if args.workload == "c5":
         for k, v in C5_PRESET.items():
             setattr(args, k, v)

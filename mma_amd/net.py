@@ -169,6 +169,10 @@ class Net(torch.nn.Module):
         for conv, batch_norm in zip(self.convs, self.batch_norms):
             h = conv(x, edge_index, edge_attr)
             x = F.relu(batch_norm(h)) if n_valid is None else masked_bn_relu(h, batch_norm, n_valid)
-        # the padded step (n_graphs given) has a sorted batch vector by construction (GraphedNetStep.load checks the caller's part)
+        # the padded step (n_graphs given) takes the contiguous-range pooling, which needs a SORTED batch vector: GraphedNetStep.load checks
+        # its callers' batches; any other caller of the padded forward is checked here (device-side assert, no host sync) whenever the
+        # stream is not being captured (round-4 ADVICE: an unsorted vector would silently pool wrong sums)
+        if n_graphs is not None and batch.is_cuda and batch.numel() > 1 and not torch.cuda.is_current_stream_capturing():
+            torch._assert_async((batch[1:] >= batch[:-1]).all())
         x = global_add_pool(x, batch, None if n_graphs is None else n_graphs + 1, assume_sorted=n_graphs is not None)
         return self.mlp(x)

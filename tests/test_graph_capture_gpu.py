@@ -124,11 +124,11 @@ def _net_batches(n_batches, n_graphs, seed=5):
     return out
 
 
-def _make_net(seed, hist, p):
+def _make_net(seed, hist, p, aggregators=("min", "max")):
     import mma_amd
     from mma_amd.net import Net
     torch.manual_seed(seed)
-    net = Net(["min", "max"], ["identity", "amplification", "linear"], hist).to(DEV)
+    net = Net(list(aggregators), ["identity", "amplification", "linear"], hist).to(DEV)
     for conv in net.convs:
         conv.dropout = p
     return net, mma_amd.FusedAdam([q for q in net.parameters() if q.requires_grad], lr=1e-3)
@@ -146,7 +146,6 @@ def test_graphed_net_step_equals_the_eager_padded_step_bit_for_bit():
     e_pad = max(b["E"] for b in batches) + 14
     net_g, opt_g = _make_net(3, hist, 0.0)
     net_e, opt_e = _make_net(3, hist, 0.0)
-    net_u, opt_u = _make_net(3, hist, 0.0)
     sg = mma_amd.GraphedNetStep(net_g, opt_g, 16, n_pad, e_pad, DEV, warmup=2)
     se = mma_amd.GraphedNetStep(net_e, opt_e, 16, n_pad, e_pad, DEV)
     b0 = batches[0]
@@ -167,31 +166,43 @@ def test_graphed_net_step_equals_the_eager_padded_step_bit_for_bit():
         assert torch.equal(p1, p2), n1
     for m1, m2 in zip(net_g.batch_norms, net_e.batch_norms):
         assert torch.equal(m1.running_mean, m2.running_mean) and torch.equal(m1.running_var, m2.running_var)
-    # the padded step against the reference's own (unpadded) step on the same first batch, from the same initial parameters
+    # the padded step against the reference's own (unpadded) step on the same first batch, from the same initial parameters.
+    # Gradients, not parameters after Adam: the first Adam step is g / (|g| + 1e-8), ill-conditioned wherever |g| is near eps.
+    # (a) [sum, mean]: no routing decision anywhere, so the padded step must reproduce the unpadded one entry by entry to 2e-5 of a
+    #     gradient's largest entry (round-3's bar; round-4 ADVICE: the bar below alone cannot see a 1e-3-level regression of the padded step).
+    # (b) [min, max], mma.py's setting: the two forwards differ in their last bits (BatchNorm's reduction order) and a min / max aggregator
+    #     hands its gradient to ONE edge: a near-tie can go to another edge in the other run, and the rows of a gradient that edge feeds
+    #     then differ at 1e-3 of the largest entry (measured with the fp32 kernels of round 3 as well: seed 4, batches 3 and 4 of this
+    #     generator: 5e-4 and 5e-3; with K13 on bf16 pieces seed 3, batch 0: 1e-3 in two rows of node_emb, and - the edge sits in the last
+    #     layer - 1e-4 in everything the back-propagation reaches from there).  A discontinuity of the reference's own formula, so this
+    #     leg keeps the loose bar (norm 5e-3, entries 1e-2 of the largest) and is a sanity check only; the loss, which no routing
+    #     decision enters, agrees to 1e-5 in both legs.
+    _padded_step_vs_unpadded(batches[0], hist, n_pad, e_pad, ("sum", "mean"), 2e-5, 2e-5)
+    _padded_step_vs_unpadded(batches[0], hist, n_pad, e_pad, ("min", "max"), 1e-2, 5e-3)
+
+
+def _padded_step_vs_unpadded(b, hist, n_pad, e_pad, aggregators, elem_bar, norm_bar):
+    import mma_amd
+    net_u, opt_u = _make_net(3, hist, 0.0, aggregators)
     net_u.train()
-    b = batches[0]
     opt_u.zero_grad(set_to_none=False)
     out = net_u(b["x"], b["ei"], b["ea"], b["batch"])
     loss_u = mma_amd.fused_l1_loss(out.squeeze(-1), b["y"])
-    net_p, opt_p = _make_net(3, hist, 0.0)
+    net_p, opt_p = _make_net(3, hist, 0.0, aggregators)
     sp = mma_amd.GraphedNetStep(net_p, opt_p, 16, n_pad, e_pad, DEV)
     sp.load(b["x"], b["ei"], b["ea"], b["batch"], b["y"])
     loss_p = sp.forward_backward()
-    assert abs(loss_u.item() - loss_p.item()) <= 1e-5 * max(1.0, abs(loss_u.item())), (loss_u.item(), loss_p.item())
+    assert abs(loss_u.item() - loss_p.item()) <= 1e-5 * max(1.0, abs(loss_u.item())), (aggregators, loss_u.item(), loss_p.item())
     loss_u.backward()
-    # gradients, not parameters after Adam: the first Adam step is g / (|g| + 1e-8), ill-conditioned wherever |g| is near eps.
-    # The two forwards differ in their last bits (BatchNorm's reduction order), and a min / max aggregator hands its gradient to ONE edge: a
-    # near-tie can go to another edge in the other run, and the rows of a gradient that edge feeds then differ at 1e-3 of the largest entry
-    # (measured with the fp32 kernels of round 3 as well: seed 4, batches 3 and 4 of this generator: 5e-4 and 5e-3; with K13 on bf16 pieces
-    # seed 3, batch 0: 1e-3 in two rows of node_emb, and - the edge sits in the last layer - 1e-4 in everything the back-propagation
-    # reaches from there).  So: every parameter's gradient agrees in norm to 5e-3 and entry by entry to 1e-2 of its largest entry; the
-    # loss above, which no routing decision enters, agrees to 1e-5.
+    worst = 0.0
     for (n1, p1), (_, p2) in zip(net_u.named_parameters(), net_p.named_parameters()):
         g1 = p1.grad if p1.grad is not None else torch.zeros_like(p1)
         g2 = p2.grad if p2.grad is not None else torch.zeros_like(p2)
         d = (g1 - g2).abs()                                # (a bias in front of BatchNorm has an exactly-zero gradient: both sides hold rounding noise)
-        assert d.max().item() <= max(1e-2 * g1.abs().max().item(), 1e-6), (n1, d.max().item(), g1.abs().max().item())
-        assert (g1 - g2).norm().item() <= 5e-3 * g1.norm().item() + 1e-6, (n1, (g1 - g2).norm().item(), g1.norm().item())
+        worst = max(worst, d.max().item() / max(g1.abs().max().item(), 1e-6))
+        assert d.max().item() <= max(elem_bar * g1.abs().max().item(), 1e-6), (aggregators, n1, d.max().item(), g1.abs().max().item())
+        assert (g1 - g2).norm().item() <= norm_bar * g1.norm().item() + 1e-6, (aggregators, n1, (g1 - g2).norm().item(), g1.norm().item())
+    print("padded vs unpadded step, aggregators %s: worst |dg| / max|g| over the parameters = %.2e (bar %g)" % (",".join(aggregators), worst, elem_bar))
 
 
 def test_graphed_net_step_refuses_a_batch_that_does_not_fit():

@@ -13,15 +13,17 @@ if [ "$1" = "post" ]; then
   shift
   for b in "$@"; do
     /opt/rocm/bin/hipcc $FLAGS -DMMA_POST_ABL=$b -c tower_post.hip -o ../../scratch/abl/tower_post_abl$b.o || exit 1
+    /opt/rocm/bin/hipcc $FLAGS "-DMMA_BUILD_SHA_SUFFIX=\"+postabl$b\"" -c abi.hip -o ../../scratch/abl/abi_post$b.o || exit 1
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../scratch/abl/libmma_amd_post$b.so \
-        abi.o nc_fused.o spmm_rows.o gr_fused.o gemm_x3.o tower.o ../../scratch/abl/tower_post_abl$b.o train_step.o pack.o || exit 1
+        ../../scratch/abl/abi_post$b.o nc_fused.o spmm_rows.o gr_fused.o gemm_x3.o tower.o ../../scratch/abl/tower_post_abl$b.o train_step.o pack.o || exit 1
     echo "built scratch/abl/libmma_amd_post$b.so"
   done
   exit 0
 fi
 for b in "$@"; do
   /opt/rocm/bin/hipcc $FLAGS -DMMA_ABL=$b -c gemm_x3.hip -o ../../scratch/abl/gemm_x3_abl$b.o || exit 1
+  /opt/rocm/bin/hipcc $FLAGS "-DMMA_BUILD_SHA_SUFFIX=\"+abl$b\"" -c abi.hip -o ../../scratch/abl/abi_abl$b.o || exit 1
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../scratch/abl/libmma_amd_abl$b.so \
-      abi.o nc_fused.o spmm_rows.o gr_fused.o ../../scratch/abl/gemm_x3_abl$b.o tower.o tower_post.o train_step.o pack.o || exit 1
+      ../../scratch/abl/abi_abl$b.o nc_fused.o spmm_rows.o gr_fused.o ../../scratch/abl/gemm_x3_abl$b.o tower.o tower_post.o train_step.o pack.o || exit 1
   echo "built scratch/abl/libmma_amd_abl$b.so"
 done

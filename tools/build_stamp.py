@@ -59,7 +59,9 @@ def build_stamp():
             "library": "loaded" if lib is not None else "not loadable: the tree's source SHA",
             "stale_build": bool(lib is not None and lib != src),
             "host_sha": _sha([os.path.join(ROOT, "mma_amd", f) for f in HOST_FILES]),
-            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MMA_") and k != "MMA_LIB_OVERRIDE"}}
+            # MMA_LIB_OVERRIDE included (round-4 ADVICE): a measurement library (tools/build_ablation.sh: wrong results on purpose) must not
+            # pass for the product build - its abi.o also carries a "+abl..." suffix in kernel_sha, and bench.py refuses to run on one
+            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MMA_") and k != "MMA_BENCH_DETAIL"}}
 
 
 if __name__ == "__main__":
