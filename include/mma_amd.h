@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 33
+#define MMA_ABI_VERSION 34
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -39,8 +39,9 @@ enum {
 enum { MMA_ACT_SIGMOID = 0, MMA_ACT_RAW = 1 };
 
 /* dropout of the mask (F.dropout(mask0, p), training=True always: layers.py:219).
- *   mode NONE: p == 0.  mode HASH: counter-based keep bits, DESIGN.md "dropout RNG"; p is quantised
- *   to thr/256.  mode EXPLICIT: keep[(k*E + e)*H + h] in {0,1} supplied by the caller (parity tests). */
+ *   mode NONE: p == 0.  mode HASH: counter-based keep bits, DESIGN.md "dropout RNG"; every `drop_thr` of this header is a
+ *   16-bit threshold (ABI 34): P(drop) = drop_thr / 65536, 0..65535, survivors scale by 65536 / (65536 - drop_thr) - any p to
+ *   2^-17.  mode EXPLICIT: keep[(k*E + e)*H + h] in {0,1} supplied by the caller (parity tests), scale by the same formula. */
 enum { MMA_DROP_NONE = 0, MMA_DROP_HASH = 1, MMA_DROP_EXPLICIT = 2 };
 
 int mma_abi_version(void);

@@ -80,8 +80,12 @@ __device__ __forceinline__ float sigmoid_fast(float z) { return __builtin_amdgcn
 // ONE full 32-bit hash per (edge position e, feature quad q) - h = mix32(edge_key(e) ^ col_key(q)) - serves all K masks of
 // a launch group (round 3; round 2 ran one full hash per mask): mask 0 uses h itself, mask k >= 1 the folded 64-bit product
 // r_k = hi32(h * M_k) ^ lo32(h * M_k) with a fixed odd multiplier per mask (one v_mad_u64_u32 + one xor instead of two
-// v_mul_lo_u32 and seven ALU operations).  A word yields 4 bytes, one per feature of the quad; an element is KEPT iff its
-// byte >= thr, so P(drop) = thr/256 and survivors scale by 256/(256-thr).  The numpy restatement the parity tests use is
+// v_mul_lo_u32 and seven ALU operations).  A word yields 4 bytes, one per feature of the quad.  The drop probability is thr16/65536
+// (round 5: any p of F.dropout(mask0, p), layers.py:219, to 2^-17): an element is KEPT iff its 16-bit value v >= thr16, v = byte of the
+// mask word (high half) | the same byte of a SECOND word c_k = fold(h * M2_k) (low half); survivors scale by 65536/(65536-thr16).  When
+// thr16 is a multiple of 256 (the README's 0.5 and 0.75) the low half never decides - v >= 256 t  <=>  byte >= t - and the kernels run the
+// one-word form (internal mode HASH, thr = thr16 >> 8): the same bits at round 4's cost; otherwise mode HASH16 (+1 multiply-fold and two
+// v_perm_b32 per mask and quad).  The numpy restatement the parity tests use is
 // oracle/dropout_rng.py; tests/test_dropout_rng.py checks keep rate and the independence of masks / bytes / neighbouring
 // edges and quads (a cheaper derivation, r_k = fold16(h * M_k), failed exactly that test: the XOR of two bytes of one mask
 // was 800 sigma correlated with the same XOR of another mask).
@@ -100,11 +104,22 @@ __host__ __device__ __forceinline__ uint32_t drop_mask_word(uint32_t h, int k_ab
   const uint64_t t = (uint64_t)h * (uint64_t)mult;
   return (uint32_t)t ^ (uint32_t)(t >> 32);
 }
+// HASH16: multiplier of mask k's SECOND word (low halves of the 16-bit values); every mask folds, mask 0 too
+__host__ __device__ __forceinline__ uint32_t drop_mask_mult2(int k) {
+  constexpr uint32_t m[8] = {0x9E3779B9u, 0xB5297A4Du, 0x68E31DA5u, 0x1B56C4E9u, 0xD6E8FEB9u, 0xA3D95FA9u, 0x7F4A7C15u, 0x94D049BBu};
+  return m[k & 7];
+}
+__host__ __device__ __forceinline__ uint32_t drop_low_word(uint32_t h, uint32_t mult2) {
+  const uint64_t t = (uint64_t)h * (uint64_t)mult2;
+  return (uint32_t)t ^ (uint32_t)(t >> 32);
+}
+// internal kernel mode beside the MMA_DROP_* of the header: HASH with a threshold that is no multiple of 256
+#define MMA_DROP_HASH16 3
 
 struct DropParams {
-  int mode;             // MMA_DROP_*
-  uint32_t thr;         // 0..255
-  float scale;          // 256/(256-thr) (HASH) or 1/(1-p) = same formula (EXPLICIT)
+  int mode;             // MMA_DROP_* or MMA_DROP_HASH16 (set by drop_make from the caller's HASH + thr16)
+  uint32_t thr;         // HASH: 0..255 (= thr16 >> 8, thr16 a multiple of 256); HASH16: 1..65535
+  float scale;          // 65536/(65536-thr16) (HASH, HASH16) or 1/(1-p) = the same formula (EXPLICIT)
   uint32_t seed_lo, seed_hi;
   const uint64_t* seed_dev;   // optional: the seed lives in device memory (graph replays draw a fresh one without re-capture)
   const uint8_t* keep;  // EXPLICIT: (K_total, E, H)
@@ -114,7 +129,7 @@ struct DropParams {
 
 // kernel entry: a seed in device memory overrides the one passed by value (one uniform 8-byte load per wave)
 __device__ __forceinline__ DropParams drop_resolve(DropParams d) {
-  if (d.mode == MMA_DROP_HASH && d.seed_dev != nullptr) {
+  if ((d.mode == MMA_DROP_HASH || d.mode == MMA_DROP_HASH16) && d.seed_dev != nullptr) {
     const uint64_t s = *d.seed_dev;
     d.seed_lo = (uint32_t)s; d.seed_hi = (uint32_t)(s >> 32);
   }
@@ -133,6 +148,25 @@ __device__ __forceinline__ void drop_unpack(const DropParams& d, uint32_t r, int
     f[i] = byte >= d.thr ? d.scale : 0.f;
   }
 }
+// HASH16: r = the mask word (high bytes), lo = its second word (low bytes); element i of the quad takes byte (c+i)&3 of both
+template <int VEC>
+__device__ __forceinline__ void drop_unpack16(const DropParams& d, uint32_t r, uint32_t lo, int c, float (&f)[VEC]) {
+  if constexpr (VEC == 4) {          // c % 4 == 0: two v_perm_b32 interleave the bytes into four 16-bit values
+    const uint32_t v01 = __builtin_amdgcn_perm(r, lo, 0x05010400u);      // [r1 lo1 | r0 lo0]
+    const uint32_t v23 = __builtin_amdgcn_perm(r, lo, 0x07030602u);      // [r3 lo3 | r2 lo2]
+    f[0] = (v01 & 0xFFFFu) >= d.thr ? d.scale : 0.f;
+    f[1] = (v01 >> 16) >= d.thr ? d.scale : 0.f;
+    f[2] = (v23 & 0xFFFFu) >= d.thr ? d.scale : 0.f;
+    f[3] = (v23 >> 16) >= d.thr ? d.scale : 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int sh = 8 * ((c + i) & 3);
+      const uint32_t v = (((r >> sh) & 0xFFu) << 8) | ((lo >> sh) & 0xFFu);
+      f[i] = v >= d.thr ? d.scale : 0.f;
+    }
+  }
+}
 template <int VEC>
 __device__ __forceinline__ void drop_explicit(const DropParams& d, uint32_t e, int k_abs, int c, int H, float (&f)[VEC]) {
   const uint32_t bits = ldb<VEC>(d.keep + ((size_t)k_abs * (size_t)d.E + e) * (size_t)H + c);
@@ -147,9 +181,19 @@ __device__ __forceinline__ void drop_factors(const DropParams& d, uint32_t e, in
                                              float (&f)[VEC]) {
   if (d.mode == MMA_DROP_HASH) {
     drop_unpack<VEC>(d, drop_mask_word(drop_base_word(d, e, c >> 2), k_abs, drop_mask_mult(k_abs)), c, f);
+  } else if (d.mode == MMA_DROP_HASH16) {
+    const uint32_t h = drop_base_word(d, e, c >> 2);
+    drop_unpack16<VEC>(d, drop_mask_word(h, k_abs, drop_mask_mult(k_abs)), drop_low_word(h, drop_mask_mult2(k_abs)), c, f);
   } else {  // EXPLICIT
     drop_explicit<VEC>(d, e, k_abs, c, H, f);
   }
+}
+
+// the caller's (mode, thr16) -> the kernels' (mode, thr, scale): HASH with thr16 % 256 == 0 keeps the one-word form
+__host__ inline void drop_set_threshold(DropParams* d, int mode, uint32_t thr16) {
+  d->scale = 65536.0f / (65536.0f - (float)thr16);
+  if (mode == MMA_DROP_HASH && (thr16 & 0xFFu)) { d->mode = MMA_DROP_HASH16; d->thr = thr16; }
+  else { d->mode = mode; d->thr = mode == MMA_DROP_HASH ? (thr16 >> 8) : thr16; }
 }
 
 __host__ inline int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }

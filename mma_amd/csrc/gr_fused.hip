@@ -683,6 +683,10 @@ __device__ __forceinline__ bool blk_stage(const GrParams& p, const BlkLds& L, in
 // keep multipliers of the GR dropout (HASH mode only; keyed by the original edge id, mask index 0)
 __device__ __forceinline__ void blk_drop(const DropParams& d, uint32_t e, int c, float (&f)[4]) {
   const uint32_t r = drop_mix(drop_edge_key(e + d.edge_base, d.seed_lo) ^ drop_col_key((uint32_t)(c >> 2), d.seed_hi));
+  if (d.mode == MMA_DROP_HASH16) {      // wave-uniform: a threshold that is no multiple of 256 (mma_conv.py:67 hard-codes 0.5; `dropout` is public)
+    drop_unpack16<4>(d, r, drop_low_word(r, drop_mask_mult2(0)), 0, f);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) f[i] = ((r >> (8 * i)) & 0xFFu) >= d.thr ? d.scale : 0.f;
 }
@@ -1177,15 +1181,14 @@ static int gr_fill_common(GrParams& p, const int32_t* rowptr, const int32_t* src
                           int64_t ldsave, int64_t N, int64_t E, int32_t T, int32_t F, float avg_log, float avg_lin, int32_t drop_mode,
                           uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev) {
   MMA_REQUIRE(drop_mode == MMA_DROP_NONE || drop_mode == MMA_DROP_HASH, "GR dropout: NONE or HASH");
-  MMA_REQUIRE(drop_mode == MMA_DROP_NONE || drop_thr < 256, "drop_thr out of range");
+  MMA_REQUIRE(drop_mode == MMA_DROP_NONE || drop_thr < 65536, "drop_thr out of range (0..65535: P(drop) = thr / 65536)");
   MMA_REQUIRE((amin8 == nullptr) == (amin_side == nullptr) && (amax8 == nullptr) == (amax_side == nullptr),
               "arg8 (N,ldsave) bytes and arg_side (mma_gr_arg_side_rows(E), ldsave) int32 come in pairs");
   p.rowptr = rowptr; p.src = src; p.perm = perm; p.U = U; p.V = V; p.lduv = lduv; p.Z = Z; p.ldz = ldz; p.by_pos = by_pos ? 1 : 0;
   p.inputs = inputs; p.ldi = ldi; p.amin8 = amin8; p.amax8 = amax8; p.amin_side = amin_side; p.amax_side = amax_side;
   p.mean = mean; p.var = var; p.ldsave = ldsave;
   p.N = (int)N; p.D = T * F; p.T = T; p.F = F; p.avg_log = avg_log; p.avg_lin = avg_lin;
-  p.drop.mode = (drop_mode == MMA_DROP_HASH && drop_thr > 0 && !inputs) ? MMA_DROP_HASH : MMA_DROP_NONE;
-  p.drop.thr = drop_thr; p.drop.scale = 256.f / (256.f - (float)drop_thr);
+  drop_set_threshold(&p.drop, (drop_mode == MMA_DROP_HASH && drop_thr > 0 && !inputs) ? MMA_DROP_HASH : MMA_DROP_NONE, drop_thr);
   p.drop.seed_lo = (uint32_t)seed; p.drop.seed_hi = (uint32_t)(seed >> 32); p.drop.seed_dev = seed_dev; p.drop.keep = nullptr;
   p.drop.E = E; p.drop.edge_base = 0;
   return 0;

@@ -126,10 +126,10 @@ __device__ __forceinline__ void nc_fwd_finalize_body(const NcFwdParams& p, const
 // and leaves the counter at zero.  The chunk items head the longest-first list, so this happens while the short items still run.
 template <int K, int VEC, bool SAVE, int DM, bool MULTI, bool ONE = false>
 __device__ __forceinline__ void nc_fwd_body(const NcFwdParams& p, const int bx, const int nbx) {
-  const DropParams dp = DM == MMA_DROP_HASH ? drop_resolve(p.drop) : p.drop;
-  uint32_t mult[K];
+  const DropParams dp = (DM == MMA_DROP_HASH || DM == MMA_DROP_HASH16) ? drop_resolve(p.drop) : p.drop;
+  uint32_t mult[K], mult2[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) mult[k] = drop_mask_mult(p.k_base + k);
+  for (int k = 0; k < K; ++k) { mult[k] = drop_mask_mult(p.k_base + k); mult2[k] = drop_mask_mult2(p.k_base + k); }
   // edge steps in flight per lane: 2 (2*(K+1) row loads before the first use); 1 for K = 8, where two would need all
   // 256 VGPRs and leave a single wave per SIMD
   constexpr int U = NC_FWD_UNROLL(K);
@@ -210,13 +210,15 @@ __device__ __forceinline__ void nc_fwd_body(const NcFwdParams& p, const int bx, 
           for (int i = 0; i < VEC; ++i) xj[u].v[i] = ev[u] ? xj[u].v[i] : 0.f;
           // inactive: edge 0 (any valid position; EXPLICIT mode reads keep[(k*E + e)*H + c], and ebeg may equal E)
           const uint32_t eu = (uint32_t)(ev[u] ? ebeg + base + tt[u] : 0);
-          const uint32_t hw = DM == MMA_DROP_HASH ? drop_base_word(dp, eu, cc >> 2) : 0u;      // ONE full hash for the K masks
+          const uint32_t hw = (DM == MMA_DROP_HASH || DM == MMA_DROP_HASH16) ? drop_base_word(dp, eu, cc >> 2) : 0u;      // ONE full hash for the K masks
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const bool raw = (p.acts >> (p.k_base + k)) & 1u;
             float f[VEC];
             if (DM == MMA_DROP_HASH) {
               drop_unpack<VEC>(dp, drop_mask_word(hw, k == 0 ? p.k_base : 1, mult[k]), cc, f);     // k > 0: never the base word (compile time)
+            } else if (DM == MMA_DROP_HASH16) {
+              drop_unpack16<VEC>(dp, drop_mask_word(hw, k == 0 ? p.k_base : 1, mult[k]), drop_low_word(hw, mult2[k]), cc, f);
             } else if (DM == MMA_DROP_EXPLICIT) {
               drop_explicit<VEC>(dp, eu, p.k_base + k, cc, p.H, f);
             } else {
@@ -516,10 +518,10 @@ __device__ __forceinline__ void nc_bwd_finalize_body(const NcBwdParams& p, const
 template <int K, int VEC, int DM, bool SHARED, bool MULTI, bool EPI, bool ONE = false>
 __device__ __forceinline__ void nc_bwd_body(const NcBwdParams& p, const int bx, const int nbx) {
   constexpr bool DROP = DM != MMA_DROP_NONE;
-  const DropParams dp = DM == MMA_DROP_HASH ? drop_resolve(p.drop) : p.drop;
-  uint32_t mult[K];
+  const DropParams dp = (DM == MMA_DROP_HASH || DM == MMA_DROP_HASH16) ? drop_resolve(p.drop) : p.drop;
+  uint32_t mult[K], mult2[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) mult[k] = drop_mask_mult(p.k_base + k);
+  for (int k = 0; k < K; ++k) { mult[k] = drop_mask_mult(p.k_base + k); mult2[k] = drop_mask_mult2(p.k_base + k); }
   constexpr int U = NC_BWD_UNROLL(K);           // edge steps in flight per lane (see nc_fwd_kernel)
   const int lane = threadIdx.x & (kWave - 1);
   const int lpr = 1 << p.lpr_log;
@@ -619,7 +621,7 @@ __device__ __forceinline__ void nc_bwd_body(const NcBwdParams& p, const int bx, 
           for (int kk = 0; kk < (SHARED ? 1 : K); ++kk)
 #pragma unroll
             for (int i = 0; i < VEC; ++i) gv[u][kk].v[i] = live ? gv[u][kk].v[i] : 0.f;
-          const uint32_t hw = DM == MMA_DROP_HASH ? drop_base_word(dp, eid[u], cc >> 2) : 0u;      // ONE full hash for the K masks
+          const uint32_t hw = (DM == MMA_DROP_HASH || DM == MMA_DROP_HASH16) ? drop_base_word(dp, eid[u], cc >> 2) : 0u;      // ONE full hash for the K masks
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const bool raw = (p.acts >> (p.k_base + k)) & 1u;
@@ -628,6 +630,8 @@ __device__ __forceinline__ void nc_bwd_body(const NcBwdParams& p, const int bx, 
             float f[VEC];
             if (DM == MMA_DROP_HASH) {
               drop_unpack<VEC>(dp, drop_mask_word(hw, k == 0 ? p.k_base : 1, mult[k]), cc, f);     // k > 0: never the base word (compile time)
+            } else if (DM == MMA_DROP_HASH16) {
+              drop_unpack16<VEC>(dp, drop_mask_word(hw, k == 0 ? p.k_base : 1, mult[k]), drop_low_word(hw, mult2[k]), cc, f);
             } else if (DM == MMA_DROP_EXPLICIT) {
               drop_explicit<VEC>(dp, eid[u], p.k_base + k, cc, p.H, f);
             } else {
@@ -869,9 +873,9 @@ static int make_drop(int32_t mode, uint32_t thr, uint64_t seed, const uint64_t* 
   MMA_REQUIRE(edge_base >= 0 && edge_base + E < (1LL << 32), "drop_edge_base %lld out of range", (long long)edge_base);
   d->edge_base = (uint32_t)edge_base;
   MMA_REQUIRE(mode >= MMA_DROP_NONE && mode <= MMA_DROP_EXPLICIT, "drop_mode %d unknown", mode);
-  MMA_REQUIRE(mode == MMA_DROP_NONE || thr < 256, "drop_thr %u out of range (0..255)", thr);
+  MMA_REQUIRE(mode == MMA_DROP_NONE || thr < 65536, "drop_thr %u out of range (0..65535: P(drop) = thr / 65536)", thr);
   MMA_REQUIRE(mode != MMA_DROP_EXPLICIT || keep != nullptr, "drop_mode EXPLICIT needs a keep mask");
-  d->mode = mode; d->thr = thr; d->scale = 256.0f / (256.0f - (float)thr);
+  drop_set_threshold(d, mode, thr);
   d->seed_lo = (uint32_t)seed; d->seed_hi = (uint32_t)(seed >> 32); d->keep = keep; d->E = E;
   return 0;
 }
@@ -899,9 +903,9 @@ template <int K, int VEC, bool MULTI>
 static void launch_fwd(const NcFwdParams& p, dim3 grid, bool save, int dm, hipStream_t st) {
 #define MMA_FWD(SAVE, DM) hipLaunchKernelGGL((nc_fwd_kernel<K, VEC, SAVE, DM, MULTI>), grid, dim3(kBlock), 0, st, p)
   if (save) {
-    if (dm == MMA_DROP_HASH) MMA_FWD(true, MMA_DROP_HASH); else if (dm == MMA_DROP_EXPLICIT) MMA_FWD(true, MMA_DROP_EXPLICIT); else MMA_FWD(true, MMA_DROP_NONE);
+    if (dm == MMA_DROP_HASH) MMA_FWD(true, MMA_DROP_HASH); else if (dm == MMA_DROP_HASH16) MMA_FWD(true, MMA_DROP_HASH16); else if (dm == MMA_DROP_EXPLICIT) MMA_FWD(true, MMA_DROP_EXPLICIT); else MMA_FWD(true, MMA_DROP_NONE);
   } else {
-    if (dm == MMA_DROP_HASH) MMA_FWD(false, MMA_DROP_HASH); else if (dm == MMA_DROP_EXPLICIT) MMA_FWD(false, MMA_DROP_EXPLICIT); else MMA_FWD(false, MMA_DROP_NONE);
+    if (dm == MMA_DROP_HASH) MMA_FWD(false, MMA_DROP_HASH); else if (dm == MMA_DROP_HASH16) MMA_FWD(false, MMA_DROP_HASH16); else if (dm == MMA_DROP_EXPLICIT) MMA_FWD(false, MMA_DROP_EXPLICIT); else MMA_FWD(false, MMA_DROP_NONE);
   }
 #undef MMA_FWD
 }
@@ -921,7 +925,7 @@ static void launch_bwd(const NcBwdParams& p, dim3 grid, int dm, hipStream_t st) 
   const bool epi = p.T != nullptr;
 #define MMA_BWD(DM, SHARED, EPI) hipLaunchKernelGGL((nc_bwd_kernel<K, VEC, DM, SHARED, MULTI, EPI>), grid, dim3(kBlock), 0, st, p)
 #define MMA_BWD_DM(SHARED, EPI) \
-  do { if (dm == MMA_DROP_HASH) MMA_BWD(MMA_DROP_HASH, SHARED, EPI); else if (dm == MMA_DROP_EXPLICIT) MMA_BWD(MMA_DROP_EXPLICIT, SHARED, EPI); \
+  do { if (dm == MMA_DROP_HASH) MMA_BWD(MMA_DROP_HASH, SHARED, EPI); else if (dm == MMA_DROP_HASH16) MMA_BWD(MMA_DROP_HASH16, SHARED, EPI); else if (dm == MMA_DROP_EXPLICIT) MMA_BWD(MMA_DROP_EXPLICIT, SHARED, EPI); \
        else MMA_BWD(MMA_DROP_NONE, SHARED, EPI); } while (0)
   if (shared) { if (epi) MMA_BWD_DM(true, true); else MMA_BWD_DM(true, false); }
   else MMA_BWD_DM(false, false);
@@ -943,16 +947,16 @@ static void launch_bwd_k(int Ks, const NcBwdParams& p, dim3 grid, int dm, hipStr
 template <int K>
 static void launch_fwd_small(const NcFwdParams& p, const NcSmallPlan& sp, dim3 grid, bool save, int dm, hipStream_t st) {
 #define MMA_FWD_S(SAVE, DM) hipLaunchKernelGGL((nc_fwd_small_kernel<K, 4, SAVE, DM>), grid, dim3(kBlock), 0, st, p, sp)
-  if (save) { if (dm == MMA_DROP_HASH) MMA_FWD_S(true, MMA_DROP_HASH); else MMA_FWD_S(true, MMA_DROP_NONE); }
-  else { if (dm == MMA_DROP_HASH) MMA_FWD_S(false, MMA_DROP_HASH); else MMA_FWD_S(false, MMA_DROP_NONE); }
+  if (save) { if (dm == MMA_DROP_HASH) MMA_FWD_S(true, MMA_DROP_HASH); else if (dm == MMA_DROP_HASH16) MMA_FWD_S(true, MMA_DROP_HASH16); else MMA_FWD_S(true, MMA_DROP_NONE); }
+  else { if (dm == MMA_DROP_HASH) MMA_FWD_S(false, MMA_DROP_HASH); else if (dm == MMA_DROP_HASH16) MMA_FWD_S(false, MMA_DROP_HASH16); else MMA_FWD_S(false, MMA_DROP_NONE); }
 #undef MMA_FWD_S
 }
 template <int K>
 static void launch_bwd_small(const NcBwdParams& p, const NcSmallPlan& sp, dim3 grid, int dm, hipStream_t st) {
   const bool epi = p.T != nullptr;
 #define MMA_BWD_S(DM, EPI) hipLaunchKernelGGL((nc_bwd_small_kernel<K, 4, DM, EPI>), grid, dim3(kBlock), 0, st, p, sp)
-  if (epi) { if (dm == MMA_DROP_HASH) MMA_BWD_S(MMA_DROP_HASH, true); else MMA_BWD_S(MMA_DROP_NONE, true); }
-  else { if (dm == MMA_DROP_HASH) MMA_BWD_S(MMA_DROP_HASH, false); else MMA_BWD_S(MMA_DROP_NONE, false); }
+  if (epi) { if (dm == MMA_DROP_HASH) MMA_BWD_S(MMA_DROP_HASH, true); else if (dm == MMA_DROP_HASH16) MMA_BWD_S(MMA_DROP_HASH16, true); else MMA_BWD_S(MMA_DROP_NONE, true); }
+  else { if (dm == MMA_DROP_HASH) MMA_BWD_S(MMA_DROP_HASH, false); else if (dm == MMA_DROP_HASH16) MMA_BWD_S(MMA_DROP_HASH16, false); else MMA_BWD_S(MMA_DROP_NONE, false); }
 #undef MMA_BWD_S
 }
 // Is the one-launch form possible?  Fills the plan (grid = blocks_a + blocks_b) when it is.  The hub sums are done by ONE wavefront
@@ -1012,7 +1016,7 @@ extern "C" int mma_nc_fused_fwd(
   if (int rc = pack_codes(kind_host, act_host, K, &kinds, &acts)) return rc;
   NcFwdParams p{};
   if (int rc = make_drop(drop_mode, drop_thr, seed, seed_dev, drop_edge_base, keep, E, &p.drop)) return rc;
-  const int dm = (drop_mode == MMA_DROP_HASH && drop_thr == 0) ? MMA_DROP_NONE : drop_mode;
+  const int dm = (drop_mode == MMA_DROP_HASH && drop_thr == 0) ? MMA_DROP_NONE : p.drop.mode;          // HASH or HASH16 by the threshold
   const bool save = T != nullptr;
   if (crow) {
     const int64_t crow_len = fill_sel_slots(kind_host, K, H, &p.sel_slots);
@@ -1154,7 +1158,7 @@ extern "C" int mma_nc_fused_bwd(
   if (int rc = pack_codes(shared ? kind_host : nullptr, act_host, K, &kinds, &acts)) return rc;
   NcBwdParams p{};
   if (int rc = make_drop(drop_mode, drop_thr, seed, seed_dev, drop_edge_base, keep, E, &p.drop)) return rc;
-  const int dm = (drop_mode == MMA_DROP_HASH && drop_thr == 0) ? MMA_DROP_NONE : drop_mode;
+  const int dm = (drop_mode == MMA_DROP_HASH && drop_thr == 0) ? MMA_DROP_NONE : p.drop.mode;          // HASH or HASH16 by the threshold
   const bool v4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldp % 4 == 0) && (ldq % 4 == 0) && (epi || (ldgx % 4 == 0 && aligned16(gxs))) && (ldgq % 4 == 0) &&
                   (shared ? (ldgg % 4 == 0 && aligned16(g) && ldc % 4 == 0 && aligned16(crow)) : (ldg % 4 == 0 && aligned16(gs))) &&
                   (!epi || (ldt % 4 == 0 && aligned16(T) && ldgp % 4 == 0 && aligned16(gP))) &&

@@ -38,14 +38,42 @@ def mask_words(seed, K, E, HQ, edge_ids=None):
     return np.stack(out)
 
 
-def keep_mask(seed, thr, K, E, H, edge_ids=None):
-    """(K,E,H) uint8 in {0,1}: element kept iff its hash byte >= thr.  scale for survivors: 256/(256-thr).
-    edge_ids: the (global) edge positions to generate for (default arange(E))."""
+_MULT2 = [0x9E3779B9, 0xB5297A4D, 0x68E31DA5, 0x1B56C4E9, 0xD6E8FEB9, 0xA3D95FA9, 0x7F4A7C15, 0x94D049BB]    # common.h drop_mask_mult2
+
+
+def low_words(seed, K, E, HQ, edge_ids=None):
+    """(K,E,HQ) uint64: the SECOND word of every (mask, edge, quad) - fold(h * M2_k), every mask (common.h: drop_low_word).  Its bytes
+    are the low halves of the 16-bit values a threshold that is no multiple of 256 is compared with."""
+    h = mask_words(seed, 1, E, HQ, edge_ids)[0]
+    out = []
+    for k in range(K):
+        t = h * np.uint64(_MULT2[k])
+        out.append((t & _M32) ^ (t >> np.uint64(32)))
+    return np.stack(out)
+
+
+def keep_mask16(seed, thr16, K, E, H, edge_ids=None):
+    """(K,E,H) uint8 in {0,1}: element kept iff its 16-bit value (byte of the mask word << 8 | the same byte of the second word) >= thr16:
+    P(drop) = thr16 / 65536, scale for survivors 65536 / (65536 - thr16) (common.h: drop_unpack / drop_unpack16; for thr16 = 256 t the
+    low byte never decides and the kernels compare the high byte with t).  edge_ids: the (global) edge positions (default arange(E))."""
+    assert 0 <= int(thr16) < 65536
     HQ = (H + 3) // 4
     r = mask_words(seed, K, E, HQ, edge_ids)                                              # (K,E,HQ)
+    lo = low_words(seed, K, E, HQ, edge_ids)
     h = np.arange(H)
-    byte = (r[:, :, h >> 2] >> (np.uint64(8) * (h & 3).astype(np.uint64))) & np.uint64(0xFF)
-    return np.ascontiguousarray((byte >= np.uint64(thr)).astype(np.uint8))
+    sh = np.uint64(8) * (h & 3).astype(np.uint64)
+    v = (((r[:, :, h >> 2] >> sh) & np.uint64(0xFF)) << np.uint64(8)) | ((lo[:, :, h >> 2] >> sh) & np.uint64(0xFF))
+    return np.ascontiguousarray((v >= np.uint64(thr16)).astype(np.uint8))
+
+
+def keep_mask(seed, thr, K, E, H, edge_ids=None):
+    """keep_mask16 for a threshold in units of 1/256 (the README's p = 0.5, 0.75): element kept iff its hash byte >= thr."""
+    return keep_mask16(seed, int(thr) * 256, K, E, H, edge_ids)
+
+
+def threshold16(p):
+    """The 16-bit threshold mma_amd.functional.DropoutSpec hands the kernels for probability p (|thr16 / 65536 - p| <= 2^-17)."""
+    return min(65535, max(1, int(round(float(p) * 65536)))) if p > 0 else 0
 
 
 def splitmix64(state):

@@ -58,7 +58,7 @@ def recipe(lib, name, rng, keep):
         hubs = rng.random() < 0.5
         d = dict(ldx=H + pad, ldp=K * H + pad, ldq=K * H + pad, n_items=n_items, n_wave_items=rng.choice([0, n_items // 2, n_items]),
                  n_hubs=5 if hubs else 0, n_slots=40 if hubs else 0, ldms=H + pad, ldt=K * H, N=N, E=E, H=H, K=K, kind_host=codes(kinds),
-                 act_host=codes([rng.randrange(0, 2) for _ in range(K)]), drop_mode=rng.choice([0, 1, 2]), drop_thr=rng.choice([0, 128, 255]),
+                 act_host=codes([rng.randrange(0, 2) for _ in range(K)]), drop_mode=rng.choice([0, 1, 2]), drop_thr=rng.choice([0, 128, 255, 32768, 39322, 65535]),
                  drop_edge_base=rng.choice([0, 0, 1 << 20]), g_kstride=rng.choice([0, 4 * ((N * H + 3) // 4)]), ldgr=H + pad, ldgs=K * H,
                  ldgp=K * H, ldgx=H + pad, ldg=K * H, ldgq=K * H, ldgxo=H + pad)
         lib.mma_nc_crow_floats.restype = ctypes.c_int64
@@ -79,7 +79,7 @@ def recipe(lib, name, rng, keep):
         Nn = min(N, (1 << 31) - (1 << 20) - 1)
         d = dict(lduv=2 * D, ldz=D, by_pos=rng.choice([0, 1]), ldi=D, ldsave=D, ldg=D, ldgu=2 * D, N=Nn, E=E, T=T, F=F, aggr_host=codes(aggs),
                  K=len(aggs), scaler_host=codes(scal), S=len(scal), avg_log=1.2, avg_lin=2.1, drop_mode=rng.choice([0, 1]),
-                 drop_thr=rng.choice([0, 128, 255]))
+                 drop_thr=rng.choice([0, 128, 255, 32768, 39322, 65535]))
         if rng.random() < 0.4:
             d.update(U=None, V=None, Z=None)          # given-messages form
         else:

@@ -109,11 +109,13 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("cfg", CONV_CASES, ids=lambda c: "T%d_F%d_%s" % (c["towers"], c["F"], "".join(a[:2] for a in c["aggregators"])))
-@pytest.mark.parametrize("p", [0.0, 0.5])
+@pytest.mark.parametrize("p", [0.0, 0.5, 0.3])          # 0.3: a 16-bit threshold (round 5; mma_conv.py:67 hard-codes 0.5, `dropout` is public)
 def test_mmaconv_forward_backward_vs_oracle(cfg, p):
     from mma_amd import functional as Fn
     from oracle import gr_oracle as G
-    from oracle.dropout_rng import keep_mask
+    from oracle.dropout_rng import keep_mask16, threshold16
+    thr16 = threshold16(p)
+    p_asked, p = p, thr16 / 65536.0                                   # the oracle divides by 1 - the applied probability
     rng = np.random.default_rng(7)
     conv = make_conv(**cfg)
     T, F = cfg["towers"], cfg["F"]
@@ -124,11 +126,12 @@ def test_mmaconv_forward_backward_vs_oracle(cfg, p):
     ea = rng.standard_normal((E, cfg["edge_dim"])).astype(np.float32) if cfg.get("edge_dim") else None
     cot = rng.standard_normal((N, conv.out_channels)).astype(np.float32)
     seed = 0x5EED5EED12345
-    conv.drop_override = Fn.DropoutSpec(p, seed=seed)
+    conv.drop_override = Fn.DropoutSpec(p_asked, seed=seed)
+    assert conv.drop_override.thr == thr16
     keep = None
     if p > 0:
         Fw = conv.fused_width()      # the kernel's dropout stream is indexed by the 16-byte-aligned column t*Fw + f
-        keep = torch.from_numpy(keep_mask(seed, int(p * 256), 1, E, T * Fw)[0].reshape(E, T, Fw)[:, :, :F].astype(np.float32))
+        keep = torch.from_numpy(keep_mask16(seed, thr16, 1, E, T * Fw)[0].reshape(E, T, Fw)[:, :, :F].astype(np.float32))
     # oracle
     xo = torch.from_numpy(x).requires_grad_(True)
     eo = torch.from_numpy(ea).requires_grad_(True) if ea is not None else None

@@ -111,6 +111,11 @@ CONFIGS = [
     (64, 260, 3, 70, ["sum", "mean", "max", "min", "sum2", "mean2", "max2", "min2"], "new_sigmoid", 0.5, 16),  # K=8, H>256
     (200, 32, 5, 100, ["sum", "mean", "max", "min", "sum2"], "sigmoid", 0.5, 48),   # K=5 -> slices 4+1
     (150, 20, 4, 0, ["sum", "mean", "max", "min", "softmin", "mean4", "max4"], "new_sigmoid", 0.0, 512),  # K=7
+    # round 5: probabilities that are no multiple of 1/256 (16-bit thresholds, kernels' HASH16 form): vector + hub, scalar path, K=8, slices 4+1
+    (300, 128, 6, 700, ["sum", "mean", "max", "min"], "new_sigmoid", 0.6, 256),
+    (120, 75, 5, 90, ["sum3", "max2", "softmax"], "sigmoid", 0.3, 32),
+    (64, 260, 3, 70, ["sum", "mean", "max", "min", "sum2", "mean2", "max2", "min2"], "new_sigmoid", 0.1, 16),
+    (200, 32, 5, 100, ["sum", "mean", "max", "min", "sum2"], "sigmoid", 0.9373, 48),
 ]
 
 
@@ -119,8 +124,10 @@ def test_random_graph_vs_oracle(cfg):
     import mma_amd
     from mma_amd import functional as Fn
     from oracle import nc_oracle as O
-    from oracle.dropout_rng import keep_mask
-    N, H, avg_deg, hub, names, act, p, chunk = cfg
+    from oracle.dropout_rng import keep_mask16, threshold16
+    N, H, avg_deg, hub, names, act, p_asked, chunk = cfg
+    thr = threshold16(p_asked)
+    p = thr / 65536.0                      # the probability the kernels apply (|p - p_asked| <= 2^-17); the oracle divides by 1 - p
     rng = np.random.default_rng(1234 + N + H)
     rowptr, col = random_graph(rng, N, avg_deg, hub)
     E = int(rowptr[-1])
@@ -128,10 +135,10 @@ def test_random_graph_vs_oracle(cfg):
     x = torch.from_numpy(np.maximum(rng.standard_normal((N, H)), 0).astype(np.float32))
     Ws = {n: torch.from_numpy(((rng.random((2 * H, H)) * 2 - 1) / np.sqrt(H)).astype(np.float32)) for n in names}
     cot = torch.from_numpy(rng.standard_normal((K, N, H)).astype(np.float32))
-    seed, thr = 0x1234567890ABCDEF, int(round(p * 256))
+    seed = 0x1234567890ABCDEF
 
     # oracle (CPU), fed the keep mask the kernel's RNG produces
-    keep = keep_mask(seed, thr, K, E, H) if p > 0 else None
+    keep = keep_mask16(seed, thr, K, E, H) if p > 0 else None
 
     def oracle(dtype):
         xo = x.to(dtype).requires_grad_(True)
@@ -152,7 +159,9 @@ def test_random_graph_vs_oracle(cfg):
     acts = [Fn.ACT_RAW if O.uses_raw_logits(n, act) else Fn.ACT_SIGMOID for n in names]
     P = xg @ torch.cat([Wg[n][:H] for n in names], 1)
     Q = xg @ torch.cat([Wg[n][H:] for n in names], 1)
-    mg = Fn.nc_fused_aggregate(xg, P, Q, graph, kinds, acts, Fn.DropoutSpec(p, seed=seed))
+    spec = Fn.DropoutSpec(p_asked, seed=seed)
+    assert spec.thr == thr and abs(spec.p_applied - p_asked) <= 8e-6
+    mg = Fn.nc_fused_aggregate(xg, P, Q, graph, kinds, acts, spec)
     gg = torch.autograd.grad((mg * cot.to(DEV)).sum(), [xg] + [Wg[n] for n in names])
 
     rows = np.arange(N)
@@ -166,7 +175,7 @@ def test_random_graph_vs_oracle(cfg):
     if p > 0:
         with torch.no_grad():
             me = Fn.nc_fused_aggregate(xg.detach(), P.detach(), Q.detach(), graph, kinds, acts,
-                                       Fn.DropoutSpec(thr / 256.0, keep=torch.from_numpy(keep).to(DEV)))
+                                       Fn.DropoutSpec(p, keep=torch.from_numpy(keep).to(DEV)))
         assert torch.equal(me, mg.detach()), "hash-mode and explicit-mode dropout disagree"
     # determinism: no atomics anywhere, a second run is bitwise identical
     with torch.no_grad():
