@@ -253,6 +253,47 @@ class HaloPlan:
         self.send_offsets = np.concatenate([[0], np.cumsum(self.send_counts)]).astype(np.int64)
         self.build_unpack()
 
+    @classmethod
+    def from_full_graph(cls, rowptr, col, rank, world, bounds=None):
+        """The plan of `rank` of `world` WITHOUT the index exchange, for a caller that holds the whole CSR (tools/shard_sim.py and
+        tests/test_c5_rank_gpu.py rehearse one rank of eight on one GPU): what the peers would ask for is read off their rows of the
+        full graph.  Same fields as the collective constructor (host numpy form).  Returns (plan, e0 = global position of the shard's
+        first edge: the dropout hash is keyed by global edge ids)."""
+        rowptr = np.asarray(rowptr, dtype=np.int64)
+        bounds = partition_bounds(rowptr, world) if bounds is None else np.asarray(bounds, dtype=np.int64)
+        p = object.__new__(cls)
+        p.rank, p.world, p.group = rank, world, None
+        p.plan_device = p.rowptr_dev = p.col_dev = None
+        p.lo, p.hi = int(bounds[rank]), int(bounds[rank + 1])
+        p.n_own = p.hi - p.lo
+        e0, e1 = int(rowptr[p.lo]), int(rowptr[p.hi])
+        cg = np.asarray(col[e0:e1], dtype=np.int64)
+        own = (cg >= p.lo) & (cg < p.hi)
+        p.halo_ids = np.unique(cg[~own])
+        p.n_halo = len(p.halo_ids)
+        p.n_src = p.n_own + p.n_halo
+        owner = np.searchsorted(bounds, p.halo_ids, side="right") - 1
+        p.recv_counts = np.bincount(owner, minlength=world).astype(np.int64)
+        cl = np.where(own, cg - p.lo, 0)
+        cl[~own] = p.n_own + np.searchsorted(p.halo_ids, cg[~own])
+        p.rowptr, p.col = rowptr[p.lo:p.hi + 1] - e0, cl
+        sc, give = [], []
+        for q in range(world):                                   # the rows of this rank every peer reads
+            if q == rank:
+                sc.append(0)
+                continue
+            lo, hi = int(bounds[q]), int(bounds[q + 1])
+            cq = np.asarray(col[int(rowptr[lo]):int(rowptr[hi])], dtype=np.int64)
+            need = np.unique(cq[(cq >= p.lo) & (cq < p.hi)])
+            sc.append(len(need))
+            give.append(need)
+        p.send_counts = np.array(sc, dtype=np.int64)
+        p.send_idx = (np.concatenate(give) - p.lo).astype(np.int64) if give else np.zeros(0, np.int64)
+        p.send_offsets = np.concatenate([[0], np.cumsum(p.send_counts)]).astype(np.int64)
+        p.n_total = int(bounds[-1])
+        p.build_unpack()
+        return p, e0
+
     def build_unpack(self):
         """The reverse exchange in ONE launch: every local row that is sent to anyone, with the positions of its copies in the
         concatenated receive buffer (ascending = by peer rank: a fixed summation order) - mma_unpack_add_rows_csr."""

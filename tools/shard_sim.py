@@ -55,32 +55,7 @@ def fake_rows(send, send_counts, recv_counts, group=None):
 S.all_to_all_rows_start = fake_start; S.all_to_all_rows = fake_rows
 
 def make_plan(rank, world):
-    bounds = S.partition_bounds(rowptr, world)
-    p = object.__new__(S.HaloPlan)
-    p.rank, p.world, p.group = rank, world, None
-    p.lo, p.hi = int(bounds[rank]), int(bounds[rank + 1]); p.n_own = p.hi - p.lo
-    e0, e1 = int(rowptr[p.lo]), int(rowptr[p.hi])
-    cg = np.asarray(col[e0:e1], dtype=np.int64)
-    own = (cg >= p.lo) & (cg < p.hi)
-    p.halo_ids = np.unique(cg[~own]); p.n_halo = len(p.halo_ids); p.n_src = p.n_own + p.n_halo
-    owner = np.searchsorted(bounds, p.halo_ids, side="right") - 1
-    p.recv_counts = np.bincount(owner, minlength=world).astype(np.int64)
-    cl = np.where(own, cg - p.lo, 0); cl[~own] = p.n_own + np.searchsorted(p.halo_ids, cg[~own])
-    p.rowptr, p.col = np.asarray(rowptr[p.lo:p.hi + 1], dtype=np.int64) - e0, cl
-    # rows of this rank the others need
-    sc, give = [], []
-    for q in range(world):
-        if q == rank: sc.append(0); continue
-        lo, hi = int(bounds[q]), int(bounds[q + 1])
-        cq = np.asarray(col[int(rowptr[lo]):int(rowptr[hi])], dtype=np.int64)
-        need = np.unique(cq[(cq >= p.lo) & (cq < p.hi)])
-        sc.append(len(need)); give.append(need)
-    p.send_counts = np.array(sc, dtype=np.int64)
-    p.send_idx = (np.concatenate(give) - p.lo).astype(np.int64) if give else np.zeros(0, np.int64)
-    p.send_offsets = np.concatenate([[0], np.cumsum(p.send_counts)]).astype(np.int64)
-    p.n_total = N
-    p.build_unpack()
-    return p, e0
+    return S.HaloPlan.from_full_graph(rowptr, col, rank, world)
 
 def run(rank, world, steps=5):
     t0 = time.perf_counter()

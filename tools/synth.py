@@ -52,6 +52,20 @@ def feature_rows(lo, hi, width, seed, relu=True):
     return np.maximum(out, 0) if relu else out
 
 
+def feature_rows_by_id(ids, width, seed, relu=True):
+    """The rows `ids` (ascending) of the same synthetic matrix as feature_rows(): what a rank RECEIVES for its halo rows."""
+    ids = np.asarray(ids, dtype=np.int64)
+    out = np.empty((len(ids), width), dtype=np.float32)
+    blk = ids // _BLOCK
+    starts = np.flatnonzero(np.r_[True, blk[1:] != blk[:-1]]) if len(ids) else np.zeros(0, np.int64)
+    ends = np.r_[starts[1:], len(ids)]
+    for s, e in zip(starts, ends):
+        b = int(blk[s])
+        rows = np.random.default_rng([seed, b]).standard_normal((_BLOCK, width), dtype=np.float32)
+        out[s:e] = rows[ids[s:e] - b * _BLOCK]
+    return np.maximum(out, 0) if relu else out
+
+
 def molecule_batch(rng, n_graphs=12, return_sizes=False):
     """ZINC-like: trees of ~23 nodes + ring closures, max degree 4, symmetrised."""
     src, dst, off, sizes = [], [], 0, []
