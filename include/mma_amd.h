@@ -163,6 +163,13 @@ int mma_csr_spmm(
     const float* B, int64_t ldb, int64_t rows_per_block, int32_t K,
     const float* bias, float* out, int64_t ldo,
     int64_t n_rows, int32_t C, void* stream);
+/* the same, and row_max[i] = max(row_max[i], max_c |out[i,c]|) (ABI 34; row_max (n_rows,) zeroed or pre-filled by the caller; the bits of
+ * a non-negative float merged by atomicMax): the dV segment sum of graph regression's backward leaves the row scales of the GEMMs behind it */
+int mma_csr_spmm_rm(
+    const int32_t* rowptr, const int32_t* col, const float* val,
+    const float* B, int64_t ldb, int64_t rows_per_block, int32_t K,
+    const float* bias, float* out, int64_t ldo,
+    int64_t n_rows, int32_t C, float* row_max, void* stream);
 
 /* K5, item-driven form for K = 1 (the form MMA.forward and GraphConvolution use): rows cut into work items
  * {row, ebeg, eend, slot} (longest first) with hub partials, exactly as in mma_nc_fused_fwd; partial is (n_slots, C). */
@@ -491,13 +498,17 @@ int mma_gr_fused_fwd(
  * min/max route the gradient to the saved arg edge only (torch_scatter), mean divides by the count, var/std use the
  * saved mean/var; in fused-message mode the dropout factor of the edge is applied, so gmsg = dL/d(U[i]+V[j]+Z[r]).
  * gU (may be NULL): (N, ldgu >= T*F) receives dL/dU[i] = the sum of gmsg over target i's segment (a zero row for an empty
- * target) from the same pass - the kernel walks exactly those segments, so the separate segment sum is not needed. */
+ * target) from the same pass - the kernel walks exactly those segments, so the separate segment sum is not needed.
+ * gmsg_row_max (E,) / gu_row_max (N,) (ABI 34; both or neither, gu_row_max needs gU; the CALLER ZEROES them): every gmsg row r and
+ * every gU row n merge max |row| into its entry (the bits of a non-negative float, by atomicMax - mma_csr_spmm_rm merges the dV rows
+ * into the same (N,) array): the row scales of the three-product GEMMs that take these gradients (mma_gemm_f16x2_tn / _nlp). */
 int mma_gr_fused_bwd(
     const int32_t* rowptr, const int32_t* src, const int32_t* perm,
     const float* U, const float* V, int64_t lduv, const float* Z, int64_t ldz, int32_t by_pos, const uint8_t* z_index,
     const float* inputs, int64_t ldi,
     const float* gout, const uint8_t* amin8, const uint8_t* amax8, const int32_t* amin_side, const int32_t* amax_side,
     const float* mean, const float* var, int64_t ldsave, const int32_t* long_nodes, float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
+    float* gmsg_row_max, float* gu_row_max,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream);
 

@@ -30,6 +30,9 @@ struct GrParams {
   float* mean; float* var; int64_t ldsave;                                      // (N,ldsave>=D)
   float* gmsg; int64_t ldg;                                                      // backward: (E,D) message gradients
   float* gU; int64_t ldgu;                                                       // backward, optional: (N,D) sum of gmsg over each target's segment
+  // backward, optional (round 5): max |gmsg[r,:]| per message-gradient row and max |gU[n,:]| per node, as the bit patterns of non-negative
+  // floats merged by atomicMax into ZEROED arrays - the row scales of the three-product weight-gradient / dL/dx GEMMs behind K4
+  uint32_t* gmsg_rmax; uint32_t* gu_rmax;
   int N, D, T, F, K, S, lpr_log;
   int by_pos;                                        // 1: Z and gmsg rows are indexed by the target-sorted POSITION p, 0: by perm[p]
   int wave_min_deg;                                  // wave-per-node pass: skip segments shorter than this
@@ -497,6 +500,12 @@ __device__ __forceinline__ Vec<VEC> gr_bwd_edge(const GrParams& p, const DropPar
     g.v[i] = gi * fd[i];
   }
   stv<VEC>(p.gmsg + (size_t)(p.by_pos ? pos : e) * p.ldg + l.cc, g);
+  if (p.gmsg_rmax) {                                          // wave-uniform; the generic kernels merge per lane (the block kernel reduces in LDS first)
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) m = fmaxf(m, fabsf(g.v[i]));
+    if (m > 0.f) atomicMax(p.gmsg_rmax + (p.by_pos ? pos : e), __float_as_uint(m));
+  }
   return g;
 }
 
@@ -533,7 +542,15 @@ __device__ __forceinline__ void gr_node_bwd(const GrParams& p, const DropParams&
 #pragma unroll
       for (int i = 0; i < VEC; ++i) su.v[i] += __shfl_xor(su.v[i], off, kWave);
     }
-    if (l.sub == 0 && l.valid) stv<VEC>(p.gU + (size_t)node * p.ldgu + l.c, su);
+    if (l.sub == 0 && l.valid) {
+      stv<VEC>(p.gU + (size_t)node * p.ldgu + l.c, su);
+      if (p.gu_rmax) {
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) m = fmaxf(m, fabsf(su.v[i]));
+        if (m > 0.f) atomicMax(p.gu_rmax + node, __float_as_uint(m));
+      }
+    }
   }
 }
 
@@ -608,7 +625,15 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_flat_kernel(const GrParams p) {
           for (int cidx = 0; cidx < VEC; ++cidx) su.v[cidx] += g.v[cidx];
         }
       }
-      if (p.gU) stv<VEC>(p.gU + (size_t)node * p.ldgu + l.c, su);
+      if (p.gU) {
+        stv<VEC>(p.gU + (size_t)node * p.ldgu + l.c, su);
+        if (p.gu_rmax) {
+          float m = 0.f;
+#pragma unroll
+          for (int cidx = 0; cidx < VEC; ++cidx) m = fmaxf(m, fabsf(su.v[cidx]));
+          if (m > 0.f) atomicMax(p.gu_rmax + node, __float_as_uint(m));
+        }
+      }
     }
   }
 }
@@ -865,6 +890,15 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
   constexpr int I_ALL = 0, I_MIN = (NEEDS & NEED_SUM) ? 1 : 0, I_MAX = I_MIN + ((NEEDS & NEED_MIN) ? 1 : 0);
   const int items = n_here * (int)p.qd;
   const int KS = p.K * p.S;                                   // <= kBlkMaxKS on this path
+  // row maxima (optional): a row's 4-column items sit in different lanes and waves - merged in LDS (edges of a staged block, the
+  // block's nodes), then ONE global merge per row; blocks whose edges do not fit the staging area merge per item in global memory
+  __shared__ uint32_t rmax_e[kBlkCap];
+  __shared__ uint32_t rmax_n[32];
+  const bool want_rmax = p.gmsg_rmax != nullptr;              // both arrays or neither (host check)
+  if (want_rmax) {
+    for (int i = tid; i < kBlkCap; i += kBlock) rmax_e[i] = 0u;
+    if (tid < 32) rmax_n[tid] = 0u;
+  }
 
   for (int it = tid; it < items; it += kBlock) {
     const int dn = (int)udiv((uint32_t)it, p.qd_magic);
@@ -944,9 +978,30 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
           su.v[i] += g.v[i];
         }
         stv_nt<4>(p.gmsg + (size_t)(p.by_pos ? pos : ee) * p.ldg + c, g);
+        if (want_rmax) {
+          const float m = fmaxf(fmaxf(fabsf(g.v[0]), fabsf(g.v[1])), fmaxf(fabsf(g.v[2]), fabsf(g.v[3])));
+          if (m > 0.f) {
+            if (staged) atomicMax(&rmax_e[pos - p0], __float_as_uint(m));
+            else atomicMax(p.gmsg_rmax + (p.by_pos ? pos : ee), __float_as_uint(m));
+          }
+        }
       }
     }
-    if (p.gU) stv<4>(p.gU + (size_t)node * p.ldgu + c, su);
+    if (p.gU) {
+      stv<4>(p.gU + (size_t)node * p.ldgu + c, su);
+      if (want_rmax) {
+        const float m = fmaxf(fmaxf(fabsf(su.v[0]), fabsf(su.v[1])), fmaxf(fabsf(su.v[2]), fabsf(su.v[3])));
+        if (m > 0.f) atomicMax(&rmax_n[dn], __float_as_uint(m));
+      }
+    }
+  }
+  if (want_rmax) {
+    __syncthreads();
+    if (staged) {             // every position of the block belongs to this workgroup alone, but a long segment's rows are the list pass's: merge, not store
+      for (int i = tid; i < p1 - p0; i += kBlock)
+        if (rmax_e[i]) atomicMax(p.gmsg_rmax + (p.by_pos ? p0 + i : L.perm[i]), rmax_e[i]);
+    }
+    if (tid < n_here && rmax_n[tid]) atomicMax(p.gu_rmax + n0 + tid, rmax_n[tid]);
   }
 }
 
@@ -1261,6 +1316,7 @@ extern "C" int mma_gr_fused_bwd(
     const float* inputs, int64_t ldi,
     const float* gout, const uint8_t* amin8, const uint8_t* amax8, const int32_t* amin_side, const int32_t* amax_side,
     const float* mean, const float* var, int64_t ldsave, const int32_t* long_nodes, float* gmsg, int64_t ldg, float* gU, int64_t ldgu,
+    float* gmsg_row_max, float* gu_row_max,
     int64_t N, int64_t E, int32_t T, int32_t F, const uint8_t* aggr_host, int32_t K, const uint8_t* scaler_host, int32_t S,
     float avg_log, float avg_lin, int32_t drop_mode, uint32_t drop_thr, uint64_t seed, const uint64_t* seed_dev, void* stream) {
   MMA_REQUIRE(N >= 0 && E >= 0 && N < (1LL << 31) - (1 << 20) && E < (1LL << 31) && T >= 1 && F >= 1 && (int64_t)T * F < (1 << 24),
@@ -1269,9 +1325,11 @@ extern "C" int mma_gr_fused_bwd(
   if (int rc = fill_codes(aggr_host, K, scaler_host, S, &p)) return rc;
   p.long_nodes = long_nodes;
   p.long_cap = (int)min((int64_t)0x7fffffff, E / (kGroupMaxDeg + 1) + 1);
+  MMA_REQUIRE((gmsg_row_max == nullptr) == (gu_row_max == nullptr) && (!gu_row_max || gU), "the row maxima come as a pair, with gU");
   if (N == 0 || E == 0) return 0;
   const int D = T * F;
   MMA_REQUIRE(rowptr && src && perm && gout && gmsg && ldg >= D, "NULL argument or pitch too small");
+  p.gmsg_rmax = reinterpret_cast<uint32_t*>(gmsg_row_max); p.gu_rmax = reinterpret_cast<uint32_t*>(gu_row_max);
   bool need_min = false, need_max = false, need_stats = false;
   for (int k = 0; k < K; ++k) {
     need_min |= p.aggr[k] == GR_MIN; need_max |= p.aggr[k] == GR_MAX; need_stats |= p.aggr[k] >= GR_VAR;

@@ -9,6 +9,7 @@ struct SpmmParams {
   const int32_t* rowptr; const int32_t* col; const float* val;
   const float* B; int64_t ldb; int64_t rpb; int K;
   const float* bias; float* out; int64_t ldo; int64_t n_rows; int C; int lpr_log;
+  uint32_t* rowmax;       // optional (n_rows,): max |out[row,:]| merged into a caller-zeroed array (bits of a non-negative float, atomicMax)
 };
 
 // One wave per output row; LPR lanes span the C columns, 64/LPR edges are gathered per step.
@@ -53,6 +54,15 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const SpmmParams p) {
         for (int i = 0; i < VEC; ++i) acc.v[i] += b.v[i];
       }
       stv<VEC>(p.out + (size_t)row * p.ldo + c, acc);
+    }
+    if (p.rowmax) {                                           // wave-uniform
+      float m = 0.f;
+      if (sub == 0 && fvalid) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) m = fmaxf(m, fabsf(acc.v[i]));
+      }
+      for (int off = kWave / 2; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+      if (lane == 0 && m > 0.f) atomicMax(p.rowmax + row, __float_as_uint(m));      // one merge per row and column chunk
     }
   }
 }
@@ -323,9 +333,9 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) 
 
 using namespace mma;
 
-extern "C" int mma_csr_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, int64_t ldb,
-                            int64_t rows_per_block, int32_t K, const float* bias, float* out, int64_t ldo,
-                            int64_t n_rows, int32_t C, void* stream) {
+static int csr_spmm_impl(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, int64_t ldb,
+                         int64_t rows_per_block, int32_t K, const float* bias, float* out, int64_t ldo,
+                         int64_t n_rows, int32_t C, float* row_max, void* stream) {
   MMA_REQUIRE(n_rows >= 0 && n_rows < (1LL << 31) && C >= 1 && K >= 1, "n_rows=%lld C=%d K=%d unsupported", (long long)n_rows, C, K);
   MMA_REQUIRE(ldb >= C && ldo >= C && rows_per_block >= 0, "row pitch too small");
   if (n_rows == 0) return 0;
@@ -333,7 +343,7 @@ extern "C" int mma_csr_spmm(const int32_t* rowptr, const int32_t* col, const flo
   const bool v4 = (C % 4 == 0) && (ldb % 4 == 0) && (ldo % 4 == 0) && al16(B) && al16(out) && (!bias || al16(bias));
   const int vec = v4 ? 4 : 1;
   const int per_row = (C + vec - 1) / vec;
-  SpmmParams p{rowptr, col, val, B, ldb, rows_per_block, K, bias, out, ldo, n_rows, C, 0};
+  SpmmParams p{rowptr, col, val, B, ldb, rows_per_block, K, bias, out, ldo, n_rows, C, 0, reinterpret_cast<uint32_t*>(row_max)};
   p.lpr_log = min(ilog2_ceil(per_row), 6);
   const int chunks = (per_row + (1 << p.lpr_log) - 1) >> p.lpr_log;
   int64_t blocks = (n_rows + 3) / 4;
@@ -343,6 +353,17 @@ extern "C" int mma_csr_spmm(const int32_t* rowptr, const int32_t* col, const flo
   if (v4) hipLaunchKernelGGL((spmm_kernel<4>), grid, dim3(kBlock), 0, st, p);
   else hipLaunchKernelGGL((spmm_kernel<1>), grid, dim3(kBlock), 0, st, p);
   return check_launch("spmm_kernel");
+}
+
+extern "C" int mma_csr_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, int64_t ldb,
+                            int64_t rows_per_block, int32_t K, const float* bias, float* out, int64_t ldo,
+                            int64_t n_rows, int32_t C, void* stream) {
+  return csr_spmm_impl(rowptr, col, val, B, ldb, rows_per_block, K, bias, out, ldo, n_rows, C, nullptr, stream);
+}
+extern "C" int mma_csr_spmm_rm(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, int64_t ldb,
+                               int64_t rows_per_block, int32_t K, const float* bias, float* out, int64_t ldo,
+                               int64_t n_rows, int32_t C, float* row_max, void* stream) {
+  return csr_spmm_impl(rowptr, col, val, B, ldb, rows_per_block, K, bias, out, ldo, n_rows, C, row_max, stream);
 }
 
 extern "C" int mma_csr_spmm_items(const int32_t* col, const float* val, const float* B, int64_t ldb, const float* bias, float* out,

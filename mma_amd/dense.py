@@ -456,6 +456,7 @@ def linear(x, weight, bias=None):
 X3_LINEAR = True
 FUSED_PAD = __import__("os").environ.get("MMA_PAD_ONES", "1") != "0"        # 0: torch's pad + a strided fill (round 3)
 X3_LINEAR_MIN_ROWS = 32768
+X3_ROW_MAX = __import__("os").environ.get("MMA_X3_ROW_MAX", "1") != "0"     # 0: round 4's six-product backward of the tall Linears (A/B)
 _PADDED = {}          # data_ptr -> weakref to a (rows, pitch) fp32 buffer whose columns beyond the payload are ZERO
 
 
@@ -463,13 +464,15 @@ def _round_up(v, m):
     return -(-v // m) * m
 
 
-def padded_empty(rows, cols, device, multiple=128):
+def padded_empty(rows, cols, device, multiple=128, row_max=None):
     """The (rows, cols) leading-columns view of a new (rows, round_up(cols, multiple)) fp32 buffer whose pad columns are zero
     and which is REGISTERED: a consumer (linear_x3's backward) can take the whole buffer as a GEMM operand without a copy.
-    Producers that fill such a view must leave the pad columns alone."""
+    Producers that fill such a view must leave the pad columns alone.  row_max (rows,), optional: the producer will leave
+    max |row| there (K4 / the dV segment sum, round 5) - it travels with the buffer, and the consumer's GEMMs take the three-product form."""
     import weakref
     pitch = _round_up(cols, multiple)
     buf = torch.empty((rows, pitch), device=device, dtype=torch.float32)
+    buf._mma_row_max = row_max
     if pitch > cols:
         buf[:, cols:].zero_()
     for k in [k for k, r in _PADDED.items() if r() is None]:
@@ -514,7 +517,9 @@ class _LinearX3(torch.autograd.Function):
             if bias is not None:
                 wt[fin, :fout] = bias
             wpad = None
-        y = gemm_bf16x3(xp, wt)                                      # (N, OP); columns beyond fout are exact zeros
+        box = []
+        y = gemm_bf16x3(xp, wt, row_max_box=box)                     # (N, OP); columns beyond fout are exact zeros
+        ctx.x_rm = box[0] if box else None                           # max |[x | 1]| per row, formed by the three-product forward for its own scales
         if wpad is not None:
             ctx.save_for_backward(xp, weight, wpad)
         else:
@@ -531,12 +536,19 @@ class _LinearX3(torch.autograd.Function):
         if gp is None:
             gp = torch.nn.functional.pad(g, (0, OP - fout))
         gx = gw = gb = None
+        # [r5] the producer of g (K4 + the dV segment sum) left max |g row| with its padded buffer: both products take the THREE-product
+        # fp16 x 2 kernels (round 4: six bf16 products, because nobody knew the row maxima - 15 % of the C2L step)
+        g_rm = getattr(gp, "_mma_row_max", None) if (USE_F16X2 and USE_F16X2_TN and X3_ROW_MAX) else None
+        three = g_rm is not None and xp.shape[0] >= _MIN_ROWS_F16X2_TN
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             KA = _round_up(fin + 1, 32)
-            gwb = gemm_bf16x3_tn(xp[:, :KA], gp)                     # (KA, OP) = [x | 1]^T g
+            gwb = gemm_f16x2_tn(xp[:, :KA], gp, ctx.x_rm, g_rm) if three else gemm_bf16x3_tn(xp[:, :KA], gp)   # (KA, OP) = [x | 1]^T g
             gw = gwb[:fin, :fout].t().contiguous()
             gb = gwb[fin, :fout].contiguous() if has_bias else None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and three and wpad is not None and f16x2_n128_ok(gp.shape[0], OP, 128) and OP % 128 == 0 and OP >= 256:
+            # dL/dx = g [W | b | 0]: one pass over g on the one-accumulator kernel; column `fin` (the bias column) is dropped by the slice
+            gx = gemm_f16x2_n128(gp, g_rm, wpad, torch.empty((gp.shape[0], 128), device=gp.device, dtype=torch.float32))[:, :fin]
+        elif ctx.needs_input_grad[0]:
             NP = _round_up(fin, 32)
             if wpad is not None:
                 wp = wpad[:, :NP]           # column fin (the bias) lands in a pad column of gx that the slice below drops

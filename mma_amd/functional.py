@@ -446,6 +446,14 @@ class GRGraph:
             self.__dict__["_type_onehot"] = hit
         return hit[1]
 
+    def type_onehot_row_max(self, z_index):
+        """(E,) ones: max |row| of the one-hot operand (cached with the graph) - the x_row_max of its three-product TN form."""
+        hit = self.__dict__.get("_type_onehot_rm")
+        if hit is None or hit.device != z_index.device:
+            hit = torch.ones((self.E,), device=z_index.device, dtype=torch.float32)
+            self.__dict__["_type_onehot_rm"] = hit
+        return hit
+
     @property
     def by_source_pos(self):
         """(E,) int32: the by-source grouping expressed in target-sorted POSITIONS (rows of a by_pos message-gradient buffer)."""
@@ -559,8 +567,12 @@ class _GRAggregate(torch.autograd.Function):
         gout = gout.contiguous()
         from . import dense
         tall = dense.X3_LINEAR and fused
-        # the gradients of [U|V] and Z feed tall GEMMs: as views of zero-padded, registered buffers dense.linear_tall takes them as they are
-        gmsg = (dense.padded_empty(E, D, gout.device) if tall and has_z and E >= dense.X3_LINEAR_MIN_ROWS
+        # the gradients of [U|V] and Z feed tall GEMMs: as views of zero-padded, registered buffers dense.linear_tall takes them as they are -
+        # [r5] with their row maxima (K4 and the dV segment sum merge max |row| into one zeroed (E + N,) array): the GEMMs behind take three
+        # products instead of six
+        pad_m, pad_u = tall and has_z and E >= dense.X3_LINEAR_MIN_ROWS, tall and fused and N >= dense.X3_LINEAR_MIN_ROWS
+        rm = torch.zeros((E + N,), device=gout.device, dtype=torch.float32) if (pad_m or pad_u) and dense.X3_ROW_MAX and E > 0 else None
+        gmsg = (dense.padded_empty(E, D, gout.device, row_max=rm[:E] if rm is not None else None) if pad_m
                 else torch.empty((E, D), device=gout.device, dtype=torch.float32))
         if E == 0:
             if not fused:
@@ -572,25 +584,31 @@ class _GRAggregate(torch.autograd.Function):
         # edges leaving j: one segment sum (K5 kernel) over the by-source grouping.  Both land in the halves of one (N, 2D) buffer.
         gUV = None
         if fused:
-            gUV = (dense.padded_empty(N, 2 * D, gout.device) if tall and N >= dense.X3_LINEAR_MIN_ROWS
+            gUV = (dense.padded_empty(N, 2 * D, gout.device, row_max=rm[E:] if rm is not None else None) if pad_u
                    else torch.empty((N, 2 * D), device=gout.device, dtype=torch.float32))
         with _span("gr_fused_bwd"):
             _gr_call("mma_gr_fused_bwd", csr, U, V, Z, by_pos, inputs,
                      (ptr(gout), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), ptr(mean), ptr(var), D, ptr(csr.long_nodes), ptr(gmsg),
-                      gmsg.stride(0), ptr(gUV), gUV.stride(0) if fused else 0),
+                      gmsg.stride(0), ptr(gUV), gUV.stride(0) if fused else 0, ptr(rm[:E]) if rm is not None else None,
+                      ptr(rm[E:]) if rm is not None else None),
                      N, E, T, F, aggr, scalers, avg_log, avg_lin, drop, z_index)
         if not fused:
             return (gmsg.view(E, T, F),) + (None,) * 12
         cs = graph.by_source
         rows = graph.by_source_pos if by_pos else cs.perm      # gmsg rows: positions (by_pos) or original edge ids
         with _span("gr_segsum", nbytes=E * (4 + 4 * D) + N * (4 + 4 * D), flops=E * D):
-            call("mma_csr_spmm", ptr(cs.rowptr), ptr(rows), None, ptr(gmsg), gmsg.stride(0), E, 1, None, ptr(gUV[:, D:]), gUV.stride(0), N, D,
-                 stream_ptr())
+            if rm is not None:          # the dV rows' maxima join dU's: one bound for the whole [dU | dV] row
+                call("mma_csr_spmm_rm", ptr(cs.rowptr), ptr(rows), None, ptr(gmsg), gmsg.stride(0), E, 1, None, ptr(gUV[:, D:]), gUV.stride(0), N, D,
+                     ptr(rm[E:]), stream_ptr())
+            else:
+                call("mma_csr_spmm", ptr(cs.rowptr), ptr(rows), None, ptr(gmsg), gmsg.stride(0), E, 1, None, ptr(gUV[:, D:]), gUV.stride(0), N, D,
+                     stream_ptr())
         gz = gmsg if has_z else None
         if has_z and z_index is not None:
             # dL/dZ_table = onehot(z_index)^T gmsg: a fixed-order reduction (index_add_ would use atomics), one row per edge type
             gp = dense._padded_parent(gmsg, dense._round_up(D, 128))          # the zero-padded buffer itself: bf16x3 TN kernel, no copy
-            gz = dense.xt_g(graph.type_onehot(z_index, Z.shape[0]), gp if gp is not None else gmsg)[:Z.shape[0], :D]
+            gz = dense.xt_g(graph.type_onehot(z_index, Z.shape[0]), gp if gp is not None else gmsg, graph.type_onehot_row_max(z_index),
+                            rm[:E] if (rm is not None and gp is not None) else None)[:Z.shape[0], :D]
         return (None, gUV, gz) + (None,) * 10
 
 
