@@ -196,6 +196,17 @@ __host__ inline void drop_set_threshold(DropParams* d, int mode, uint32_t thr16)
   else { d->mode = mode; d->thr = mode == MMA_DROP_HASH ? (thr16 >> 8) : thr16; }
 }
 
+// max over the ACTIVE lanes of a wavefront of a non-negative value (inactive lanes read as 0: bound_ctrl), in every active lane:
+// four DPP steps inside the 16-lane row, one swizzle across the two rows of a half, one bpermute across the halves
+__device__ __forceinline__ float wave_max_nonneg(float m) {
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xF, 0xF, true)));
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x4E, 0xF, 0xF, true)));
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x141, 0xF, 0xF, true)));
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x140, 0xF, 0xF, true)));
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(m), 0x401F)));
+  return fmaxf(m, __shfl_xor(m, 32, 64));
+}
+
 __host__ inline int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 }  // namespace mma

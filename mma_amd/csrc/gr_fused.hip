@@ -954,6 +954,11 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
     const int c = (it - dn * (int)p.qd) * 4;
     const int node = n0 + dn;
     const int b = L.rowptr[dn], deg = L.rowptr[dn + 1] - b;
+    // row maxima: when all active lanes of the wavefront work on ONE node (a row is 95 items at ZINC's shape: most wavefronts), the edge
+    // loop below is wave-uniform and the row's maximum is formed across the lanes first - one LDS merge per wavefront and row instead of
+    // one per lane (64 lanes merging into the same word serialise: +0.04 ms of K4 at C2L)
+    const bool uni = want_rmax && __all(dn == __builtin_amdgcn_readfirstlane(dn));
+    const bool elect = (int)(threadIdx.x & (kWave - 1)) == __builtin_amdgcn_readfirstlane((int)(threadIdx.x & (kWave - 1)));
     if (deg > kGroupMaxDeg) continue;
     Vec<4> su = vzero<4>();                                   // dL/dU[node]: the sum of the segment's message gradients, in position order
     if (deg > 0) {
@@ -979,8 +984,9 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
         }
         stv_nt<4>(p.gmsg + (size_t)(p.by_pos ? pos : ee) * p.ldg + c, g);
         if (want_rmax) {
-          const float m = fmaxf(fmaxf(fabsf(g.v[0]), fabsf(g.v[1])), fmaxf(fabsf(g.v[2]), fabsf(g.v[3])));
-          if (m > 0.f) {
+          float m = fmaxf(fmaxf(fabsf(g.v[0]), fabsf(g.v[1])), fmaxf(fabsf(g.v[2]), fabsf(g.v[3])));
+          if (uni) m = wave_max_nonneg(m);
+          if (m > 0.f && (!uni || elect)) {
             if (staged) atomicMax(&rmax_e[pos - p0], __float_as_uint(m));
             else atomicMax(p.gmsg_rmax + (p.by_pos ? pos : ee), __float_as_uint(m));
           }
@@ -990,8 +996,9 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
     if (p.gU) {
       stv<4>(p.gU + (size_t)node * p.ldgu + c, su);
       if (want_rmax) {
-        const float m = fmaxf(fmaxf(fabsf(su.v[0]), fabsf(su.v[1])), fmaxf(fabsf(su.v[2]), fabsf(su.v[3])));
-        if (m > 0.f) atomicMax(&rmax_n[dn], __float_as_uint(m));
+        float m = fmaxf(fmaxf(fabsf(su.v[0]), fabsf(su.v[1])), fmaxf(fabsf(su.v[2]), fabsf(su.v[3])));
+        if (uni) m = wave_max_nonneg(m);
+        if (m > 0.f && (!uni || elect)) atomicMax(&rmax_n[dn], __float_as_uint(m));
       }
     }
   }

@@ -54,17 +54,25 @@ struct PostParams {
   int tiles_per_wave;       // 64-node tiles a wavefront walks with the tower's weights staged once
   int vec4;                 // rows of agg / gagg are 16-byte aligned (pitch % 4 == 0, KF % 4 == 0): float4 row segments; else dwords
   const float* bias;        // PLAIN forward only, may be NULL
-  int tower_major;          // 1: the round-3 launch order (all node blocks of tower 0, then tower 1, ...) - the A/B of post_block()
+  int order;                // workgroup -> (tower, node block) map of post_block(): 0 XCD-grouped [r5], 1 tower-major (round 3), 2 tower-fastest (round 4)
+  int64_t nbx;              // node blocks per tower (the grid holds nbx rounded up to a multiple of 8, times T, in order 0)
 };
 
-// [r4] Workgroup -> (tower, node block), TOWER FASTEST: the workgroups that run at the same time then read (K13, K15) or write (K14) whole
+// Workgroup -> (tower, node block).  [r4] TOWER FASTEST: the workgroups that run at the same time read (K13, K15) or write (K14) whole
 // rows of agg - T x 608 bytes at C2L - instead of every fifth 608-byte run of them.  With the tower on blockIdx.y the chip walked ONE
-// tower's column block of all rows at a time: 20 % of every DRAM page it opened, and no kernel of the family - fp32 or bf16 pieces, with or
-// without its MFMAs, one k-step or three in flight - moved more than 3.7 TB/s.
-__device__ __forceinline__ void post_block(const PostParams& p, int& t, int64_t& bx) {
+// tower's column block of all rows at a time: 20 % of every DRAM page it opened, and no kernel of the family moved more than 3.7 TB/s.
+// [r5] XCD-GROUPED: consecutive block ids are dealt round-robin over the 8 XCDs, so under the tower-fastest order the T workgroups of one
+// node block sat on T different XCDs - and a tower's 608-byte run of a row starts and ends inside 128-byte lines it shares with its
+// neighbours (608 = 4.75 lines; rows are 3040 bytes apart): every L2 fetched those lines again (PMC: 1.39x / 1.41x / 1.82x the algorithmic
+// bytes for K13 / K14 / K15).  Now a group of 8 T consecutive ids covers 8 node blocks, id i of the group -> node block i % 8, tower i / 8:
+// all towers of a node block have the same id mod 8 = the same XCD (speed only: nothing depends on the placement), a few ids apart.
+// false: this workgroup is padding of the last group.
+__device__ __forceinline__ bool post_block(const PostParams& p, int& t, int64_t& bx) {
   const unsigned lin = blockIdx.x, T = (unsigned)p.T;
-  if (p.tower_major) { const unsigned nbx = gridDim.x / T; t = (int)(lin / nbx); bx = lin % nbx; }
-  else { t = (int)(lin % T); bx = lin / T; }
+  if (p.order == 1) { const unsigned nbx = gridDim.x / T; t = (int)(lin / nbx); bx = lin % nbx; }
+  else if (p.order == 2) { t = (int)(lin % T); bx = lin / T; }
+  else { const unsigned g = lin / (8u * T), i = lin - g * 8u * T; t = (int)(i >> 3); bx = (int64_t)g * 8 + (i & 7u); }
+  return bx < p.nbx;
 }
 
 // running products of the scalers for one node, in the reference's multiplication order ((v f0) f1) ...
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams
   float* Wl = post_smem;                                       // (KFp, R)
   float* tile = post_smem + (size_t)p.KFp * R + wave * (kWave * kPostPitch);
   int t; int64_t bx;
-  post_block(p, t, bx);
+  if (!post_block(p, t, bx)) return;                           // (before any barrier: the whole workgroup leaves)
   post_stage_weights(Wl, Wa + (size_t)t * p.KFp * R, p.KFp * R);
   __syncthreads();                                             // weights staged: the only workgroup barrier
   const int j = lane & 15, kq = lane >> 4;                     // MFMA 16x16x4 operand lane: row/column j, k index kq
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams
   float* Wl = post_smem;                                       // (R, wb_pitch): pitch = KFp + 16, so that k and k+1 fall on different banks
   float* tile = post_smem + (size_t)R * wb_pitch + wave * (kWave * kPostPitch);
   int t; int64_t bx;
-  post_block(p, t, bx);
+  if (!post_block(p, t, bx)) return;                           // (before any barrier: the whole workgroup leaves)
   post_stage_weights(Wl, Wb + (size_t)t * R * wb_pitch, R * wb_pitch);
   __syncthreads();               // weights staged: the only workgroup barrier
   const int j = lane & 15, kq = lane >> 4;
@@ -340,15 +348,16 @@ __global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams
 // LDS, no scaled copy of gy (round 3's first form wrote gys (N, T*S*16) and ran five TN launches of the bf16x3 kernel: 0.4-0.5 ms).
 // The four waves' tiles of a workgroup are added through LDS, the per-workgroup partial tiles are summed in a fixed order by
 // mma_tower_post_gw_reduce / mma_col_sum.
-template <int S>
+template <int S, int G>
 __global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams p, const float* __restrict__ gy, const float* __restrict__ agg,
                                                                const float* __restrict__ pre_tab, float* __restrict__ part, int64_t npw,
                                                                int kfp16) {
-  constexpr int G = S <= 2 ? 10 : 5;                           // kf tiles per pass: S*G accumulator tiles + two operand groups in flight
+  // G: kf tiles per pass (post_gw_tiles): S*G accumulator tiles + two operand groups in flight
+  constexpr int GH = G > 5 ? G / 2 : G;                        // tiles per LDS reduction round (the LDS holds 4 waves x S x GH tiles)
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   int t; int64_t bx;
-  post_block(p, t, bx);
+  if (!post_block(p, t, bx)) return;                           // (before any barrier: the whole workgroup leaves)
   const int64_t chunk = bx * (kBlock / kWave) + wave;
   const int64_t nb = chunk * npw, ne = min(p.N, nb + npw);
   const int j = lane & 15, kq = lane >> 4;
@@ -408,22 +417,25 @@ __global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams 
       multiply(r1);                                            // past the range: valid is false, the operands are zeros
       __builtin_amdgcn_sched_barrier(0);
     }
-    // D: row = 4 * kq + reg = o, column = lane & 15 = kf inside the tile.  red[wave][(q, c, r)][lane]
+    // D: row = 4 * kq + reg = o, column = lane & 15 = kf inside the tile.  red[wave][(q, c, r)][lane], GH tiles of every q per round
 #pragma unroll
-    for (int q = 0; q < S; ++q)
+    for (int h = 0; h < G; h += GH) {
 #pragma unroll
-      for (int c = 0; c < G; ++c)
+      for (int q = 0; q < S; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) post_smem[((wave * S + q) * G + c) * 4 * kWave + r * kWave + lane] = acc[q][c][r];
-    __syncthreads();
-    constexpr int kItems = S * G * 4, kWaveStride = S * G * 4 * kWave;
-    for (int it = wave; it < kItems; it += kBlock / kWave) {
-      const int q = it / (G * 4), c = (it >> 2) % G, r = it & 3;
-      const float* rp = post_smem + it * kWave + lane;
-      const float v = (rp[0] + rp[kWaveStride]) + (rp[2 * kWaveStride] + rp[3 * kWaveStride]);
-      if (kt0 + c < n_kft) out[(size_t)(q * kPostO + 4 * kq + r) * kfp16 + (kt0 + c) * 16 + j] = v;
+        for (int c = 0; c < GH; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) post_smem[((wave * S + q) * GH + c) * 4 * kWave + r * kWave + lane] = acc[q][h + c][r];
+      __syncthreads();
+      constexpr int kItems = S * GH * 4, kWaveStride = S * GH * 4 * kWave;
+      for (int it = wave; it < kItems; it += kBlock / kWave) {
+        const int q = it / (GH * 4), c = (it >> 2) % GH, r = it & 3;
+        const float* rp = post_smem + it * kWave + lane;
+        const float v = (rp[0] + rp[kWaveStride]) + (rp[2 * kWaveStride] + rp[3 * kWaveStride]);
+        if (kt0 + h + c < n_kft) out[(size_t)(q * kPostO + 4 * kq + r) * kfp16 + (kt0 + h + c) * 16 + j] = v;
+      }
+      __syncthreads();                                         // the next round / pass writes the same LDS
     }
-    __syncthreads();                                           // the next pass writes the same LDS
   }
 }
 
@@ -513,7 +525,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   int t; int64_t bx;
-  post_block(p, t, bx);
+  if (!post_block(p, t, bx)) return;                           // (before any barrier: the whole workgroup leaves)
   const int j = lane & 15, kg = lane >> 4;
   const int nks = p.KFp / 32;
   const int64_t tiles = (p.N + kWave - 1) / kWave;
@@ -620,6 +632,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
 }
 
+// K15: kf tiles (16 columns) per pass - S x G accumulator tiles of 4 registers + two operand sets in flight.  [r5] S <= 3 takes 10: ZINC's
+// 152 columns (10 tiles) are ONE pass over the nodes instead of two (each pass re-read gy, the scaler table and the lines of agg that
+// straddle the two column halves)
+static constexpr int post_gw_tiles(int S) { return S <= 3 ? 10 : 5; }
 static int64_t post_gw_npw(int64_t N, int T) {
   // about two waves per SIMD over the whole grid (1024 SIMDs), node ranges in multiples of 64
   int64_t waves = 2048 / (T < 1 ? 1 : T);
@@ -640,7 +656,7 @@ static int post_fill(PostParams* p, int64_t N, int T, int KF, int S, int O, cons
   }
   p->N = N; p->T = T; p->KF = KF; p->KFp = (KF + kPostTile - 1) / kPostTile * kPostTile; p->S = S; p->O = O; p->avg_log = avg_log; p->avg_lin = avg_lin;
   p->tiles_per_wave = 1;
-  { const char* e = getenv("MMA_POST_TOWER_MAJOR"); p->tower_major = (e && e[0] == '1') ? 1 : 0; }       // read per call (A/B)
+  { const char* e = getenv("MMA_POST_ORDER"); p->order = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0; }       // read per call (A/B)
   MMA_REQUIRE(((N + kWave - 1) / kWave + 3) / 4 * (int64_t)T < (1LL << 31), "N=%lld x T=%d workgroups exceed the grid", (long long)N, T);
   return 0;
 }
@@ -664,10 +680,12 @@ static int post_tiles_per_wave(int64_t N, int T) {
   }
   return best;
 }
-static dim3 post_grid(const PostParams& p, int T) {       // one-dimensional: post_block() takes it apart
+static dim3 post_grid(PostParams& p, int T) {       // one-dimensional: post_block() takes it apart; sets p.nbx
   const int64_t tiles = (p.N + kWave - 1) / kWave;
   const int64_t per_block = (int64_t)(kBlock / kWave) * p.tiles_per_wave;
-  return dim3((unsigned)((tiles + per_block - 1) / per_block * T));
+  p.nbx = (tiles + per_block - 1) / per_block;
+  const int64_t nbx = p.order == 0 ? (p.nbx + 7) / 8 * 8 : p.nbx;
+  return dim3((unsigned)(nbx * T));
 }
 
 static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -822,10 +840,20 @@ extern "C" int mma_tower_post_gw(const float* gy, int64_t ldg, const float* agg,
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int kfp16 = (KF + 15) / 16 * 16;
   const int64_t npw = post_gw_npw(N, T);
-  const dim3 grid((unsigned)(n_chunks * T));
-  const int G = S <= 2 ? 10 : 5;
-  const unsigned lds = (unsigned)((kBlock / kWave) * S * G * 4 * kWave * sizeof(float));
-  MMA_POST_LAUNCH(tower_post_gw_kernel, lds, gy, agg, pre, part, npw, kfp16)
+  p.nbx = n_chunks;
+  const dim3 grid((unsigned)((p.order == 0 ? (n_chunks + 7) / 8 * 8 : n_chunks) * T));
+  int G = post_gw_tiles(S);
+  { const char* e = getenv("MMA_POST_GW_TILES"); if (e && e[0] == '5') G = 5; }       // read per call (A/B): round 4's two passes at S = 3
+  const unsigned lds = (unsigned)((kBlock / kWave) * S * (G > 5 ? G / 2 : G) * 4 * kWave * sizeof(float));
+#define MMA_GW(SS, GG) hipLaunchKernelGGL((tower_post_gw_kernel<SS, GG>), grid, dim3(kBlock), lds, st, p, gy, agg, pre, part, npw, kfp16)
+  switch (S) {
+    case 1: MMA_GW(1, 10); break;
+    case 2: MMA_GW(2, 10); break;
+    case 3: if (G == 10) MMA_GW(3, 10); else MMA_GW(3, 5); break;
+    case 4: MMA_GW(4, 5); break;
+    default: MMA_GW(5, 5); break;
+  }
+#undef MMA_GW
   return check_launch("tower_post_gw_kernel");
 }
 
