@@ -395,8 +395,10 @@ int mma_masked_bn_relu_bwd(const float* gy, int64_t ldg, const float* y, int64_t
  * regression: the pre-NN on [x_i | x_j | e], mma_conv.py:81-84,170-176, as ONE GEMM per operand with the bias riding on a ones column):
  * A = [x | 1 | 0], and [W | b | 0] - the weight operand of the forward (as its transposed view) and of dL/dx (its leading columns) - one
  * launch each; was torch's pad (a zero fill of the whole buffer + a strided copy) and a strided fill per operand. */
-int mma_pad_rows(const float* x, int64_t ldx, int64_t M, int32_t fin, const float* col /* (M,) or NULL */, float* out, int64_t ldo,
-                 int32_t width, int64_t M_out, void* stream);
+int mma_pad_rows(const float* x, int64_t ldx, int64_t M, int32_t fin, const float* col /* (M,) or NULL */,
+                 const int32_t* row_index /* ABI 34: (M,) or NULL - out row r takes x row row_index[r] (the edge rows of graph regression in
+                                             target-sorted position order: the permuting copy in front of the pad is gone) */,
+                 float* out, int64_t ldo, int32_t width, int64_t M_out, void* stream);
 int mma_pack_blocks(const int64_t* table, int64_t n_blocks, float* a_base, float* b0, float* b1, float* b2, float* b3, float* b4,
                     float* b5, float* b6, float* b7, int32_t unpack, void* stream);
 

@@ -148,7 +148,8 @@ static int fold_check(int64_t TF, int32_t F, int32_t ED) {
 // forward (as its transposed view) AND of dL/dx (as its leading columns).  As torch ops: a zero fill of the whole buffer, a strided copy
 // and a strided fill per operand, and a second zero-padded copy of W in backward.
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int fin, const float* __restrict__ col,
-                                                       float* __restrict__ out, int64_t ldo, int width, int64_t M_out) {
+                                                       const int32_t* __restrict__ row_index, float* __restrict__ out, int64_t ldo, int width,
+                                                       int64_t M_out) {
   const int q4 = width / 4;
   const int64_t total = M_out * q4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__
     const int c = (int)(i % q4) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < M) {
-      const float* xr = x + r * ldx;
+      const float* xr = x + (row_index ? (int64_t)row_index[r] : r) * ldx;     // [r5] out row r = x row row_index[r]: the gather rides along
       const float one = col ? col[r] : 1.f;
       v.x = c < fin ? xr[c] : (c == fin ? one : 0.f);
       v.y = c + 1 < fin ? xr[c + 1] : (c + 1 == fin ? one : 0.f);
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__
   }
 }
 
-extern "C" int mma_pad_rows(const float* x, int64_t ldx, int64_t M, int32_t fin, const float* col, float* out, int64_t ldo, int32_t width,
-                            int64_t M_out, void* stream) {
+extern "C" int mma_pad_rows(const float* x, int64_t ldx, int64_t M, int32_t fin, const float* col, const int32_t* row_index, float* out,
+                            int64_t ldo, int32_t width, int64_t M_out, void* stream) {
   MMA_REQUIRE(M >= 0 && M_out >= M && fin >= 1 && width > fin && width % 4 == 0 && ldx >= fin && ldo >= width && ldo % 4 == 0,
               "M=%lld M_out=%lld fin=%d width=%d ldx=%lld ldo=%lld unsupported (fin < width, width and ldo multiples of 4)", (long long)M,
               (long long)M_out, fin, width, (long long)ldx, (long long)ldo);
@@ -177,8 +178,8 @@ extern "C" int mma_pad_rows(const float* x, int64_t ldx, int64_t M, int32_t fin,
   const int64_t total = M_out * (width / 4);
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8 * kMaxGrid) blocks = 8 * kMaxGrid;
-  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, M, (int)fin, col, out, ldo,
-                     (int)width, M_out);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, M, (int)fin, col, row_index,
+                     out, ldo, (int)width, M_out);
   return check_launch("pad_rows_kernel");
 }
 

@@ -405,17 +405,30 @@ __global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams 
         for (int c = 0; c < G; ++c) acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c], acc[q][c], 0, 0, 0);
       }
     };
-    Raw r0, r1;                                                // two operand sets used in turn (no register copies: a copy of a set
-    fetch(nb, r0);                                             // that is still in flight is a wait for it in the middle of the MFMAs)
-    for (int64_t n4 = nb; n4 < ne; n4 += 8) {
-      fetch(n4 + 4, r1);
-      __builtin_amdgcn_sched_barrier(0);                       // the scheduler otherwise sinks these loads to their first use
+    // [r5] FOUR operand sets in a ring, each requested four k-steps (16 nodes) ahead of its MFMAs.  A k-step is S*G MFMAs = 0.4 us at
+    // ZINC's shape against a loaded memory latency of 2 us and more, and a SIMD holds one or two of these wavefronts: with round 4's two
+    // sets (one step ahead) the matrix pipe sat idle two thirds of the time (0.32 ms against 0.10 ms of MFMAs; one pass or two over the
+    // nodes, XCD placement of the towers, 1.8x or 1.0x the algorithmic bytes in the L2 fetch counters - none of it moved the time).
+    // No register copies: a copy of a set that is still in flight is a wait for it in the middle of the MFMAs.
+    Raw r0, r1, r2, r3;
+    fetch(nb, r0); fetch(nb + 4, r1); fetch(nb + 8, r2); fetch(nb + 12, r3);
+    for (int64_t n4 = nb; n4 < ne; n4 += 16) {                 // past the range: valid is false, the operands are zeros
+      __builtin_amdgcn_sched_barrier(0);                       // the scheduler otherwise sinks the loads to their first use
       multiply(r0);
       __builtin_amdgcn_sched_barrier(0);
-      fetch(n4 + 8, r0);
+      fetch(n4 + 16, r0);
       __builtin_amdgcn_sched_barrier(0);
-      multiply(r1);                                            // past the range: valid is false, the operands are zeros
+      multiply(r1);
       __builtin_amdgcn_sched_barrier(0);
+      fetch(n4 + 20, r1);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(r2);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(n4 + 24, r2);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(r3);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(n4 + 28, r3);
     }
     // D: row = 4 * kq + reg = o, column = lane & 15 = kf inside the tile.  red[wave][(q, c, r)][lane], GH tiles of every q per round
 #pragma unroll
@@ -841,6 +854,9 @@ extern "C" int mma_tower_post_gw(const float* gy, int64_t ldg, const float* agg,
   const int kfp16 = (KF + 15) / 16 * 16;
   const int64_t npw = post_gw_npw(N, T);
   p.nbx = n_chunks;
+  // K15 keeps the tower-fastest order: under the XCD-grouped one it ran 0.32 -> 0.44 ms at C2L (its ~500 workgroups are all resident at
+  // once; only their placement changes - not explained), while K13 / K14 gain 3-5 % from it
+  { const char* e = getenv("MMA_POST_ORDER"); if (!(e && e[0] >= '0' && e[0] <= '2')) p.order = 2; }
   const dim3 grid((unsigned)((p.order == 0 ? (n_chunks + 7) / 8 * 8 : n_chunks) * T));
   int G = post_gw_tiles(S);
   { const char* e = getenv("MMA_POST_GW_TILES"); if (e && e[0] == '5') G = 5; }       // read per call (A/B): round 4's two passes at S = 3

@@ -492,22 +492,27 @@ def _padded_parent(v, pitch):
 
 class _LinearX3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, row_index=None, inv_index=None):
+        """row_index (N,) int32 / inv_index (N,) int64, a permutation and its inverse (optional): y = linear(x[row_index]) - the gather rides
+        on the pad launch (graph regression's edge rows in target-sorted position order), dL/dx is gathered back with inv_index."""
         N, fin = x.shape
+        ctx.inv_index = inv_index
         fout = weight.shape[0]
         OP = _round_up(fout, 128)
         fused = FUSED_PAD and x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and weight.dtype == torch.float32
+        if row_index is not None and not fused:
+            x = x.index_select(0, row_index.long())
         if fused:
             # [r4] both padded operands in ONE launch each (mma_pad_rows): A = [x | 1 | 0] (N, 128), and wpad = [W | b | 0] (OP, 128), whose
             # transposed VIEW is the forward's B and whose leading columns are dL/dx's B - no second padded copy of W in backward
             xp = torch.empty((N, 128), device=x.device, dtype=torch.float32)
-            call("mma_pad_rows", ptr(x), x.stride(0), N, fin, None, ptr(xp), 128, 128, N, stream_ptr())
+            call("mma_pad_rows", ptr(x), x.stride(0), N, fin, None, ptr(row_index), ptr(xp), 128, 128, N, stream_ptr())
             w2 = weight if weight.stride(1) == 1 else weight.contiguous()
             wpad = torch.empty((OP, 128), device=x.device, dtype=torch.float32)
             if bias is not None:
-                call("mma_pad_rows", ptr(w2), w2.stride(0), fout, fin, ptr(bias.contiguous()), ptr(wpad), 128, 128, OP, stream_ptr())
+                call("mma_pad_rows", ptr(w2), w2.stride(0), fout, fin, ptr(bias.contiguous()), None, ptr(wpad), 128, 128, OP, stream_ptr())
             else:
-                call("mma_pad_rows", ptr(w2), w2.stride(0), fout, fin + 0, ptr(torch.zeros((fout,), device=x.device)), ptr(wpad), 128, 128, OP, stream_ptr())
+                call("mma_pad_rows", ptr(w2), w2.stride(0), fout, fin + 0, ptr(torch.zeros((fout,), device=x.device)), None, ptr(wpad), 128, 128, OP, stream_ptr())
             wt = wpad.t()
         else:
             xp = torch.nn.functional.pad(x, (0, 128 - fin))         # (N, 128): [x | 1 | 0 ...]
@@ -556,7 +561,9 @@ class _LinearX3(torch.autograd.Function):
                 wp = weight.new_zeros((OP, NP))
                 wp[:fout, :fin] = weight
             gx = gemm_bf16x3(gp, wp)[:, :fin]
-        return gx, gw, gb
+        if gx is not None and ctx.inv_index is not None:
+            gx = gx.index_select(0, ctx.inv_index)                   # back to the caller's row order (deterministic: a gather, no index_add)
+        return gx, gw, gb, None, None
 
 
 def linear_x3_ok(x, weight):
@@ -569,6 +576,14 @@ def linear_tall(x, weight, bias=None):
     if linear_x3_ok(x, weight):
         return _LinearX3.apply(x, weight, bias)
     return _Linear.apply(x, weight, bias)
+
+
+def linear_tall_rows(x, row_index, inv_index, weight, bias=None):
+    """linear_tall(x[row_index]) for a PERMUTATION row_index (int32) with inverse inv_index (int64): on the zero-padded path the gather
+    is part of the pad launch; None: the caller permutes first."""
+    if linear_x3_ok(x, weight) and FUSED_PAD and x.stride(1) == 1:
+        return _LinearX3.apply(x, weight, bias, row_index, inv_index)
+    return None
 
 
 class _BiasAdd(torch.autograd.Function):

@@ -364,7 +364,10 @@ class MMAConv(torch.nn.Module):
                     Z = dense.linear(edge_attr.table, wz, bz)
                     z_index = edge_attr.types_by_position(graph)
                 else:
-                    Z = dense.linear_tall(Fn.rows_by_position(edge_attr, graph), wz, bz)                         # (E, T*Fw) by position
+                    # (E, T*Fw) by position; [r5] on the zero-padded path the permutation rides on the pad launch (no permuted copy of edge_attr)
+                    Z = dense.linear_tall_rows(edge_attr, graph.perm, graph.inv_perm, wz, bz) if graph.E else None
+                    if Z is None:
+                        Z = dense.linear_tall(Fn.rows_by_position(edge_attr, graph), wz, bz)
             # Round 3: when the post-NN is a single small Linear, the degree scalers - per-target row factors - move from the
             # aggregates into it (Fn.tower_post): K3 then runs with the identity scaler only and leaves the K UNSCALED aggregates
             # (N,T,K*Fw), a third of `out` at S = 3; the (N,T,S*K*F) tensor of mma_conv.py:196 and its gradient never exist

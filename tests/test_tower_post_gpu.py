@@ -256,8 +256,13 @@ def test_pad_rows_equals_pad_and_fill(N, fin, pitch):
     want = torch.nn.functional.pad(x, (0, 128 - fin))
     want[:, fin] = 1.0
     got = torch.full((N, 128), float("nan"), device=DEV)
-    call("mma_pad_rows", ptr(x), x.stride(0), N, fin, None, ptr(got), 128, 128, N, stream_ptr())
+    call("mma_pad_rows", ptr(x), x.stride(0), N, fin, None, None, ptr(got), 128, 128, N, stream_ptr())
     assert torch.equal(got, want)
+    # [r5] with a row index: out row r = x row idx[r] (the permutation of graph regression's edge rows rides on the pad)
+    idx = torch.randperm(N, generator=g).to(DEV)
+    got_p = torch.full((N, 128), float("nan"), device=DEV)
+    call("mma_pad_rows", ptr(x), x.stride(0), N, fin, None, ptr(idx.to(torch.int32)), ptr(got_p), 128, 128, N, stream_ptr())
+    assert torch.equal(got_p, want[idx])
     # a given column and zero rows below (the weight operand)
     col = torch.randn(N, generator=g).to(DEV)
     rows_out = -(-N // 128) * 128 + 128
@@ -265,7 +270,7 @@ def test_pad_rows_equals_pad_and_fill(N, fin, pitch):
     want2[:N, :fin] = x
     want2[:N, fin] = col
     got2 = torch.full((rows_out, 128), float("nan"), device=DEV)
-    call("mma_pad_rows", ptr(x), x.stride(0), N, fin, ptr(col), ptr(got2), 128, 128, rows_out, stream_ptr())
+    call("mma_pad_rows", ptr(x), x.stride(0), N, fin, ptr(col), None, ptr(got2), 128, 128, rows_out, stream_ptr())
     assert torch.equal(got2, want2)
 
 
