@@ -349,8 +349,10 @@ int mma_tower_post_gw(const float* gy, int64_t ldg, const float* agg, int64_t ld
  *   fwd:    y (N,O)  = x (N,K) W^T + bias            Wa (KFp, S*16): Wa[k][o] = W[o][k], zero-padded, S = ceil(O/16), KFp = mma_tower_post_kfp(K)
  *   bwd_dx: gx (N,K) = gy (N,O) W                    Wb (S*16, KFp + 16): Wb[o][k] = W[o][k], zero-padded
  * O <= 80, K <= 512, any row pitches (16-byte aligned rows take the float4 path).  bias may be NULL. */
-int mma_skinny_linear_fwd(const float* x, int64_t ldx, const float* Wa, const float* bias, float* y, int64_t ldy,
-                          int64_t N, int32_t K, int32_t O, void* stream);
+int mma_skinny_linear_fwd(const float* x, int64_t ldx, const float* Wa, const float* bias,
+                          const float* addend, int64_t ldadd,      /* ABI 34, may be NULL: y = (x W^T + bias) + addend (N, ldadd >= O) - the two
+                                                                      halves of MMAConv's post-NN (mma_conv.py:132-134) meet in the epilogue */
+                          float* y, int64_t ldy, int64_t N, int32_t K, int32_t O, void* stream);
 int mma_skinny_linear_bwd_dx(const float* gy, int64_t ldg, const float* Wb, float* gx, int64_t ldx,
                              int64_t N, int32_t K, int32_t O, void* stream);
 

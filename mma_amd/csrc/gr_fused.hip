@@ -892,13 +892,11 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
   const int KS = p.K * p.S;                                   // <= kBlkMaxKS on this path
   // row maxima (optional): a row's 4-column items sit in different lanes and waves - merged in LDS (edges of a staged block, the
   // block's nodes), then ONE global merge per row; blocks whose edges do not fit the staging area merge per item in global memory
-  __shared__ uint32_t rmax_e[kBlkCap];
-  __shared__ uint32_t rmax_n[32];
+  __shared__ uint32_t rmax_b[32];                             // per node of the block: the bound of its edges' rows (phase A)
+  __shared__ uint32_t rmax_n[32];                             // per node: max |dL/dU row| (phase B, exact)
   const bool want_rmax = p.gmsg_rmax != nullptr;              // both arrays or neither (host check)
-  if (want_rmax) {
-    for (int i = tid; i < kBlkCap; i += kBlock) rmax_e[i] = 0u;
-    if (tid < 32) rmax_n[tid] = 0u;
-  }
+  if (want_rmax && tid < 32) { rmax_b[tid] = 0u; rmax_n[tid] = 0u; }
+  if (want_rmax) __syncthreads();
 
   for (int it = tid; it < items; it += kBlock) {
     const int dn = (int)udiv((uint32_t)it, p.qd_magic);
@@ -940,6 +938,20 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
         }
       }
     }
+    if (want_rmax) {
+      // every message gradient of this node is c_all + [arg hit] c_min + [arg hit] c_max, times the keep factor: ONE bound per node, formed
+      // here (per item, across the wavefront when it holds a single node - the usual case: a row is 95 items), stands for the row maximum
+      // of each of its edges - an upper bound (the three-product GEMMs take bounds; an edge is the arg of about 1/deg of the columns, so the
+      // bound is rarely more than a binade loose), at a cost per NODE instead of per edge and lane (measured: +0.05 ms of K4 at C2L)
+      float m = 0.f;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) m = fmaxf(m, fabsf(c_all[x]) + fabsf(c_min[x]) + fabsf(c_max[x]));
+      if (DROP) m *= dp.scale;
+      const bool uni = __all(dn == __builtin_amdgcn_readfirstlane(dn));
+      const bool elect = (int)(threadIdx.x & (kWave - 1)) == __builtin_amdgcn_readfirstlane((int)(threadIdx.x & (kWave - 1)));
+      if (uni) m = wave_max_nonneg(m);
+      if (m > 0.f && (!uni || elect)) atomicMax(&rmax_b[dn], __float_as_uint(m));
+    }
     float* cf = L.agg + (size_t)dn * NC * p.D + c;
     if (NEEDS & NEED_SUM) { Vec<4> v; for (int i = 0; i < 4; ++i) v.v[i] = c_all[i]; stv<4>(cf + I_ALL * p.D, v); }
     if (NEEDS & NEED_MIN) { Vec<4> v; for (int i = 0; i < 4; ++i) v.v[i] = c_min[i]; stv<4>(cf + I_MIN * p.D, v); }
@@ -954,9 +966,8 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
     const int c = (it - dn * (int)p.qd) * 4;
     const int node = n0 + dn;
     const int b = L.rowptr[dn], deg = L.rowptr[dn + 1] - b;
-    // row maxima: when all active lanes of the wavefront work on ONE node (a row is 95 items at ZINC's shape: most wavefronts), the edge
-    // loop below is wave-uniform and the row's maximum is formed across the lanes first - one LDS merge per wavefront and row instead of
-    // one per lane (64 lanes merging into the same word serialise: +0.04 ms of K4 at C2L)
+    // dL/dU row maxima (exact): when all active lanes of the wavefront work on ONE node the maximum is formed across the lanes first -
+    // one LDS merge per wavefront and row instead of one per lane (64 lanes merging into the same word serialise)
     const bool uni = want_rmax && __all(dn == __builtin_amdgcn_readfirstlane(dn));
     const bool elect = (int)(threadIdx.x & (kWave - 1)) == __builtin_amdgcn_readfirstlane((int)(threadIdx.x & (kWave - 1)));
     if (deg > kGroupMaxDeg) continue;
@@ -983,14 +994,6 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
           su.v[i] += g.v[i];
         }
         stv_nt<4>(p.gmsg + (size_t)(p.by_pos ? pos : ee) * p.ldg + c, g);
-        if (want_rmax) {
-          float m = fmaxf(fmaxf(fabsf(g.v[0]), fabsf(g.v[1])), fmaxf(fabsf(g.v[2]), fabsf(g.v[3])));
-          if (uni) m = wave_max_nonneg(m);
-          if (m > 0.f && (!uni || elect)) {
-            if (staged) atomicMax(&rmax_e[pos - p0], __float_as_uint(m));
-            else atomicMax(p.gmsg_rmax + (p.by_pos ? pos : ee), __float_as_uint(m));
-          }
-        }
       }
     }
     if (p.gU) {
@@ -1004,9 +1007,15 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
   }
   if (want_rmax) {
     __syncthreads();
-    if (staged) {             // every position of the block belongs to this workgroup alone, but a long segment's rows are the list pass's: merge, not store
-      for (int i = tid; i < p1 - p0; i += kBlock)
-        if (rmax_e[i]) atomicMax(p.gmsg_rmax + (p.by_pos ? p0 + i : L.perm[i]), rmax_e[i]);
+    // the node's bound goes to each of its edges' rows (positions are this block's alone; a long segment's rows are the list pass's,
+    // its bound here is 0: merged, not stored) and the exact dL/dU maximum to the node
+    for (int w = tid; w < n_here * kGroupMaxDeg; w += kBlock) {
+      const int dn = w / kGroupMaxDeg, tt = w - dn * kGroupMaxDeg;
+      const int b = L.rowptr[dn], deg = L.rowptr[dn + 1] - b;
+      if (tt >= deg || deg > kGroupMaxDeg || rmax_b[dn] == 0u) continue;
+      const int pos = b + tt;
+      const int row = p.by_pos ? pos : (staged ? L.perm[pos - p0] : p.perm[pos]);
+      atomicMax(p.gmsg_rmax + row, rmax_b[dn]);
     }
     if (tid < n_here && rmax_n[tid]) atomicMax(p.gu_rmax + n0 + tid, rmax_n[tid]);
   }

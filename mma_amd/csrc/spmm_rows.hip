@@ -67,6 +67,104 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const SpmmParams p) {
   }
 }
 
+
+// ---- [r5] segment sum of short rows, block form: out[r, :] = sum_{e in row r} B[col[e], :] (K = 1, unit weights, no bias) ----------------
+// The dV segment sum of graph regression's backward (rows = source nodes, ~2 edges each, C = T*F = 380 floats) on the structure of the GR
+// block kernels (gr_fused.hip): ONE workgroup per kSegRows rows; row pointers and edge ids staged in LDS; phase A = loads only - a lane
+// owns a (row, 4 columns) item, issues its gathers in a fixed batch (four edge slots, clamped, + a rare tail) and leaves the sum in LDS;
+// phase B = stores only.  The wave-per-row kernel above spends a dependent round trip on the row pointers, another on the edge ids and a
+// third on the gathered rows for every row of two edges: 0.27 ms at C2L for 0.96 GB (3.5 TB/s).  Same bits: a row's members are added
+// sequentially in edge order.  Rows above kSegLong edges are left to a column-parallel tail inside the same workgroup (same order).
+constexpr int kSegRows = 16;         // rows per workgroup
+constexpr int kSegCap = 512;         // edge ids of a block staged in LDS; blocks with more read them from memory
+constexpr int kSegLong = 64;
+struct SegSumParams {
+  const int32_t* rowptr; const int32_t* col; const float* B; int64_t ldb; float* out; int64_t ldo; int n_rows; int C; uint32_t qd, qd_magic;
+  uint32_t* rowmax;
+};
+__device__ __forceinline__ uint32_t seg_udiv(uint32_t n, uint32_t magic) { return magic ? __umulhi(n, magic) : n; }
+
+__global__ __launch_bounds__(kBlock) void segsum_block_kernel(const SegSumParams p) {
+  extern __shared__ __attribute__((aligned(16))) float seg_out[];          // (kSegRows, C)
+  __shared__ int s_rp[kSegRows + 1];
+  __shared__ int s_idx[kSegCap];
+  __shared__ uint32_t s_rm[kSegRows];
+  const int tid = threadIdx.x;
+  const int n0 = (int)blockIdx.x * kSegRows;
+  const int n_here = min(kSegRows, p.n_rows - n0);
+  if (n_here <= 0) return;
+  const int p0 = p.rowptr[n0], p1 = p.rowptr[n0 + n_here];
+  const bool staged = p1 - p0 <= kSegCap;
+  if (tid <= n_here) s_rp[tid] = p.rowptr[n0 + tid];
+  if (tid < kSegRows) s_rm[tid] = 0u;
+  if (staged) for (int i = tid; i < p1 - p0; i += kBlock) s_idx[i] = p.col[p0 + i];
+  __syncthreads();
+  const int items = n_here * (int)p.qd;
+  for (int it = tid; it < items; it += kBlock) {
+    const int dn = (int)seg_udiv((uint32_t)it, p.qd_magic);
+    const int c = (it - dn * (int)p.qd) * 4;
+    const int b = s_rp[dn], deg = s_rp[dn + 1] - b;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (deg <= kSegLong && deg > 0) {
+      int j[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int pos = b + min(i, deg - 1); j[i] = staged ? s_idx[pos - p0] : p.col[pos]; }
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(p.B + (size_t)j[i] * p.ldb + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < deg) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+      for (int t = 4; t < deg; ++t) {
+        const int jj = staged ? s_idx[b + t - p0] : p.col[b + t];
+        const float4 vv = *reinterpret_cast<const float4*>(p.B + (size_t)jj * p.ldb + c);
+        acc.x += vv.x; acc.y += vv.y; acc.z += vv.z; acc.w += vv.w;
+      }
+    }
+    *reinterpret_cast<float4*>(seg_out + (size_t)dn * p.C + c) = acc;
+    if (p.rowmax && deg <= kSegLong) {
+      float m = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+      const bool uni = __all(dn == __builtin_amdgcn_readfirstlane(dn));
+      const bool elect = (int)(threadIdx.x & (kWave - 1)) == __builtin_amdgcn_readfirstlane((int)(threadIdx.x & (kWave - 1)));
+      if (uni) m = wave_max_nonneg(m);
+      if (m > 0.f && (!uni || elect)) atomicMax(&s_rm[dn], __float_as_uint(m));
+    }
+  }
+  // long rows (rare): the whole workgroup, one lane per 4 columns, eight gathers in flight, members added in edge order
+  for (int dn = 0; dn < n_here; ++dn) {
+    const int b = s_rp[dn], deg = s_rp[dn + 1] - b;
+    if (deg <= kSegLong) continue;                              // workgroup-uniform
+    for (int q = tid; q < (int)p.qd; q += kBlock) {
+      const int c = q * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t0 = 0; t0 < deg; t0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int pos = b + min(t0 + i, deg - 1);
+          const int jj = staged ? s_idx[pos - p0] : p.col[pos];
+          v[i] = *reinterpret_cast<const float4*>(p.B + (size_t)jj * p.ldb + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (t0 + i < deg) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+      }
+      *reinterpret_cast<float4*>(seg_out + (size_t)dn * p.C + c) = acc;
+      if (p.rowmax) {
+        const float m = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+        if (m > 0.f) atomicMax(&s_rm[dn], __float_as_uint(m));
+      }
+    }
+  }
+  __syncthreads();
+  for (int it = tid; it < items; it += kBlock) {
+    const int dn = (int)seg_udiv((uint32_t)it, p.qd_magic);
+    const int c = (it - dn * (int)p.qd) * 4;
+    *reinterpret_cast<float4*>(p.out + (size_t)(n0 + dn) * p.ldo + c) = *reinterpret_cast<const float4*>(seg_out + (size_t)dn * p.C + c);
+  }
+  if (p.rowmax && tid < n_here && s_rm[tid]) atomicMax(p.rowmax + n0 + tid, s_rm[tid]);
+}
+
 // Item-driven variant (K = 1): rows are cut into work items of bounded length, longest first (mma_amd/graph.py),
 // so one 26 k-edge hub row no longer serialises the launch on a single wave.  Hub chunks write partials that the
 // finalize kernel sums in slot order (deterministic, no atomics).
@@ -343,6 +441,18 @@ static int csr_spmm_impl(const int32_t* rowptr, const int32_t* col, const float*
   const bool v4 = (C % 4 == 0) && (ldb % 4 == 0) && (ldo % 4 == 0) && al16(B) && al16(out) && (!bias || al16(bias));
   const int vec = v4 ? 4 : 1;
   const int per_row = (C + vec - 1) / vec;
+  hipStream_t st0 = static_cast<hipStream_t>(stream);
+  {   // [r5] plain segment sums of vector rows: the block form (see segsum_block_kernel); MMA_SEGSUM_BLOCK=0: the wave-per-row kernel (A/B)
+    const char* e = getenv("MMA_SEGSUM_BLOCK");
+    const int qd = C / 4;
+    if (K == 1 && !val && !bias && v4 && col && C >= 32 && C <= 2048 && (int64_t)kSegRows * C * 4 <= 64 * 1024 && qd < 65536 && !(e && e[0] == '0')) {
+      SegSumParams sp{rowptr, col, B, ldb, out, ldo, (int)n_rows, C, (uint32_t)qd, qd <= 1 ? 0u : (uint32_t)((1ULL << 32) / (uint32_t)qd) + 1u,
+                      reinterpret_cast<uint32_t*>(row_max)};
+      const int64_t blocks = (n_rows + kSegRows - 1) / kSegRows;
+      hipLaunchKernelGGL(segsum_block_kernel, dim3((unsigned)blocks), dim3(kBlock), (unsigned)(kSegRows * C * 4), st0, sp);
+      return check_launch("segsum_block_kernel");
+    }
+  }
   SpmmParams p{rowptr, col, val, B, ldb, rows_per_block, K, bias, out, ldo, n_rows, C, 0, reinterpret_cast<uint32_t*>(row_max)};
   p.lpr_log = min(ilog2_ceil(per_row), 6);
   const int chunks = (per_row + (1 << p.lpr_log) - 1) >> p.lpr_log;

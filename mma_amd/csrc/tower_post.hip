@@ -54,6 +54,7 @@ struct PostParams {
   int tiles_per_wave;       // 64-node tiles a wavefront walks with the tower's weights staged once
   int vec4;                 // rows of agg / gagg are 16-byte aligned (pitch % 4 == 0, KF % 4 == 0): float4 row segments; else dwords
   const float* bias;        // PLAIN forward only, may be NULL
+  const float* addend; int64_t ldadd;   // PLAIN forward only, may be NULL: y = (x W^T + bias) + addend (the post-NN's two halves meet in the epilogue)
   int order;                // workgroup -> (tower, node block) map of post_block(): 0 XCD-grouped [r5], 1 tower-major (round 3), 2 tower-fastest (round 4)
   int64_t nbx;              // node blocks per tower (the grid holds nbx rounded up to a multiple of 8, times T, in order 0)
 };
@@ -221,7 +222,10 @@ __global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int col = q * kPostO + 4 * kq + r;
-            if (col < p.O) y[(size_t)node * p.ldy + col] = acc[nt][q][r] + (p.bias ? p.bias[col] : 0.f);
+            if (col < p.O) {
+              const float v = acc[nt][q][r] + (p.bias ? p.bias[col] : 0.f);
+              y[(size_t)node * p.ldy + col] = p.addend ? v + p.addend[(size_t)node * p.ldadd + col] : v;
+            }
           }
       }
       continue;
@@ -935,15 +939,16 @@ extern "C" int mma_tower_post_bwd(const float* gy, int64_t ldg, const float* pre
 // The 75 -> 75 Linear layers around MMAConv's fused kernels (the x-part of the post-NN, `lin`: mma_conv.py:99-105,132-136) are four
 // library GEMMs per layer step at ~0.11 ms each for 61 MB in / 61 MB out (rocBLAS picks a 16x256 macro tile for a 75-wide output).
 // Wa (KFp, S*16) / Wb (S*16, KFp + 16) zero-padded as for mma_tower_post_*, S = ceil(O / 16), KFp = mma_tower_post_kfp(K).
-extern "C" int mma_skinny_linear_fwd(const float* x, int64_t ldx, const float* Wa, const float* bias, float* y, int64_t ldy,
-                                     int64_t N, int32_t K, int32_t O, void* stream) {
+extern "C" int mma_skinny_linear_fwd(const float* x, int64_t ldx, const float* Wa, const float* bias, const float* addend, int64_t ldadd,
+                                     float* y, int64_t ldy, int64_t N, int32_t K, int32_t O, void* stream) {
   MMA_REQUIRE(O >= 1 && O <= kPostMaxS * kPostO, "O=%d unsupported (<= %d)", O, kPostMaxS * kPostO);
   const int S = (O + kPostO - 1) / kPostO;
   PostParams p{};
   if (int rc = post_fill(&p, N, 1, K, S, O, nullptr, 1.f, 1.f)) return rc;
   if (N == 0) return 0;
   MMA_REQUIRE(x && Wa && y && al16(Wa) && ldx >= K && ldy >= O && (reinterpret_cast<uintptr_t>(x) & 3) == 0, "NULL / misaligned argument or row pitch too small");
-  p.lda = ldx; p.ldy = ldy; p.bias = bias; p.vec4 = (K % 4 == 0 && ldx % 4 == 0 && al16(x)) ? 1 : 0;
+  MMA_REQUIRE(!addend || ldadd >= O, "ldadd=%lld < O", (long long)ldadd);
+  p.lda = ldx; p.ldy = ldy; p.bias = bias; p.addend = addend; p.ldadd = ldadd; p.vec4 = (K % 4 == 0 && ldx % 4 == 0 && al16(x)) ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   p.tiles_per_wave = post_tiles_per_wave(N, 1);
   const dim3 grid = post_grid(p, 1);

@@ -399,7 +399,9 @@ class _Linear(torch.autograd.Function):
     sum, dL/dx the K16 kernel again."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, addend=None):
+        """addend (rows, out), optional: y = linear(x) + addend - on the K16 path the addition is the kernel's epilogue (one pass less over
+        two (rows, out) tensors and one launch less: MMAConv's post-NN, y_aggregates + x W_x^T + b)."""
         ctx.has_bias = bias is not None
         x2 = x.reshape(-1, x.shape[-1])
         ctx.skinny = _skinny_ok(x2, weight)
@@ -407,19 +409,25 @@ class _Linear(torch.autograd.Function):
             O, K = weight.shape
             Wa, Wb = _skinny_weights(weight)
             y = torch.empty((x2.shape[0], O), device=x.device, dtype=torch.float32)
-            with _span("skinny_linear_fwd", nbytes=4 * x2.shape[0] * (K + O), flops=2 * x2.shape[0] * Wa.shape[0] * Wa.shape[1], mfma="f32"):
-                call("mma_skinny_linear_fwd", ptr(x2), x2.stride(0), ptr(Wa), ptr(bias.contiguous() if bias is not None else None), ptr(y), O,
-                     x2.shape[0], K, O, stream_ptr())
+            add2 = None
+            if addend is not None:
+                add2 = addend.reshape(-1, O)
+                add2 = add2 if add2.stride(1) == 1 else add2.contiguous()
+            with _span("skinny_linear_fwd", nbytes=4 * x2.shape[0] * (K + O * (2 if add2 is not None else 1)), flops=2 * x2.shape[0] * Wa.shape[0] * Wa.shape[1], mfma="f32"):
+                call("mma_skinny_linear_fwd", ptr(x2), x2.stride(0), ptr(Wa), ptr(bias.contiguous() if bias is not None else None), ptr(add2),
+                     add2.stride(0) if add2 is not None else 0, ptr(y), O, x2.shape[0], K, O, stream_ptr())
             ctx.save_for_backward(x, weight, Wb)
             return y.view(x.shape[:-1] + (O,))
         ctx.save_for_backward(x, weight)
-        return torch.nn.functional.linear(x, weight, bias)
+        y = torch.nn.functional.linear(x, weight, bias)
+        return y if addend is None else y + addend.reshape(y.shape)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors[:2]
         g2 = g.reshape(-1, g.shape[-1])
         gx = gw = gb = None
+        g_add = g if (len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3]) else None      # d(y)/d(addend) = identity
         if ctx.needs_input_grad[0]:
             if ctx.skinny:
                 O, K = weight.shape
@@ -436,17 +444,17 @@ class _Linear(torch.autograd.Function):
             # tall input: the bias gradient rides on the weight-gradient GEMM as the row of a ones column appended to x, so the
             # (rows, out) gradient is read once instead of twice (C2L: 2 x 0.13 ms of column sums over 0.62 / 0.65 GB)
             gw1 = xt_g(g2, torch.cat([x2, x2.new_ones((x2.shape[0], 1))], 1))               # (out, in + 1)
-            return gx, gw1[:, :-1].contiguous(), gw1[:, -1].contiguous()
+            return gx, gw1[:, :-1].contiguous(), gw1[:, -1].contiguous(), g_add
         if ctx.needs_input_grad[1]:
             gw = xt_g(g2, x2)                                           # (out, in)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = col_sum(g2)
-        return gx, gw, gb
+        return gx, gw, gb, g_add
 
 
-def linear(x, weight, bias=None):
-    """F.linear with the tall-input backward (GPU tensors only)."""
-    return _Linear.apply(x, weight, bias)
+def linear(x, weight, bias=None, addend=None):
+    """F.linear (+ addend) with the tall-input backward (GPU tensors only)."""
+    return _Linear.apply(x, weight, bias, addend)
 
 
 # ---- tall Linear layers with odd widths on the bf16x3 kernels (graph regression: 75 -> 760 on 2e5 rows, 50 -> 380 on 4e5) ------
@@ -574,8 +582,8 @@ def linear_x3_ok(x, weight):
 def linear_tall(x, weight, bias=None):
     """F.linear for a tall 2-D x: zero-padded onto the bf16x3 kernels where that pays (see above), else `linear`."""
     if linear_x3_ok(x, weight):
-        return _LinearX3.apply(x, weight, bias)
-    return _Linear.apply(x, weight, bias)
+        return _LinearX3.apply(x, weight, bias, None, None)
+    return _Linear.apply(x, weight, bias, None)
 
 
 def linear_tall_rows(x, row_index, inv_index, weight, bias=None):

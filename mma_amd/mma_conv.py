@@ -403,7 +403,7 @@ class MMAConv(torch.nn.Module):
                 y = y + torch.bmm(x.transpose(0, 1), Wx.transpose(1, 2)).transpose(0, 1)
                 out = dense.bias_add(y.reshape(N, T * self.F_out), bp)
             else:                                                                        # bias rides on the shared-x GEMM
-                out = y.reshape(N, T * self.F_out) + dense.linear(x2, Wx.reshape(T * self.F_out, Fi), bp)
+                out = dense.linear(x2, Wx.reshape(T * self.F_out, Fi), bp, addend=y.reshape(N, T * self.F_out))     # [r5] the add is K16's epilogue
         else:
             if Fw != Fi:
                 out = out.view(N, T, KS, Fw)[..., :Fi].reshape(N, T, KS * Fi)

@@ -63,7 +63,7 @@ kernels = {
                                         stream_ptr()), 4 * N * (T * KF + T * O + 8)),
     "K15 tower_post_gw": (lambda: call("mma_tower_post_gw", ptr(gy), T * O, ptr(agg), T * KF, ptr(pre), ptr(part), n_chunks, N, T, KF, S, O, codes, 1.3, 2.2,
                                        stream_ptr()), 4 * N * (T * KF + T * O + 8) + 4 * part.numel()),
-    "K16 skinny fwd 75->75": (lambda: call("mma_skinny_linear_fwd", ptr(x16), K16, ptr(Wa16), ptr(b16), ptr(y16), K16, N, K16, K16, stream_ptr()), 4 * N * 2 * K16),
+    "K16 skinny fwd 75->75": (lambda: call("mma_skinny_linear_fwd", ptr(x16), K16, ptr(Wa16), ptr(b16), None, 0, ptr(y16), K16, N, K16, K16, stream_ptr()), 4 * N * 2 * K16),
     "K16 skinny bwd 75->75": (lambda: call("mma_skinny_linear_bwd_dx", ptr(x16), K16, ptr(Wb16), ptr(gx16), K16, N, K16, K16, stream_ptr()), 4 * N * 2 * K16),
 }
 
