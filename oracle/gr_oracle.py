@@ -91,24 +91,37 @@ def avg_deg_from_histogram(deg_hist):
     return {"lin": d.mean().item(), "log": (d + 1).log().mean().item(), "exp": d.exp().mean().item()}
 
 
+def _stack(h, ws, bs):
+    """A Sequential(Linear, (ReLU, Linear) x (layers - 1)) of mma_conv.py:92-103: ws / bs a tensor (one layer) or a list of tensors."""
+    if not isinstance(ws, (list, tuple)):
+        ws, bs = [ws], [bs]
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        if i:
+            h = torch.relu(h)
+        h = h @ w.t() + b
+    return h
+
+
 def message(x_i, x_j, edge_attr, enc_w, enc_b, pre_w, pre_b, towers, keep=None, p=0.5):
-    """MMAConv.message (mma_conv.py:138-157) for pre_layers == 1.
-    pre_w/pre_b: per tower (F, 3F|2F)/(F,) of the LAST aggregator (G1).  keep: (E,T,F) {0,1} or None (p treated as 0)."""
+    """MMAConv.message (mma_conv.py:138-157).
+    pre_w/pre_b: per tower (F, 3F|2F)/(F,) of the LAST aggregator (G1) - or, for pre_layers > 1, per tower the LIST of the stack's
+    layer weights / biases (mma_conv.py:92-96: Linear, then (ReLU, Linear) per extra layer).  keep: (E,T,F) {0,1} or None (p treated as 0)."""
     if edge_attr is not None:
         e = edge_attr @ enc_w.t() + enc_b
         e = e.view(-1, 1, e.shape[-1]).repeat(1, towers, 1)
         h = torch.cat([x_i, x_j, e], dim=-1)
     else:
         h = torch.cat([x_i, x_j], dim=-1)
-    hs = torch.stack([h[:, t] @ pre_w[t].t() + pre_b[t] for t in range(towers)], dim=1)
+    hs = torch.stack([_stack(h[:, t], pre_w[t], pre_b[t]) for t in range(towers)], dim=1)
     if keep is not None:
         hs = hs * keep / (1.0 - p)                                     # F.dropout(hs, 0.5), training=True always (G4)
     return hs
 
 
 def conv_forward(x, edge_index, edge_attr, prm, aggregators, scalers, avg_deg, towers, divide_input=False, keep=None, p=0.5):
-    """MMAConv.forward (mma_conv.py:121-136) for pre_layers == post_layers == 1.
-    prm: dict with enc_w, enc_b, pre_w[t], pre_b[t], post_w[t], post_b[t], lin_w, lin_b."""
+    """MMAConv.forward (mma_conv.py:121-136).
+    prm: dict with enc_w, enc_b, pre_w[t], pre_b[t], post_w[t], post_b[t], lin_w, lin_b; pre_* / post_* entries are tensors (one layer)
+    or lists of tensors (pre_layers / post_layers > 1: mma_conv.py:92-103)."""
     N = x.shape[0]
     F_in = x.shape[1] // towers if divide_input else x.shape[1]
     xt = x.view(-1, towers, F_in) if divide_input else x.view(-1, 1, F_in).repeat(1, towers, 1)
@@ -116,7 +129,7 @@ def conv_forward(x, edge_index, edge_attr, prm, aggregators, scalers, avg_deg, t
     hs = message(xt[dst], xt[src], edge_attr, prm.get("enc_w"), prm.get("enc_b"), prm["pre_w"], prm["pre_b"], towers, keep, p)
     out = aggregate(hs, dst, N, aggregators, scalers, avg_deg)
     out = torch.cat([xt, out], dim=-1)
-    outs = [out[:, t] @ prm["post_w"][t].t() + prm["post_b"][t] for t in range(towers)]
+    outs = [_stack(out[:, t], prm["post_w"][t], prm["post_b"][t]) for t in range(towers)]
     out = torch.cat(outs, dim=1)
     return out @ prm["lin_w"].t() + prm["lin_b"]
 

@@ -83,10 +83,16 @@ def test_aggregate_random_vs_oracle(aggs, scalers, T, F):
 
 def conv_params(conv):
     last = conv.aggregators[-1]
-    lins = [seq[0].active_linear() for seq in conv.pre_nns[last]]
-    prm = {"pre_w": [l.weight.detach().cpu() for l in lins], "pre_b": [l.bias.detach().cpu() for l in lins],
-           "post_w": [s[0].weight.detach().cpu() for s in conv.post_nns], "post_b": [s[0].bias.detach().cpu() for s in conv.post_nns],
-           "lin_w": conv.lin.weight.detach().cpu(), "lin_b": conv.lin.bias.detach().cpu()}
+    if conv.pre_layers == 1 and conv.post_layers == 1:
+        lins = [seq[0].active_linear() for seq in conv.pre_nns[last]]
+        prm = {"pre_w": [l.weight.detach().cpu() for l in lins], "pre_b": [l.bias.detach().cpu() for l in lins],
+               "post_w": [s[0].weight.detach().cpu() for s in conv.post_nns], "post_b": [s[0].bias.detach().cpu() for s in conv.post_nns]}
+    else:           # stacks (mma_conv.py:92-103): every other module of a Sequential is a ReLU
+        pre = [[m.active_linear() for m in seq if hasattr(m, "active_linear")] for seq in conv.pre_nns[last]]
+        post = [[m for m in seq if hasattr(m, "weight")] for seq in conv.post_nns]
+        prm = {"pre_w": [[l.weight.detach().cpu() for l in st] for st in pre], "pre_b": [[l.bias.detach().cpu() for l in st] for st in pre],
+               "post_w": [[l.weight.detach().cpu() for l in st] for st in post], "post_b": [[l.bias.detach().cpu() for l in st] for st in post]}
+    prm.update({"lin_w": conv.lin.weight.detach().cpu(), "lin_b": conv.lin.bias.detach().cpu()})
     if conv.edge_dim is not None:
         prm["enc_w"], prm["enc_b"] = conv.edge_encoder.weight.detach().cpu(), conv.edge_encoder.bias.detach().cpu()
     return prm
@@ -94,7 +100,9 @@ def conv_params(conv):
 
 def to64(prm):
     """The oracle's parameter dict in float64 (truth passes of golden_util.check_close)."""
-    return {k: ([t.double() for t in v] if isinstance(v, list) else v.double()) for k, v in prm.items()}
+    def d(v):
+        return [d(t) for t in v] if isinstance(v, list) else v.double()
+    return {k: d(v) for k, v in prm.items()}
 
 
 from tools.synth import molecule_batch  # noqa: E402,F401  (ZINC-like batches, SURVEY 8d C2; shared with bench.py)
@@ -105,10 +113,15 @@ CONV_CASES = [
     dict(aggregators=["sum", "mean"], scalers=["identity", "attenuation"], towers=2, F=6, edge_dim=None),
     dict(aggregators=["max", "sum", "min"], scalers=["inverse_linear"], towers=3, F=4, edge_dim=5, divide_input=True),
     dict(aggregators=["mean"], scalers=["identity"], towers=1, F=16, edge_dim=3),
+    # [r5] the reference's non-default options (which parts then run as torch ops): multi-layer pre / post stacks
+    dict(aggregators=["min", "max"], scalers=["identity", "amplification"], towers=2, F=8, edge_dim=5, pre_layers=2),
+    dict(aggregators=["sum", "max"], scalers=["identity", "linear", "attenuation"], towers=3, F=4, edge_dim=None, post_layers=2),
+    dict(aggregators=["mean", "min"], scalers=["identity"], towers=2, F=8, edge_dim=3, pre_layers=3, post_layers=2, divide_input=True),
 ]
 
 
-@pytest.mark.parametrize("cfg", CONV_CASES, ids=lambda c: "T%d_F%d_%s" % (c["towers"], c["F"], "".join(a[:2] for a in c["aggregators"])))
+@pytest.mark.parametrize("cfg", CONV_CASES, ids=lambda c: "T%d_F%d_%s%s" % (c["towers"], c["F"], "".join(a[:2] for a in c["aggregators"]),
+                                                  "_pre%d_post%d" % (c.get("pre_layers", 1), c.get("post_layers", 1)) if ("pre_layers" in c or "post_layers" in c) else ""))
 @pytest.mark.parametrize("p", [0.0, 0.5, 0.3])          # 0.3: a 16-bit threshold (round 5; mma_conv.py:67 hard-codes 0.5, `dropout` is public)
 def test_mmaconv_forward_backward_vs_oracle(cfg, p):
     from mma_amd import functional as Fn
@@ -116,8 +129,13 @@ def test_mmaconv_forward_backward_vs_oracle(cfg, p):
     from oracle.dropout_rng import keep_mask16, threshold16
     thr16 = threshold16(p)
     p_asked, p = p, thr16 / 65536.0                                   # the oracle divides by 1 - the applied probability
+    if cfg.get("pre_layers", 1) > 1 and p > 0:
+        pytest.skip("pre_layers > 1 takes the reference's own message() on torch ops: its F.dropout draws from torch's generator, whose bits "
+                    "no oracle can be handed (INTEGRATION.md 1); the path is compared at p = 0")
     rng = np.random.default_rng(7)
     conv = make_conv(**cfg)
+    if cfg.get("pre_layers", 1) > 1:
+        conv.dropout = 0.0
     T, F = cfg["towers"], cfg["F"]
     ei, N = molecule_batch(rng)
     E = ei.shape[1]
