@@ -318,7 +318,7 @@ def test_csr_build_inside_a_graph_rezeroes_the_long_list_and_a_bad_count_is_not_
 
 
 def test_bench_c2net_flow_eager_phase_then_graphed_step_replays_without_a_fault():
-    """The exact process history in which bench.py's default run faulted in round 4: an eager training phase
+    """The exact process history in which bench.py's default run faulted in round 4 (docs/DESIGN_rounds_1-4.md section 0, item 0): an eager training phase
     of the Net on rotating batches, THEN a second Net captured as one hipGraph and replayed past the fifth replay.  A fault would take the
     test process down; the replayed losses must also be finite and the long-segment list of the captured CSR empty after every replay."""
     import os, sys
