@@ -403,7 +403,9 @@ class MMAConv(torch.nn.Module):
                 y = y + torch.bmm(x.transpose(0, 1), Wx.transpose(1, 2)).transpose(0, 1)
                 out = dense.bias_add(y.reshape(N, T * self.F_out), bp)
             else:                                                                        # bias rides on the shared-x GEMM
-                out = dense.linear(x2, Wx.reshape(T * self.F_out, Fi), bp, addend=y.reshape(N, T * self.F_out))     # [r5] the add is K16's epilogue
+                # (the addition as K16's epilogue - dense.linear(..., addend=y) - was built and measured in round 5: the kernel's dword-wise
+                # epilogue pays 0.157 ms for what the plain kernel + a separate add launch do in 0.092 + 0.027: not used)
+                out = y.reshape(N, T * self.F_out) + dense.linear(x2, Wx.reshape(T * self.F_out, Fi), bp)
         else:
             if Fw != Fi:
                 out = out.view(N, T, KS, Fw)[..., :Fi].reshape(N, T, KS * Fi)
