@@ -533,7 +533,9 @@ __device__ __forceinline__ void post_stage_x3_fwd(post_bf16x8* Wl, const float* 
 
 // One k-step of B rows (8 KB per wave) is requested ahead of the step being multiplied; the A fragments of a scaler are read once per
 // step and used for the four node tiles.
-template <int S, bool VEC4>
+// PLAIN [r5]: K16's forward on the same kernel - y[n, r] = bias[r] + sum_k x[n, k] Wa[k][r], every 16-row tile 16 more outputs, no scaler
+// table (the exact-fp32 MFMA form of it ran 4.6x above its own matrix-core time: 0.092 ms per 75 -> 75 layer at C2L)
+template <int S, bool VEC4, bool PLAIN = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void tower_post_fwd_x3_kernel(const PostParams p, const float* __restrict__ agg, const float* __restrict__ pre_tab,
                                                                    const float* __restrict__ Wa, float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float post_smem[];
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int q = 0; q < S; ++q) pre[nt][q] = 0.f;
   for (int step = 0; step < steps; ++step) {
-    if (ks == 0) {
+    if (ks == 0 && !PLAIN) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -630,16 +632,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       for (int nt = 0; nt < 4; ++nt) {
         const int64_t node = n0 + nt * 16 + j;
         const bool valid = node < p.N;
-        float yv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (PLAIN) {
+          if (valid) {
 #pragma unroll
-        for (int q = 0; q < S; ++q)
+            for (int q = 0; q < S; ++q)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) yv[r] = fmaf(pre[nt][q], acc[nt][q][r], yv[r]);
-        if (valid) {
-          float* yr = y + (size_t)node * p.ldy + (size_t)t * p.O + 4 * kg;
+              for (int r = 0; r < 4; ++r) {
+                const int col = q * kPostO + 4 * kg + r;
+                if (col < p.O) y[(size_t)node * p.ldy + col] = acc[nt][q][r] + (p.bias ? p.bias[col] : 0.f);
+              }
+          }
+        } else {
+          float yv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (4 * kg + r < p.O) yr[r] = yv[r];
+          for (int q = 0; q < S; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[r] = fmaf(pre[nt][q], acc[nt][q][r], yv[r]);
+          if (valid) {
+            float* yr = y + (size_t)node * p.ldy + (size_t)t * p.O + 4 * kg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (4 * kg + r < p.O) yr[r] = yv[r];
+          }
         }
 #pragma unroll
         for (int q = 0; q < S; ++q) acc[nt][q] = post_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -953,6 +967,23 @@ extern "C" int mma_skinny_linear_fwd(const float* x, int64_t ldx, const float* W
   p.tiles_per_wave = post_tiles_per_wave(N, 1);
   const dim3 grid = post_grid(p, 1);
   const float* pre = nullptr;
+  // [r5] on three bf16 pieces per operand (tower_post_fwd_x3_kernel<.., PLAIN>) where the split weights fit the LDS; MMA_POST_EXACT=1 or an
+  // addend: the exact-fp32 kernel
+  if (const unsigned lx = post_x3_lds_bytes(p.KFp, S); lx <= 160 * 1024 && !post_exact() && !addend) {
+    const char* e = getenv("MMA_SKINNY_X3");                    // read per call (A/B): 0 = the fp32 kernel
+    if (!(e && e[0] == '0')) {
+#define MMA_SK(SS, V4) hipLaunchKernelGGL((tower_post_fwd_x3_kernel<SS, V4, true>), grid, dim3(kBlock), lx, st, p, x, pre, Wa, y)
+      switch (S) {
+        case 1: if (p.vec4) MMA_SK(1, true); else MMA_SK(1, false); break;
+        case 2: if (p.vec4) MMA_SK(2, true); else MMA_SK(2, false); break;
+        case 3: if (p.vec4) MMA_SK(3, true); else MMA_SK(3, false); break;
+        case 4: if (p.vec4) MMA_SK(4, true); else MMA_SK(4, false); break;
+        default: if (p.vec4) MMA_SK(5, true); else MMA_SK(5, false); break;
+      }
+#undef MMA_SK
+      return check_launch("tower_post_fwd_x3_kernel (plain)");
+    }
+  }
   const unsigned lds = post_lds_bytes(p.KFp, S, false);
   MMA_REQUIRE(lds <= 160 * 1024, "the weights (%u bytes with the tiles) do not fit the LDS", lds);
   if (p.vec4) { MMA_POST_LAUNCH3(tower_post_fwd_kernel, true, true, lds, x, pre, Wa, y) } else { MMA_POST_LAUNCH3(tower_post_fwd_kernel, true, false, lds, x, pre, Wa, y) }

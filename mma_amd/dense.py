@@ -413,7 +413,9 @@ class _Linear(torch.autograd.Function):
             if addend is not None:
                 add2 = addend.reshape(-1, O)
                 add2 = add2 if add2.stride(1) == 1 else add2.contiguous()
-            with _span("skinny_linear_fwd", nbytes=4 * x2.shape[0] * (K + O * (2 if add2 is not None else 1)), flops=2 * x2.shape[0] * Wa.shape[0] * Wa.shape[1], mfma="f32"):
+            x3 = add2 is None and __import__("os").environ.get("MMA_SKINNY_X3", "1") != "0" and __import__("os").environ.get("MMA_POST_EXACT") != "1"
+            with _span("skinny_linear_fwd", nbytes=4 * x2.shape[0] * (K + O * (2 if add2 is not None else 1)), flops=2 * x2.shape[0] * Wa.shape[0] * Wa.shape[1],
+                       mfma="bf16x6" if x3 else "f32"):
                 call("mma_skinny_linear_fwd", ptr(x2), x2.stride(0), ptr(Wa), ptr(bias.contiguous() if bias is not None else None), ptr(add2),
                      add2.stride(0) if add2 is not None else 0, ptr(y), O, x2.shape[0], K, O, stream_ptr())
             ctx.save_for_backward(x, weight, Wb)

@@ -52,9 +52,13 @@ def test_tower_post_forward_backward_against_float64(N, T, KF, O, scalers):
         assert err <= 2e-5 * ref.abs().max().item() + 1e-7, (what, err, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("x3", ["1", "0"], ids=["bf16x3_forward", "fp32_forward"])
 @pytest.mark.parametrize("N,K,O,bias", [(5000, 75, 75, True), (4097, 50, 80, False), (4200, 128, 16, True), (4500, 3, 1, True), (6000, 129, 33, True)])
-def test_skinny_linear_against_float64(N, K, O, bias):
+def test_skinny_linear_against_float64(N, K, O, bias, x3, monkeypatch):
+    """[r5] the forward runs on three bf16 pieces per operand (the K13 kernel's PLAIN form) by default, MMA_SKINNY_X3=0 (read per call) is
+    the exact-fp32 MFMA kernel: both inside 3e-7 sum|x||w| of float64."""
     from mma_amd import dense
+    monkeypatch.setenv("MMA_SKINNY_X3", x3)
     g = torch.Generator().manual_seed(N + K + O)
     x = torch.randn(N, K, generator=g)
     W = torch.randn(O, K, generator=g) / np.sqrt(K)
