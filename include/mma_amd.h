@@ -451,8 +451,10 @@ int mma_adam_step_grads(const void* table, int64_t n_tensors, int64_t total_chun
  *   resolve to the lowest edge position, like torch_scatter), other_sorted[p] = other[perm[p]] (may be NULL).
  * Replaces the implicit grouping inside torch_scatter.scatter / PyG propagate (mma_conv.py:130,166). */
 /*   long_nodes (may be NULL): mma_gr_long_nodes_len(E) int32 = [count, ids of the nodes whose group holds more than
- *   MMA_GR_LONG_SEGMENT entries ...] (ids in no particular order): K3/K4 hand exactly these segments to their
- *   wave-per-node pass, everything shorter runs in the block kernels. */
+ *   MMA_GR_LONG_SEGMENT entries ..., error flag] (ids in no particular order): K3/K4 hand exactly these segments to their
+ *   wave-per-node pass, everything shorter runs in the block kernels.  The LAST word (ABI 34) is an error flag: zeroed here, set by
+ *   K3 / K4 when they meet a count beyond the list's capacity (1) or an id that is not a node (2) - which they skip; read it
+ *   (outside any graph capture) to learn that a list was clobbered. */
 #define MMA_GR_LONG_SEGMENT 64
 int64_t mma_csr_workspace_bytes(int64_t E, int64_t N);
 int64_t mma_gr_long_nodes_len(int64_t E);

@@ -394,11 +394,9 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
   for (int r = 0; r < 16; ++r) prev[r] = 0.f;
   __amdgpu_buffer_rsrc_t crow_p = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000);
   uint32_t pcol = 0;
-  // [r4] the rows of a unit are requested ONE UNIT AHEAD, before the stores of the unit in between: vmcnt is one in-order counter for
-  // loads and stores, so rows requested at the start of their own unit could only be waited for together with every store the wave had
-  // issued before them - up to 63 of them queued behind a saturated write path, ~5 us per unit with all eight waves of the CU waiting at
-  // once (measurement builds, C4: 1.04 ms with the loads, 0.81 without, 0.75 for the stores alone).  Requested a unit ahead they are
-  // older than the 128 stores that follow, and their wait leaves the youngest 63 of those in flight.
+  // The rows of a unit are requested at the START of their own unit.  vmcnt is one in-order counter for loads and stores, so waiting for
+  // them also waits for every store the wave issued before them (measurement builds, C4: 1.04 ms with the loads, 0.81 without, 0.75 for
+  // the stores alone).
   // [r4, measured and NOT kept] requesting a unit's rows one unit ahead (inline-asm loads, hand-placed vmcnt(63): hipcc otherwise merges
   // the loop's entry and back edge into a vmcnt(14) .. vmcnt(0) ladder, a full drain of the wave's stores per unit) changed nothing:
   // 1.04 -> 1.06-1.12 ms at C4.  Measurement builds (MMA_ABL): the stores alone 0.75 ms, everything but the A loads 0.81, with them

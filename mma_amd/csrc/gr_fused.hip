@@ -317,14 +317,21 @@ __device__ __forceinline__ void gr_node_fwd(const GrParams& p, const DropParams&
 // second pass behind the flat / block kernels when mma_build_csr listed the long segments: one wave per listed node
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void gr_fwd_list_kernel(const GrParams p) {
-  const int count = min(p.long_nodes[0], p.long_cap);    // never walk past the list, whatever the count word holds
+  const int raw_count = p.long_nodes[0];
+  const int count = min(raw_count, p.long_cap);          // never walk past the list, whatever the count word holds -
+  // - but SAY so (round-4 ADVICE: a clobbered count or id would otherwise drop long segments silently): the word behind the list is an
+  // error flag the host reads outside capture (functional.DeviceCSR.check)
+  if ((raw_count < 0 || raw_count > p.long_cap) && blockIdx.x == 0 && threadIdx.x == 0) const_cast<int32_t*>(p.long_nodes)[1 + p.long_cap] = 1;
   if (count <= 0) return;
   const DropParams dp = drop_resolve(p.drop);
   const GrLane l = gr_lane(p, VEC);
   const int stride = (int)gridDim.x * (kBlock / kWave);
   for (int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6))); i < count; i += stride) {
     const int n = __builtin_amdgcn_readfirstlane(p.long_nodes[1 + i]);
-    if ((unsigned)n >= (unsigned)p.N) continue;                                 // (wave-uniform) not a node: nothing is read or written for it
+    if ((unsigned)n >= (unsigned)p.N) {                                         // (wave-uniform) not a node: nothing is read or written for it
+      if ((threadIdx.x & (kWave - 1)) == 0) const_cast<int32_t*>(p.long_nodes)[1 + p.long_cap] = 2;
+      continue;
+    }
     const Seg s = seg_load(p, n);
     const SegIdx i0 = idx_load(p, s.b, s.e, l.lane);
     const Vec<VEC> u0 = l.fused ? ldv<VEC>(p.U + (size_t)n * p.lduv + l.cc) : vzero<VEC>();
@@ -556,14 +563,21 @@ __device__ __forceinline__ void gr_node_bwd(const GrParams& p, const DropParams&
 
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void gr_bwd_list_kernel(const GrParams p) {
-  const int count = min(p.long_nodes[0], p.long_cap);    // never walk past the list, whatever the count word holds
+  const int raw_count = p.long_nodes[0];
+  const int count = min(raw_count, p.long_cap);          // never walk past the list, whatever the count word holds -
+  // - but SAY so (round-4 ADVICE: a clobbered count or id would otherwise drop long segments silently): the word behind the list is an
+  // error flag the host reads outside capture (functional.DeviceCSR.check)
+  if ((raw_count < 0 || raw_count > p.long_cap) && blockIdx.x == 0 && threadIdx.x == 0) const_cast<int32_t*>(p.long_nodes)[1 + p.long_cap] = 1;
   if (count <= 0) return;
   const DropParams dp = drop_resolve(p.drop);
   const GrLane l = gr_lane(p, VEC);
   const int stride = (int)gridDim.x * (kBlock / kWave);
   for (int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6))); i < count; i += stride) {
     const int n = __builtin_amdgcn_readfirstlane(p.long_nodes[1 + i]);
-    if ((unsigned)n >= (unsigned)p.N) continue;
+    if ((unsigned)n >= (unsigned)p.N) {
+      if ((threadIdx.x & (kWave - 1)) == 0) const_cast<int32_t*>(p.long_nodes)[1 + p.long_cap] = 2;
+      continue;
+    }
     const Seg s = seg_load(p, n);
     gr_node_bwd<VEC>(p, dp, l, n, s, idx_load(p, s.b, s.e, l.lane));
   }
@@ -1026,7 +1040,7 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
 // hipMemsetAsync; inside a captured step - where the call becomes a memset NODE - the list kernels of bench.py's C2net graph read a
 // count of 0x03030303 on the fifth replay, bytes that had lived at that address before the capture's pool took it over; [r4])
 __global__ void csr_prepare_kernel(const int64_t* key, int64_t E, int32_t* key32, int32_t* iota, int32_t* long_count) {
-  if (long_count && blockIdx.x == 0 && threadIdx.x == 0) *long_count = 0;
+  if (long_count && blockIdx.x == 0 && threadIdx.x == 0) { *long_count = 0; long_count[E / (kGroupMaxDeg + 1) + 2] = 0; }      // count and error flag
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += (int64_t)gridDim.x * blockDim.x) {
     key32[i] = (int32_t)key[i];
     iota[i] = (int32_t)i;
@@ -1206,7 +1220,9 @@ extern "C" int64_t mma_csr_workspace_bytes(int64_t E, int64_t N) {
   return (int64_t)(3 * align256((size_t)E * 4) + align256(temp) + 256);
 }
 
-extern "C" int64_t mma_gr_long_nodes_len(int64_t E) { return E < 0 ? -1 : E / (kGroupMaxDeg + 1) + 2; }
+// [count | ids (capacity E / 65 + 1) | error flag]: the flag (ABI 34) is zeroed by mma_build_csr and set by K3 / K4's list passes when the
+// count word exceeds the capacity (1) or an id is not a node (2) - the cases they refuse to believe
+extern "C" int64_t mma_gr_long_nodes_len(int64_t E) { return E < 0 ? -1 : E / (kGroupMaxDeg + 1) + 3; }
 
 extern "C" int mma_build_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N, int32_t* rowptr, int32_t* perm,
                              int32_t* other_sorted, int32_t* long_nodes, void* workspace, int64_t workspace_bytes, void* stream) {

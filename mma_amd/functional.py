@@ -395,6 +395,21 @@ class DeviceCSR:
                  ptr(self.perm), ptr(self.other) if other is not None else None, ptr(self.long_nodes), ptr(ws), ws.numel(), stream_ptr())
 
 
+def _csr_check(self):
+    """Host-side check of the long-segment list's error flag (one small device-to-host copy: call it OUTSIDE timed or captured regions).
+    K3 / K4 skip a list whose count word or ids cannot be right instead of walking off it - and leave a flag so that the skip is not
+    silent (round-4 ADVICE)."""
+    if self.long_nodes is None:
+        return
+    flag = int(self.long_nodes[-1].item())
+    if flag:
+        raise _lib.MMALibraryError("mma_amd: the long-segment list of this CSR was clobbered (%s): aggregates of segments above 64 edges "
+                                   "were skipped" % ("count beyond the list's capacity" if flag == 1 else "an id that is not a node"))
+
+
+DeviceCSR.check = _csr_check
+
+
 class GRGraph:
     """Both groupings of one edge_index (by target for the forward, by source for dV), built lazily, cached per
     edge_index tensor by the caller."""

@@ -498,3 +498,64 @@ def test_pack_blocks_against_numpy():
     want[2][1] = a[2][1]
     assert np.array_equal(f, want)
     assert np.array_equal(keep.cpu().numpy(), 1.0 + a[1])
+
+
+@pytest.mark.parametrize("aggs,p,by_hub", [(["min", "max"], 0.5, False), (["sum", "mean", "max"], 0.0, False), (["min", "max"], 0.3, True)])
+def test_backward_row_maxima_bound_the_rows_they_stand_for(aggs, p, by_hub):
+    """[r5] K4 and the dV segment sum leave the row scales of the three-product GEMMs behind them (mma_gr_fused_bwd's gmsg_row_max /
+    gu_row_max, mma_csr_spmm_rm).  A scale below the true maximum would overflow the fp16 pieces, a scale far above it would waste their
+    bits: every entry must be >= max |row| (message gradients: a per-node BOUND; dL/dU and dL/dV: exact) and, over the rows that carry a
+    gradient, the message-gradient bounds must stay within a factor 8 of the true maxima for all but a few rows.  A 150-edge hub goes
+    through the wave-per-node list pass (exact maxima there)."""
+    from mma_amd import functional as Fn
+    from mma_amd._lib import call, ptr, stream_ptr
+    from mma_amd.functional import GR_AGGR, GR_SCALER, host_codes
+    rng = np.random.default_rng(3)
+    ei, N = molecule_batch(rng, 40)
+    if by_hub:
+        extra = np.stack([rng.integers(0, N, 150), np.full(150, 7)])
+        ei = np.concatenate([ei, extra], 1)
+    E = ei.shape[1]
+    T, F = 5, 76
+    D = T * F
+    graph = Fn.gr_graph(torch.from_numpy(ei).to(DEV), N)
+    csr = graph.by_target
+    g = torch.Generator().manual_seed(1)
+    UV = torch.randn(N, 2 * D, generator=g).to(DEV)
+    Z = torch.randn(E, D, generator=g).to(DEV)
+    aggr, scal = tuple(GR_AGGR[a] for a in aggs), (GR_SCALER["identity"],)
+    K = len(aggr)
+    drop = Fn.DropoutSpec(p, seed=77)
+    out = torch.empty((N, T, K * F), device=DEV)
+    amin = torch.empty((N, D), dtype=torch.uint8, device=DEV) if 2 in aggr else None
+    amax = torch.empty((N, D), dtype=torch.uint8, device=DEV) if 3 in aggr else None
+    side = int(Fn._lib.lib().mma_gr_arg_side_rows(E))
+    amin_s = torch.empty((side, D), dtype=torch.int32, device=DEV) if amin is not None else None
+    amax_s = torch.empty((side, D), dtype=torch.int32, device=DEV) if amax is not None else None
+    Fn._gr_call("mma_gr_fused_fwd", csr, UV[:, :D], UV[:, D:], Z, True, None,
+                (ptr(out), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), None, None, D, ptr(csr.long_nodes)), N, E, T, F, aggr, scal, 1.0, 2.0, drop)
+    gout = torch.randn(N, T, K * F, generator=g).to(DEV) * torch.exp(torch.randn(N, 1, 1, generator=g) * 2).to(DEV)      # rows of very different size
+    gmsg = torch.full((E, D), float("nan"), device=DEV)
+    gUV = torch.full((N, 2 * D), float("nan"), device=DEV)
+    rm = torch.zeros(E + N, device=DEV)
+    Fn._gr_call("mma_gr_fused_bwd", csr, UV[:, :D], UV[:, D:], Z, True, None,
+                (ptr(gout), ptr(amin), ptr(amax), ptr(amin_s), ptr(amax_s), None, None, D, ptr(csr.long_nodes), ptr(gmsg), D, ptr(gUV), 2 * D,
+                 ptr(rm[:E]), ptr(rm[E:])), N, E, T, F, aggr, scal, 1.0, 2.0, drop)
+    csr.check()
+    true_m = gmsg.abs().amax(1)
+    assert not torch.isnan(gmsg).any() and bool((rm[:E] >= true_m).all()), "a message-gradient bound below its row's maximum"
+    live = true_m > 0
+    ratio = rm[:E][live] / true_m[live]
+    assert float((ratio > 8).float().mean()) < 0.02, ("bounds too loose", float(ratio.max()), float((ratio > 8).float().mean()))
+    print("message-gradient row bounds / true maxima: median %.2f, 99 %% %.2f, max %.1f" % (
+        float(ratio.median()), float(ratio.quantile(0.99)), float(ratio.max())))
+    assert torch.equal(rm[E:], gUV[:, :D].abs().amax(1)), "dL/dU row maxima are exact"
+    cs = graph.by_source
+    call("mma_csr_spmm_rm", ptr(cs.rowptr), ptr(graph.by_source_pos), None, ptr(gmsg), D, E, 1, None, ptr(gUV[:, D:]), 2 * D, N, D, ptr(rm[E:]),
+         stream_ptr())
+    assert not torch.isnan(gUV).any()
+    assert torch.equal(rm[E:], gUV.abs().amax(1)), "[dL/dU | dL/dV] row maxima after the segment sum are exact"
+    # the same segment sum without the maxima: same bits
+    gV2 = torch.empty((N, D), device=DEV)
+    call("mma_csr_spmm", ptr(cs.rowptr), ptr(graph.by_source_pos), None, ptr(gmsg), D, E, 1, None, ptr(gV2), D, N, D, stream_ptr())
+    assert torch.equal(gV2, gUV[:, D:])

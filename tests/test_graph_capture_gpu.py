@@ -309,12 +309,22 @@ def test_csr_build_inside_a_graph_rezeroes_the_long_list_and_a_bad_count_is_not_
         out.sum().backward()
         return out.detach().clone(), UV.grad.clone()
     ref = run()
+    conv_graph.by_target.check()                               # a healthy list: the error flag behind it is clear
     ln = conv_graph.by_target.long_nodes
-    assert int(ln[0]) == 0
-    ln.fill_(0x7f7f7f7f)                                      # count and ids: garbage far beyond the list and beyond N
+    assert int(ln[0]) == 0 and int(ln[-1]) == 0
+    ln[:-1].fill_(0x7f7f7f7f)                                 # count and ids: garbage far beyond the list and beyond N
     got = run()
     ln[0] = 0
     assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+    # [r5] ... and the skip is not silent (round-4 ADVICE): the list kernels raised the flag behind the list, check() reports it
+    assert int(ln[-1]) == 1
+    with pytest.raises(mma_amd._lib.MMALibraryError, match="clobbered"):
+        conv_graph.by_target.check()
+    ln[-1] = 0
+    ln[0] = 3; ln[1:4] = N + 7                                # a believable count, ids that are not nodes
+    got = run()
+    assert torch.equal(ref[0], got[0]) and int(ln[-1]) == 2
+    ln[0] = 0; ln[-1] = 0
 
 
 def test_bench_c2net_flow_eager_phase_then_graphed_step_replays_without_a_fault():
