@@ -196,8 +196,11 @@ __host__ inline void drop_set_threshold(DropParams* d, int mode, uint32_t thr16)
   else { d->mode = mode; d->thr = mode == MMA_DROP_HASH ? (thr16 >> 8) : thr16; }
 }
 
-// max over the ACTIVE lanes of a wavefront of a non-negative value (inactive lanes read as 0: bound_ctrl), in every active lane:
-// four DPP steps inside the 16-lane row, one swizzle across the two rows of a half, one bpermute across the halves
+// max over the lanes of a FULLY ACTIVE wavefront of a non-negative value, in every lane: four DPP steps inside the 16-lane row (two quad
+// permutes, two mirrors), one swizzle across the two rows of a half, one bpermute across the halves.  ONLY with all 64 lanes active: a
+// mirror step hands a lane nothing when its partner is inactive, and the maximum then never reaches the lanes below (found in round 5:
+// with lanes 60..63 off, a maximum held by lanes 56..59 did not reach lane 0 - callers test `__ballot(1) == ~0ull` and fall back to
+// per-lane merges)
 __device__ __forceinline__ float wave_max_nonneg(float m) {
   m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xF, 0xF, true)));
   m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x4E, 0xF, 0xF, true)));

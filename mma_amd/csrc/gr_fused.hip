@@ -961,7 +961,7 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
 #pragma unroll
       for (int x = 0; x < 4; ++x) m = fmaxf(m, fabsf(c_all[x]) + fabsf(c_min[x]) + fabsf(c_max[x]));
       if (DROP) m *= dp.scale;
-      const bool uni = __all(dn == __builtin_amdgcn_readfirstlane(dn));
+      const bool uni = (__all(dn == __builtin_amdgcn_readfirstlane(dn)) && __ballot(1) == ~0ull);
       const bool elect = (int)(threadIdx.x & (kWave - 1)) == __builtin_amdgcn_readfirstlane((int)(threadIdx.x & (kWave - 1)));
       if (uni) m = wave_max_nonneg(m);
       if (m > 0.f && (!uni || elect)) atomicMax(&rmax_b[dn], __float_as_uint(m));
@@ -982,7 +982,7 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
     const int b = L.rowptr[dn], deg = L.rowptr[dn + 1] - b;
     // dL/dU row maxima (exact): when all active lanes of the wavefront work on ONE node the maximum is formed across the lanes first -
     // one LDS merge per wavefront and row instead of one per lane (64 lanes merging into the same word serialise)
-    const bool uni = want_rmax && __all(dn == __builtin_amdgcn_readfirstlane(dn));
+    const bool uni = want_rmax && (__all(dn == __builtin_amdgcn_readfirstlane(dn)) && __ballot(1) == ~0ull);
     const bool elect = (int)(threadIdx.x & (kWave - 1)) == __builtin_amdgcn_readfirstlane((int)(threadIdx.x & (kWave - 1)));
     if (deg > kGroupMaxDeg) continue;
     Vec<4> su = vzero<4>();                                   // dL/dU[node]: the sum of the segment's message gradients, in position order

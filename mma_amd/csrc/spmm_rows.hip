@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void segsum_block_kernel(const SegSumParams
     *reinterpret_cast<float4*>(seg_out + (size_t)dn * p.C + c) = acc;
     if (p.rowmax && deg <= kSegLong) {
       float m = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
-      const bool uni = __all(dn == __builtin_amdgcn_readfirstlane(dn));
+      const bool uni = (__all(dn == __builtin_amdgcn_readfirstlane(dn)) && __ballot(1) == ~0ull);
       const bool elect = (int)(threadIdx.x & (kWave - 1)) == __builtin_amdgcn_readfirstlane((int)(threadIdx.x & (kWave - 1)));
       if (uni) m = wave_max_nonneg(m);
       if (m > 0.f && (!uni || elect)) atomicMax(&s_rm[dn], __float_as_uint(m));

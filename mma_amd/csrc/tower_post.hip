@@ -265,11 +265,42 @@ __global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams
   post_stage_weights(Wl, Wb + (size_t)t * R * wb_pitch, R * wb_pitch);
   __syncthreads();               // weights staged: the only workgroup barrier
   const int j = lane & 15, kq = lane >> 4;
-  for (int rt = 0; rt < p.tiles_per_wave; ++rt) {
+  // [r5] the raw inputs of a tile (this lane's four gy values and S scaler products per 16-node tile: 28 dwords) are requested ONE TILE
+  // AHEAD, by unconditional loads from clamped addresses (zeroed by selects at use): a tile is 5 x 96 MFMAs = 6.4 us, its inputs used to be
+  // requested and waited for at its start - 2 us of every 8.4 with nothing to multiply (SQ: 52 % of the wave cycles waiting on instruction
+  // dependencies).  PLAIN: R/4 dwords of gy per node tile.
+  constexpr int NG = PLAIN ? R / 4 : 4;
+  constexpr int NSETS = PLAIN ? 1 : 2;                         // PLAIN (K16: one tile per wave at C2L, 20 dwords per node tile): no second set
+  float rg[NSETS][4][NG], rp[NSETS][4][PLAIN ? 1 : S];
+  auto fetch = [&](int rt_, float (&g_)[4][NG], float (&p_)[4][PLAIN ? 1 : S]) {
+    const int64_t nb_ = (bx * (kBlock / kWave) + wave) * p.tiles_per_wave + rt_;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int64_t node = min(nb_ * kWave + nt * 16 + j, p.N - 1);
+      if (PLAIN) {
+#pragma unroll
+        for (int s = 0; s < NG; ++s) g_[nt][s] = gy[(size_t)node * p.ldg + min(4 * s + kq, p.O - 1)];
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) g_[nt][m] = gy[(size_t)node * p.ldg + (size_t)t * p.O + min(4 * m + kq, p.O - 1)];
+#pragma unroll
+        for (int q = 0; q < (PLAIN ? 1 : S); ++q) p_[nt][q] = pre_tab[(size_t)node * kPostPrePitch + q];
+      }
+    }
+  };
+  if (!PLAIN) fetch(0, rg[0], rp[0]);
+#pragma unroll 1
+  for (int rt2 = 0; rt2 < p.tiles_per_wave; rt2 += NSETS) {
+#pragma unroll
+  for (int par = 0; par < NSETS; ++par) {                       // two tiles per trip: the raw sets alternate without register copies
+  const int rt = rt2 + par;
+  if (rt >= p.tiles_per_wave) break;
   const int64_t nblk = (bx * (kBlock / kWave) + wave) * p.tiles_per_wave + rt;
   const bool tvalid = nblk * kWave < p.N;
   if (!tvalid) break;
   const int64_t n0 = nblk * kWave;
+  constexpr int ps = PLAIN ? 0 : 1;                             // set index = par * ps
+  if (PLAIN) fetch(rt, rg[0], rp[0]);
   // B fragments: this lane's node (per 16-node tile nt) and its k index kq: gys[node][4*s + kq], s = 0 .. R/4 - 1
   float bf[4][R / 4];
 #pragma unroll
@@ -278,23 +309,21 @@ __global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams
     const bool valid = tvalid && node < p.N;
     if (PLAIN) {
 #pragma unroll
-      for (int s = 0; s < R / 4; ++s) bf[nt][s] = (valid && 4 * s + kq < p.O) ? gy[(size_t)node * p.ldg + 4 * s + kq] : 0.f;
+      for (int s = 0; s < R / 4; ++s) bf[nt][s] = (valid && 4 * s + kq < p.O) ? rg[0][nt][s % NG] : 0.f;
       continue;
     }
-    float pre[S];
-#pragma unroll
-    for (int q = 0; q < S; ++q) pre[q] = pre_tab[(size_t)min(node, p.N - 1) * kPostPrePitch + q];
     // r = 4*s + kq  ->  o = r % 16 = 4*(s % 4) + kq,  q = s / 4: the lane needs gy[o] for o = kq, 4 + kq, 8 + kq, 12 + kq
     float g4[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) g4[m] = (valid && 4 * m + kq < p.O) ? gy[(size_t)node * p.ldg + (size_t)t * p.O + 4 * m + kq] : 0.f;
+    for (int m = 0; m < 4; ++m) g4[m] = (valid && 4 * m + kq < p.O) ? rg[par * ps][nt][m % NG] : 0.f;
 #pragma unroll
-    for (int s = 0; s < R / 4; ++s) bf[nt][s] = pre[s / 4] * g4[s % 4];
+    for (int s = 0; s < R / 4; ++s) bf[nt][s] = rp[par * ps][nt][(s / 4) % (PLAIN ? 1 : S)] * g4[s % 4];
     if (gys && valid) {          // the left operand of the weight-gradient product; 4-byte stores, 16 lanes of a node tile cover 64 B runs
 #pragma unroll
       for (int s = 0; s < R / 4; ++s) gys[(size_t)node * p.ldgs + (size_t)t * R + 4 * s + kq] = bf[nt][s];
     }
   }
+  if (!PLAIN && rt + 1 < p.tiles_per_wave) fetch(rt + 1, rg[(1 - par) * ps], rp[(1 - par) * ps]);       // in flight behind this tile's MFMAs
   for (int kf0 = 0; kf0 < p.KFp; kf0 += kPostTile) {
     post_f32x4 acc[2][4];        // two 16-row kf tiles x four node tiles
 #pragma unroll
@@ -341,6 +370,7 @@ __global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams
     }
     post_wave_sync();
   }
+  }   // the pair
   }   // tiles of this wave
 }
 
