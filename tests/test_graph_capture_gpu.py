@@ -317,7 +317,7 @@ def test_csr_build_inside_a_graph_rezeroes_the_long_list_and_a_bad_count_is_not_
     ln[0] = 0
     assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
     # [r5] ... and the skip is not silent (round-4 ADVICE): the list kernels raised the flag behind the list, check() reports it
-    assert int(ln[-1]) == 1
+    assert int(ln[-1]) in (1, 2)                               # the count beyond the capacity (1), then the garbage ids it did walk (2)
     with pytest.raises(mma_amd._lib.MMALibraryError, match="clobbered"):
         conv_graph.by_target.check()
     ln[-1] = 0
