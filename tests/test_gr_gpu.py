@@ -559,3 +559,94 @@ def test_backward_row_maxima_bound_the_rows_they_stand_for(aggs, p, by_hub):
     gV2 = torch.empty((N, D), device=DEV)
     call("mma_csr_spmm", ptr(cs.rowptr), ptr(graph.by_source_pos), None, ptr(gmsg), D, E, 1, None, ptr(gV2), D, N, D, stream_ptr())
     assert torch.equal(gV2, gUV[:, D:])
+
+
+# ---- the HIP path against the REFERENCE'S OWN MODULE CODE (round 5) ------------------------------------------------------------------------
+from gr_golden_util import GR_FIXTURES, GRFixture  # noqa: E402
+
+
+def _load_reference_parameters(conv, fx):
+    """Copy the fixture's parameters (the reference module's own, as its constructor drew them) into the drop-in module."""
+    last = fx.cfg["aggregators"][-1]
+    with torch.no_grad():
+        for t in range(fx.T):
+            pre = [m.active_linear() for m in conv.pre_nns[last][t] if hasattr(m, "active_linear")]
+            post = [m for m in conv.post_nns[t] if hasattr(m, "weight")]
+            assert len(pre) == fx.pre_layers and len(post) == fx.post_layers
+            for li, l in enumerate(pre):
+                l.weight.copy_(fx.t("param/pre_w/%d/%d" % (t, li))); l.bias.copy_(fx.t("param/pre_b/%d/%d" % (t, li)))
+            for li, l in enumerate(post):
+                l.weight.copy_(fx.t("param/post_w/%d/%d" % (t, li))); l.bias.copy_(fx.t("param/post_b/%d/%d" % (t, li)))
+        conv.lin.weight.copy_(fx.t("param/lin_w")); conv.lin.bias.copy_(fx.t("param/lin_b"))
+        if fx.has("param/enc_w"):
+            conv.edge_encoder.weight.copy_(fx.t("param/enc_w")); conv.edge_encoder.bias.copy_(fx.t("param/enc_b"))
+
+
+def _drop_in_parameters(conv, fx):
+    last = fx.cfg["aggregators"][-1]
+    out = {}
+    for t in range(fx.T):
+        for li, l in enumerate(m.active_linear() for m in conv.pre_nns[last][t] if hasattr(m, "active_linear")):
+            out["pre_w/%d/%d" % (t, li)], out["pre_b/%d/%d" % (t, li)] = l.weight, l.bias
+        for li, l in enumerate(m for m in conv.post_nns[t] if hasattr(m, "weight")):
+            out["post_w/%d/%d" % (t, li)], out["post_b/%d/%d" % (t, li)] = l.weight, l.bias
+    out["lin_w"], out["lin_b"] = conv.lin.weight, conv.lin.bias
+    if fx.has("param/enc_w"):
+        out["enc_w"], out["enc_b"] = conv.edge_encoder.weight, conv.edge_encoder.bias
+    return out
+
+
+@pytest.mark.parametrize("tag", ["p0", "p50"])
+@pytest.mark.parametrize("name", GR_FIXTURES)
+def test_mmaconv_against_the_reference_module_run(name, tag):
+    """The drop-in mma_amd.MMAConv on the HIP path against what the reference's OWN graph_regression/mma_conv.py computed (tests/golden/
+    gr_*.npz: the reference module executed on CPU over stand-ins for its absent third-party imports - tests/golden/gen_gr_golden.py): the
+    same parameters, inputs and cotangent; layer output, dL/dx, dL/d(edge_attr) and every parameter gradient.  p50 replays the reference's
+    always-on dropout (mma_conv.py:157) from the keep mask the kernels' counter hash generates for the fixture's seed, so the HIP path runs
+    in HASH mode (not with an explicit mask).  Bars: golden_util.check_close - strict for the output, the data-following noise bar (float64
+    oracle run as the truth) for the gradients."""
+    import mma_amd
+    from mma_amd import functional as Fn
+    from oracle import gr_oracle as G
+    fx = GRFixture(name)
+    c = fx.cfg
+    if tag == "p50" and fx.pre_layers > 1:
+        pytest.skip("pre_layers > 1 runs the reference's own message() on torch ops: its F.dropout draws from torch's generator (INTEGRATION.md 1)")
+    torch.manual_seed(0)
+    conv = mma_amd.MMAConv(fx.cin, fx.cout, c["aggregators"], c["scalers"], fx.t("hist", torch.int64), edge_dim=c["edge_dim"], towers=fx.T,
+                           pre_layers=fx.pre_layers, post_layers=fx.post_layers, divide_input=fx.divide_input).to(DEV)
+    assert abs(conv.avg_deg["lin"] - fx.avg_deg["lin"]) < 1e-6 and abs(conv.avg_deg["log"] - fx.avg_deg["log"]) < 1e-6      # G8, the reference's own attribute
+    _load_reference_parameters(conv, fx)
+    p = 0.0 if tag == "p0" else fx.p
+    conv.dropout = p
+    conv.drop_override = Fn.DropoutSpec(p, seed=fx.seed)
+    x = fx.t("x").to(DEV).requires_grad_(True)
+    ea = fx.t("edge_attr").to(DEV).requires_grad_(True) if fx.has("edge_attr") else None
+    prm = _drop_in_parameters(conv, fx)
+    out = conv(x, fx.t("edge_index", torch.int64).to(DEV), ea)
+    leaves = [x] + ([ea] if ea is not None else []) + list(prm.values())
+    # .backward() + .grad, not autograd.grad: the unregistered mask Linears (G2) receive their gradient as an accumulating .grad written by
+    # the K18 unpack launch (a fresh module: .grad starts from nothing, one backward leaves the gradient itself)
+    (out * fx.t("cot").to(DEV)).sum().backward()
+    grads = [q.grad for q in leaves]
+    # float64 truth from the oracle (itself pinned to these fixtures by tests/test_gr_oracle.py)
+    prm64, flat64 = fx.oracle_params(torch.float64, requires_grad=True)
+    x64 = fx.t("x", torch.float64).requires_grad_(True)
+    ea64 = fx.t("edge_attr", torch.float64).requires_grad_(True) if ea is not None else None
+    keep = fx.t("keep", torch.float64) if tag == "p50" else None
+    o64 = G.conv_forward(x64, fx.t("edge_index", torch.int64), ea64, prm64, c["aggregators"], c["scalers"], fx.avg_deg, fx.T, fx.divide_input, keep, p)
+    g64 = torch.autograd.grad((o64 * fx.t("cot", torch.float64)).sum(), [x64] + ([ea64] if ea64 is not None else []) + list(flat64.values()),
+                              allow_unused=True)
+    what = "refmod/%s/%s/" % (name, tag)
+    check_close(out, fx.d[tag + "/out"], None, None, what=what + "out", signed_sum=True, truth=o64.detach().numpy())
+    check_close(grads[0], fx.d[tag + "/gx"], None, None, what=what + "gx", signed_sum=True, truth=g64[0].numpy())
+    k0 = 1
+    if ea is not None:
+        check_close(grads[1], fx.d[tag + "/gea"], None, None, what=what + "gea", signed_sum=True, truth=g64[1].numpy())
+        k0 = 2
+    assert list(prm.keys()) == list(flat64.keys())
+    for key, g, t64 in zip(prm.keys(), grads[k0:], g64[k0:]):
+        want = fx.d[tag + "/g/" + key]
+        got = g if g is not None else torch.zeros(want.shape, device=DEV)
+        check_close(got, want, None, None, what=what + "g/" + key, signed_sum=True,
+                    truth=(t64 if t64 is not None else torch.zeros(want.shape, dtype=torch.float64)).numpy())

@@ -4,6 +4,7 @@
 import math
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import gr_oracle as G
@@ -94,3 +95,47 @@ def test_two_scatter_restatements_agree_on_ties_and_empty_targets():
                 assert (arg[max(N - 2, 1):] == -1).all() and (b[max(N - 2, 1):] == 0).all()     # empty targets: 0, no arg
             else:
                 assert np.allclose(a.detach().numpy(), b, rtol=1e-6, atol=1e-6), (trial, red)     # summation order differs
+
+
+# ---- the oracle against the REFERENCE'S OWN MODULE CODE (round 5) ------------------------------------------------------------------------
+from gr_golden_util import GR_FIXTURES, GRFixture  # noqa: E402
+
+
+def test_gr_fixtures_exist():
+    assert len(GR_FIXTURES) >= 4, "tests/golden/gr_*.npz missing: python tests/golden/gen_gr_golden.py (build container only)"
+
+
+@pytest.mark.parametrize("tag", ["p0", "p50"])
+@pytest.mark.parametrize("name", GR_FIXTURES)
+def test_oracle_matches_the_reference_module_run(name, tag):
+    """tests/golden/gr_*.npz hold what graph_regression/mma_conv.py::MMAConv (+ mask_aggr.py) computed in the build container - the
+    reference's own __init__ / forward / message / aggregate executed on CPU over stand-ins for torch_scatter.scatter and PyG's
+    MessagePassing / Linear / degree (tests/golden/gen_gr_golden.py states exactly what the stand-ins restate).  The oracle restatement
+    must reproduce the layer output, dL/dx, dL/d(edge_attr) and EVERY parameter gradient within the strict bar 1e-5 + 1e-5 |ref|
+    (both sides are fp32 torch-CPU: they differ by summation order only), without dropout and with the recorded keep mask: this pins
+    the oracle's reading of G1 (last aggregator's pre-NN), G4 (always-on dropout), G7 (compounding scalers), G8 (avg_deg from the
+    histogram values), the tower layout and the multi-layer stacks to the reference's own control flow."""
+    fx = GRFixture(name)
+    c = fx.cfg
+    prm, flat = fx.oracle_params(requires_grad=True)
+    x = fx.t("x").requires_grad_(True)
+    ea = fx.t("edge_attr").requires_grad_(True) if fx.has("edge_attr") else None
+    p = 0.0 if tag == "p0" else fx.p
+    keep = fx.t("keep") if tag == "p50" else None
+    assert abs(G.avg_deg_from_histogram(fx.t("hist", torch.int64))["lin"] - fx.avg_deg["lin"]) < 1e-12          # G8, from the reference's own attribute
+    assert abs(G.avg_deg_from_histogram(fx.t("hist", torch.int64))["log"] - fx.avg_deg["log"]) < 1e-6
+    out = G.conv_forward(x, fx.t("edge_index", torch.int64), ea, prm, c["aggregators"], c["scalers"], fx.avg_deg, fx.T, fx.divide_input, keep, p)
+    leaves = [x] + ([ea] if ea is not None else []) + list(flat.values())
+    grads = torch.autograd.grad((out * fx.t("cot")).sum(), leaves, allow_unused=True)
+
+    def close(got, key):
+        want = fx.t(key)
+        got = torch.zeros_like(want) if got is None else got
+        err = (got.detach() - want).abs()
+        assert bool((err <= 1e-5 + 1e-5 * want.abs()).all()), (name, key, float(err.max()), float(want.abs().max()))
+    close(out, tag + "/out")
+    close(grads[0], tag + "/gx")
+    if ea is not None:
+        close(grads[1], tag + "/gea")
+    for k, g in zip(flat.keys(), grads[(2 if ea is not None else 1):]):
+        close(g, tag + "/g/" + k)
