@@ -1164,7 +1164,7 @@ def _bcast_cpu(q, dist):
 
 
 def gr_cpu_baseline(n_graphs):
-    """The GR CPU oracle (oracle/gr_oracle.conv_forward, parity unpinned - see its header) fwd+bwd on a small batch."""
+    """The GR CPU oracle (oracle/gr_oracle.conv_forward, pinned to the reference module run over third-party stand-ins - see its header) fwd+bwd on a small batch."""
     from oracle import gr_oracle as G
     threads = _threads()
     rng = np.random.default_rng(1)
