@@ -233,6 +233,27 @@ def main():
         np.savez_compressed(path, **out_blob)
         print("wrote %s: N=%d E=%d, %d arrays, %.0f KB, |out| max %.3g" % (path, N, E, len(out_blob), os.path.getsize(path) / 1024,
                                                                       float(np.abs(out_blob["p50/out"]).max())))
+    if only in "graggr_all":
+        # MMAConv.aggregate() called directly (mma_conv.py:159-196): the only way to its var / std branch (forward() raises on
+        # those names first) - all six aggregators x all five scalers on given messages, targets 5 and 11 empty, one tie-heavy column
+        rng = np.random.default_rng(77)
+        aggs = ["sum", "mean", "min", "max", "var", "std"]
+        scal = ["identity", "amplification", "attenuation", "linear", "inverse_linear"]
+        T, Fi, N, E = 2, 6, 14, 60
+        conv = R.MMAConv(Fi, Fi * T, ["sum"], scal, torch.tensor([0, 3, 9, 5, 2]), towers=T)
+        conv.aggregators = aggs                                  # aggregate() walks the attribute
+        index = torch.from_numpy(rng.choice([i for i in range(N) if i not in (5, 11)], E))
+        inp = rng.standard_normal((E, T, Fi)).astype(np.float32)
+        inp[:, 0, 0] = rng.integers(-2, 3, E)                    # ties: the first extremal edge must win, alone
+        inputs = torch.from_numpy(inp).requires_grad_(True)
+        out = conv.aggregate(inputs, index, N)
+        cot = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32))
+        (out * cot).sum().backward()
+        path = os.path.join(HERE, "graggr_all.npz")
+        np.savez_compressed(path, inputs=inp, index=index.numpy(), N=np.int64(N), cot=cot.numpy(), out=out.detach().numpy(), ginputs=inputs.grad.numpy(),
+                            avg_deg_lin=np.float64(conv.avg_deg["lin"]), avg_deg_log=np.float64(conv.avg_deg["log"]),
+                            meta=np.array(repr(dict(aggregators=aggs, scalers=scal, towers=T, F=Fi, hist=[0, 3, 9, 5, 2]))))
+        print("wrote %s: out %s, |out| max %.3g" % (path, tuple(out.shape), float(out.abs().max())))
 
 
 if __name__ == "__main__":

@@ -650,3 +650,21 @@ def test_mmaconv_against_the_reference_module_run(name, tag):
         got = g if g is not None else torch.zeros(want.shape, device=DEV)
         check_close(got, want, None, None, what=what + "g/" + key, signed_sum=True,
                     truth=(t64 if t64 is not None else torch.zeros(want.shape, dtype=torch.float64)).numpy())
+
+
+def test_aggregate_against_the_reference_aggregate_with_var_and_std():
+    """MMAConv.aggregate() on the HIP path (K3/K4 in given-messages mode, generic kernels: var / std) against the reference's own aggregate()
+    (tests/golden/graggr_all.npz, see tests/test_gr_oracle.py): six aggregators x five compounding scalers, empty targets, ties."""
+    import ast
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graggr_all.npz"))
+    c = ast.literal_eval(str(d["meta"]))
+    conv = make_conv(["sum"], c["scalers"], towers=c["towers"], F=c["F"], hist=tuple(c["hist"]))
+    conv.aggregators = c["aggregators"]
+    assert abs(conv.avg_deg["lin"] - float(d["avg_deg_lin"])) < 1e-6 and abs(conv.avg_deg["log"] - float(d["avg_deg_log"])) < 1e-6
+    inputs = torch.from_numpy(d["inputs"]).to(DEV).requires_grad_(True)
+    out = conv.aggregate(inputs, torch.from_numpy(d["index"]).to(DEV), int(d["N"]))
+    g, = torch.autograd.grad((out * torch.from_numpy(d["cot"]).to(DEV)).sum(), [inputs])
+    check_close(out, d["out"], None, None, what="refmod/aggregate/out")
+    check_close(g, d["ginputs"], None, None, what="refmod/aggregate/ginputs", signed_sum=True)
+    assert torch.equal((g[:, 0, 0] != 0).cpu(), torch.from_numpy(d["ginputs"])[:, 0, 0] != 0)        # ties: the same single edge

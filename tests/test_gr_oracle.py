@@ -139,3 +139,24 @@ def test_oracle_matches_the_reference_module_run(name, tag):
         close(grads[1], tag + "/gea")
     for k, g in zip(flat.keys(), grads[(2 if ea is not None else 1):]):
         close(g, tag + "/g/" + k)
+
+
+def test_oracle_aggregate_matches_the_reference_aggregate_with_var_and_std():
+    """tests/golden/graggr_all.npz: the reference's MMAConv.aggregate() (mma_conv.py:159-196) called directly - the only way to its var / std
+    branch - with all six aggregators and all five compounding scalers on given messages (two empty targets, a tie-heavy
+    column).  Output and the gradient of the messages within the strict bar."""
+    import ast
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graggr_all.npz"))
+    c = ast.literal_eval(str(d["meta"]))
+    inputs = torch.from_numpy(d["inputs"]).requires_grad_(True)
+    out = G.aggregate(inputs, torch.from_numpy(d["index"]), int(d["N"]), c["aggregators"], c["scalers"],
+                      {"lin": float(d["avg_deg_lin"]), "log": float(d["avg_deg_log"])})
+    g, = torch.autograd.grad((out * torch.from_numpy(d["cot"])).sum(), [inputs])
+    for got, key in ((out.detach(), "out"), (g, "ginputs")):
+        want = torch.from_numpy(d[key])
+        err = (got - want).abs()
+        assert got.shape == want.shape and bool((err <= 1e-5 + 1e-5 * want.abs()).all()), (key, float(err.max()))
+    # ties: the tie-heavy column hands every target's max / min gradient to exactly ONE edge
+    gt = torch.from_numpy(d["ginputs"])
+    assert torch.equal(g[:, 0, 0] != 0, gt[:, 0, 0] != 0)
