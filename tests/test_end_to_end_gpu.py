@@ -98,3 +98,20 @@ def test_bench_default_run_ends_with_one_compact_strict_metric_line():
     assert d["roofline"]["kernel"] in ("nc_fused_fwd", "nc_fused_bwd") and d["roofline"]["frac"] > 0.5
     assert set(det["extra"]) >= {"C1", "C3", "C2", "C2L", "C5shard"} and not any("error" in v for v in det["extra"].values()), det["extra"]
     assert abs(d["value"] - d["config"]["edges"] / d["ms_per_step"] * 1e3) <= 1e-3 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_c2l_line_is_compact_strict_and_names_the_fused_gr_kernel():
+    """`python bench.py --workload c2l` (the graph-regression leg): the same contract for its line - one strict-JSON line < 4096 bytes with
+    `roofline` (K3 / K4 by their algorithmic bytes) and `cpu_baseline` (the GR oracle on a small batch); the per-call table is on stderr."""
+    import subprocess
+    import sys
+    from bench_util import parse_bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "c2l", "--molecules", "2000", "--steps", "3", "--warmup", "1"], capture_output=True,
+                       text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d, det = parse_bench(r, need_cpu=True)
+    assert d["scaling"] == "weak" and d["roofline"]["kernel"] in ("gr_fused_fwd", "gr_fused_bwd") and d["roofline_other"]["kernel"].startswith("gr_fused")
+    assert {"gr_fused_fwd", "gr_fused_bwd", "gr_segsum", "tower_post_gw"} <= set(det["kernels"]) and det["kernels"]["gr_fused_fwd"]["bytes"] > 0
