@@ -698,8 +698,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // straddle the two column halves)
 static constexpr int post_gw_tiles(int S) { return S <= 3 ? 10 : 5; }
 static int64_t post_gw_npw(int64_t N, int T) {
-  // about two waves per SIMD over the whole grid (1024 SIMDs), node ranges in multiples of 64
-  int64_t waves = 2048 / (T < 1 ? 1 : T);
+  // node ranges in multiples of 64; [r5] ONE wave per SIMD over the whole grid (1024 SIMDs): K15 holds S x G accumulator tiles + four
+  // operand sets - 372 registers at S = 3, one workgroup per CU - so 256 workgroups are exactly one round of the chip.  Measured at C2L
+  // (MMA_POST_GW_WAVES sweep): 512 waves 0.366 ms, 768 0.267, 1024 0.249, 1280 0.354 (310 workgroups: a second, badly filled round),
+  // 1536 0.335, 2048 0.268 (round 4's choice: two rounds)
+  int64_t total = 1024;
+  { const char* e = getenv("MMA_POST_GW_WAVES"); if (e && atoi(e) >= 64) total = atoi(e); }      // plan sweep, read per call
+  int64_t waves = total / (T < 1 ? 1 : T);
   if (waves < 4) waves = 4;
   int64_t npw = (N + waves - 1) / waves;
   npw = (npw + 63) / 64 * 64;
