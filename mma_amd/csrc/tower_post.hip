@@ -730,6 +730,7 @@ static int post_fill(PostParams* p, int64_t N, int T, int KF, int S, int O, cons
 // tiles per wave: the tower's weights are staged once per workgroup, so a workgroup should walk many node tiles - but the grid must
 // still fill the chip (>= ~4 workgroups per CU over all towers)
 static int post_tiles_per_wave(int64_t N, int T) {
+  { const char* e = getenv(T == 1 ? "MMA_SKINNY_TPW" : "MMA_POST_TPW_ALL"); if (e && atoi(e) > 0) return atoi(e); }      // plan sweeps, read per call
   // Two workgroups fit a CU (65 KB of LDS each): 512 run at a time.  A workgroup's fixed costs (dispatch, staging 30 KB of weights, the
   // first tile's round trip, the epilogue stores: ~13 us at C2L against 7 us of MFMAs per tile) are paid once per workgroup, so a wave
   // should walk several tiles - but only in a way that keeps the number of workgroup ROUNDS integral: 4000 workgroups at one tile per
@@ -740,7 +741,10 @@ static int post_tiles_per_wave(int64_t N, int T) {
   int64_t best_cost = ((blocks1 + 511) / 512);
   for (int r = 2; r <= 8; ++r) {
     const int64_t blocks = (blocks1 + r - 1) / r;
-    if (blocks < 512) break;                                   // never leave CUs without a workgroup
+    // never leave CUs without a workgroup.  [r5] A single product (T == 1: K16) may go down to one workgroup per CU: its 800 workgroups at
+    // C2L were 1.56 rounds of 512 - two tiles per wave, 400 workgroups in ONE round, pay the weight staging once (0.169 -> 0.152 ms for the
+    // two forward layers; for T = 5 the same rule picks 8 tiles per wave, measured slower: 0.183 -> 0.245 ms)
+    if (blocks < (T == 1 ? 256 : 512)) break;
     const int64_t cost = ((blocks + 511) / 512) * r;
     if (cost <= best_cost) { best = r; best_cost = cost; }
   }
