@@ -1166,7 +1166,9 @@ static int gr_block_mode(GrParams* p, int64_t E, bool v4, bool backward) {
   const uint32_t qd = (uint32_t)p->D / 4, f4 = (uint32_t)p->F / 4, skf4 = (uint32_t)(p->S * p->K) * f4, tskf4 = (uint32_t)p->T * skf4;
   const uint32_t head = kBlkHead;
   const int planes = backward ? n_coef : p->K;
-  for (int nb = 16; nb >= 2; nb >>= 1) {
+  int nb_max = 16;
+  { const char* e = getenv("MMA_GR_NB"); if (e && atoi(e) >= 2 && atoi(e) <= 16) nb_max = atoi(e); }       // plan sweep, read per call
+  for (int nb = nb_max; nb >= 2; nb >>= 1) {
     const uint32_t agg = (uint32_t)nb * planes * p->D * 4, arg = 2u * nb * p->D;
     if (head + agg + arg > 40 * 1024 || (uint32_t)nb * tskf4 > 65535u || (uint32_t)nb * qd > 65535u) continue;
     p->nb = nb; p->qd = qd; p->qd_magic = div_magic(qd);
