@@ -237,7 +237,9 @@ int mma_gemm_f16x2_nlp(const float* A, int64_t lda, const float* row_max, const 
  * once, and share the fp16 pieces through LDS.  Same products in the same order as mma_gemm_f16x2: bit-identical results.  Bt2 = (2, N, K)
  * and col_unscale (N,) from mma_split_f16x2 (plain_lo = 0).  a_row_max (M,) or NULL: receives max |A[i,:]| (K = 256 callers no longer
  * need the mma_row_absmax pass).  MMA_FWD_WS=1 in the environment makes mma_gemm_f16x2 take this kernel when the shape fits (default: the
- * column-group kernel, which is faster as measured in round 4: 1.06 vs 1.37 ms at M = 2^20, N = 1024). */
+ * column-group kernel, which is faster as measured in round 4: 1.06 vs 1.37 ms at M = 2^20, N = 1024).
+ * A MEASUREMENT kernel (ABI 34): compiled only with -DMMA_EXPERIMENTAL_FWD (make EXTRA=...); a product library validates the arguments,
+ * then returns an error whose text says so, and does not read MMA_FWD_WS. */
 int mma_gemm_f16x2_ws(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,
                       float* a_row_max, int64_t M, int32_t N, int32_t K, void* stream);
 /* TN form for the weight gradients (autograd's x^T g of layers.py:215-216's torch.mm): C (KA,NC) = X^T G with X (M,KA),

@@ -505,6 +505,11 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
                                           kCgStoreAux);
 }
 
+// [r5] The two forward forms below (W-stationary, loader waves) are MEASUREMENT kernels: built, bit-equal to the column-group kernels,
+// and slower (C4 1.37 / 1.19-1.27 ms against 1.04).  They are compiled only with -DMMA_EXPERIMENTAL_FWD (make EXTRA=-DMMA_EXPERIMENTAL_FWD;
+// round-4 ADVICE: ~400 lines of slower kernels and an environment switch do not belong in the product library's hot path); without it
+// mma_gemm_f16x2_ws reports that, and MMA_FWD_WS is not read.
+#ifdef MMA_EXPERIMENTAL_FWD
 // ---- forward, W-STATIONARY (round 4): C (M, N) = x (M, K) W (K, N), K = 128 or 256, N % 256 == 0 ------------------------------------------
 // The column-group kernels above keep W in LDS and stream x through registers in the MFMA's fragment shape: 32 rows x 32 bytes per load
 // instruction - ~32 line requests to the texture addresser for 1 KB, and every 256-column (K = 256: 128-column) group of the same
@@ -904,6 +909,8 @@ __global__ __launch_bounds__(kLwThreads, 1) void gemm_f16x2_lw_kernel(const Gemm
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[r]), crow_p, c_off, (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc) * 4u + pcol,
                                           kCgStoreAux);
 }
+
+#endif  // MMA_EXPERIMENTAL_FWD
 
 // ---- K == 256, three products (round 2, late): the forward [P|Q] = x [Wtop|Wbot] of hidden width 256 (C5) -----------------------------
 // The column-group form with a 256-deep reduction: a workgroup owns 128 columns, their B slab (2 pieces x 128 columns x 256 k fp16 = 135 KB
@@ -2189,6 +2196,7 @@ extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, cons
   MMA_REQUIRE(A && Bt2 && col_unscale && C && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt2) & 15) == 0,
               "NULL or misaligned argument");
   GemmParams p{A, lda, static_cast<const __bf16*>(Bt2), C, ldc, M, N, 128, 0};
+#ifdef MMA_EXPERIMENTAL_FWD
   // MMA_FWD_WS=1: the W-stationary kernel (A/B switch, read per call).  Measured SLOWER than the column-group kernel (C4 1.37 vs 1.06 ms,
   // C5 8.4 vs 7.8 ms): its waves meet at a barrier every 64 rows, and a wave's wait for the next rows is a wait for every store it issued
   // before them (one in-order vmcnt) - see DESIGN.md "forward GEMM, round 4"; kept for the next step (loader waves that never store).
@@ -2204,6 +2212,7 @@ extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, cons
                        (M + 63) / 64, N / 256, a_row_max);
     return check_launch("gemm_f16x2_ws_kernel");
   }
+#endif
   const int64_t n_units = (M + kCgRows - 1) / kCgRows;
   const int groups = N / 128;
   if (groups % 2 == 0)        // pairs of column groups per workgroup
@@ -2237,11 +2246,17 @@ extern "C" int mma_gemm_f16x2_ws(const float* A, int64_t lda, const void* Bt2, c
   if (M == 0) return 0;
   MMA_REQUIRE(A && Bt2 && col_unscale && C && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt2) & 15) == 0,
               "NULL or misaligned argument");
+#ifdef MMA_EXPERIMENTAL_FWD
   GemmParams p{A, lda, static_cast<const __bf16*>(Bt2), C, ldc, M, N, K, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (K == 128) hipLaunchKernelGGL((gemm_f16x2_ws_kernel<8, 2>), dim3(256), dim3(kCgThreads), 0, st, p, col_unscale, (M + 63) / 64, N / 256, a_row_max);
   else hipLaunchKernelGGL((gemm_f16x2_ws_kernel<16, 1>), dim3(256), dim3(kCgThreads), 0, st, p, col_unscale, (M + 31) / 32, N / 256, a_row_max);
   return check_launch("gemm_f16x2_ws_kernel");
+#else
+  (void)a_row_max; (void)stream;
+  return fail(3, "mma_gemm_f16x2_ws: built without -DMMA_EXPERIMENTAL_FWD (the W-stationary / loader-wave forward kernels are measurement "
+                 "forms, slower than mma_gemm_f16x2 / _k256; `make -C mma_amd/csrc clean all EXTRA=-DMMA_EXPERIMENTAL_FWD` builds them)");
+#endif
 }
 
 extern "C" int mma_gemm_f16x2_n128(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale, float* C,

@@ -63,8 +63,8 @@ USE_F16X2_K256 = __import__("os").environ.get("MMA_F16X2_K256", "1") != "0"
 
 
 def ws_ok(N):
-    """mma_gemm_f16x2_ws takes N: whole 256-column groups, a divisor of the 32 workgroup slots of an XCD.  Opt-in (MMA_FWD_WS=1): measured
-    slower than the column-group kernels so far (gemm_x3.hip)."""
+    """mma_gemm_f16x2_ws takes N: whole 256-column groups, a divisor of the 32 workgroup slots of an XCD.  Opt-in (MMA_FWD_WS=1) AND only in
+    a library built with -DMMA_EXPERIMENTAL_FWD [r5]: measured slower than the column-group kernels (gemm_x3.hip)."""
     return N % 256 == 0 and 32 % (N // 256) == 0 and __import__("os").environ.get("MMA_FWD_WS", "0") == "1"
 
 

@@ -420,6 +420,23 @@ def test_gemm_f16x2_n128(M, K, acc):
     assert torch.equal(again, out)
 
 
+def _need_experimental_fwd():
+    """[r5] The W-stationary / loader-wave forward kernels are measurement forms (slower than the column-group kernels): the product
+    library is built without them (`make EXTRA=-DMMA_EXPERIMENTAL_FWD` builds them) and mma_gemm_f16x2_ws then says so."""
+    from mma_amd import dense
+    from mma_amd._lib import call, ptr, stream_ptr, MMALibraryError
+    a = torch.zeros((64, 128), device=DEV)
+    w = torch.zeros((128, 256), device=DEV)
+    bt2, cu = dense._split_f16x2(w)
+    out = torch.empty((64, 256), device=DEV)
+    try:
+        call("mma_gemm_f16x2_ws", ptr(a), 128, ptr(bt2), ptr(cu), ptr(out), 256, None, 64, 256, 128, stream_ptr())
+    except MMALibraryError as e:
+        if "MMA_EXPERIMENTAL_FWD" in str(e):
+            pytest.skip("libmma_amd.so is built without -DMMA_EXPERIMENTAL_FWD (the measurement forms of the forward GEMM)")
+        raise
+
+
 @pytest.mark.parametrize("M,K,N", [(1, 128, 256), (63, 128, 256), (64, 128, 512), (4099, 128, 1024), (70001, 128, 2048), (140001, 128, 256),
                                    (1, 256, 256), (31, 256, 512), (4100, 256, 1024), (66001, 256, 4096), (131075, 256, 256)])
 def test_gemm_f16x2_ws_is_bit_equal_to_the_column_group_kernels(M, K, N, monkeypatch):
@@ -428,6 +445,7 @@ def test_gemm_f16x2_ws_is_bit_equal_to_the_column_group_kernels(M, K, N, monkeyp
     spread over e^+-6, a row pitch wider than K, an output that is a column block of a wider buffer; and the fp64 error bar on a sample."""
     from mma_amd import dense
     from mma_amd._lib import call, ptr, stream_ptr
+    _need_experimental_fwd()
     rng = np.random.default_rng(M + K + N)
     a_np = (rng.standard_normal((M, K + 8)) * np.exp(rng.uniform(-6, 6, (M, 1)))).astype(np.float32)
     a_np[::17] = 0
@@ -471,6 +489,7 @@ def test_gemm_f16x2_ws_is_bit_equal_to_the_column_group_kernels(M, K, N, monkeyp
 def test_gemm_f16x2_ws_rejects_shapes_it_does_not_take():
     from mma_amd import dense
     from mma_amd._lib import call, ptr, stream_ptr, MMALibraryError as MMAError
+    _need_experimental_fwd()
     a = torch.zeros((64, 128), device=DEV)
     for N, K in ((768, 128), (128, 128), (256, 64), (256, 512)):
         w = torch.zeros((2, N, K), device=DEV, dtype=torch.float16)
