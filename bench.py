@@ -441,6 +441,11 @@ def gr_setup(n_graphs, dev, seed=0, categorical=False):
         for q in params:                   # optimizer.zero_grad(): the backward then assigns instead of launching an add per tensor
             q.grad = None
         conv(x, eig, ea).backward(cot)
+
+    def check():          # outside every timed region: the long-segment list of the layer's CSR was never found clobbered (K3 / K4 skip such a list and flag it)
+        from mma_amd import functional as Fn
+        Fn.gr_graph(eig, N).by_target.check()
+    step.check = check
     return conv, step, N, E
 
 
@@ -454,6 +459,7 @@ def gr_config(tag, n_graphs, dev, reps=20, replay=True, categorical=False):
     for _ in range(reps):
         step()
     spans = t.summary(); Fn.TIMER = prev
+    step.check()
     r = {"config": tag, "graphs": n_graphs, "nodes": N, "edges": E, "towers": 5, "F": 75, "ms_per_step_eager": ms,
          "edges_per_s_eager": E / ms * 1e3,
          "kernels": _kernel_table(spans, reps, gr_algorithmic_bytes(N, E, 5, 75, 2, 1 if __import__("mma_amd").mma_conv.FACTOR_SCALERS else 3,
@@ -1115,6 +1121,7 @@ def run_c2l(args, dev, rank=0, world=1, barrier=None):
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    fwd_bwd.check()
     tot = torch.tensor([float(E), float(N)], dtype=torch.float64)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
