@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MMA_ABI_VERSION 34
+#define MMA_ABI_VERSION 35
 #define MMA_MAX_K 8          /* masks fused per launch; more are issued as several launches */
 
 /* combine kinds of the node-classification aggregators (layers.py:201-728) */
@@ -212,6 +212,11 @@ int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, const float* co
                    float* a_row_max,             /* optional (M,) out: max |a| of every row (the kernel forms it for its row scales
                                                     anyway) - the x_row_max of the weight-gradient product mma_gemm_f16x2_tn */
                    int64_t M, int32_t N, void* stream);
+/* ABI 35: the same product for K in {64, 96, 128} (Bt2 (2, N, K), lda >= K): the zero-padded tall Linears of graph regression (50 + 1 ->
+ * 64 columns, 75 + 1 -> 96) stop loading, splitting and multiplying pad columns up to 128; the narrow B slabs leave room for THREE
+ * resident column groups per workgroup (N / 128 a multiple of 3: A is read once for 384 output columns). */
+int mma_gemm_f16x2_k(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,
+                     float* a_row_max, int64_t M, int32_t N, int32_t K, void* stream);
 /* The three-product column-group form for K = 256 (the forward product of hidden width 256: C5): as mma_gemm_f16x2 with Bt2 = (2, N, 256),
  * but the row scales come from the caller's row_max (M,) >= max |a| of every row (mma_row_absmax, or a producer's bound; 0 marks an
  * all-zero row): 256 floats per row do not fit the registers beside their own fp16 pieces while an in-kernel maximum forms. */
@@ -357,6 +362,12 @@ int mma_skinny_linear_fwd(const float* x, int64_t ldx, const float* Wa, const fl
                           float* y, int64_t ldy, int64_t N, int32_t K, int32_t O, void* stream);
 int mma_skinny_linear_bwd_dx(const float* gy, int64_t ldg, const float* Wb, float* gx, int64_t ldx,
                              int64_t N, int32_t K, int32_t O, void* stream);
+/* ABI 35: gw (O,K) = gy^T x and gb (O) = column sums of gy (may be NULL) from ONE pass over gy (N,O) and x (N,K) - K15's kernel in its plain
+ * form, the bias gradient as the product with a ones column behind x; part: workspace of mma_skinny_linear_gw_part(N, K, O) floats (one
+ * partial tile per workgroup, summed in a fixed order: deterministic).  Replaces the TN GEMM + column sum of autograd's F.linear backward. */
+int64_t mma_skinny_linear_gw_part(int64_t N, int32_t K, int32_t O);
+int mma_skinny_linear_gw(const float* gy, int64_t ldg, const float* x, int64_t ldx, float* part, int64_t n_part,
+                         float* gw, float* gb, int64_t N, int32_t K, int32_t O, void* stream);
 
 /* ---- K10: fused log_softmax + nll_loss of the training step (models.py:68 F.log_softmax(x, dim=1) + train.py:77
  * F.nll_loss(output[idx_train], labels[idx_train])) ------------------------------------------------------------------------

@@ -348,20 +348,30 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_x3_colgroup_kernel(const G
 // structure as gemm_x3_colgroup_kernel (resident B slab: 70 KB, pipelined fragments, nt buffer stores); handles a ragged M itself.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 struct HFrag { f16x8 b1, b2; };
-constexpr int kHgTile = 2 * kCgPiece, kHgLds = 4 * kHgTile;
+// [r5] KS k-steps of 16: K = 16 KS in {64, 96, 128}.  The B slab of a 128-column group is 2 pieces x 128 columns x (32 KS + 16) bytes - 68 KB at
+// K = 128, 36 KB at K = 64, 52 KB at K = 96 - so the narrow forms keep THREE groups resident (G2 = 3: 108 / 156 KB).
+template <int KS> struct HgGeom {
+  static constexpr int pitch = KS * 32 + 16, piece = 32 * pitch, tile = 2 * piece, group = 4 * tile;
+};
+template <int KS>
 __device__ __forceinline__ HFrag hg_frag(const unsigned char* sb, int ks) {
   HFrag f;
-  f.b1 = *reinterpret_cast<const f16x8*>(sb + 0 * kCgPiece + ks * 32);
-  f.b2 = *reinterpret_cast<const f16x8*>(sb + 1 * kCgPiece + ks * 32);
+  f.b1 = *reinterpret_cast<const f16x8*>(sb + 0 * HgGeom<KS>::piece + ks * 32);
+  f.b2 = *reinterpret_cast<const f16x8*>(sb + 1 * HgGeom<KS>::piece + ks * 32);
   return f;
 }
 // G2 = 2: a workgroup owns TWO adjacent 128-column groups (136 KB of B in LDS): a wave's rows are loaded, scaled and split once for
 // 256 columns of C instead of once per 128 - half the A traffic through L2 and half the split work per output (N/128 even).
-template <int G2>
+// [r5] KS < 8: the zero-padded tall Linears of graph regression (50 + 1 -> 64 columns, 75 + 1 -> 96) no longer multiply, load, split and
+// write pad columns up to 128: at C2L the edge-feature product (4e5 x 51 -> 380) read its 205 MB padded operand three times (G2 = 1, 384 = 3
+// groups) for 614 MB of output; K = 64 with G2 = 3 reads 102 MB once.
+template <int G2, int KS = 8>
 __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(const GemmParams p, const float* col_unscale, int64_t n_units,
                                                                            int n_groups, float* a_row_max) {
   constexpr int dbg = kAbl;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[G2 * kHgLds];
+  using Geo = HgGeom<KS>;
+  constexpr int K = 16 * KS;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G2 * Geo::group];
   constexpr int NT = 4 * G2;                                           // 32-column tiles per workgroup
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -371,16 +381,17 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
   if (slot >= streams_per_xcd * n_groups) return;
   const int g = slot % n_groups;
   const int64_t stream = xcd * streams_per_xcd + slot / n_groups, n_streams = 8 * streams_per_xcd;
-  const _Float16* Bh = reinterpret_cast<const _Float16*>(p.Bt);            // (2, N, 128) fp16: hi, lo * 2^11
-  for (int q = tid; q < NT * 2 * 32 * 16; q += kCgThreads) {
-    const int kq = q & 15, col = (q >> 4) & 31, tp = q >> 9, piece = tp % 2, tile = tp / 2;
-    *reinterpret_cast<uint4*>(lds + tile * kHgTile + piece * kCgPiece + col * kCgPitch + kq * 16) =
-        *reinterpret_cast<const uint4*>(Bh + ((size_t)piece * p.N + (size_t)(g * 32 * NT + tile * 32 + col)) * 128 + kq * 8);
+  const _Float16* Bh = reinterpret_cast<const _Float16*>(p.Bt);            // (2, N, K) fp16: hi, lo * 2^11
+  constexpr int CH = 2 * KS;                                               // 16-byte chunks per column and piece
+  for (int q = tid; q < NT * 2 * 32 * CH; q += kCgThreads) {
+    const int kq = q % CH, col = (q / CH) & 31, tp = q / (CH * 32), piece = tp % 2, tile = tp / 2;
+    *reinterpret_cast<uint4*>(lds + tile * Geo::tile + piece * Geo::piece + col * Geo::pitch + kq * 16) =
+        *reinterpret_cast<const uint4*>(Bh + ((size_t)piece * p.N + (size_t)(g * 32 * NT + tile * 32 + col)) * K + kq * 8);
   }
   __syncthreads();
   const uint32_t c_off = 4u * h * (uint32_t)p.ldc + (uint32_t)r31;
-  const unsigned char* sb0 = lds + r31 * kCgPitch + h * 16;
-  HFrag cur = hg_frag(sb0, 0);
+  const unsigned char* sb0 = lds + r31 * Geo::pitch + h * 16;
+  HFrag cur = hg_frag<KS>(sb0, 0);
   // this lane's column in each of the 4 tiles: log2 of its un-scale (an exact power of two), applied together with the row's by ONE
   // ldexp (two multiplications overflow / underflow in between for rows or columns near the ends of the fp32 range).  Loaded
   // ONCE: a load inside the tile loop would sit behind the previous tile's 16 stores in the in-order vmcnt queue.
@@ -407,14 +418,14 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
     const int64_t row0 = u * kCgRows + wave * 32;
     if (row0 >= p.M) continue;                                      // the last unit may be ragged: rows past M are re-read (the last
     const int64_t rows_here = min((int64_t)32, p.M - row0);          // row) and their stores dropped by the buffer range check
-    float4 raw[16];
+    float4 raw[2 * KS];
     if (dbg & 8) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) raw[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+      for (int i = 0; i < 2 * KS; ++i) raw[i] = make_float4(1.f, 1.f, 1.f, 1.f);
     } else {
       const float* ap = p.A + min(row0 + r31, p.M - 1) * p.lda + 8 * h;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         raw[2 * ks] = *reinterpret_cast<const float4*>(ap + ks * 16);
         raw[2 * ks + 1] = *reinterpret_cast<const float4*>(ap + ks * 16 + 4);
       }
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
     // row scale: a power of two that puts the row maximum into [2^14, 2^15)
     float rmax = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(raw[i].x), fabsf(raw[i].y)), fmaxf(fabsf(raw[i].z), fabsf(raw[i].w))));
+    for (int i = 0; i < 2 * KS; ++i) rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(raw[i].x), fabsf(raw[i].y)), fmaxf(fabsf(raw[i].z), fabsf(raw[i].w))));
     rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
     if (a_row_max && g == 0 && h == 0 && r31 < rows_here) a_row_max[row0 + r31] = rmax;     // for the weight-gradient product (TN form)
     const int ex = (int)((__float_as_uint(rmax) >> 23) & 0xFF);
@@ -431,9 +442,9 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
     int rse[16];                                                   // accumulator register r holds row (r&3) + 8 (r>>2) + 4h: that row's
 #pragma unroll                                                     // scale exponent, fetched ONCE per block (not per tile and store)
     for (int r = 0; r < 16; ++r) rse[r] = __shfl(sce, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
-    f16x8 af[8][2];
+    f16x8 af[KS][2];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const float v[8] = {raw[2*ks].x, raw[2*ks].y, raw[2*ks].z, raw[2*ks].w, raw[2*ks+1].x, raw[2*ks+1].y, raw[2*ks+1].z, raw[2*ks+1].w};
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -453,12 +464,13 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
       f32x16 acc, acl;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acl[r] = 0.f; }
-      const unsigned char* sb = sb0 + ct * kHgTile;
-      const unsigned char* sbn = sb0 + ((ct + 1) & (NT - 1)) * kHgTile;
+      const unsigned char* sb = sb0 + ct * Geo::tile;
+      const unsigned char* sbn = sb0 + (ct + 1 == NT ? 0 : ct + 1) * Geo::tile;
+      constexpr int SPK = (16 + KS - 1) / KS;                          // stores of the previous tile behind every k-step
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         if (!(dbg & 2)) {
-          const HFrag nxt = ks < 7 ? hg_frag(sb, ks + 1) : hg_frag(sbn, 0);
+          const HFrag nxt = ks < KS - 1 ? hg_frag<KS>(sb, ks + 1) : hg_frag<KS>(sbn, 0);
           __builtin_amdgcn_sched_barrier(0);
           acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b2, acl, 0, 0, 0);
           acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], cur.b1, acl, 0, 0, 0);
@@ -471,7 +483,7 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
         // stores of a tile issued in one burst after its MFMAs, all eight waves of the CU multiplied together and then all sat in front
         // of the full store queue together: stores alone 0.74 ms, everything but the stores 0.64 ms, both 1.05 ms (measurement
         // builds, C4) - nothing overlapped.  Spread out, a wave that waits for a store slot has its MFMAs in between.
-        if (dbg & 64) {                          // measurement: the tile as FOUR 16-byte stores (8 whole 128-byte rows each), wrong data
+        if (KS == 8 && (dbg & 64)) {             // measurement: the tile as FOUR 16-byte stores (8 whole 128-byte rows each), wrong data
           if (ks & 1) {
             const int q4 = ks >> 1;
             typedef unsigned int su4 __attribute__((ext_vector_type(4)));
@@ -481,13 +493,14 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_kernel(cons
           }
         } else if (!(dbg & 4)) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int r = 2 * ks + j;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[r]), crow_p, c_off * 4u,
-                                                  (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc) * 4u + pcol, kCgStoreAux);
+          for (int j = 0; j < SPK; ++j) {
+            const int r = SPK * ks + j;
+            if (r < 16)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[r]), crow_p, c_off * 4u,
+                                                    (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc) * 4u + pcol, kCgStoreAux);
           }
         } else {
-          asm volatile("" :: "v"(prev[2 * ks]), "v"(prev[2 * ks + 1]));
+          asm volatile("" :: "v"(prev[(2 * ks) & 15]), "v"(prev[(2 * ks + 1) & 15]));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -2222,6 +2235,29 @@ extern "C" int mma_gemm_f16x2(const float* A, int64_t lda, const void* Bt2, cons
     hipLaunchKernelGGL(gemm_f16x2_colgroup_kernel<1>, dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p, col_unscale,
                        n_units, groups, a_row_max);
   return check_launch("gemm_f16x2_colgroup_kernel");
+}
+
+// [r5] K in {64, 96}: the narrow forms of the column-group kernel (Bt2 (2, N, K)); three resident groups where N / 128 is a multiple of 3
+extern "C" int mma_gemm_f16x2_k(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,
+                                float* a_row_max, int64_t M, int32_t N, int32_t K, void* stream) {
+  if (K == 128) return mma_gemm_f16x2(A, lda, Bt2, col_unscale, C, ldc, a_row_max, M, N, stream);
+  MMA_REQUIRE(K == 64 || K == 96, "K=%d unsupported (64, 96 or 128)", K);
+  MMA_REQUIRE(M >= 0 && N >= 128 && N % 128 == 0 && N / 128 <= kCgSlotsPerXcd, "M=%lld N=%d: need N %% 128 == 0, N <= 4096", (long long)M, N);
+  MMA_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && lda < (1 << 24) && ldc < (1 << 24), "row pitch too small, unaligned or >= 2^24");
+  if (M == 0) return 0;
+  MMA_REQUIRE(A && Bt2 && col_unscale && C && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt2) & 15) == 0,
+              "NULL or misaligned argument");
+  GemmParams p{A, lda, static_cast<const __bf16*>(Bt2), C, ldc, M, N, K, 0};
+  const int64_t n_units = (M + kCgRows - 1) / kCgRows;
+  const int groups = N / 128;
+  int g2 = groups % 3 == 0 ? 3 : (groups % 2 == 0 ? 2 : 1);
+  { const char* e = getenv("MMA_F16X2_G2"); if (e && e[0] >= '1' && e[0] <= '3' && groups % (e[0] - '0') == 0) g2 = e[0] - '0'; }      // A/B, read per call
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define MMA_CG(GG, KK) hipLaunchKernelGGL((gemm_f16x2_colgroup_kernel<GG, KK>), dim3(256), dim3(kCgThreads), 0, st, p, col_unscale, n_units, groups / GG, a_row_max)
+  if (K == 64) { if (g2 == 3) MMA_CG(3, 4); else if (g2 == 2) MMA_CG(2, 4); else MMA_CG(1, 4); }
+  else         { if (g2 == 3) MMA_CG(3, 6); else if (g2 == 2) MMA_CG(2, 6); else MMA_CG(1, 6); }
+#undef MMA_CG
+  return check_launch("gemm_f16x2_colgroup_kernel (narrow)");
 }
 
 extern "C" int mma_gemm_f16x2_k256(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale, float* C,

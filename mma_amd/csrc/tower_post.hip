@@ -382,7 +382,10 @@ __global__ __launch_bounds__(kBlock) void tower_post_bwd_kernel(const PostParams
 // LDS, no scaled copy of gy (round 3's first form wrote gys (N, T*S*16) and ran five TN launches of the bf16x3 kernel: 0.4-0.5 ms).
 // The four waves' tiles of a workgroup are added through LDS, the per-workgroup partial tiles are summed in a fixed order by
 // mma_tower_post_gw_reduce / mma_col_sum.
-template <int S, int G>
+// PLAIN [r5]: the weight AND bias gradient of a plain skinny Linear (K16) on the same kernel - gW[r][k] = sum_n gy[n][r] x[n][k] for r < O
+// <= S*16, k < K, every 16-row tile 16 more outputs (A[i][k = node] = gy[node][q*16 + i], no scaler table), and the column k = K of the B
+// operand is a column of ONES: gW[r][K] = sum_n gy[n][r] = the bias gradient, from the same pass (K < kfp16 is required for it).
+template <int S, int G, bool PLAIN = false>
 __global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams p, const float* __restrict__ gy, const float* __restrict__ agg,
                                                                const float* __restrict__ pre_tab, float* __restrict__ part, int64_t npw,
                                                                int kfp16) {
@@ -418,9 +421,15 @@ __global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams 
       const int64_t node = n4 + kq;
       r.valid = node < ne;
       const int64_t nc = node < nlast ? node : nlast;
-      r.g = gy[(size_t)nc * p.ldg + (size_t)t * p.O + jo];
+      if (PLAIN) {                                              // r.pre[q] carries gy[node][q*16 + j] (clamped column, zeroed at use)
+        r.g = 1.f;
 #pragma unroll
-      for (int q = 0; q < S; ++q) r.pre[q] = pre_tab[(size_t)nc * kPostPrePitch + q];
+        for (int q = 0; q < S; ++q) r.pre[q] = gy[(size_t)nc * p.ldg + min(q * kPostO + j, p.O - 1)];
+      } else {
+        r.g = gy[(size_t)nc * p.ldg + (size_t)t * p.O + jo];
+#pragma unroll
+        for (int q = 0; q < S; ++q) r.pre[q] = pre_tab[(size_t)nc * kPostPrePitch + q];
+      }
 #pragma unroll
       for (int c = 0; c < G; ++c) {
         const int col = min((kt0 + c) * 16 + j, p.KF - 1);
@@ -431,10 +440,13 @@ __global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams 
       const float g = (r.valid && j < p.O) ? r.g : 0.f;
       float b[G];
 #pragma unroll
-      for (int c = 0; c < G; ++c) b[c] = (r.valid && (kt0 + c) * 16 + j < p.KF) ? r.b[c] : 0.f;
+      for (int c = 0; c < G; ++c) {
+        const int col = (kt0 + c) * 16 + j;
+        b[c] = (r.valid && col < p.KF) ? r.b[c] : ((PLAIN && r.valid && col == p.KF) ? 1.f : 0.f);      // PLAIN: the ones column behind x
+      }
 #pragma unroll
       for (int q = 0; q < S; ++q) {
-        const float a = r.pre[q] * g;
+        const float a = PLAIN ? ((r.valid && q * kPostO + j < p.O) ? r.pre[q] : 0.f) : r.pre[q] * g;
 #pragma unroll
         for (int c = 0; c < G; ++c) acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c], acc[q][c], 0, 0, 0);
       }
@@ -1027,6 +1039,79 @@ extern "C" int mma_skinny_linear_fwd(const float* x, int64_t ldx, const float* W
   MMA_REQUIRE(lds <= 160 * 1024, "the weights (%u bytes with the tiles) do not fit the LDS", lds);
   if (p.vec4) { MMA_POST_LAUNCH3(tower_post_fwd_kernel, true, true, lds, x, pre, Wa, y) } else { MMA_POST_LAUNCH3(tower_post_fwd_kernel, true, false, lds, x, pre, Wa, y) }
   return check_launch("tower_post_fwd_kernel (plain)");
+}
+
+// [r5] the weight and the bias gradient of the plain skinny Linear from ONE pass over gy and x (K15 in its PLAIN form): the TN library
+// GEMM + three column-sum launches it replaces read gy twice and ran 47 + ~40 us per 75 -> 75 layer at C2L.
+// part (n_chunks, S*16, kfp16): one partial tile per workgroup, kfp16 = round_up(K + 1, 16) - the ones column sits at k = K.
+__global__ __launch_bounds__(kBlock) void skinny_gw_reduce_kernel(const float* __restrict__ part, int R, int O, int K, int S, int kfp16,
+                                                                  float* __restrict__ gw, float* __restrict__ gb) {
+  // 16 outputs x 16 partial sums per workgroup: lane (sub, i) sums the partials r = sub, sub + 16, ... of output i in order, the 16 sums
+  // are added in a fixed tree through LDS - every load of a lane is independent of the others (one round trip, not R of them)
+  __shared__ float red[16][17];
+  const int i = threadIdx.x & 15, sub = threadIdx.x >> 4;
+  const int64_t total = (int64_t)O * (K + 1);
+  const int64_t idx = (int64_t)blockIdx.x * 16 + i;
+  const bool ok = idx < total;
+  const int o = ok ? (int)(idx / (K + 1)) : 0, k = ok ? (int)(idx % (K + 1)) : 0;
+  const size_t ld = (size_t)S * kPostO * kfp16;
+  const float* qp = part + (size_t)o * kfp16 + k;
+  float a = 0.f;
+  for (int r = sub; r < R; r += 16) a += qp[(size_t)r * ld];
+  red[sub][i] = a;
+  __syncthreads();
+  if (sub == 0 && ok) {
+    float v[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = red[m][i];
+#pragma unroll
+    for (int w = 1; w < 16; w *= 2)
+#pragma unroll
+      for (int m = 0; m < 16; m += 2 * w) v[m] = v[m] + v[m + w];
+    if (k < K) gw[(size_t)o * K + k] = v[0];
+    else if (gb) gb[o] = v[0];
+  }
+}
+extern "C" int64_t mma_skinny_linear_gw_part(int64_t N, int32_t K, int32_t O) {          // floats of the partial-tile workspace
+  if (N <= 0 || K < 1 || K > 512 || O < 1 || O > kPostMaxS * kPostO) return 0;
+  const int64_t S = ((int64_t)O + kPostO - 1) / kPostO, kfp16 = ((int64_t)K + 1 + 15) / 16 * 16;
+  return mma_tower_post_gw_chunks(N, 1) * S * kPostO * kfp16;
+}
+extern "C" int mma_skinny_linear_gw(const float* gy, int64_t ldg, const float* x, int64_t ldx, float* part, int64_t n_part,
+                                    float* gw, float* gb, int64_t N, int32_t K, int32_t O, void* stream) {
+  MMA_REQUIRE(O >= 1 && O <= kPostMaxS * kPostO && K >= 1 && K <= 512, "O=%d K=%d unsupported (O <= %d, K <= 512)", O, K, kPostMaxS * kPostO);
+  MMA_REQUIRE(N >= 1 && N < (1LL << 31), "N=%lld unsupported", (long long)N);
+  MMA_REQUIRE(n_part == mma_skinny_linear_gw_part(N, K, O), "n_part=%lld, expected mma_skinny_linear_gw_part(N, K, O)=%lld", (long long)n_part,
+              (long long)mma_skinny_linear_gw_part(N, K, O));
+  MMA_REQUIRE(gy && x && part && gw && ldx >= K && ldg >= O, "NULL argument or row pitch too small");
+  const int S = (O + kPostO - 1) / kPostO;
+  PostParams p{};
+  p.N = N; p.T = 1; p.KF = K; p.KFp = (K + kPostTile - 1) / kPostTile * kPostTile; p.S = S; p.O = O; p.avg_log = 1.f; p.avg_lin = 1.f;
+  p.lda = ldx; p.ldg = ldg; p.order = 2;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int kfp16 = (K + 1 + 15) / 16 * 16;
+  const int64_t npw = post_gw_npw(N, 1);
+  const int64_t n_chunks = mma_tower_post_gw_chunks(N, 1);
+  p.nbx = n_chunks;
+  const dim3 grid((unsigned)n_chunks);
+  const float* pre = nullptr;
+  // G = 5 kf tiles per pass for every S here: S x 5 accumulator tiles + four operand sets of S + 5 + 1 registers stay inside one
+  // workgroup per CU at S = 5 (the 75 -> 75 layers: 76 columns = 5 tiles, ONE pass over the rows)
+  const unsigned lds = (unsigned)((kBlock / kWave) * S * 5 * 4 * kWave * sizeof(float));
+#define MMA_GWP(SS) hipLaunchKernelGGL((tower_post_gw_kernel<SS, 5, true>), grid, dim3(kBlock), lds, st, p, gy, x, pre, part, npw, kfp16)
+  switch (S) {
+    case 1: MMA_GWP(1); break;
+    case 2: MMA_GWP(2); break;
+    case 3: MMA_GWP(3); break;
+    case 4: MMA_GWP(4); break;
+    default: MMA_GWP(5); break;
+  }
+#undef MMA_GWP
+  if (int rc = check_launch("tower_post_gw_kernel (plain)")) return rc;
+  const int64_t total = (int64_t)O * (K + 1);
+  hipLaunchKernelGGL(skinny_gw_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(kBlock), 0, st, part, (int)n_chunks, (int)O, (int)K, S,
+                     kfp16, gw, gb);
+  return check_launch("skinny_gw_reduce_kernel");
 }
 
 extern "C" int mma_skinny_linear_bwd_dx(const float* gy, int64_t ldg, const float* Wb, float* gx, int64_t ldx,

@@ -34,8 +34,11 @@ def _x3_ok(a, w):
 USE_F16X2 = True      # K == 128 products on the three-product fp16 x 2 kernel (csrc/gemm_x3.hip) instead of the six-product bf16 x 3 one
 
 
+F16X2_K = (64, 96, 128)      # reduction widths of the whole-row three-product kernel (mma_gemm_f16x2_k)
+
+
 def gemm_f16x2(a, w, out=None, row_max_out=None):
-    """a (M,128) @ w (128,N), N % 128 == 0: the three-product form (fp16 hi/lo pieces, power-of-two row and column scales).
+    """a (M,K) @ w (K,N), K in F16X2_K, N % 128 == 0: the three-product form (fp16 hi/lo pieces, power-of-two row and column scales).
     row_max_out (M,): the kernel also leaves max |a[i,:]| there (it forms them for its row scales anyway)."""
     M, K = a.shape
     N = w.shape[1]
@@ -43,7 +46,7 @@ def gemm_f16x2(a, w, out=None, row_max_out=None):
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     with _span("gemm_x3_k128", nbytes=4 * M * (K + N), flops=2 * M * K * N, mfma="f16x3"):        # A in, C out (B is 0.5 MB)
-        call("mma_gemm_f16x2", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(out), out.stride(0), ptr(row_max_out), M, N, stream_ptr())
+        call("mma_gemm_f16x2_k", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(out), out.stride(0), ptr(row_max_out), M, N, K, stream_ptr())
     return out
 
 
@@ -126,7 +129,7 @@ def gemm_bf16x3(a, w, out=None, accumulate=False, row_max_box=None):
         a = a.contiguous()
     M, K = a.shape
     N = w.shape[1]
-    if (USE_F16X2 and K == 128 and not accumulate and N % 128 == 0 and N <= 4096 and M >= _MIN_ROWS_X3
+    if (USE_F16X2 and K in F16X2_K and not accumulate and N % 128 == 0 and N <= 4096 and M >= _MIN_ROWS_X3
             and (out is None or (out.stride(1) == 1 and out.dtype == torch.float32))):
         rm = torch.empty((M,), device=a.device, dtype=torch.float32) if row_max_box is not None else None
         if rm is not None:
@@ -392,6 +395,22 @@ def _skinny_weights(weight):
     return Wa, Wb
 
 
+SKINNY_GW = __import__("os").environ.get("MMA_SKINNY_GW", "1") != "0"      # 0: round 4's TN GEMM + column sum (A/B)
+
+
+def skinny_gw(g2, x2, want_bias=True):
+    """(gw (O, K), gb (O) or None) = (g2^T x2, column sums of g2) for tall fp32 rows, O <= 80, K <= 512: mma_skinny_linear_gw."""
+    rows, O = g2.shape
+    K = x2.shape[1]
+    n_part = int(_lib.query("mma_skinny_linear_gw_part", rows, K, O))
+    part = torch.empty(n_part, device=g2.device, dtype=torch.float32)
+    gw = torch.empty((O, K), device=g2.device, dtype=torch.float32)
+    gb = torch.empty(O, device=g2.device, dtype=torch.float32) if want_bias else None
+    with _span("skinny_linear_gw", nbytes=4 * rows * (K + O), flops=2 * rows * (-(-O // 16) * 16) * (-(-(K + 1) // 16) * 16), mfma="f32"):
+        call("mma_skinny_linear_gw", ptr(g2), g2.stride(0), ptr(x2), x2.stride(0), ptr(part), n_part, ptr(gw), ptr(gb), rows, K, O, stream_ptr())
+    return gw, gb
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b over the last dimension (torch_geometric Linear / F.linear: mma_conv.py:82,99-105, mask_aggr.py:50).
     Forward is the library GEMM - or, for tall rows through a narrow layer, the K16 fp32 matrix-core kernel; backward replaces
@@ -442,6 +461,11 @@ class _Linear(torch.autograd.Function):
             else:
                 gx = torch.mm(g2, weight).view(x.shape)
         x2 = x.reshape(-1, x.shape[-1])
+        if ctx.skinny and SKINNY_GW and ctx.needs_input_grad[1] and x2.stride(1) == 1:
+            # K15 in its plain form: the weight and the bias gradient from ONE pass over g and x (the bias gradient as the product with a
+            # ones column behind x) - the TN library GEMM + the column sum read g twice and took ~0.09 ms per 75 -> 75 layer at C2L
+            gw, gb = skinny_gw(g2 if g2.stride(1) == 1 else g2.contiguous(), x2, ctx.has_bias and ctx.needs_input_grad[2])
+            return gx, gw, gb, g_add
         if ctx.has_bias and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and x2.shape[0] >= 4 * _ROWS_PER_BATCH and not ctx.skinny:
             # tall input: the bias gradient rides on the weight-gradient GEMM as the row of a ones column appended to x, so the
             # (rows, out) gradient is read once instead of twice (C2L: 2 x 0.13 ms of column sums over 0.62 / 0.65 GB)
@@ -467,6 +491,7 @@ X3_LINEAR = True
 FUSED_PAD = __import__("os").environ.get("MMA_PAD_ONES", "1") != "0"        # 0: torch's pad + a strided fill (round 3)
 X3_LINEAR_MIN_ROWS = 32768
 X3_ROW_MAX = __import__("os").environ.get("MMA_X3_ROW_MAX", "1") != "0"     # 0: round 4's six-product backward of the tall Linears (A/B)
+X3_NARROW_K = __import__("os").environ.get("MMA_X3_NARROW_K", "1") != "0"   # 0: every padded A operand 128 columns wide (A/B)
 _PADDED = {}          # data_ptr -> weakref to a (rows, pitch) fp32 buffer whose columns beyond the payload are ZERO
 
 
@@ -510,24 +535,27 @@ class _LinearX3(torch.autograd.Function):
         fout = weight.shape[0]
         OP = _round_up(fout, 128)
         fused = FUSED_PAD and x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and weight.dtype == torch.float32
+        # [r5] the A operand is padded to 64 / 96 columns where [x | 1] fits (edge features 50 + 1, node features 75 + 1): the forward and
+        # the weight-gradient product stop reading, splitting and multiplying pad columns up to 128
+        KP = next(k for k in F16X2_K if fin + 1 <= k) if (X3_NARROW_K and USE_F16X2 and N >= _MIN_ROWS_X3) else 128
         if row_index is not None and not fused:
             x = x.index_select(0, row_index.long())
         if fused:
             # [r4] both padded operands in ONE launch each (mma_pad_rows): A = [x | 1 | 0] (N, 128), and wpad = [W | b | 0] (OP, 128), whose
             # transposed VIEW is the forward's B and whose leading columns are dL/dx's B - no second padded copy of W in backward
-            xp = torch.empty((N, 128), device=x.device, dtype=torch.float32)
-            call("mma_pad_rows", ptr(x), x.stride(0), N, fin, None, ptr(row_index), ptr(xp), 128, 128, N, stream_ptr())
+            xp = torch.empty((N, KP), device=x.device, dtype=torch.float32)
+            call("mma_pad_rows", ptr(x), x.stride(0), N, fin, None, ptr(row_index), ptr(xp), KP, KP, N, stream_ptr())
             w2 = weight if weight.stride(1) == 1 else weight.contiguous()
             wpad = torch.empty((OP, 128), device=x.device, dtype=torch.float32)
             if bias is not None:
                 call("mma_pad_rows", ptr(w2), w2.stride(0), fout, fin, ptr(bias.contiguous()), None, ptr(wpad), 128, 128, OP, stream_ptr())
             else:
                 call("mma_pad_rows", ptr(w2), w2.stride(0), fout, fin + 0, ptr(torch.zeros((fout,), device=x.device)), None, ptr(wpad), 128, 128, OP, stream_ptr())
-            wt = wpad.t()
+            wt = wpad.t()[:KP]                                       # (KP, OP) view: rows beyond fin + 1 are zero anyway
         else:
-            xp = torch.nn.functional.pad(x, (0, 128 - fin))         # (N, 128): [x | 1 | 0 ...]
+            xp = torch.nn.functional.pad(x, (0, KP - fin))          # (N, KP): [x | 1 | 0 ...]
             xp[:, fin] = 1.0
-            wt = weight.new_zeros((128, OP))                         # [W^T ; b ; 0 ...], pad columns zero
+            wt = weight.new_zeros((KP, OP))                          # [W^T ; b ; 0 ...], pad columns zero
             wt[:fin, :fout] = weight.t()
             if bias is not None:
                 wt[fin, :fout] = bias

@@ -329,6 +329,45 @@ def test_linear_tall_on_the_bf16x3_kernels(N, fin, fout, bias, padded_grad):
         dense.X3_LINEAR = True
 
 
+@pytest.mark.parametrize("K", [64, 96])
+@pytest.mark.parametrize("M,N", [(4099, 128), (9001, 256), (40037, 384), (70001, 768), (5000, 640), (33001, 1152)])
+def test_gemm_f16x2_narrow_reductions(M, N, K, monkeypatch):
+    """[r5] mma_gemm_f16x2_k, K in {64, 96}: the column-group kernel with 4 / 6 k-steps and one, two or THREE resident 128-column groups
+    (N / 128 = 1, 2, 3, 6, 5, 9): the accuracy of the K = 128 form, the same bits as that form on the operand padded with zero columns
+    (zero products add exactly), the row maxima, a ragged last block, a row-strided A, and the exported G2 switch."""
+    from mma_amd import dense
+    rng = np.random.default_rng(M + N + K)
+    a = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, 1)))).astype(np.float32)
+    a[3] = 0.0
+    a[5] = 0.0; a[5, K - 1] = 1.0e-30
+    buf = torch.zeros((M, 128 + 12), device=DEV)
+    buf[:, :K] = torch.from_numpy(a).to(DEV)
+    av = buf[:, :K]                                              # row-strided view (pitch 140 floats)
+    w = torch.from_numpy(((rng.random((K, N)) * 2 - 1) * np.exp(rng.uniform(-3, 3, (1, N)))).astype(np.float32)).to(DEV)
+    rm = torch.empty(M, device=DEV)
+    got = dense.gemm_f16x2(av, w, row_max_out=rm)
+    ref = av.double() @ w.double()
+    scale = av.double().abs() @ w.double().abs()
+    err = (got.double() - ref).abs() / scale.clamp_min(1e-300)
+    assert torch.isfinite(got).all() and (got[3] == 0).all()
+    assert err[scale > 0].max().item() < 5e-7, err[scale > 0].max().item()
+    assert torch.equal(rm, av.abs().amax(1))
+    assert torch.equal(got, dense.gemm_f16x2(av, w))
+    wide = torch.zeros((128, N), device=DEV); wide[:K] = w
+    assert torch.equal(got, dense.gemm_f16x2(buf[:, :128], wide)), "zero pad columns change no bit"
+    assert torch.equal(got, dense.gemm_f16x2(av.contiguous(), w))
+    monkeypatch.setenv("MMA_F16X2_G2", "1")                      # read per call: one resident group per workgroup
+    assert torch.equal(got, dense.gemm_f16x2(av, w))
+
+
+def test_gemm_f16x2_narrow_rejects_other_widths():
+    from mma_amd import dense
+    from mma_amd._lib import MMALibraryError
+    a, w = torch.randn(5000, 80, device=DEV), torch.randn(80, 128, device=DEV)
+    with pytest.raises(MMALibraryError, match="K=80"):
+        dense.gemm_f16x2(a, w)
+
+
 def test_gemm_f16x2_edge_rows():
     """Three-product kernel: all-zero rows, rows of one huge / one tiny value (the power-of-two row scale must keep both exact),
     a ragged last block, a row-strided A, and a wide dynamic range INSIDE rows."""

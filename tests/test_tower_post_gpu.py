@@ -85,6 +85,49 @@ def test_skinny_linear_against_float64(N, K, O, bias, x3, monkeypatch):
     assert (y2.double() - ref2).abs().max().item() <= 1e-5 * ref2.abs().max().item()
 
 
+@pytest.mark.parametrize("N,K,O,bias", [(5000, 75, 75, True), (199999, 75, 75, True), (4097, 80, 80, True), (4100, 16, 5, False),
+                                        (70000, 512, 64, True), (4099, 1, 1, True), (4, 7, 3, True)])
+def test_skinny_weight_and_bias_gradient_in_one_pass(N, K, O, bias):
+    """[r5] mma_skinny_linear_gw (K15's kernel in its plain form): gw = g^T x and gb = column sums of g from one pass, the ones column at
+    k = K (K = 80 / 16 / 512: a tile of its own).  Inside 1e-6 sum|g||x| of float64 (fp32 matrix cores, fp32 partial sums), the same
+    bits run after run, row-strided operands included."""
+    from mma_amd import dense
+    gen = torch.Generator().manual_seed(N + 3 * K + O)
+    gbuf = torch.randn(N, O + 3, generator=gen).to(DEV)
+    xbuf = torch.randn(N, K + 6, generator=gen).to(DEV)
+    g2, x2 = gbuf[:, 1:1 + O], xbuf[:, 4:4 + K]                 # row-strided views (pitches O + 3 / K + 6: the dword loads)
+    gw, gb = dense.skinny_gw(g2, x2, bias)
+    gw_b, gb_b = dense.skinny_gw(g2, x2, bias)
+    assert torch.equal(gw, gw_b) and (not bias or torch.equal(gb, gb_b)), "fixed summation order: run-to-run bit equality"
+    g64, x64 = g2.double(), x2.double()
+    ref = g64.t() @ x64
+    mag = g64.abs().t() @ x64.abs()
+    assert ((gw.double() - ref).abs() <= 1e-6 * mag + 1e-9).all().item(), (gw.double() - ref).abs().max().item()
+    if bias:
+        assert ((gb.double() - g64.sum(0)).abs() <= 1e-6 * g64.abs().sum(0) + 1e-9).all().item()
+    else:
+        assert gb is None
+    # contiguous operands take the same kernel: same values up to the loads' alignment (no arithmetic differs) -> bit-equal
+    gw_c, _ = dense.skinny_gw(g2.contiguous(), x2.contiguous(), bias)
+    assert torch.equal(gw, gw_c)
+
+
+def test_skinny_gradient_switch_matches_the_library_path(monkeypatch):
+    """MMA_SKINNY_GW=0 (module switch) is round 4's TN GEMM + column sum: the two backward forms of a 75 -> 75 layer agree to fp32 noise."""
+    from mma_amd import dense
+    gen = torch.Generator().manual_seed(11)
+    x, W, b = torch.randn(9000, 75, generator=gen).to(DEV), (torch.randn(75, 75, generator=gen) / 8).to(DEV), torch.randn(75, generator=gen).to(DEV)
+    cot = torch.randn(9000, 75, generator=gen).to(DEV)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(dense, "SKINNY_GW", on)
+        xd, wd, bd = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        res.append(torch.autograd.grad((dense.linear(xd, wd, bd) * cot).sum(), [xd, wd, bd]))
+    for a, c in zip(*res):
+        assert (a - c).abs().max().item() <= 2e-5 * c.abs().max().item()
+    assert torch.equal(res[0][0], res[1][0]), "dL/dx does not depend on the switch"
+
+
 def test_shapes_inside_the_old_gates_but_outside_the_kernels_take_the_library_path():
     """Linear(512 -> 80) on >= 4096 rows passed `_skinny_ok` (O <= 80, K <= 512) but its 160 KB of staged weights do
     not fit the LDS beside the wave tiles - MMA_REQUIRE raised where round 2 ran the library GEMM.  The gate now asks
