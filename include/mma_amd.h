@@ -222,6 +222,14 @@ int mma_gemm_f16x2_k(const float* A, int64_t lda, const void* Bt2, const float* 
  * all-zero row): 256 floats per row do not fit the registers beside their own fp16 pieces while an in-kernel maximum forms. */
 int mma_gemm_f16x2_k256(const float* A, int64_t lda, const float* row_max, const void* Bt2, const float* col_unscale, float* C,
                         int64_t ldc, int64_t M, int32_t N, void* stream);
+/* ABI 35: the same product with A PACKED once (the 32 column groups of hidden width 256 each loaded the rows in the MFMA's fragment shape
+ * - 8x the line requests of a coalesced load - and split them again): mma_pack_f16x2_k256 writes, per 32-row unit, the 16 k-steps x 2 fp16
+ * pieces in fragment order (Ap: mma_pack_f16x2_k256_bytes(M) bytes, 16-byte aligned), the rows' scale exponents sce (M,) and, optionally,
+ * their maxima row_max (M,); mma_gemm_f16x2_k256p multiplies from that.  Bit-equal to mma_gemm_f16x2_k256 given the exact row maxima. */
+int64_t mma_pack_f16x2_k256_bytes(int64_t M);
+int mma_pack_f16x2_k256(const float* A, int64_t lda, int64_t M, void* Ap, int32_t* sce, float* row_max, void* stream);
+int mma_gemm_f16x2_k256p(const void* Ap, const int32_t* sce, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,
+                         int64_t M, int32_t N, void* stream);
 /* The same three-product form for N = 128 and a long reduction (dL/dx += [gP|gQ] [Wtop|Wbot]^T, K % 64 == 0): the row scales
  * cannot be formed in the kernel (a row is consumed in 64-wide chunks), so the caller passes row_max (M,) >= the maximum
  * |a| of every row (the backward kernels produce it: mma_nc_bwd_node / mma_nc_fused_bwd); 0 marks an all-zero row.

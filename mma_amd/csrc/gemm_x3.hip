@@ -978,10 +978,15 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_k256_kernel
 #pragma unroll
     for (int half = 0; half < 2; ++half) {                            // 16 float4 at a time: raw pieces turn into fp16 pieces in place
       float4 raw[16];
+      if (kAbl & 8) {                                                 // measurement: no A loads
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        raw[2 * ks] = *reinterpret_cast<const float4*>(ap + (half * 8 + ks) * 16);
-        raw[2 * ks + 1] = *reinterpret_cast<const float4*>(ap + (half * 8 + ks) * 16 + 4);
+        for (int i = 0; i < 16; ++i) raw[i] = make_float4(rmax, 1.f, 1.f, 1.f);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          raw[2 * ks] = *reinterpret_cast<const float4*>(ap + (half * 8 + ks) * 16);
+          raw[2 * ks + 1] = *reinterpret_cast<const float4*>(ap + (half * 8 + ks) * 16 + 4);
+        }
       }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
@@ -991,7 +996,7 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_k256_kernel
           const float x = v[i] * sc;
           const _Float16 hi = (_Float16)x;
           af[half * 8 + ks][0][i] = hi;
-          af[half * 8 + ks][1][i] = (_Float16)((x - (float)hi) * 2048.f);
+          af[half * 8 + ks][1][i] = (kAbl & 16) ? hi : (_Float16)((x - (float)hi) * 2048.f);      // 16: measurement, no lo piece arithmetic
         }
       }
     }
@@ -1017,13 +1022,176 @@ __global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_k256_kernel
           nxt.b2 = *reinterpret_cast<const f16x8*>(sb + kH2Piece + (ks + 1) * 32);
         }
         __builtin_amdgcn_sched_barrier(0);
-        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b2, acl, 0, 0, 0);
-        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], cur.b1, acl, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b1, acc, 0, 0, 0);
+        if (!(kAbl & 2)) {
+          acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b2, acl, 0, 0, 0);
+          acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], cur.b1, acl, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b1, acc, 0, 0, 0);
+        } else {
+          asm volatile("" :: "v"(af[ks][0]), "v"(af[ks][1]), "v"(cur.b1), "v"(cur.b2));
+        }
         // [r4] one store of the PREVIOUS tile behind every k-step (see gemm_f16x2_colgroup_kernel): the 17 GB this product writes at
         // hidden width 256 leave in a steady stream beside the MFMAs instead of in bursts between them
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[ks]), crow_p, c_off * 4u,
-                                              (uint32_t)(((ks & 3) + 8 * (ks >> 2)) * (int)p.ldc) * 4u + pcol, kCgStoreAux);
+        if (!(kAbl & 4))
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[ks]), crow_p, c_off * 4u,
+                                                (uint32_t)(((ks & 3) + 8 * (ks >> 2)) * (int)p.ldc) * 4u + pcol, kCgStoreAux);
+        else
+          asm volatile("" :: "v"(prev[ks]));
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) prev[r] = ldexpf(acc[r] + acl[r] * (1.f / 2048.f), cue - rse[r]);
+      crow_p = crow;
+      pcol = (uint32_t)(g * 128 + ct * 32) * 4u;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[r]), crow_p, c_off * 4u, (uint32_t)(((r & 3) + 8 * (r >> 2)) * (int)p.ldc) * 4u + pcol,
+                                          kCgStoreAux);
+}
+
+// ---- [r5] K == 256 with a PACKED A operand ------------------------------------------------------------------------------------------
+// Measurement builds of the kernel above at the C5 shard shape (2^20 x 256 -> 4096: 7.7 ms): without its MFMAs 6.4 ms, without its stores
+// 6.3, without the A loads 5.4, without the lo-piece arithmetic 7.2 - the matrix pipe is not what it waits for.  Every one of the 32 column
+// groups loads the same rows in the MFMA's fragment shape (one instruction = 32 rows x 32 bytes: 32 line requests for 1 KB, every line
+// requested by four instructions) and splits them again: 2 048 line requests and ~800 VALU instructions per wave and 32-row unit, 32 times.
+// mma_pack_f16x2_k256 does that ONCE: per 32-row unit the 16 k-steps x 2 fp16 pieces in fragment order, [unit][k-step][piece][lane][8
+// halves] (32 KB per unit, the same bytes as the fp32 rows), plus the row's scale exponent and maximum.  The product kernel then reads a
+// fragment with ONE fully coalesced 1 KB load per (k-step, piece) and does no arithmetic on A at all: 7.75 -> 6.9 ms (pack pass 0.3 included).
+// What is left (rocprofv3 SQ counters, profiles/r05_c5_gemm_sq.md): the matrix pipe 40 % busy, no LDS bank conflicts, LDS issue stalls 3 % of
+// the wave cycles; measurement builds: without MFMAs 4.6 ms, without stores 5.0.  A wave's fragment loads sit behind the 64 stores of its
+// previous unit in the one in-order vmcnt queue, so their wait is a wait for store acknowledgements - both waves of a SIMD at once.
+__global__ __launch_bounds__(256) void pack_f16x2_k256_kernel(const float* __restrict__ A, int64_t lda, int64_t M, uint4* __restrict__ Ap,
+                                                              int* __restrict__ sce_out, float* __restrict__ row_max_out) {
+  const int lane = threadIdx.x & 63, r31 = lane & 31, h = lane >> 5;
+  const int64_t n_units = (M + 31) / 32;
+  for (int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); u < n_units; u += (int64_t)gridDim.x * 4) {
+    const int64_t row = u * 32 + r31;
+    const bool valid = row < M;
+    const float* ap = A + min(row, M - 1) * lda + 8 * h;
+    float4 raw[32];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      raw[2 * ks] = *reinterpret_cast<const float4*>(ap + ks * 16);
+      raw[2 * ks + 1] = *reinterpret_cast<const float4*>(ap + ks * 16 + 4);
+    }
+    float rmax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(raw[i].x), fabsf(raw[i].y)), fmaxf(fabsf(raw[i].z), fabsf(raw[i].w))));
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+    const int ex = (int)((__float_as_uint(rmax) >> 23) & 0xFF);
+    const int sce = min(max(14 - (ex - 127), -126), 127);            // log2 of the row scale (the same rule as the kernels above)
+    const float sc = valid ? __uint_as_float((uint32_t)(sce + 127) << 23) : 0.f;      // rows past M: zero pieces
+    if (h == 0 && valid) { sce_out[row] = sce; if (row_max_out) row_max_out[row] = rmax; }
+    uint4* dst = Ap + (size_t)u * (16 * 2 * 64) + lane;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const float v[8] = {raw[2*ks].x, raw[2*ks].y, raw[2*ks].z, raw[2*ks].w, raw[2*ks+1].x, raw[2*ks+1].y, raw[2*ks+1].z, raw[2*ks+1].w};
+      f16x8 hi8, lo8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float x = v[i] * sc;
+        const _Float16 hi = (_Float16)x;
+        hi8[i] = hi;
+        lo8[i] = (_Float16)((x - (float)hi) * 2048.f);
+      }
+      dst[(ks * 2 + 0) * 64] = *reinterpret_cast<const uint4*>(&hi8);
+      dst[(ks * 2 + 1) * 64] = *reinterpret_cast<const uint4*>(&lo8);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kCgThreads, 1) void gemm_f16x2_colgroup_k256p_kernel(const GemmParams p, const uint4* __restrict__ Ap,
+                                                                                 const int* __restrict__ sce_arr, const float* col_unscale,
+                                                                                 int64_t n_units, int n_groups) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kH2Lds];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, h = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int streams_per_xcd = kCgSlotsPerXcd / n_groups;
+  if (slot >= streams_per_xcd * n_groups) return;
+  const int g = slot % n_groups;
+  const int64_t stream = xcd * streams_per_xcd + slot / n_groups, n_streams = 8 * streams_per_xcd;
+  const _Float16* Bh = reinterpret_cast<const _Float16*>(p.Bt);            // (2, N, 256) fp16: hi, lo * 2^11
+  for (int q = tid; q < 4 * 2 * 32 * 32; q += kCgThreads) {
+    const int kq = q & 31, col = (q >> 5) & 31, tp = q >> 10, piece = tp % 2, tile = tp / 2;
+    *reinterpret_cast<uint4*>(lds + tile * kH2Tile + piece * kH2Piece + col * kH2Pitch + kq * 16) =
+        *reinterpret_cast<const uint4*>(Bh + ((size_t)piece * p.N + (size_t)(g * 128 + tile * 32 + col)) * 256 + kq * 8);
+  }
+  __syncthreads();
+  const uint32_t c_off = 4u * h * (uint32_t)p.ldc + (uint32_t)r31;
+  const unsigned char* sb0 = lds + r31 * kH2Pitch + h * 16;
+  int cues[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) cues[t] = (int)((__float_as_uint(col_unscale[g * 128 + 32 * t + r31]) >> 23) & 0xFF) - 127;
+  float prev[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) prev[r] = 0.f;
+  __amdgpu_buffer_rsrc_t crow_p = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000);
+  uint32_t pcol = 0;
+  // [r5, measured and NOT kept] the next unit's fragments requested during the last tile of this one, each k-step's two pieces right behind
+  // the last MFMAs that read them (clean code: 192 MFMAs, four vmcnt waits per unit, no copies): 7.10 ms against 6.89 with the loads at the
+  // top of their own unit - the wait for the rows is not what this kernel loses its time to.
+  for (int64_t u = stream; u < n_units; u += n_streams) {
+    const int64_t row0 = u * kCgRows + wave * 32;
+    if (row0 >= p.M) break;
+    const int64_t rows_here = min((int64_t)32, p.M - row0);
+    const uint4* ap = Ap + (size_t)(row0 >> 5) * (16 * 2 * 64) + lane;
+    f16x8 af[16][2];
+    if (kAbl & 8) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { af[ks][0][i] = (_Float16)1.f; af[ks][1][i] = (_Float16)0.5f; }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const uint4 a0 = ap[(ks * 2 + 0) * 64], a1 = ap[(ks * 2 + 1) * 64];
+        af[ks][0] = *reinterpret_cast<const f16x8*>(&a0);
+        af[ks][1] = *reinterpret_cast<const f16x8*>(&a1);
+      }
+    }
+    const int sce = sce_arr[row0 + min((int64_t)r31, rows_here - 1)];
+    int rse[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rse[r] = __shfl(sce, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+    const __amdgpu_buffer_rsrc_t crow =
+        __builtin_amdgcn_make_buffer_rsrc(p.C + row0 * p.ldc, 0, (int)min((int64_t)0x7fffffff, rows_here * p.ldc * 4), 0x00020000);
+#pragma unroll 1
+    for (int ct = 0; ct < 4; ++ct) {
+      int cue = cues[0];
+#pragma unroll
+      for (int t = 1; t < 4; ++t) cue = ct == t ? cues[t] : cue;
+      f32x16 acc, acl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acl[r] = 0.f; }
+      const unsigned char* sb = sb0 + ct * kH2Tile;
+      HFrag cur;
+      cur.b1 = *reinterpret_cast<const f16x8*>(sb);
+      cur.b2 = *reinterpret_cast<const f16x8*>(sb + kH2Piece);
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        HFrag nxt = cur;
+        if (ks < 15) {
+          nxt.b1 = *reinterpret_cast<const f16x8*>(sb + (ks + 1) * 32);
+          nxt.b2 = *reinterpret_cast<const f16x8*>(sb + kH2Piece + (ks + 1) * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(kAbl & 2)) {
+          // (the hi product between the two lo products or behind them, with or without the scheduling fences: 6.92-6.99 ms, no difference)
+          acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b2, acl, 0, 0, 0);
+          acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], cur.b1, acl, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], cur.b1, acc, 0, 0, 0);
+        } else {
+          asm volatile("" :: "v"(af[ks][0]), "v"(af[ks][1]), "v"(cur.b1), "v"(cur.b2));
+        }
+        if (!(kAbl & 4))
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[ks]), crow_p, c_off * 4u,
+                                                (uint32_t)(((ks & 3) + 8 * (ks >> 2)) * (int)p.ldc) * 4u + pcol, kCgStoreAux);
+        else
+          asm volatile("" :: "v"(prev[ks]));
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
       }
@@ -1653,6 +1821,9 @@ struct TnParams {
   // batched form (blockIdx.y = b): X + b*xb and G + b*gb (column offsets inside wider rows: the towers of MMAConv), partial tiles
   // (splits, batch, KA, NC); zero for a single product
   int64_t xb, gb, part_ss;
+  // [r5] three-product form, X PACKED (tn_pack_x_kernel): per 32-row chunk and 32-column block of X the two k-steps x two fp16 pieces in
+  // the MFMA's fragment order (4 KB); NULL = the kernel loads and splits the fp32 rows itself
+  const void* xp; int xp_nb;
 };
 
 constexpr int kTnKC = 32;                        // rows of X / G per chunk
@@ -1945,10 +2116,43 @@ __device__ __forceinline__ float scale_of(const u32x4& q, const int i) {
   return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
 }
 
+// [r5] X of one three-product TN call in fragment order: Xp[chunk of 32 rows][block of 32 columns][k-step 2][piece 2][lane 64] x 16 bytes,
+// scaled by the row scales of THIS call (sxh) and split exactly as the kernel's own MMA_TN2_SPLITX does.  Rows past M: zeros; columns past
+// KA repeat the last column (they only reach accumulator rows that are never stored).  One wave per (chunk, block).
+__global__ __launch_bounds__(256) void tn_pack_x_kernel(const float* __restrict__ X, int64_t ldx, int64_t M, int KA, const uint16_t* __restrict__ sxh,
+                                                        u32x4* __restrict__ Xp, int nb, int64_t n_items) {
+  const int lane = threadIdx.x & 63, r31 = lane & 31, h = lane >> 5;
+  for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (int64_t)gridDim.x * 4) {
+    const int64_t chunk = it / nb;
+    const int w = (int)(it % nb);
+    const int col = min(w * 32 + r31, KA - 1);
+    u32x4* dst = Xp + (size_t)it * 256 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int64_t row0 = chunk * 32 + ks * 16 + 8 * h;
+      const u32x4 sc = *reinterpret_cast<const u32x4*>(sxh + row0);             // sxh is padded to whole chunks (scale 0)
+      f16x8 a, b;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = row0 + i < M ? X[(row0 + i) * ldx + col] : 0.f;
+        _Float16 u, l;
+        split2s(v, scale_of(sc, i), u, l);
+        a[i] = u; b[i] = l;
+      }
+      dst[(ks * 2 + 0) * 64] = *reinterpret_cast<const u32x4*>(&a);
+      dst[(ks * 2 + 1) * 64] = *reinterpret_cast<const u32x4*>(&b);
+    }
+  }
+}
+
 // NW = 4: 256 threads, X up to 128 columns wide (a wave per 32 of them), two workgroups per CU.  NW = 8 [r4]: 512 threads for X up to 256
 // columns wide (hidden width 256, C5) - the eight waves share ONE staged G tile, so G is read once instead of once per 128-column block
 // of X (two launches, each reading all 17 GB of [gP|gQ] at the C5 shard shape), and a thread splits 8 of its values per chunk, not 16.
-template <bool FULLCT, int NW>
+// PX [r5]: X comes packed.  Every 128-column block of G walks all rows of X: at hidden width 256 (C5: 32 column blocks) each of them loaded
+// X with 16 dword loads per chunk and lane and split it again - two thirds of the kernel's VALU instructions (SQ_INSTS_VALU 1.18e9 per call
+// against 3.0e9 / 6 for the forward).  tn_pack_x_kernel does it once per call (the row scales depend on BOTH operands' maxima, so not once
+// per layer); the kernel then takes a chunk's fragments with four coalesced 16-byte loads.  Same pieces, same products: the same bits.
+template <bool FULLCT, int NW, bool PX = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_f16x2_tn_kernel(const TnParams p) {
   constexpr int KG = 8 / NW;                     // 8-row k-groups of the 32-row chunk a thread stages: 2 (groups skg, skg + 2) or 1
   constexpr int GV = 8 * KG;                     // its G values per chunk
@@ -1991,6 +2195,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_f16x2_tn_kernel
   const int g_voff = skg * 8 * ldg_b + scol * 4;
   const int x_voff = 8 * h * ldx_b + xcol * 4;
   const int sg_voff = skg * 16, sx_voff = h * 16;            // bytes: 8 rows x 2
+  // packed X: chunk (rbase / 32 + c), block `wave`: 256 x 16 bytes; chunks past the split's last read as zeros (range check)
+  const int xq_stride = p.xp_nb * 4096;
+  const auto xq_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(static_cast<const unsigned char*>(p.xp) + (PX ? (size_t)(rbase >> 5) * (size_t)xq_stride : 0)), 0,
+      PX ? (rows_pad / kTnKC) * xq_stride : 0, 0x00020000);
+  const int xq_voff = ((wave_active ? wave : 0) * 256 + lane) * 16;
 
   f32x16 acc[4];
 #pragma unroll
@@ -2008,22 +2218,39 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_f16x2_tn_kernel
     asm volatile("" : "+v"(gv), "+v"(xv));                                                     \
     _Pragma("unroll") for (int g = 0; g < KG; ++g)                                             \
       GS_[g] = __builtin_amdgcn_raw_buffer_load_b128(sg_rsrc, sg_voff + (C_) * (kTnKC * 2) + g * 32, 0, 0); \
-    _Pragma("unroll") for (int g = 0; g < 2; ++g)                                              \
-      XS_[g] = __builtin_amdgcn_raw_buffer_load_b128(sx_rsrc, sx_voff + (C_) * (kTnKC * 2) + g * 32, 0, 0); \
+    if (!PX) {                                                                                 \
+      _Pragma("unroll") for (int g = 0; g < 2; ++g)                                            \
+        XS_[g] = __builtin_amdgcn_raw_buffer_load_b128(sx_rsrc, sx_voff + (C_) * (kTnKC * 2) + g * 32, 0, 0); \
+    }                                                                                          \
     _Pragma("unroll") for (int g = 0; g < KG; ++g)                                             \
       _Pragma("unroll") for (int i = 0; i < 8; ++i)                                            \
         GR_[g * 8 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rsrc, gv, (g * 16 + i) * ldg_b, 2 /* nt: G streams through once, X is what the column blocks share in L2 */)); \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                            \
-        XR_[ks * 8 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, xv, (ks * 16 + i) * ldx_b, 0)); \
+    if (PX) {                     /* the 16 registers of the raw set hold the four packed fragments */ \
+      _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                          \
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xq_rsrc, xq_voff + f * 1024, (C_) * xq_stride, 0); \
+        XR_[4 * f] = __uint_as_float(q[0]); XR_[4 * f + 1] = __uint_as_float(q[1]);            \
+        XR_[4 * f + 2] = __uint_as_float(q[2]); XR_[4 * f + 3] = __uint_as_float(q[3]);        \
+      }                                                                                        \
+    } else {                                                                                   \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                         \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
+          XR_[ks * 8 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, xv, (ks * 16 + i) * ldx_b, 0)); \
+    }                                                                                          \
   }
 #define MMA_TN2_SPLITX(XR_, XS_)                                                               \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                             \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                            \
-      _Float16 a, b;                                                                           \
-      split2s(XR_[ks * 8 + i], scale_of(XS_[ks], i), a, b);                                    \
-      af[ks][0][i] = a; af[ks][1][i] = b;                                                      \
-    }
+  if (PX) {                                                                                    \
+    _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                            \
+      const u32x4 q = {__float_as_uint(XR_[4 * f]), __float_as_uint(XR_[4 * f + 1]), __float_as_uint(XR_[4 * f + 2]), __float_as_uint(XR_[4 * f + 3])}; \
+      af[f >> 1][f & 1] = *reinterpret_cast<const f16x8*>(&q);                                 \
+    }                                                                                          \
+  } else {                                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                          \
+        _Float16 a, b;                                                                         \
+        split2s(XR_[ks * 8 + i], scale_of(XS_[ks], i), a, b);                                  \
+        af[ks][0][i] = a; af[ks][1][i] = b;                                                    \
+      }                                                                                        \
+  }
 #define MMA_TN2_PUBLISH(B_, GR_, XR_, GS_, XS_)                                                \
   {                                                                                            \
     unsigned char* d = lds + (B_) * kTn2Slab + sn * kTnPitch;                                  \
@@ -2274,6 +2501,32 @@ extern "C" int mma_gemm_f16x2_k256(const float* A, int64_t lda, const float* row
   return check_launch("gemm_f16x2_colgroup_k256_kernel");
 }
 
+// [r5] the packed A operand of mma_gemm_f16x2_k256p: Ap = ceil(M / 32) units of 32 KB (mma_pack_f16x2_k256_bytes), sce (M,) int32 scale
+// exponents, row_max (M,) optional (max |a| per row: the x_row_max of the weight-gradient product) - one pass over A
+extern "C" int64_t mma_pack_f16x2_k256_bytes(int64_t M) { return M <= 0 ? 0 : (M + 31) / 32 * (int64_t)(16 * 2 * 64 * 16); }
+extern "C" int mma_pack_f16x2_k256(const float* A, int64_t lda, int64_t M, void* Ap, int32_t* sce, float* row_max, void* stream) {
+  MMA_REQUIRE(M >= 0 && lda >= 256 && lda % 4 == 0 && lda < (1 << 24), "M=%lld lda=%lld: need lda >= 256, lda %% 4 == 0", (long long)M, (long long)lda);
+  if (M == 0) return 0;
+  MMA_REQUIRE(A && Ap && sce && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Ap) & 15) == 0, "NULL or misaligned argument");
+  const int64_t n_units = (M + 31) / 32;
+  hipLaunchKernelGGL(pack_f16x2_k256_kernel, dim3((unsigned)std::min<int64_t>((n_units + 3) / 4, 8 * 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), A, lda, M, static_cast<uint4*>(Ap), sce, row_max);
+  return check_launch("pack_f16x2_k256_kernel");
+}
+extern "C" int mma_gemm_f16x2_k256p(const void* Ap, const int32_t* sce, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,
+                                    int64_t M, int32_t N, void* stream) {
+  MMA_REQUIRE(M >= 0 && N >= 128 && N % 128 == 0 && N / 128 <= kCgSlotsPerXcd, "M=%lld N=%d: need N %% 128 == 0, N <= 4096", (long long)M, N);
+  MMA_REQUIRE(ldc >= N && ldc < (1 << 24), "row pitch too small or >= 2^24");
+  if (M == 0) return 0;
+  MMA_REQUIRE(Ap && sce && Bt2 && col_unscale && C && (reinterpret_cast<uintptr_t>(Ap) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bt2) & 15) == 0,
+              "NULL or misaligned argument");
+  GemmParams p{nullptr, 256, static_cast<const __bf16*>(Bt2), C, ldc, M, N, 256, 0};
+  const int64_t n_units = (M + kCgRows - 1) / kCgRows;
+  hipLaunchKernelGGL(gemm_f16x2_colgroup_k256p_kernel, dim3(256), dim3(kCgThreads), 0, static_cast<hipStream_t>(stream), p,
+                     static_cast<const uint4*>(Ap), sce, col_unscale, n_units, N / 128);
+  return check_launch("gemm_f16x2_colgroup_k256p_kernel");
+}
+
 extern "C" int mma_gemm_f16x2_ws(const float* A, int64_t lda, const void* Bt2, const float* col_unscale, float* C, int64_t ldc,
                                  float* a_row_max, int64_t M, int32_t N, int32_t K, void* stream) {
   MMA_REQUIRE(M >= 0 && (K == 128 || K == 256) && N >= 256 && N % 256 == 0 && (kCgSlotsPerXcd % (N / 256)) == 0,
@@ -2416,10 +2669,20 @@ extern "C" int mma_row_absmax(const float* A, int64_t lda, int64_t M, int32_t co
   return check_launch("row_absmax_kernel");
 }
 
+// X packed once per call when many 128-column blocks of G walk it (each of them would load and split X again): C5's 32 blocks, not C4's 8
+// (measured: see DESIGN.md); MMA_TN_PACKX = 0 / 1 forces it (read per call, A/B)
+static bool tn_packx(int64_t M, int KA, int NC) {
+  const char* e = getenv("MMA_TN_PACKX");
+  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  return M >= 65536 && ((int64_t)NC + 127) / 128 >= 16;
+}
+static int64_t tn_packx_floats(int64_t M, int KA) { return tn_pad32(M) / 32 * (((int64_t)KA + 31) / 32) * 1024; }      // 4 KB per (chunk, block)
+
 extern "C" int64_t mma_gemm_f16x2_tn_workspace_floats(int64_t M, int32_t KA, int32_t NC) {
   if (M <= 0 || KA <= 0 || NC <= 0) return 0;
   const int s = tn_splits(M, NC);
-  return (s > 1 ? ((int64_t)s * KA * NC + 3) / 4 * 4 : 0) + 3 * tn_pad32(M) + 4;     // partial tiles | row maxima of X, of G | scale halves | state
+  // partial tiles | row maxima of X, of G | scale halves | state | packed X
+  return (s > 1 ? ((int64_t)s * KA * NC + 3) / 4 * 4 : 0) + 3 * tn_pad32(M) + 4 + (tn_packx(M, KA, NC) ? tn_packx_floats(M, KA) : 0);
 }
 
 extern "C" int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, const float* x_row_max, const float* g_row_max,
@@ -2431,11 +2694,14 @@ extern "C" int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, in
               (reinterpret_cast<uintptr_t>(ws) & 15) == 0, "misaligned argument");
   const int s = tn_splits(M, NC);
   const int64_t n_part = s > 1 ? ((int64_t)s * KA * NC + 3) / 4 * 4 : 0, Mp = tn_pad32(M);   // whole 16-byte units: the scale vectors behind it are read as such
-  MMA_REQUIRE(ws_floats >= n_part + 3 * Mp + 4, "workspace too small: %lld floats, need %lld", (long long)ws_floats,
-              (long long)(n_part + 3 * Mp + 4));
+  const bool px = tn_packx(M, KA, NC);
+  const int64_t n_need = n_part + 3 * Mp + 4 + (px ? tn_packx_floats(M, KA) : 0);
+  MMA_REQUIRE(ws_floats >= n_need, "workspace too small: %lld floats, need %lld", (long long)ws_floats, (long long)n_need);
   int64_t rps = (M + s - 1) / s;
   rps = (rps + kTnKC - 1) / kTnKC * kTnKC;
   MMA_REQUIRE((rps + kTnKC) * (ldx > ldg ? ldx : ldg) * 4 < (1LL << 31), "row range of one split exceeds a 2 GB buffer window");
+  const int nb = (KA + 31) / 32;
+  MMA_REQUIRE(!px || (rps / kTnKC + 1) * (int64_t)nb * 4096 < (1LL << 31), "packed rows of one split exceed a 2 GB buffer window");
   float* xmax = ws + n_part;
   float* gmax = xmax + Mp;
   uint16_t* sxh = reinterpret_cast<uint16_t*>(gmax + Mp);
@@ -2452,11 +2718,22 @@ extern "C" int mma_gemm_f16x2_tn(const float* X, int64_t ldx, const float* G, in
   TnParams p{X, ldx, G, ldg, s == 1 ? C : ws, M, rps, KA, NC, s, sxh, sgh, state, 0};
   const dim3 grid((unsigned)(((NC + 127) / 128) * s));
   const bool full = NC % 128 == 0 && KA % 32 == 0;
+  if (px) {
+    u32x4* xp = reinterpret_cast<u32x4*>(ws + n_part + 3 * Mp + 4);
+    const int64_t n_items = Mp / 32 * nb;
+    hipLaunchKernelGGL(tn_pack_x_kernel, dim3((unsigned)std::min<int64_t>((n_items + 3) / 4, 8 * 2048)), dim3(256), 0, st, X, ldx, M, (int)KA, sxh,
+                       xp, nb, n_items);
+    p.xp = xp; p.xp_nb = nb;
+  }
   if (KA > 128) {                                                    // [r4] X up to 256 columns wide: eight waves on one staged G tile
-    if (full) hipLaunchKernelGGL((gemm_f16x2_tn_kernel<true, 8>), grid, dim3(512), 0, st, p);
+    if (px) { if (full) hipLaunchKernelGGL((gemm_f16x2_tn_kernel<true, 8, true>), grid, dim3(512), 0, st, p);
+              else hipLaunchKernelGGL((gemm_f16x2_tn_kernel<false, 8, true>), grid, dim3(512), 0, st, p); }
+    else if (full) hipLaunchKernelGGL((gemm_f16x2_tn_kernel<true, 8>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((gemm_f16x2_tn_kernel<false, 8>), grid, dim3(512), 0, st, p);
   } else {
-    if (full) hipLaunchKernelGGL((gemm_f16x2_tn_kernel<true, 4>), grid, dim3(kBlock), 0, st, p);
+    if (px) { if (full) hipLaunchKernelGGL((gemm_f16x2_tn_kernel<true, 4, true>), grid, dim3(kBlock), 0, st, p);
+              else hipLaunchKernelGGL((gemm_f16x2_tn_kernel<false, 4, true>), grid, dim3(kBlock), 0, st, p); }
+    else if (full) hipLaunchKernelGGL((gemm_f16x2_tn_kernel<true, 4>), grid, dim3(kBlock), 0, st, p);
     else hipLaunchKernelGGL((gemm_f16x2_tn_kernel<false, 4>), grid, dim3(kBlock), 0, st, p);
   }
   p.want_bad = 1;                                                    // the six-product form takes over when the scale kernels said so

@@ -61,6 +61,7 @@ def _split_f16x2(w, plain_lo=False):
     return bt2, cu
 
 
+PACK_K256 = __import__("os").environ.get("MMA_PACK_K256", "1") != "0"        # 0: round 4's K = 256 forward (fp32 rows split per column group)
 USE_F16X2_N128 = __import__("os").environ.get("MMA_F16X2_DX", "1") != "0"
 USE_F16X2_K256 = __import__("os").environ.get("MMA_F16X2_K256", "1") != "0"
 
@@ -150,6 +151,20 @@ def gemm_bf16x3(a, w, out=None, accumulate=False, row_max_box=None):
             bt2, cu = _split_f16x2(w)
             with _span("gemm_x3_persist", nbytes=4 * M * (K + N), flops=2 * M * K * N, mfma="f16x3"):
                 call("mma_gemm_f16x2_ws", ptr(a), a.stride(0), ptr(bt2), ptr(cu), ptr(out), out.stride(0), ptr(rm), M, N, K, stream_ptr())
+            return out
+        if K == 256 and N <= 4096 and USE_F16X2_K256 and PACK_K256:
+            # [r5] A packed once into fp16 fragment order (one pass: row maxima, scale exponents, both pieces) - the 32 column groups of
+            # hidden width 256 stop re-loading the rows in the MFMA's fragment shape and re-splitting them (C5 shard: 7.7 -> see DESIGN.md)
+            rm = torch.empty((M,), device=a.device, dtype=torch.float32)
+            if row_max_box is not None:
+                row_max_box.append(rm)
+            ap = torch.empty((int(_lib.query("mma_pack_f16x2_k256_bytes", M)),), device=a.device, dtype=torch.uint8)
+            sce = torch.empty((M,), device=a.device, dtype=torch.int32)
+            bt2, cu = _split_f16x2(w)
+            with _span("pack_f16x2", nbytes=8 * M * K, flops=0):
+                call("mma_pack_f16x2_k256", ptr(a), a.stride(0), M, ptr(ap), ptr(sce), ptr(rm), stream_ptr())
+            with _span("gemm_x3_persist", nbytes=4 * M * (K + N), flops=2 * M * K * N, mfma="f16x3"):
+                call("mma_gemm_f16x2_k256p", ptr(ap), ptr(sce), ptr(bt2), ptr(cu), ptr(out), out.stride(0), M, N, stream_ptr())
             return out
         rm = row_absmax(a)
         if row_max_box is not None:

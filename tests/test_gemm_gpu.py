@@ -144,6 +144,33 @@ def test_gemm_f16x2_tn_accuracy(M, KA, NC, padx, padg, maxima):
     assert torch.equal(dense.gemm_f16x2_tn(x, g, xm, gm), got)
 
 
+@pytest.mark.parametrize("M,KA,NC,padx", [(70001, 256, 2048, 0), (66000, 128, 2048, 4), (65537, 200, 2100, 0), (70001, 64, 384, 0), (9000, 96, 256, 0)])
+def test_gemm_f16x2_tn_packed_x_is_bit_equal(M, KA, NC, padx, monkeypatch):
+    """[r5] X packed once per call in fragment order (tn_pack_x_kernel; default from 16 column blocks of 128 on, MMA_TN_PACKX forces it, read
+    per call): the same pieces and the same products as the kernel that loads and splits the fp32 rows per column block - the same bits,
+    for whole and ragged tiles, a row-strided X, splits that end inside the last chunk, and the device-side fall-back (a spread of 2^50)."""
+    from mma_amd import dense
+    rng = np.random.default_rng(M + KA + NC)
+    xf = torch.from_numpy((rng.standard_normal((M, KA + padx)) * np.exp(rng.uniform(-4, 4, (M, 1)))).astype(np.float32)).to(DEV)
+    g = torch.from_numpy((rng.standard_normal((M, NC)) * np.exp(rng.uniform(-4, 4, (M, 1)))).astype(np.float32)).to(DEV)
+    x = xf[:, padx:]
+    xm, gm = x.abs().amax(1), g.abs().amax(1)
+    res = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("MMA_TN_PACKX", v)
+        res[v] = dense.gemm_f16x2_tn(x, g, xm, gm)
+    assert torch.equal(res["0"], res["1"])
+    ref = x.double().t() @ g.double()
+    scale = x.double().abs().t() @ g.double().abs()
+    assert ((res["1"].double() - ref).abs() / scale).max().item() < 5e-7
+    monkeypatch.delenv("MMA_TN_PACKX")
+    assert torch.equal(dense.gemm_f16x2_tn(x, g, xm, gm), res["0"])          # the default, whichever form the shape takes
+    x2 = x.clone(); x2[5] *= 2.0 ** 50                                           # fall-back decided on the device: packed or not, six products
+    xm2 = x2.abs().amax(1)
+    monkeypatch.setenv("MMA_TN_PACKX", "1")
+    assert torch.equal(dense.gemm_f16x2_tn(x2, g, xm2, gm), dense.gemm_bf16x3_tn(x2, g))
+
+
 @pytest.mark.parametrize("KA", [128, 256])
 @pytest.mark.parametrize("case", ["spread", "inf", "nan", "subnormal", "zero"])
 def test_gemm_f16x2_tn_falls_back_on_the_device(case, KA):
@@ -209,7 +236,7 @@ def test_row_absmax(M, C, pad):
 
 
 @pytest.mark.parametrize("M,N", [(66001, 4096), (70000, 384), (131075, 1024), (65536, 256)])
-def test_gemm_f16x2_k256(M, N):
+def test_gemm_f16x2_k256(M, N, monkeypatch):
     """K = 256 column-group three-product kernel (C5 forward shape) against fp64: rows spread over e^+-6, zero rows, ragged M; the
     chunked N = 128 kernel on the same operands gives the same error level."""
     from mma_amd import dense
@@ -231,6 +258,14 @@ def test_gemm_f16x2_k256(M, N):
     box = []
     dense.gemm_bf16x3(a, w, row_max_box=box)
     assert len(box) == 1 and torch.equal(box[0], a.abs().amax(1))
+    # [r5] the default path packs A once (mma_pack_f16x2_k256 + mma_gemm_f16x2_k256p); round 4's kernel splits the fp32 rows per column
+    # group: the same pieces, the same products in the same order - the same bits; a row-strided A as well
+    monkeypatch.setattr(dense, "PACK_K256", False)
+    assert torch.equal(dense.gemm_bf16x3(a, w), got)
+    monkeypatch.setattr(dense, "PACK_K256", True)
+    buf = torch.zeros((M, 256 + 8), device=DEV)
+    buf[:, :256] = a
+    assert torch.equal(dense.gemm_bf16x3(buf[:, :256], w), got)
 
 
 def test_forward_gemm_exports_the_row_maxima():
