@@ -210,6 +210,27 @@ __device__ __forceinline__ float wave_max_nonneg(float m) {
   return fmaxf(m, __shfl_xor(m, 32, 64));
 }
 
+// the upper 16 bits of a non-negative fp32 pattern, rounded UP: as an unsigned 16-bit number it orders like the value, and (v << 16) read as
+// fp32 is >= the value and within 2^-7 of it (inf and NaN patterns stay what they are)
+__device__ __forceinline__ uint32_t up16_nonneg(const float m) {
+  const uint32_t b = __float_as_uint(m);
+  return b >= 0x7F800000u ? b >> 16 : (b + 0xFFFFu) >> 16;
+}
+// lane-wise maximum of two packed unsigned 16-bit fields over a FULLY ACTIVE wavefront (see wave_max_nonneg), result in every lane
+__device__ __forceinline__ uint32_t wave_pkmax_u16(uint32_t v) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  auto pk = [](uint32_t a, uint32_t b) {
+    const us2 r = __builtin_elementwise_max(*reinterpret_cast<const us2*>(&a), *reinterpret_cast<const us2*>(&b));
+    return *reinterpret_cast<const uint32_t*>(&r);
+  };
+  v = pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));
+  v = pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true));
+  v = pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true));
+  v = pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true));
+  v = pk(v, (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F));
+  return pk(v, (uint32_t)__shfl_xor((int)v, 32, 64));
+}
+
 __host__ inline int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 }  // namespace mma

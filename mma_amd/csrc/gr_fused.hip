@@ -909,8 +909,7 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
   __shared__ uint32_t rmax_b[32];                             // per node of the block: the bound of its edges' rows (phase A)
   __shared__ uint32_t rmax_n[32];                             // per node: max |dL/dU row| (phase B, exact)
   const bool want_rmax = p.gmsg_rmax != nullptr;              // both arrays or neither (host check)
-  if (want_rmax && tid < 32) { rmax_b[tid] = 0u; rmax_n[tid] = 0u; }
-  if (want_rmax) __syncthreads();
+  if (want_rmax && tid < 32) { rmax_b[tid] = 0u; rmax_n[tid] = 0u; }      // (first merged in phase B: the barrier between the phases orders this)
 
   for (int it = tid; it < items; it += kBlock) {
     const int dn = (int)udiv((uint32_t)it, p.qd_magic);
@@ -952,20 +951,6 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
         }
       }
     }
-    if (want_rmax) {
-      // every message gradient of this node is c_all + [arg hit] c_min + [arg hit] c_max, times the keep factor: ONE bound per node, formed
-      // here (per item, across the wavefront when it holds a single node - the usual case: a row is 95 items), stands for the row maximum
-      // of each of its edges - an upper bound (the three-product GEMMs take bounds; an edge is the arg of about 1/deg of the columns, so the
-      // bound is rarely more than a binade loose), at a cost per NODE instead of per edge and lane (measured: +0.05 ms of K4 at C2L)
-      float m = 0.f;
-#pragma unroll
-      for (int x = 0; x < 4; ++x) m = fmaxf(m, fabsf(c_all[x]) + fabsf(c_min[x]) + fabsf(c_max[x]));
-      if (DROP) m *= dp.scale;
-      const bool uni = (__all(dn == __builtin_amdgcn_readfirstlane(dn)) && __ballot(1) == ~0ull);
-      const bool elect = (int)(threadIdx.x & (kWave - 1)) == __builtin_amdgcn_readfirstlane((int)(threadIdx.x & (kWave - 1)));
-      if (uni) m = wave_max_nonneg(m);
-      if (m > 0.f && (!uni || elect)) atomicMax(&rmax_b[dn], __float_as_uint(m));
-    }
     float* cf = L.agg + (size_t)dn * NC * p.D + c;
     if (NEEDS & NEED_SUM) { Vec<4> v; for (int i = 0; i < 4; ++i) v.v[i] = c_all[i]; stv<4>(cf + I_ALL * p.D, v); }
     if (NEEDS & NEED_MIN) { Vec<4> v; for (int i = 0; i < 4; ++i) v.v[i] = c_min[i]; stv<4>(cf + I_MIN * p.D, v); }
@@ -982,10 +967,18 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
     const int b = L.rowptr[dn], deg = L.rowptr[dn + 1] - b;
     // dL/dU row maxima (exact): when all active lanes of the wavefront work on ONE node the maximum is formed across the lanes first -
     // one LDS merge per wavefront and row instead of one per lane (64 lanes merging into the same word serialise)
-    const bool uni = want_rmax && (__all(dn == __builtin_amdgcn_readfirstlane(dn)) && __ballot(1) == ~0ull);
+    // a wavefront's 64 consecutive items lie in at most two nodes when a row has >= 63 items (ZINC: 95): each node's maximum is formed
+    // across the lanes (the other node's lanes hold 0) - one LDS merge per wavefront and node instead of one per lane (64 lanes merging
+    // into one or two words serialise; only a third of the wavefronts sit inside ONE row).  Partly active wavefronts and rows shorter
+    // than that merge per lane.  What the maxima cost K4 at C2L (run-time switches, same box): 0.43 ms with them, 0.385 without; without
+    // the LDS merges and their control flow 0.39, without the butterflies 0.41, without the final stage 0.405 - K4 is bound by the
+    // instructions it issues (8 nodes = 760 items per workgroup, 16 wavefronts per CU), and these are ~40 more per item.
+    const int d0 = __builtin_amdgcn_readfirstlane(dn), d1 = __builtin_amdgcn_readlane(dn, kWave - 1);
+    const bool seg2 = want_rmax && __ballot(1) == ~0ull && __all(dn == d0 || dn == d1);
     const bool elect = (int)(threadIdx.x & (kWave - 1)) == __builtin_amdgcn_readfirstlane((int)(threadIdx.x & (kWave - 1)));
     if (deg > kGroupMaxDeg) continue;
     Vec<4> su = vzero<4>();                                   // dL/dU[node]: the sum of the segment's message gradients, in position order
+    float m_b = 0.f;                                          // this item's share of the node's message-gradient bound
     if (deg > 0) {
       const float* cf = L.agg + (size_t)dn * NC * p.D + c;
       Vec<4> ca = vzero<4>(), cn = vzero<4>(), cx = vzero<4>();
@@ -993,6 +986,14 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
       if (NEEDS & NEED_SUM) ca = ldv<4>(cf + I_ALL * p.D);
       if (NEEDS & NEED_MIN) { cn = ldv<4>(cf + I_MIN * p.D); wn = *reinterpret_cast<const uint32_t*>(L.arg + (size_t)dn * p.D + c); }
       if (NEEDS & NEED_MAX) { cx = ldv<4>(cf + I_MAX * p.D); wx = *reinterpret_cast<const uint32_t*>(L.arg + (size_t)(p.nb + dn) * p.D + c); }
+      if (want_rmax) {
+        // every message gradient of this node is c_all + [arg hit] c_min + [arg hit] c_max, times the keep factor: ONE bound per node stands
+        // for the row maximum of each of its edges - an upper bound (the three-product GEMMs take bounds; an edge is the arg of about 1/deg
+        // of the columns, so the bound is rarely more than a binade loose), at a cost per NODE instead of per edge and lane
+#pragma unroll
+        for (int x = 0; x < 4; ++x) m_b = fmaxf(m_b, fabsf(ca.v[x]) + fabsf(cn.v[x]) + fabsf(cx.v[x]));
+        if (DROP) m_b *= dp.scale;
+      }
       for (int tt = 0; tt < deg; ++tt) {
         const int pos = b + tt;
         int ee = 0;
@@ -1010,26 +1011,47 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
         stv_nt<4>(p.gmsg + (size_t)(p.by_pos ? pos : ee) * p.ldg + c, g);
       }
     }
-    if (p.gU) {
-      stv<4>(p.gU + (size_t)node * p.ldgu + c, su);
-      if (want_rmax) {
-        float m = fmaxf(fmaxf(fabsf(su.v[0]), fabsf(su.v[1])), fmaxf(fabsf(su.v[2]), fabsf(su.v[3])));
-        if (uni) m = wave_max_nonneg(m);
-        if (m > 0.f && (!uni || elect)) atomicMax(&rmax_n[dn], __float_as_uint(m));
+    if (p.gU) stv<4>(p.gU + (size_t)node * p.ldgu + c, su);
+    if (want_rmax) {
+      // The consumers take only the EXPONENT of a row maximum (power-of-two scales): both maxima travel as the upper 16 bits of their
+      // fp32 patterns rounded UP (a bound within 2^-7 of the value, as good as the value), one 16-bit pair per lane, ONE butterfly
+      const float m_u = p.gU ? fmaxf(fmaxf(fabsf(su.v[0]), fabsf(su.v[1])), fmaxf(fabsf(su.v[2]), fabsf(su.v[3]))) : 0.f;
+      const uint32_t key = up16_nonneg(m_b) | (up16_nonneg(m_u) << 16);
+      if (seg2) {
+        const uint32_t k0 = wave_pkmax_u16(dn == d0 ? key : 0u);
+        if (elect) {
+          if (k0 & 0xFFFFu) atomicMax(&rmax_b[d0], k0 << 16);
+          if (k0 >> 16) atomicMax(&rmax_n[d0], k0 & 0xFFFF0000u);
+        }
+        if (d1 != d0) {                                        // wave-uniform
+          const uint32_t k1 = wave_pkmax_u16(dn == d1 ? key : 0u);
+          if (elect) {
+            if (k1 & 0xFFFFu) atomicMax(&rmax_b[d1], k1 << 16);
+            if (k1 >> 16) atomicMax(&rmax_n[d1], k1 & 0xFFFF0000u);
+          }
+        }
+      } else {
+        if (key & 0xFFFFu) atomicMax(&rmax_b[dn], key << 16);
+        if (key >> 16) atomicMax(&rmax_n[dn], key & 0xFFFF0000u);
       }
     }
   }
   if (want_rmax) {
-    __syncthreads();
-    // the node's bound goes to each of its edges' rows (positions are this block's alone; a long segment's rows are the list pass's,
-    // its bound here is 0: merged, not stored) and the exact dL/dU maximum to the node
-    for (int w = tid; w < n_here * kGroupMaxDeg; w += kBlock) {
-      const int dn = w / kGroupMaxDeg, tt = w - dn * kGroupMaxDeg;
-      const int b = L.rowptr[dn], deg = L.rowptr[dn + 1] - b;
-      if (tt >= deg || deg > kGroupMaxDeg || rmax_b[dn] == 0u) continue;
-      const int pos = b + tt;
-      const int row = p.by_pos ? pos : (staged ? L.perm[pos - p0] : p.perm[pos]);
-      atomicMax(p.gmsg_rmax + row, rmax_b[dn]);
+    // the LDS merges of all four wavefronts, NOT their global stores: __syncthreads() is also a fence, i.e. s_waitcnt vmcnt(0) - every
+    // wavefront would sit until the message-gradient rows it has just stored are acknowledged
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // the node's bound goes to each of its edges' rows - a plain store: the positions are this block's alone (a long segment's rows are the
+    // list pass's; its bound here is 0 and nothing is stored) - and the dL/dU maximum to the node (merged: the list pass and the dV segment
+    // sum write there too).  One lane per POSITION of the block's contiguous run (its node: a search of the staged row pointers): the stores
+    // of a wavefront are consecutive words (one lane per node walking its edges - 4.6e5 single-word stores from single lanes - and, before
+    // that, n_here x 64 (node, slot) pairs with atomics: 0.01-0.02 ms more each).
+    for (int j = tid; j < p1 - p0; j += kBlock) {
+      const int pos = p0 + j;
+      int lo = 0, hi = n_here;                                 // rowptr[lo] <= pos < rowptr[hi]
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.rowptr[mid] <= pos) lo = mid; else hi = mid; }
+      const uint32_t v = rmax_b[lo];
+      if (L.rowptr[lo + 1] - L.rowptr[lo] <= kGroupMaxDeg && v != 0u)
+        p.gmsg_rmax[p.by_pos ? pos : (staged ? L.perm[pos - p0] : p.perm[pos])] = v;
     }
     if (tid < n_here && rmax_n[tid]) atomicMax(p.gu_rmax + n0 + tid, rmax_n[tid]);
   }

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(kBlock) void tower_post_gw_kernel(const PostParams 
                                                                const float* __restrict__ pre_tab, float* __restrict__ part, int64_t npw,
                                                                int kfp16) {
   // G: kf tiles per pass (post_gw_tiles): S*G accumulator tiles + two operand groups in flight
-  constexpr int GH = G > 5 ? G / 2 : G;                        // tiles per LDS reduction round (the LDS holds 4 waves x S x GH tiles)
+  constexpr int GH = PLAIN ? 1 : (G > 5 ? G / 2 : G);          // tiles per LDS reduction round (the LDS holds 4 waves x S x GH tiles; PLAIN: one
+                                                               // tile per round - 20 KB at S = 5, several workgroups per CU)
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   int t; int64_t bx;
@@ -1072,10 +1073,23 @@ __global__ __launch_bounds__(kBlock) void skinny_gw_reduce_kernel(const float* _
     else if (gb) gb[o] = v[0];
   }
 }
+// node ranges of the plain form (MMA_SKINNY_GW_WAVES: plan sweep, read per call).  Its small LDS round would let several workgroups share
+// a CU, but more wavefronts only add partial tiles: C2L, kernel + reduction: 1024 waves 0.049 ms, 2048 0.058, 3072 0.058, 4096 0.075
+static int64_t skinny_gw_npw(int64_t N) {
+  int64_t waves = 1024;
+  { const char* e = getenv("MMA_SKINNY_GW_WAVES"); if (e && atoi(e) >= 64) waves = atoi(e); }
+  int64_t npw = (N + waves - 1) / waves;
+  npw = (npw + 63) / 64 * 64;
+  return npw < 64 ? 64 : npw;
+}
+static int64_t skinny_gw_chunks(int64_t N) {
+  const int64_t npw = skinny_gw_npw(N);
+  return ((N + npw - 1) / npw + kBlock / kWave - 1) / (kBlock / kWave);
+}
 extern "C" int64_t mma_skinny_linear_gw_part(int64_t N, int32_t K, int32_t O) {          // floats of the partial-tile workspace
   if (N <= 0 || K < 1 || K > 512 || O < 1 || O > kPostMaxS * kPostO) return 0;
   const int64_t S = ((int64_t)O + kPostO - 1) / kPostO, kfp16 = ((int64_t)K + 1 + 15) / 16 * 16;
-  return mma_tower_post_gw_chunks(N, 1) * S * kPostO * kfp16;
+  return skinny_gw_chunks(N) * S * kPostO * kfp16;
 }
 extern "C" int mma_skinny_linear_gw(const float* gy, int64_t ldg, const float* x, int64_t ldx, float* part, int64_t n_part,
                                     float* gw, float* gb, int64_t N, int32_t K, int32_t O, void* stream) {
@@ -1090,14 +1104,14 @@ extern "C" int mma_skinny_linear_gw(const float* gy, int64_t ldg, const float* x
   p.lda = ldx; p.ldg = ldg; p.order = 2;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int kfp16 = (K + 1 + 15) / 16 * 16;
-  const int64_t npw = post_gw_npw(N, 1);
-  const int64_t n_chunks = mma_tower_post_gw_chunks(N, 1);
+  const int64_t npw = skinny_gw_npw(N);
+  const int64_t n_chunks = skinny_gw_chunks(N);
   p.nbx = n_chunks;
   const dim3 grid((unsigned)n_chunks);
   const float* pre = nullptr;
   // G = 5 kf tiles per pass for every S here: S x 5 accumulator tiles + four operand sets of S + 5 + 1 registers stay inside one
   // workgroup per CU at S = 5 (the 75 -> 75 layers: 76 columns = 5 tiles, ONE pass over the rows)
-  const unsigned lds = (unsigned)((kBlock / kWave) * S * 5 * 4 * kWave * sizeof(float));
+  const unsigned lds = (unsigned)((kBlock / kWave) * S * 1 * 4 * kWave * sizeof(float));
 #define MMA_GWP(SS) hipLaunchKernelGGL((tower_post_gw_kernel<SS, 5, true>), grid, dim3(kBlock), lds, st, p, gy, x, pre, part, npw, kfp16)
   switch (S) {
     case 1: MMA_GWP(1); break;

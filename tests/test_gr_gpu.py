@@ -504,7 +504,7 @@ def test_pack_blocks_against_numpy():
 def test_backward_row_maxima_bound_the_rows_they_stand_for(aggs, p, by_hub):
     """[r5] K4 and the dV segment sum leave the row scales of the three-product GEMMs behind them (mma_gr_fused_bwd's gmsg_row_max /
     gu_row_max, mma_csr_spmm_rm).  A scale below the true maximum would overflow the fp16 pieces, a scale far above it would waste their
-    bits: every entry must be >= max |row| (message gradients: a per-node BOUND; dL/dU and dL/dV: exact) and, over the rows that carry a
+    bits: every entry must be >= max |row| (message gradients: a per-node BOUND; dL/dU: within 2^-7 above the maximum; dL/dV: exact) and, over the rows that carry a
     gradient, the message-gradient bounds must stay within a factor 8 of the true maxima for all but a few rows.  A 150-edge hub goes
     through the wave-per-node list pass (exact maxima there)."""
     from mma_amd import functional as Fn
@@ -549,12 +549,16 @@ def test_backward_row_maxima_bound_the_rows_they_stand_for(aggs, p, by_hub):
     assert float((ratio > 8).float().mean()) < 0.02, ("bounds too loose", float(ratio.max()), float((ratio > 8).float().mean()))
     print("message-gradient row bounds / true maxima: median %.2f, 99 %% %.2f, max %.1f" % (
         float(ratio.median()), float(ratio.quantile(0.99)), float(ratio.max())))
-    assert torch.equal(rm[E:], gUV[:, :D].abs().amax(1)), "dL/dU row maxima are exact"
+    # dL/dU: the maximum's upper 16 bits rounded up (the consumers take the exponent of a row maximum, nothing else): >= the value, within 2^-7
+    # of it; the list pass (the hub) stores the value itself
+    tu = gUV[:, :D].abs().amax(1)
+    assert bool((rm[E:] >= tu).all()) and bool((rm[E:] <= tu * (1 + 2.0 ** -7)).all()), "dL/dU row maxima: upper bounds within 2^-7"
     cs = graph.by_source
     call("mma_csr_spmm_rm", ptr(cs.rowptr), ptr(graph.by_source_pos), None, ptr(gmsg), D, E, 1, None, ptr(gUV[:, D:]), 2 * D, N, D, ptr(rm[E:]),
          stream_ptr())
     assert not torch.isnan(gUV).any()
-    assert torch.equal(rm[E:], gUV.abs().amax(1)), "[dL/dU | dL/dV] row maxima after the segment sum are exact"
+    tuv = gUV.abs().amax(1)
+    assert bool((rm[E:] >= tuv).all()) and bool((rm[E:] <= tuv * (1 + 2.0 ** -7)).all()), "[dL/dU | dL/dV] row maxima after the segment sum"
     # the same segment sum without the maxima: same bits
     gV2 = torch.empty((N, D), device=DEV)
     call("mma_csr_spmm", ptr(cs.rowptr), ptr(graph.by_source_pos), None, ptr(gmsg), D, E, 1, None, ptr(gV2), D, N, D, stream_ptr())

@@ -56,6 +56,16 @@ Wa16, Wb16 = torch.empty(kfp_16, R16, device=DEV), torch.empty(R16, kfp_16 + 16,
 call("mma_skinny_linear_weights", ptr(W16), K16, K16, ptr(Wa16), ptr(Wb16), stream_ptr())
 y16, gx16 = torch.empty(N, K16, device=DEV), torch.empty(N, K16, device=DEV)
 
+gw16, gb16 = torch.empty(K16, K16, device=DEV), torch.empty(K16, device=DEV)
+
+
+def skinny_gw():
+    # the workspace size follows MMA_SKINNY_GW_WAVES (read per call): ask per call
+    n_part = int(_lib.query("mma_skinny_linear_gw_part", N, K16, K16))
+    part16 = torch.empty(n_part, device=DEV)
+    call("mma_skinny_linear_gw", ptr(y16), K16, ptr(x16), K16, ptr(part16), n_part, ptr(gw16), ptr(gb16), N, K16, K16, stream_ptr())
+
+
 kernels = {
     "K13 tower_post_fwd": (lambda: call("mma_tower_post_fwd", ptr(agg), T * KF, ptr(pre), ptr(Wa), ptr(y), T * O, N, T, KF, S, O, codes, 1.3, 2.2, stream_ptr()),
                            4 * N * (T * KF + T * O + 8)),
@@ -65,6 +75,7 @@ kernels = {
                                        stream_ptr()), 4 * N * (T * KF + T * O + 8) + 4 * part.numel()),
     "K16 skinny fwd 75->75": (lambda: call("mma_skinny_linear_fwd", ptr(x16), K16, ptr(Wa16), ptr(b16), None, 0, ptr(y16), K16, N, K16, K16, stream_ptr()), 4 * N * 2 * K16),
     "K16 skinny bwd 75->75": (lambda: call("mma_skinny_linear_bwd_dx", ptr(x16), K16, ptr(Wb16), ptr(gx16), K16, N, K16, K16, stream_ptr()), 4 * N * 2 * K16),
+    "K16 skinny gw+gb 75->75": (lambda: skinny_gw(), 4 * N * 2 * K16),
 }
 
 
