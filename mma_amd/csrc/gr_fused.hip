@@ -909,7 +909,6 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
   __shared__ uint32_t rmax_b[32];                             // per node of the block: the bound of its edges' rows (phase A)
   __shared__ uint32_t rmax_n[32];                             // per node: max |dL/dU row| (phase B, exact)
   const bool want_rmax = p.gmsg_rmax != nullptr;              // both arrays or neither (host check)
-  if (want_rmax && tid < 32) { rmax_b[tid] = 0u; rmax_n[tid] = 0u; }      // (first merged in phase B: the barrier between the phases orders this)
 
   for (int it = tid; it < items; it += kBlock) {
     const int dn = (int)udiv((uint32_t)it, p.qd_magic);
@@ -965,17 +964,6 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
     const int c = (it - dn * (int)p.qd) * 4;
     const int node = n0 + dn;
     const int b = L.rowptr[dn], deg = L.rowptr[dn + 1] - b;
-    // dL/dU row maxima (exact): when all active lanes of the wavefront work on ONE node the maximum is formed across the lanes first -
-    // one LDS merge per wavefront and row instead of one per lane (64 lanes merging into the same word serialise)
-    // a wavefront's 64 consecutive items lie in at most two nodes when a row has >= 63 items (ZINC: 95): each node's maximum is formed
-    // across the lanes (the other node's lanes hold 0) - one LDS merge per wavefront and node instead of one per lane (64 lanes merging
-    // into one or two words serialise; only a third of the wavefronts sit inside ONE row).  Partly active wavefronts and rows shorter
-    // than that merge per lane.  What the maxima cost K4 at C2L (run-time switches, same box): 0.43 ms with them, 0.385 without; without
-    // the LDS merges and their control flow 0.39, without the butterflies 0.41, without the final stage 0.405 - K4 is bound by the
-    // instructions it issues (8 nodes = 760 items per workgroup, 16 wavefronts per CU), and these are ~40 more per item.
-    const int d0 = __builtin_amdgcn_readfirstlane(dn), d1 = __builtin_amdgcn_readlane(dn, kWave - 1);
-    const bool seg2 = want_rmax && __ballot(1) == ~0ull && __all(dn == d0 || dn == d1);
-    const bool elect = (int)(threadIdx.x & (kWave - 1)) == __builtin_amdgcn_readfirstlane((int)(threadIdx.x & (kWave - 1)));
     if (deg > kGroupMaxDeg) continue;
     Vec<4> su = vzero<4>();                                   // dL/dU[node]: the sum of the segment's message gradients, in position order
     float m_b = 0.f;                                          // this item's share of the node's message-gradient bound
@@ -1016,35 +1004,43 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
       // The consumers take only the EXPONENT of a row maximum (power-of-two scales): both maxima travel as the upper 16 bits of their
       // fp32 patterns rounded UP (a bound within 2^-7 of the value, as good as the value), one 16-bit pair per lane, ONE butterfly
       const float m_u = p.gU ? fmaxf(fmaxf(fabsf(su.v[0]), fabsf(su.v[1])), fmaxf(fabsf(su.v[2]), fabsf(su.v[3]))) : 0.f;
-      const uint32_t key = up16_nonneg(m_b) | (up16_nonneg(m_u) << 16);
-      if (seg2) {
-        const uint32_t k0 = wave_pkmax_u16(dn == d0 ? key : 0u);
-        if (elect) {
-          if (k0 & 0xFFFFu) atomicMax(&rmax_b[d0], k0 << 16);
-          if (k0 >> 16) atomicMax(&rmax_n[d0], k0 & 0xFFFF0000u);
-        }
-        if (d1 != d0) {                                        // wave-uniform
-          const uint32_t k1 = wave_pkmax_u16(dn == d1 ? key : 0u);
-          if (elect) {
-            if (k1 & 0xFFFFu) atomicMax(&rmax_b[d1], k1 << 16);
-            if (k1 >> 16) atomicMax(&rmax_n[d1], k1 & 0xFFFF0000u);
-          }
-        }
-      } else {
-        if (key & 0xFFFFu) atomicMax(&rmax_b[dn], key << 16);
-        if (key >> 16) atomicMax(&rmax_n[dn], key & 0xFFFF0000u);
-      }
+      // ... and the item leaves the pair in the LDS word its min-arg bytes came from (its own word, read above: no other item touches it).
+      // Nothing is merged here: the first two forms reduced across the wavefront and merged into a word per node for every item - ballots,
+      // lane reads, one or two butterflies, branches around elected-lane LDS atomics: ~40 instructions per item in a kernel that is bound
+      // by the instructions it issues (run-time switches, one box: K4 0.43 ms with the maxima, 0.385 without, 0.39 without the merges).
+      *reinterpret_cast<uint32_t*>(L.arg + (size_t)dn * p.D + c) = up16_nonneg(m_b) | (up16_nonneg(m_u) << 16);
     }
   }
   if (want_rmax) {
-    // the LDS merges of all four wavefronts, NOT their global stores: __syncthreads() is also a fence, i.e. s_waitcnt vmcnt(0) - every
+    // the LDS words of all four wavefronts, NOT their global stores: __syncthreads() is also a fence, i.e. s_waitcnt vmcnt(0) - every
     // wavefront would sit until the message-gradient rows it has just stored are acknowledged
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // one pass per block: 32 lanes per node fold its row of pairs (v_pk_max_u16), a five-step butterfly inside the 32, one word per node
+    {
+      typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+      auto pk = [](uint32_t a, uint32_t b) {
+        const us2 r = __builtin_elementwise_max(*reinterpret_cast<const us2*>(&a), *reinterpret_cast<const us2*>(&b));
+        return *reinterpret_cast<const uint32_t*>(&r);
+      };
+      const int sub = tid & 31;
+      for (int g = 0; g < n_here; g += kBlock / 32) {           // (every lane runs every round: the butterfly needs whole wavefronts)
+        const int dn = g + (tid >> 5);
+        uint32_t v = 0u;
+        if (dn < n_here && L.rowptr[dn + 1] - L.rowptr[dn] <= kGroupMaxDeg)
+          for (int q = sub; q < (int)p.qd; q += 32) v = pk(v, *reinterpret_cast<const uint32_t*>(L.arg + (size_t)dn * p.D + 4 * q));
+        v = pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));
+        v = pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true));
+        v = pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true));
+        v = pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true));
+        v = pk(v, (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F));
+        if (sub == 0 && dn < n_here) { rmax_b[dn] = v << 16; rmax_n[dn] = v & 0xFFFF0000u; }
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // the node's bound goes to each of its edges' rows - a plain store: the positions are this block's alone (a long segment's rows are the
     // list pass's; its bound here is 0 and nothing is stored) - and the dL/dU maximum to the node (merged: the list pass and the dV segment
     // sum write there too).  One lane per POSITION of the block's contiguous run (its node: a search of the staged row pointers): the stores
-    // of a wavefront are consecutive words (one lane per node walking its edges - 4.6e5 single-word stores from single lanes - and, before
-    // that, n_here x 64 (node, slot) pairs with atomics: 0.01-0.02 ms more each).
+    // of a wavefront are consecutive words.
     for (int j = tid; j < p1 - p0; j += kBlock) {
       const int pos = p0 + j;
       int lo = 0, hi = n_here;                                 // rowptr[lo] <= pos < rowptr[hi]
