@@ -10,6 +10,7 @@
 // lowest edge position exactly like torch_scatter's sequential CPU kernel, and the sub-row butterfly keeps that
 // order by comparing (value, edge id) lexicographically.
 #include "common.h"
+#include <type_traits>
 #include <hipcub/hipcub.hpp>
 #include <limits.h>
 
@@ -959,6 +960,13 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
   }
   __syncthreads();
 
+  // FAST = the block's edges are staged in LDS and the gradient rows are stored by position (the layer's own call).  One loop for both
+  // cases compiled `staged ? L.perm[..] : p.perm[..]` into a FLAT load from a selected address - and a flat load counts in vmcnt AND
+  // lgkmcnt, so every iteration of the edge loop began with s_waitcnt vmcnt(0) lgkmcnt(0): a wait for the acknowledgement of the gradient
+  // row the iteration before it had just stored (found in the ISA, round 5; K4 0.39 -> see DESIGN.md).  FAST also walks the rows by
+  // pointer increments (the 64-bit row x pitch product was three quarter-rate multiplies per edge and item).
+  auto phase_b = [&](auto fast_c) {
+  constexpr bool FAST = decltype(fast_c)::value;
   for (int it = tid; it < items; it += kBlock) {
     const int dn = (int)udiv((uint32_t)it, p.qd_magic);
     const int c = (it - dn * (int)p.qd) * 4;
@@ -982,10 +990,12 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
         for (int x = 0; x < 4; ++x) m_b = fmaxf(m_b, fabsf(ca.v[x]) + fabsf(cn.v[x]) + fabsf(cx.v[x]));
         if (DROP) m_b *= dp.scale;
       }
+      float* gp = p.gmsg + (size_t)b * p.ldg + c;              // FAST: row `pos` of the message gradients
       for (int tt = 0; tt < deg; ++tt) {
         const int pos = b + tt;
         int ee = 0;
-        if (DROP || !p.by_pos) ee = staged ? L.perm[pos - p0] : p.perm[pos];
+        if (FAST) { if (DROP) ee = L.perm[pos - p0]; }
+        else if (DROP || !p.by_pos) ee = staged ? L.perm[pos - p0] : p.perm[pos];
         float fd[4] = {1.f, 1.f, 1.f, 1.f};
         if (DROP) blk_drop(dp, (uint32_t)ee, c, fd);
         Vec<4> g;
@@ -996,7 +1006,8 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
           g.v[i] = gi * fd[i];
           su.v[i] += g.v[i];
         }
-        stv_nt<4>(p.gmsg + (size_t)(p.by_pos ? pos : ee) * p.ldg + c, g);
+        if (FAST) { stv_nt<4>(gp, g); gp += p.ldg; }
+        else stv_nt<4>(p.gmsg + (size_t)(p.by_pos ? pos : ee) * p.ldg + c, g);
       }
     }
     if (p.gU) stv<4>(p.gU + (size_t)node * p.ldgu + c, su);
@@ -1011,6 +1022,8 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
       *reinterpret_cast<uint32_t*>(L.arg + (size_t)dn * p.D + c) = up16_nonneg(m_b) | (up16_nonneg(m_u) << 16);
     }
   }
+  };
+  if (staged && p.by_pos) phase_b(std::true_type{}); else phase_b(std::false_type{});
   if (want_rmax) {
     // the LDS words of all four wavefronts, NOT their global stores: __syncthreads() is also a fence, i.e. s_waitcnt vmcnt(0) - every
     // wavefront would sit until the message-gradient rows it has just stored are acknowledged

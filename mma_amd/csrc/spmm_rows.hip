@@ -2,6 +2,7 @@
 // K7 (halo row pack / unpack-add for the node-sharded multi-GPU path) and
 // K8 (column sums of a tall matrix = the bias gradients of the dense transforms around the fused kernels).
 #include "common.h"
+#include <type_traits>
 
 namespace mma {
 
@@ -88,7 +89,6 @@ __global__ __launch_bounds__(kBlock) void segsum_block_kernel(const SegSumParams
   extern __shared__ __attribute__((aligned(16))) float seg_out[];          // (kSegRows, C)
   __shared__ int s_rp[kSegRows + 1];
   __shared__ int s_idx[kSegCap];
-  __shared__ uint32_t s_rm[kSegRows];
   const int tid = threadIdx.x;
   const int n0 = (int)blockIdx.x * kSegRows;
   const int n_here = min(kSegRows, p.n_rows - n0);
@@ -96,10 +96,15 @@ __global__ __launch_bounds__(kBlock) void segsum_block_kernel(const SegSumParams
   const int p0 = p.rowptr[n0], p1 = p.rowptr[n0 + n_here];
   const bool staged = p1 - p0 <= kSegCap;
   if (tid <= n_here) s_rp[tid] = p.rowptr[n0 + tid];
-  if (tid < kSegRows) s_rm[tid] = 0u;
   if (staged) for (int i = tid; i < p1 - p0; i += kBlock) s_idx[i] = p.col[p0 + i];
   __syncthreads();
   const int items = n_here * (int)p.qd;
+  // STAGED as a compile-time constant: `staged ? s_idx[..] : p.col[..]` in one loop compiled into FLAT loads from a selected address (a
+  // flat load counts in vmcnt AND lgkmcnt and takes the global path for what is an LDS word; the same pattern cost K4 0.05 ms - found in
+  // the ISA, round 5)
+  auto gather = [&](auto staged_c) {
+  constexpr bool STAGED = decltype(staged_c)::value;
+  auto col_of = [&](int pos) { return STAGED ? s_idx[pos - p0] : p.col[pos]; };
   for (int it = tid; it < items; it += kBlock) {
     const int dn = (int)seg_udiv((uint32_t)it, p.qd_magic);
     const int c = (it - dn * (int)p.qd) * 4;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void segsum_block_kernel(const SegSumParams
     if (deg <= kSegLong && deg > 0) {
       int j[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int pos = b + min(i, deg - 1); j[i] = staged ? s_idx[pos - p0] : p.col[pos]; }
+      for (int i = 0; i < 4; ++i) j[i] = col_of(b + min(i, deg - 1));
       float4 v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(p.B + (size_t)j[i] * p.ldb + c);
@@ -116,19 +121,12 @@ __global__ __launch_bounds__(kBlock) void segsum_block_kernel(const SegSumParams
       for (int i = 0; i < 4; ++i)
         if (i < deg) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
       for (int t = 4; t < deg; ++t) {
-        const int jj = staged ? s_idx[b + t - p0] : p.col[b + t];
+        const int jj = col_of(b + t);
         const float4 vv = *reinterpret_cast<const float4*>(p.B + (size_t)jj * p.ldb + c);
         acc.x += vv.x; acc.y += vv.y; acc.z += vv.z; acc.w += vv.w;
       }
     }
     *reinterpret_cast<float4*>(seg_out + (size_t)dn * p.C + c) = acc;
-    if (p.rowmax && deg <= kSegLong) {
-      float m = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
-      const bool uni = (__all(dn == __builtin_amdgcn_readfirstlane(dn)) && __ballot(1) == ~0ull);
-      const bool elect = (int)(threadIdx.x & (kWave - 1)) == __builtin_amdgcn_readfirstlane((int)(threadIdx.x & (kWave - 1)));
-      if (uni) m = wave_max_nonneg(m);
-      if (m > 0.f && (!uni || elect)) atomicMax(&s_rm[dn], __float_as_uint(m));
-    }
   }
   // long rows (rare): the whole workgroup, one lane per 4 columns, eight gathers in flight, members added in edge order
   for (int dn = 0; dn < n_here; ++dn) {
@@ -141,8 +139,7 @@ __global__ __launch_bounds__(kBlock) void segsum_block_kernel(const SegSumParams
         float4 v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int pos = b + min(t0 + i, deg - 1);
-          const int jj = staged ? s_idx[pos - p0] : p.col[pos];
+          const int jj = col_of(b + min(t0 + i, deg - 1));
           v[i] = *reinterpret_cast<const float4*>(p.B + (size_t)jj * p.ldb + c);
         }
 #pragma unroll
@@ -150,19 +147,36 @@ __global__ __launch_bounds__(kBlock) void segsum_block_kernel(const SegSumParams
           if (t0 + i < deg) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
       }
       *reinterpret_cast<float4*>(seg_out + (size_t)dn * p.C + c) = acc;
-      if (p.rowmax) {
-        const float m = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
-        if (m > 0.f) atomicMax(&s_rm[dn], __float_as_uint(m));
-      }
     }
   }
+  };
+  if (staged) gather(std::true_type{}); else gather(std::false_type{});
   __syncthreads();
   for (int it = tid; it < items; it += kBlock) {
     const int dn = (int)seg_udiv((uint32_t)it, p.qd_magic);
     const int c = (it - dn * (int)p.qd) * 4;
     *reinterpret_cast<float4*>(p.out + (size_t)(n0 + dn) * p.ldo + c) = *reinterpret_cast<const float4*>(seg_out + (size_t)dn * p.C + c);
   }
-  if (p.rowmax && tid < n_here && s_rm[tid]) atomicMax(p.rowmax + n0 + tid, s_rm[tid]);
+  // row maxima (exact), once per workgroup from the finished rows in LDS: 32 lanes per row, a five-step butterfly (the first form merged
+  // per item - ballots, a butterfly, elected-lane LDS atomics for every 4 columns; see K4)
+  if (p.rowmax) {
+    const int sub = tid & 31;
+    for (int g = 0; g < n_here; g += kBlock / 32) {             // every lane runs every round: the butterfly needs whole wavefronts
+      const int dn = g + (tid >> 5);
+      float m = 0.f;
+      if (dn < n_here)
+        for (int q = sub; q < (int)p.qd; q += 32) {
+          const float4 v = *reinterpret_cast<const float4*>(seg_out + (size_t)dn * p.C + 4 * q);
+          m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xF, 0xF, true)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x4E, 0xF, 0xF, true)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x141, 0xF, 0xF, true)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x140, 0xF, 0xF, true)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(m), 0x401F)));
+      if (sub == 0 && dn < n_here && m > 0.f) atomicMax(p.rowmax + n0 + dn, __float_as_uint(m));
+    }
+  }
 }
 
 // Item-driven variant (K = 1): rows are cut into work items of bounded length, longest first (mma_amd/graph.py),

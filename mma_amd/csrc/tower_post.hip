@@ -216,6 +216,16 @@ __global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams
     const int64_t node = n0 + nt * 16 + j;
     const bool valid = tvalid && node < p.N;
     if (PLAIN) {
+      // every load of the tile (bias, addend) ahead of its first store: a load behind a store waits for the store's acknowledgement
+      float bvv[S][4], adv[S][4];
+#pragma unroll
+      for (int q = 0; q < S; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = q * kPostO + 4 * kq + r;
+          bvv[q][r] = (valid && col < p.O && p.bias) ? p.bias[col] : 0.f;
+          adv[q][r] = (valid && col < p.O && p.addend) ? p.addend[(size_t)node * p.ldadd + col] : 0.f;
+        }
       if (valid) {
 #pragma unroll
         for (int q = 0; q < S; ++q)
@@ -223,8 +233,8 @@ __global__ __launch_bounds__(kBlock) void tower_post_fwd_kernel(const PostParams
           for (int r = 0; r < 4; ++r) {
             const int col = q * kPostO + 4 * kq + r;
             if (col < p.O) {
-              const float v = acc[nt][q][r] + (p.bias ? p.bias[col] : 0.f);
-              y[(size_t)node * p.ldy + col] = p.addend ? v + p.addend[(size_t)node * p.ldadd + col] : v;
+              const float v = acc[nt][q][r] + bvv[q][r];
+              y[(size_t)node * p.ldy + col] = p.addend ? v + adv[q][r] : v;
             }
           }
       }
@@ -625,6 +635,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int q = 0; q < S; ++q) pre[nt][q] = 0.f;
+  // PLAIN: this lane's bias values, loaded ONCE, ahead of every store.  Read inside the epilogue (`acc + bias[col]` per element) each of
+  // them was a load BEHIND the stores just issued - one in-order vmcnt: the wait for the bias was a wait for their acknowledgement, once per
+  // stored element (found in the ISA, round 5: K16's forward 0.074 ms -> see DESIGN.md)
+  float bv[S][4];
+#pragma unroll
+  for (int q = 0; q < S; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = q * kPostO + 4 * kg + r;
+      bv[q][r] = (PLAIN && p.bias && col < p.O) ? p.bias[col] : 0.f;
+    }
   for (int step = 0; step < steps; ++step) {
     if (ks == 0 && !PLAIN) {
 #pragma unroll
@@ -682,7 +703,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int col = q * kPostO + 4 * kg + r;
-                if (col < p.O) y[(size_t)node * p.ldy + col] = acc[nt][q][r] + (p.bias ? p.bias[col] : 0.f);
+                if (col < p.O) y[(size_t)node * p.ldy + col] = acc[nt][q][r] + bv[q][r];
               }
           }
         } else {
