@@ -12,7 +12,7 @@ import sys
 def main():
     d = sys.argv[1]
     n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-    f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[-1]
+    f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]      # the newest run (merged dirs keep old ones)
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     per = len(rows) // n_steps
