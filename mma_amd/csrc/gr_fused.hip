@@ -1017,8 +1017,8 @@ __global__ __launch_bounds__(kBlock) void gr_bwd_block_kernel(const GrParams p) 
       const float m_u = p.gU ? fmaxf(fmaxf(fabsf(su.v[0]), fabsf(su.v[1])), fmaxf(fabsf(su.v[2]), fabsf(su.v[3]))) : 0.f;
       // ... and the item leaves the pair in the LDS word its min-arg bytes came from (its own word, read above: no other item touches it).
       // Nothing is merged here: the first two forms reduced across the wavefront and merged into a word per node for every item - ballots,
-      // lane reads, one or two butterflies, branches around elected-lane LDS atomics: ~40 instructions per item in a kernel that is bound
-      // by the instructions it issues (run-time switches, one box: K4 0.43 ms with the maxima, 0.385 without, 0.39 without the merges).
+      // lane reads, one or two butterflies, branches around elected-lane LDS atomics: ~40 instructions per item (run-time switches, one
+      // box, on the kernel that still had the flat load below: K4 0.43 ms with the maxima, 0.385 without, 0.39 without the merges).
       *reinterpret_cast<uint32_t*>(L.arg + (size_t)dn * p.D + c) = up16_nonneg(m_b) | (up16_nonneg(m_u) << 16);
     }
   }
